@@ -1,0 +1,275 @@
+"""CPU oracle for the RepMode MoDE hot path -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this file.  Nothing under ``repmode_amd/`` imports it; the
+product path runs hand-written HIP kernels and fails loudly without them.
+
+It is a clean-room, vectorised restatement (plain PyTorch, CPU, fp32) of the
+arithmetic in the reference's ``fnet/nn_modules/RepMode.py`` -- the arithmetic
+primitives of that file live in PyTorch itself (``F.conv3d``, ``softmax``,
+``batch_norm``), so the restatement is built from the same primitives but in a
+different shape: gate probabilities are gathered by integer task id (no one-hot
+matmul), filters are merged once per sample with one contraction over a stacked
+expert bank, and the per-sample convolution loop is one grouped convolution.
+
+Pinned against the golden vectors in ``tests/golden/*.npz`` (captured by
+importing the reference; see ``tests/golden/make_golden.py``) by
+``tests/test_oracle_golden.py``.
+
+Every function cites the reference lines it restates (paths relative to the
+reference checkout).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+NUM_EXPERTS = 5          # RepMode.py:22
+KSIZE = 5                # RepMode.py:114-115 (canonical 5x5x5 filter)
+
+
+# --------------------------------------------------------------------------- #
+# functional pieces
+# --------------------------------------------------------------------------- #
+def gate_probs(gate_w, gate_b, tasks, co):
+    """g[n, e, o] = softmax_e(gate_w[e*Co+o, task_n] + gate_b[e*Co+o]).
+
+    RepMode.py:44-49 (one-hot), :198 (Linear), :199 (view N,5,Co), :200 (softmax
+    over dim 1).  A one-hot row times W^T is column ``task`` of W.
+    """
+    logits = gate_w.t()[tasks] + gate_b                      # [N, 5*Co]
+    return torch.softmax(logits.view(-1, NUM_EXPERTS, co), dim=1)
+
+
+def expert_bank(k5, k3, k1, a3, a5):
+    """Stack the five experts as canonical 5^3 filters: [5, Co, Ci, 5, 5, 5].
+
+    RepMode.py:165-169 (centre zero pad), :173-180 (conv5 as is; conv3, conv1
+    padded; avg3 = w1x1 * 1/27 over the centre 3^3; avg5 = w1x1 * 1/125).
+    """
+    co, ci = k5.shape[:2]
+    bank = k5.new_zeros((NUM_EXPERTS, co, ci, KSIZE, KSIZE, KSIZE))
+    bank[0] = k5
+    bank[1, :, :, 1:4, 1:4, 1:4] = k3
+    bank[2, :, :, 2:3, 2:3, 2:3] = k1
+    bank[3, :, :, 1:4, 1:4, 1:4] = a3 * (1.0 / 27.0)
+    bank[4] = a5 * (1.0 / 125.0)
+    return bank
+
+
+def merge_filters(bank, g):
+    """W[n, o, i, :] = sum_e g[n, e, o] * bank[e, o, i, :]   (RepMode.py:182-190)."""
+    return torch.einsum('eoidhw,neo->noidhw', bank, g)
+
+
+def conv_per_sample(x, w):
+    """y[n] = conv3d(x[n], w[n]), 5^3, stride 1, zero pad 2, no bias.
+
+    RepMode.py:204-208: the per-sample loop equals one grouped convolution with
+    groups = N (property 3).
+    """
+    n, ci = x.shape[:2]
+    co = w.shape[1]
+    y = F.conv3d(x.reshape(1, n * ci, *x.shape[2:]),
+                 w.reshape(n * co, ci, KSIZE, KSIZE, KSIZE), padding=2, groups=n)
+    return y.view(n, co, *x.shape[2:])
+
+
+def mode_conv_pre_bn(x, k5, k3, k1, a3, a5, gate_w, gate_b, tasks, training=True):
+    """The MoDE block up to (not including) ``subsequent_layer``  (RepMode.py:194-210)."""
+    co = k5.shape[0]
+    g = gate_probs(gate_w, gate_b, tasks, co)
+    w = merge_filters(expert_bank(k5, k3, k1, a3, a5), g)
+    if training:
+        return conv_per_sample(x, w)
+    return F.conv3d(x, w[0], padding=2)                      # RepMode.py:209-210
+
+
+def mode_conv_reference_style(x, k5, k3, k1, a3, a5, gate_w, gate_b, tasks):
+    """Same result, organised like the reference (python loop per sample): used
+    only as the 'reference-style' leg of the CPU baseline timing."""
+    co = k5.shape[0]
+    g = gate_probs(gate_w, gate_b, tasks, co)
+    bank = expert_bank(k5, k3, k1, a3, a5)
+    ys = []
+    for n in range(x.shape[0]):
+        wn = (bank * g[n][:, :, None, None, None, None]).sum(0)
+        ys.append(F.conv3d(x[n:n + 1], wn, padding=2))
+    return torch.cat(ys, 0)
+
+
+# --------------------------------------------------------------------------- #
+# module tree with the reference's state_dict surface (309 keys at any mult_chan)
+# --------------------------------------------------------------------------- #
+def _kaiming_param(co, ci, k):
+    w = torch.nn.Parameter(torch.empty(co, ci, k, k, k))
+    torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))          # RepMode.py:156-159
+    return w
+
+
+class MoDEConv(torch.nn.Module):
+    """Parameter surface of RepMode.py:123-154; arithmetic via the functions above."""
+
+    def __init__(self, num_experts, num_tasks, in_chan, out_chan, kernel_size=5,
+                 stride=1, padding='same', conv_type='normal'):
+        super().__init__()
+        assert num_experts == NUM_EXPERTS and kernel_size == KSIZE
+        self.num_tasks, self.in_chan, self.out_chan = num_tasks, in_chan, out_chan
+        self.conv_type = conv_type
+        self.expert_conv5x5_conv = _kaiming_param(out_chan, in_chan, 5)
+        self.expert_conv3x3_conv = _kaiming_param(out_chan, in_chan, 3)
+        self.expert_conv1x1_conv = _kaiming_param(out_chan, in_chan, 1)
+        self.register_buffer('expert_avg3x3_pool', torch.full((3, 3, 3), 1.0 / 27))
+        self.expert_avg3x3_conv = _kaiming_param(out_chan, in_chan, 1)
+        self.register_buffer('expert_avg5x5_pool', torch.full((5, 5, 5), 1.0 / 125))
+        self.expert_avg5x5_conv = _kaiming_param(out_chan, in_chan, 1)
+        if conv_type == 'normal':
+            self.subsequent_layer = torch.nn.Sequential(
+                torch.nn.BatchNorm3d(out_chan), torch.nn.ReLU(inplace=True))
+        else:
+            self.subsequent_layer = torch.nn.Identity()
+        self.gate = torch.nn.Linear(num_tasks, num_experts * out_chan, bias=True)
+
+    def forward(self, x, tasks):
+        y = mode_conv_pre_bn(x, self.expert_conv5x5_conv, self.expert_conv3x3_conv,
+                             self.expert_conv1x1_conv, self.expert_avg3x3_conv,
+                             self.expert_avg5x5_conv, self.gate.weight, self.gate.bias,
+                             tasks, self.training)
+        return self.subsequent_layer(y)                       # RepMode.py:212
+
+
+class MoDESubNet2Conv(torch.nn.Module):                       # RepMode.py:111-120
+    def __init__(self, num_experts, num_tasks, n_in, n_out):
+        super().__init__()
+        self.conv1 = MoDEConv(num_experts, num_tasks, n_in, n_out)
+        self.conv2 = MoDEConv(num_experts, num_tasks, n_out, n_out)
+
+    def forward(self, x, t):
+        return self.conv2(self.conv1(x, t), t)
+
+
+def _down(c):                                                 # RepMode.py:80-84
+    return torch.nn.Sequential(torch.nn.Conv3d(c, c, 2, stride=2, bias=False),
+                               torch.nn.BatchNorm3d(c), torch.nn.ReLU(inplace=True))
+
+
+def _up(ci, co):                                              # RepMode.py:97-101
+    return torch.nn.Sequential(torch.nn.ConvTranspose3d(ci, co, 2, stride=2, bias=False),
+                               torch.nn.BatchNorm3d(co), torch.nn.ReLU(inplace=True))
+
+
+class MoDEEncoderBlock(torch.nn.Module):                      # RepMode.py:74-89
+    def __init__(self, num_experts, num_tasks, in_chan, out_chan):
+        super().__init__()
+        self.conv_more = MoDESubNet2Conv(num_experts, num_tasks, in_chan, out_chan)
+        self.conv_down = _down(out_chan)
+
+    def forward(self, x, t):
+        skip = self.conv_more(x, t)
+        return self.conv_down(skip), skip
+
+
+class MoDEDecoderBlock(torch.nn.Module):                      # RepMode.py:92-108
+    def __init__(self, num_experts, num_tasks, in_chan, out_chan):
+        super().__init__()
+        self.convt = _up(in_chan, out_chan)
+        self.conv_less = MoDESubNet2Conv(num_experts, num_tasks, in_chan, out_chan)
+
+    def forward(self, x, skip, t):
+        return self.conv_less(torch.cat((skip, self.convt(x)), 1), t)
+
+
+class Net(torch.nn.Module):
+    """RepMode.py:8-71.  ``forward(x[N,1,D,H,W], tasks int64[N])``."""
+
+    def __init__(self, opts, mult_chan=32, in_channels=1, out_channels=1):
+        super().__init__()
+        self.opts = opts
+        self.num_tasks = len(opts.adopted_datasets)
+        e, t, m = NUM_EXPERTS, self.num_tasks, in_channels * mult_chan
+        self.encoder_block1 = MoDEEncoderBlock(e, t, in_channels, m)
+        self.encoder_block2 = MoDEEncoderBlock(e, t, m, m * 2)
+        self.encoder_block3 = MoDEEncoderBlock(e, t, m * 2, m * 4)
+        self.encoder_block4 = MoDEEncoderBlock(e, t, m * 4, m * 8)
+        self.bottle_block = MoDESubNet2Conv(e, t, m * 8, m * 16)
+        self.decoder_block4 = MoDEDecoderBlock(e, t, m * 16, m * 8)
+        self.decoder_block3 = MoDEDecoderBlock(e, t, m * 8, m * 4)
+        self.decoder_block2 = MoDEDecoderBlock(e, t, m * 4, m * 2)
+        self.decoder_block1 = MoDEDecoderBlock(e, t, m * 2, m)
+        self.conv_out = MoDEConv(e, t, mult_chan, out_channels, conv_type='final')
+
+    def forward(self, x, t):
+        t = t.long()
+        x, s1 = self.encoder_block1(x, t)
+        x, s2 = self.encoder_block2(x, t)
+        x, s3 = self.encoder_block3(x, t)
+        x, s4 = self.encoder_block4(x, t)
+        x = self.bottle_block(x, t)
+        x = self.decoder_block4(x, s4, t)
+        x = self.decoder_block3(x, s3, t)
+        x = self.decoder_block2(x, s2, t)
+        x = self.decoder_block1(x, s1, t)
+        return self.conv_out(x, t)
+
+
+# --------------------------------------------------------------------------- #
+# harness counterparts (fnet_model.py) used as checkers
+# --------------------------------------------------------------------------- #
+def train_step(net, optimizer, signal, target, tasks):
+    """fnet_model.py:105-113 without AMP (CPU): zero_grad, fwd, MSE('none')->mean,
+    backward, step.  Returns (loss, per-sample loss)."""
+    optimizer.zero_grad()
+    out = net(signal, tasks)
+    ln = F.mse_loss(out, target, reduction='none')
+    loss = ln.mean()
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), ln.detach().mean(dim=(1, 2, 3, 4))
+
+
+def gaussian_map(patch_size, sigma_scale=1.0 / 8):
+    """fnet_model.py:242-252: separable Gaussian of a centred delta (scipy
+    ``gaussian_filter(mode='constant')`` truncates each 1-D kernel at 4 sigma),
+    max-normalised, zeros replaced by the smallest non-zero value."""
+    import numpy as np
+    from scipy.ndimage import gaussian_filter
+    tmp = np.zeros(patch_size)
+    tmp[tuple(i // 2 for i in patch_size)] = 1
+    gm = gaussian_filter(tmp, [i * sigma_scale for i in patch_size], 0, mode='constant', cval=0)
+    gm = (gm / gm.max()).astype(np.float32)
+    gm[gm == 0] = gm[gm != 0].min()
+    return gm
+
+
+def patch_grid(img_size, patch_size):
+    """fnet_model.py:156-193: 50 %-overlap tiling, ends clamped, starts re-adjusted.
+    Returns the list of (starts, ends) in enumeration order (z, y, x)."""
+    strides = [int(math.ceil(p * 0.5)) for p in patch_size]
+    steps = [int(math.ceil((i - p) / s + 1)) for i, p, s in zip(img_size, patch_size, strides)]
+    out = []
+    for a in range(steps[0]):
+        for b in range(steps[1]):
+            for c in range(steps[2]):
+                st = [i * s for i, s in zip((a, b, c), strides)]
+                en = [min(s + p, im) for s, p, im in zip(st, patch_size, img_size)]
+                st = [max(e - p, 0) for e, p in zip(en, patch_size)]
+                out.append((st, en))
+    return out
+
+
+def predict(net, signal, task, patch_size, batch_size_eval):
+    """fnet_model.py:149-223: LIFO batches, Gaussian-weighted accumulate, divide."""
+    net.eval()
+    gm = torch.from_numpy(gaussian_map(tuple(patch_size)))
+    pred_sum = torch.zeros_like(signal)
+    weight_sum = torch.zeros_like(signal)
+    patches = patch_grid(signal.shape[-3:], patch_size)
+    while patches:
+        batch = [patches.pop() for _ in range(min(batch_size_eval, len(patches)))]
+        crops = torch.cat([signal[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] for s, e in batch], 0)
+        with torch.no_grad():
+            out = net(crops, task.expand(len(batch)))
+        for i, (s, e) in enumerate(batch):
+            pred_sum[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] += out[i:i + 1] * gm
+            weight_sum[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] += gm
+    return pred_sum / weight_sum

@@ -1,0 +1,38 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b|  -- the 'relative fp32' measure used by every parity test."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+class Opts:
+    adopted_datasets = ['alpha_tubulin', 'beta_actin', 'desmoplakin', 'dna',
+                        'fibrillarin', 'lamin_b1', 'membrane_caax_63x',
+                        'myosin_iib', 'sec61_beta', 'st6gal1', 'tom20', 'zo1']
+    gpu_ids = -1
+    batch_size_eval = 2
+
+
+@pytest.fixture
+def opts():
+    return Opts()
