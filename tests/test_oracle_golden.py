@@ -127,9 +127,9 @@ def test_train_loss_sequence():
         if v.dtype.is_floating_point:
             # each Adam step moves a parameter by ~lr = 1e-4 in the direction sign(grad); elements whose
             # gradient is ~0 can flip direction under fp32 reordering, so bound the worst element by
-            # half the 5-step travel and the typical element by a fraction of one step
+            # the 5-step travel and the typical element by a fraction of one step
             d = np.abs(v.numpy() - g['final.' + k])
-            assert d.max() < 2.5e-4 and (d.size < 64 or d.mean() < 3e-5), k
+            assert d.max() < 5.5e-4 and (d.size < 64 or d.mean() < 3e-5), k
 
 
 def test_gaussian_and_patch_grid():
