@@ -1,0 +1,110 @@
+/*
+ * repmode_hip.h -- C ABI of librepmode_hip.so: the MI355X (gfx950) MoDE-block hot path.
+ *
+ * This is the drop-in boundary.  Every entry point takes plain device pointers, sizes and a
+ * HIP stream handle (passed as void*); no torch / C++ types.  All functions return 0 on
+ * success and a non-zero REPMODE_E* code otherwise; repmode_last_error() gives the message.
+ * Nothing here allocates device memory or synchronises the stream: outputs and workspaces are
+ * owned by the caller, kernels are enqueued on `stream` and return immediately.
+ *
+ * The reference (Correr-Zhou/RepMode) is pure Python and has no FFI; each function below names
+ * the reference lines whose arithmetic it replaces (paths relative to the reference checkout).
+ *
+ * Layouts (MI355X-first):
+ *   activations   NDHWC ("channels last"): x[n][z][y][x][c], element type = dtype
+ *   expert params the reference's own layout and dtype: float [Co][Ci][k][k][k]
+ *   merged filter wf[slot][tap][CoP][CiP]  (tap = (dz*5+dy)*5+dx, cross-correlation order)
+ *                 wd[slot][124-tap][CiP][CoP] (taps flipped, channels transposed: the filter
+ *                 that turns the data-gradient into the same convolution)
+ *                 CoP / CiP = channel counts rounded up (zero filled) as given by
+ *                 repmode_padded_channels().
+ *   slots         a "slot" is one distinct task of the batch; slot_task[s] is its task id and
+ *                 sample_slot[n] the slot of sample n.  Filters depend on the task only, so they
+ *                 are merged once per slot, not once per sample as RepMode.py:182-190 does.
+ */
+#ifndef REPMODE_HIP_H
+#define REPMODE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REPMODE_ABI_VERSION 1
+
+/* element types of activations / merged filters */
+#define REPMODE_F32 0  /* float in, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)          */
+#define REPMODE_BF16 1 /* bfloat16 in, f32 accumulate (v_mfma_f32_32x32x16_bf16)      */
+
+/* error codes */
+#define REPMODE_OK 0
+#define REPMODE_EINVAL 1  /* bad argument (shape, dtype, null pointer, alignment) */
+#define REPMODE_ELAUNCH 2 /* HIP launch error                                    */
+#define REPMODE_ENODEV 3  /* no gfx950 device                                    */
+
+#define REPMODE_NUM_EXPERTS 5 /* RepMode.py:22      */
+#define REPMODE_KSIZE 5       /* RepMode.py:114-115 */
+#define REPMODE_TAPS 125
+
+int repmode_abi_version(void);
+const char* repmode_last_error(void);
+/* name of device `dev`'s gcnArchName into buf; REPMODE_ENODEV when there is none */
+int repmode_device_arch(int dev, char* buf, int buflen);
+
+/* Channel padding of the merged filters for a given dtype: the input-channel dimension is
+ * rounded up to the MFMA K granule, the output-channel dimension to the 32-row MFMA tile. */
+int repmode_padded_channels(int channels, int dtype, int is_reduction_dim);
+
+/* ---- gate: RepMode.py:44-49 (one-hot), :198 (Linear), :199-200 (softmax over experts) ----
+ * g[s][e][o] = softmax_e(gate_w[e*Co+o][slot_task[s]] + gate_b[e*Co+o])      (float [S][5][Co]) */
+int repmode_gate_softmax(const float* gate_w, const float* gate_b, const int32_t* slot_task,
+                         int nslots, int num_tasks, int co, float* g, void* stream);
+
+/* ---- GatRep forward: RepMode.py:165-169 (trans_kernel), :173-180, :182-190 (routing) ----
+ * W_s = g0*K5 + g1*pad(K3) + g2*pad(K1) + g3*pad(A3/27) + g4*A5/125, per output channel,
+ * written as wf and/or wd (either may be NULL, not both) in `dtype`. */
+int repmode_gatrep_fwd(const float* k5, const float* k3, const float* k1, const float* a3,
+                       const float* a5, const float* g, int nslots, int co, int ci, int dtype,
+                       void* wf, void* wd, void* stream);
+
+/* ---- conv: RepMode.py:204-208 (train, per-sample filter) and :209-210 (eval, one filter) ----
+ * y[n] = cross-correlation of x[n] with w[sample_slot[n]], 5^3, stride 1, zero pad 2, no bias.
+ * x: [N][D][H][W][Cin] dtype;  w: [nslots][125][CoutP][CinP] dtype;
+ * y: [N][D][H][W][Cout], dtype, or float when out_f32 != 0.
+ * Called with wf for the forward pass and with wd (Cin/Cout swapped) for the data gradient
+ * (autograd of RepMode.py:207, aten::convolution_backward input grad). */
+int repmode_conv5(const void* x, const void* w, const int32_t* sample_slot, void* y, int n, int d,
+                  int h, int wdim, int cin, int cout, int dtype, int out_f32, void* stream);
+
+/* ---- weight gradient of the same conv (aten::convolution_backward weight grad), summed over
+ * the samples of each slot:  dw[s][tap][o][i] = sum_{n in s} sum_v dy[n][v][o] * x[n][v+tap][i]
+ * dw: float [nslots][125][Cout][Cin], OVERWRITTEN (zeroed inside, then accumulated). */
+int repmode_conv5_wgrad(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
+                        float* dw, int n, int d, int h, int wdim, int cin, int cout, int dtype,
+                        void* stream);
+
+/* ---- GatRep backward (autograd of RepMode.py:171-200): expert, gate-probability and gate
+ * parameter gradients from the per-slot filter gradient.  Outputs are OVERWRITTEN.
+ * dk5 [Co][Ci][125], dk3 [Co][Ci][27], dk1/da3/da5 [Co][Ci], dgate_w [5*Co][T], dgate_b [5*Co].
+ * dg_ws: float workspace [nslots][5][Co]. */
+int repmode_gatrep_bwd(const float* dw, const float* k5, const float* k3, const float* k1,
+                       const float* a3, const float* a5, const float* g, const int32_t* slot_task,
+                       int nslots, int num_tasks, int co, int ci, float* dk5, float* dk3,
+                       float* dk1, float* da3, float* da5, float* dgate_w, float* dgate_b,
+                       float* dg_ws, void* stream);
+
+/* ---- diagnostics: naive one-thread-per-output direct kernels (no MFMA, no LDS).  Not on the
+ * product path; used by tests to bisect a failure between tiling and arithmetic. */
+int repmode_debug_conv5_naive(const void* x, const void* w, const int32_t* sample_slot, float* y,
+                              int n, int d, int h, int wdim, int cin, int cout, int dtype,
+                              void* stream);
+int repmode_debug_wgrad_naive(const void* x, const void* dy, const int32_t* sample_slot,
+                              int nslots, float* dw, int n, int d, int h, int wdim, int cin,
+                              int cout, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REPMODE_HIP_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of librepmode_hip.so (the C ABI declared in include/repmode_hip.h).
+
+The library is built in-tree by ``repmode_amd/csrc/build.sh`` (``__graft_entry__.build()``).
+There is NO fallback: if the shared object is missing or a call fails this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librepmode_hip.so')
+
+F32, BF16 = 0, 1
+ABI_VERSION = 1
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+
+# name -> argtypes, in the order of include/repmode_hip.h
+_SIGNATURES = {
+    'repmode_abi_version': [],
+    'repmode_device_arch': [_I, _c.c_char_p, _I],
+    'repmode_padded_channels': [_I, _I, _I],
+    'repmode_gate_softmax': [_P, _P, _P, _I, _I, _I, _P, _P],
+    'repmode_gatrep_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    'repmode_conv5': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_conv5_wgrad': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_gatrep_bwd': [_P] * 8 + [_I] * 4 + [_P] * 9,
+    'repmode_debug_conv5_naive': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_debug_wgrad_naive': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+}
+EXPORTS = sorted(list(_SIGNATURES) + ['repmode_last_error'])
+
+_lib = None
+
+
+class RepModeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library once; raise (never fall back) when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RepModeHipError(
+            'librepmode_hip.so not found at %s -- build it with '
+            '`python -c "import __graft_entry__ as g; g.build()"` (hipcc, gfx950). '
+            'repmode_amd has no CPU or eager fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _I
+    lib.repmode_last_error.argtypes = []
+    lib.repmode_last_error.restype = _c.c_char_p
+    if lib.repmode_abi_version() != ABI_VERSION:
+        raise RepModeHipError('ABI mismatch: library %d, binding %d' % (lib.repmode_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RepModeHipError('%s failed (code %d): %s' % (name, rc, lib.repmode_last_error().decode()))
+
+
+def padded_channels(channels, dtype_code, is_reduction_dim):
+    return load().repmode_padded_channels(channels, dtype_code, 1 if is_reduction_dim else 0)
+
+
+def device_arch(dev=0):
+    buf = ctypes.create_string_buffer(64)
+    call('repmode_device_arch', dev, buf, 64)
+    return buf.value.decode()

@@ -1,0 +1,134 @@
+// api.hip -- error reporting, ABI/device queries and the naive diagnostic kernels.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void repmode_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int repmode_abi_version(void) { return REPMODE_ABI_VERSION; }
+extern "C" const char* repmode_last_error(void) { return g_err; }
+
+extern "C" int repmode_device_arch(int dev, char* buf, int buflen) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || dev < 0 || dev >= count) {
+    (void)hipGetLastError();
+    repmode_set_error("no HIP device %d (count %d)", dev, count);
+    return REPMODE_ENODEV;
+  }
+  hipDeviceProp_t prop;
+  RM_HIP(hipGetDeviceProperties(&prop, dev));
+  if (buf && buflen > 0) {
+    strncpy(buf, prop.gcnArchName, buflen - 1);
+    buf[buflen - 1] = 0;
+  }
+  return REPMODE_OK;
+}
+
+namespace {
+
+// one thread per output element y[n][v][co]; f32 accumulate in tap-major, channel-minor order
+template <typename T>
+__global__ void conv5_naive_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                   const int32_t* __restrict__ sample_slot, float* __restrict__ y, int N, int D,
+                                   int H, int W, int Cin, int Cout, int CinP, int CoutP) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)N * D * H * W * Cout;
+  if (idx >= total) return;
+  const int co = (int)(idx % Cout);
+  long v = idx / Cout;
+  const int gx = (int)(v % W); v /= W;
+  const int gy = (int)(v % H); v /= H;
+  const int gz = (int)(v % D);
+  const int n = (int)(v / D);
+  const T* ws = w + (size_t)sample_slot[n] * REPMODE_TAPS * CoutP * CinP;
+  float acc = 0.f;
+  for (int tap = 0; tap < REPMODE_TAPS; ++tap) {
+    const int z = gz + tap / 25 - 2, yy = gy + (tap / 5) % 5 - 2, xx = gx + tap % 5 - 2;
+    if ((unsigned)z >= (unsigned)D || (unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+    const T* xp = x + ((((size_t)n * D + z) * H + yy) * W + xx) * Cin;
+    const T* wp = ws + ((size_t)tap * CoutP + co) * CinP;
+    for (int ci = 0; ci < Cin; ++ci) acc += to_f32<T>(xp[ci]) * to_f32<T>(wp[ci]);
+  }
+  y[idx] = acc;
+}
+
+// one thread per dw[slot][tap][co][ci]
+template <typename T>
+__global__ void wgrad_naive_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                   const int32_t* __restrict__ sample_slot, int nslots, float* __restrict__ dw,
+                                   int N, int D, int H, int W, int Cin, int Cout) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)nslots * REPMODE_TAPS * Cout * Cin;
+  if (idx >= total) return;
+  const int ci = (int)(idx % Cin);
+  long r = idx / Cin;
+  const int co = (int)(r % Cout); r /= Cout;
+  const int tap = (int)(r % REPMODE_TAPS);
+  const int slot = (int)(r / REPMODE_TAPS);
+  const int dz = tap / 25 - 2, dyy = (tap / 5) % 5 - 2, dx = tap % 5 - 2;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) {
+    if (sample_slot[n] != slot) continue;
+    for (int z = 0; z < D; ++z) {
+      const int zi = z + dz;
+      if ((unsigned)zi >= (unsigned)D) continue;
+      for (int y = 0; y < H; ++y) {
+        const int yi = y + dyy;
+        if ((unsigned)yi >= (unsigned)H) continue;
+        for (int xx = 0; xx < W; ++xx) {
+          const int xi = xx + dx;
+          if ((unsigned)xi >= (unsigned)W) continue;
+          acc += to_f32<T>(dy[((((size_t)n * D + z) * H + y) * W + xx) * Cout + co]) *
+                 to_f32<T>(x[((((size_t)n * D + zi) * H + yi) * W + xi) * Cin + ci]);
+        }
+      }
+    }
+  }
+  dw[idx] = acc;
+}
+
+}  // namespace
+
+extern "C" int repmode_debug_conv5_naive(const void* x, const void* w, const int32_t* sample_slot, float* y,
+                                         int n, int d, int h, int wdim, int cin, int cout, int dtype,
+                                         void* stream) {
+  RM_REQUIRE(x && w && sample_slot && y, "conv5_naive: null pointer");
+  const long total = (long)n * d * h * wdim * cout;
+  const int cinp = repmode_padded_channels(cin, dtype, 1), coutp = repmode_padded_channels(cout, dtype, 0);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == REPMODE_F32)
+    hipLaunchKernelGGL(conv5_naive_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (const float*)w,
+                       sample_slot, y, n, d, h, wdim, cin, cout, cinp, coutp);
+  else
+    hipLaunchKernelGGL(conv5_naive_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x,
+                       (const bf16_t*)w, sample_slot, y, n, d, h, wdim, cin, cout, cinp, coutp);
+  RM_LAUNCH_CHECK("conv5_naive");
+  return REPMODE_OK;
+}
+
+extern "C" int repmode_debug_wgrad_naive(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
+                                         float* dw, int n, int d, int h, int wdim, int cin, int cout, int dtype,
+                                         void* stream) {
+  RM_REQUIRE(x && dy && sample_slot && dw, "wgrad_naive: null pointer");
+  const long total = (long)nslots * REPMODE_TAPS * cout * cin;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == REPMODE_F32)
+    hipLaunchKernelGGL(wgrad_naive_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (const float*)dy,
+                       sample_slot, nslots, dw, n, d, h, wdim, cin, cout);
+  else
+    hipLaunchKernelGGL(wgrad_naive_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x,
+                       (const bf16_t*)dy, sample_slot, nslots, dw, n, d, h, wdim, cin, cout);
+  RM_LAUNCH_CHECK("wgrad_naive");
+  return REPMODE_OK;
+}

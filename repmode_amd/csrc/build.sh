@@ -1,0 +1,20 @@
+#!/bin/bash
+# Build librepmode_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+OUT="$HERE/../librepmode_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I$ROOT/include -I$HERE ${REPMODE_EXTRA_FLAGS:-}"
+mkdir -p "$HERE/build"
+pids=()
+for f in "$HERE"/*.hip; do
+  o="$HERE/build/$(basename "${f%.hip}").o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$ROOT/include/repmode_hip.h" -nt "$o" ]; then
+    $HIPCC $FLAGS -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/build/*.o -o "$OUT"
+echo "built $OUT"

@@ -1,0 +1,75 @@
+// Shared device/host helpers for librepmode_hip.so (gfx950 only; no other targets).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "repmode_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short bf16_t;  // storage type of a bfloat16 element
+
+void repmode_set_error(const char* fmt, ...);
+
+#define RM_REQUIRE(cond, ...)           \
+  do {                                  \
+    if (!(cond)) {                      \
+      repmode_set_error(__VA_ARGS__);   \
+      return REPMODE_EINVAL;            \
+    }                                   \
+  } while (0)
+
+#define RM_LAUNCH_CHECK(what)                                                \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      repmode_set_error("%s: %s", what, hipGetErrorString(e__));             \
+      return REPMODE_ELAUNCH;                                                \
+    }                                                                        \
+  } while (0)
+
+#define RM_HIP(call)                                                         \
+  do {                                                                       \
+    hipError_t e__ = (call);                                                 \
+    if (e__ != hipSuccess) {                                                 \
+      repmode_set_error("%s: %s", #call, hipGetErrorString(e__));            \
+      return REPMODE_ELAUNCH;                                                \
+    }                                                                        \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN kept quiet
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v);
+template <>
+__device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+
+// The dispatcher places workgroup b on XCD b % 8 (observed, speed only).  Remap so that each
+// XCD receives a contiguous range of logical ids: neighbouring bricks then share one L2.
+// Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (orig >> 3);
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

@@ -1,0 +1,381 @@
+// conv5_igemm.hip -- 5x5x5 "same" 3-D cross-correlation with a per-sample (per-slot) filter as an
+// implicit GEMM on the gfx950 matrix cores.
+//
+// Replaces the per-sample F.conv3d loop of the reference (fnet/nn_modules/RepMode.py:204-208, and
+// the single-filter eval form :209-210) and, fed with the flipped/transposed filter, the input
+// gradient of its autograd.
+//
+// GEMM view:  Y[co][voxel] = sum_{tap, ci} Wm[tap][co][ci] * X[voxel + tap][ci]
+//   MFMA "A" operand = filter rows (32 output channels), "B" operand = 32 voxels, K = input
+//   channels of one tap.  bf16: one v_mfma_f32_32x32x16_bf16 per 16 input channels; f32: four
+//   v_mfma_f32_32x32x2_f32 per 8 input channels (exact f32).  Either way a lane's fragment of
+//   one operand is 16 bytes (8 bf16 / 4 f32 of consecutive input channels), so both element
+//   types share every byte offset below.
+//
+// Data movement:
+//   * activations are NDHWC; a workgroup owns a BZ x BY x BX brick of output voxels of one sample
+//     and, per chunk of KC input channels, stages the (BZ+4)(BY+4)(BX+4) halo brick once into LDS
+//     (zero filled outside the volume) and reuses it for all 125 taps.
+//   * LDS image: two planes per chunk, plane p = 16-byte channel group p of every halo voxel,
+//     voxel-linear.  Lane l of a wave reads voxel (l & 31) of plane (l >> 5): 32 consecutive
+//     16-byte slots -> conflict-free ds_read_b128, and a tap shift is a constant byte offset.
+//   * filter fragments come straight from global/L2 (layout [tap][co][ci], 16 B per lane,
+//     1 KiB contiguous per wave load), prefetched one (dz,dy) row = 5 taps ahead.
+//   * epilogue: the 32x32 accumulator tile holds 4 consecutive output channels per lane per
+//     register quad -> 8-byte (bf16) / 16-byte (f32) channel-contiguous stores.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+struct Elem;
+
+template <>
+struct Elem<float> {
+  static constexpr int KV = 4;  // elements per 16-byte fragment
+  __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+template <>
+struct Elem<bf16_t> {
+  static constexpr int KV = 8;
+  __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+struct ConvArgs {
+  const void* x;
+  const void* w;
+  const int32_t* sample_slot;
+  void* y;
+  int N, D, H, W, Cin, Cout, CinP, CoutP;
+  int nbz, nby, nbx, ncot, ksplit;
+  int out_f32;  // 0: store as T; 1: float output (atomicAdd when ksplit > 1)
+};
+
+// Tile configuration.  BZ*BY*BX output voxels = 32 * WV * VW; 32 * WC * CW output channels.
+template <int BZ_, int BY_, int BX_, int WV_, int WC_, int VW_, int CW_>
+struct Cfg {
+  static constexpr int BZ = BZ_, BY = BY_, BX = BX_, WV = WV_, WC = WC_, VW = VW_, CW = CW_;
+  static constexpr int NV = BZ * BY * BX;
+  static constexpr int COT = 32 * WC * CW;
+  static constexpr int NT = 64 * WV * WC;
+  static constexpr int BZH = BZ + 4, BYH = BY + 4, BXH = BX + 4;
+  static constexpr int VH = BZH * BYH * BXH;
+  // plane stride in 16-byte units; == 4 (mod 8) so that the two planes of one voxel land in
+  // different halves of the 128-byte ds_write_b128 bank window
+  static constexpr int PLS = ((VH + 7) / 8) * 8 + 4;
+  static constexpr int LDS_BYTES = 2 * PLS * 16;
+  static_assert(NV == 32 * WV * VW, "voxel tile must be WV*VW MFMA columns blocks");
+};
+
+template <typename T, typename C>
+__global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
+  constexpr int KV = Elem<T>::KV;
+  constexpr int KC = 2 * KV;
+  constexpr int BZ = C::BZ, BY = C::BY, BX = C::BX, VW = C::VW, CW = C::CW;
+  constexpr int BYH = C::BYH, BXH = C::BXH, VH = C::VH, PLS = C::PLS, NT = C::NT;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* lds = reinterpret_cast<u32x4*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wv = wave % C::WV;
+  const int wc = wave / C::WV;
+  const int khalf = lane >> 5;
+  const int l31 = lane & 31;
+
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int kz = bid % a.ksplit;  bid /= a.ksplit;
+  const int cot = bid % a.ncot;   bid /= a.ncot;
+  const int bx = bid % a.nbx;     bid /= a.nbx;
+  const int by = bid % a.nby;     bid /= a.nby;
+  const int bz = bid % a.nbz;
+  const int n = bid / a.nbz;
+  const int z0 = bz * BZ, y0 = by * BY, x0 = bx * BX;
+  const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, CinP = a.CinP, CoutP = a.CoutP;
+
+  const int slot = a.sample_slot[n];
+  const T* __restrict__ xn = static_cast<const T*>(a.x) + (size_t)n * D * H * W * Cin;
+  const T* __restrict__ wsl = static_cast<const T*>(a.w) + (size_t)slot * REPMODE_TAPS * CoutP * CinP;
+  const size_t tap_stride = (size_t)CoutP * CinP;
+
+  // halo index of this lane's voxel in each of its voxel sub-tiles (tap (0,0,0))
+  int vbase[VW];
+#pragma unroll
+  for (int vs = 0; vs < VW; ++vs) {
+    const int m = (wv * VW + vs) * 32 + l31;
+    const int lx = m % BX, ly = (m / BX) % BY, lz = m / (BX * BY);
+    vbase[vs] = khalf * PLS + (lz * BYH + ly) * BXH + lx;
+  }
+  // filter row of this lane in each of its channel sub-tiles
+  const T* wrow[CW];
+#pragma unroll
+  for (int cs = 0; cs < CW; ++cs) {
+    // rows beyond CoutP (tile wider than the filter) are clamped; their results are never stored
+    const int co = min(cot * C::COT + (wc * CW + cs) * 32 + l31, CoutP - 1);
+    wrow[cs] = wsl + (size_t)co * CinP + khalf * KV;
+  }
+
+  // taps whose input plane/row lies outside the volume for every voxel of the brick are skipped
+  const int dz_lo = max(0, 2 - z0 - (BZ - 1)), dz_hi = min(4, D + 1 - z0);
+  const int dy_lo = max(0, 2 - y0 - (BY - 1)), dy_hi = min(4, H + 1 - y0);
+  const int ndy = dy_hi - dy_lo + 1;
+  const int nrows = (dz_hi - dz_lo + 1) * ndy;
+
+  f32x16 acc[CW][VW];
+#pragma unroll
+  for (int cs = 0; cs < CW; ++cs)
+#pragma unroll
+    for (int vs = 0; vs < VW; ++vs)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cs][vs][r] = 0.f;
+
+  const int nchunks = CinP / KC;
+  const int c_begin = (int)((long)kz * nchunks / a.ksplit);
+  const int c_end = (int)((long)(kz + 1) * nchunks / a.ksplit);
+  const bool vec_ok = (Cin % KV) == 0;
+
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const int ci0 = chunk * KC;
+    __syncthreads();  // all waves finished reading the previous chunk's halo image
+    // ---- stage the halo brick: item = (halo voxel, plane), two 16-byte items per voxel
+    constexpr int NITEMS = 2 * VH;
+    constexpr int UNR = 4;
+    for (int it0 = 0; it0 < NITEMS; it0 += NT * UNR) {
+      u32x4 v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int it = it0 + u * NT + tid;
+        v[u] = u32x4{0u, 0u, 0u, 0u};
+        if (it < NITEMS) {
+          const int pl = it & 1, vh = it >> 1;
+          const int xx = vh % BXH, t2 = vh / BXH;
+          const int yy = t2 % BYH, zz = t2 / BYH;
+          const int gz = z0 + zz - 2, gy = y0 + yy - 2, gx = x0 + xx - 2;
+          const int c = ci0 + pl * KV;
+          if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin) {
+            const T* p = xn + ((size_t)(gz * H + gy) * W + gx) * Cin + c;
+            if (vec_ok) {
+              v[u] = *reinterpret_cast<const u32x4*>(p);
+            } else {
+              T e[KV];
+#pragma unroll
+              for (int k = 0; k < KV; ++k) e[k] = (c + k < Cin) ? p[k] : (T)0;
+              v[u] = *reinterpret_cast<const u32x4*>(e);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int it = it0 + u * NT + tid;
+        if (it < NITEMS) lds[(it & 1) * PLS + (it >> 1)] = v[u];
+      }
+    }
+    __syncthreads();
+
+    // ---- 125 taps from the staged image.  Filter fragments are prefetched from L2 one (dz,dy)
+    // row (5 taps) ahead when one channel sub-tile is held (CW == 1), one tap ahead otherwise
+    // (register budget: two waves per SIMD must fit, i.e. <= 256 VGPR+AGPR).
+    auto wfrag = [&](int cs, int tap) -> u32x4 {
+      return *reinterpret_cast<const u32x4*>(wrow[cs] + (size_t)tap * tap_stride + ci0);
+    };
+    int dz = dz_lo, dy = dy_lo;
+    if constexpr (CW == 1) {
+      u32x4 a_cur[5], a_nxt[5];
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) a_cur[dx] = wfrag(0, (dz * 5 + dy) * 5 + dx);
+      for (int row = 0; row < nrows; ++row) {
+        int dzn = dz, dyn = dy + 1;
+        if (dyn > dy_hi) { dyn = dy_lo; dzn = dz + 1; }
+        if (row + 1 < nrows) {
+#pragma unroll
+          for (int dx = 0; dx < 5; ++dx) a_nxt[dx] = wfrag(0, (dzn * 5 + dyn) * 5 + dx);
+        }
+        const int rowoff = (dz * BYH + dy) * BXH;
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          u32x4 b[VW];
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) b[vs] = lds[vbase[vs] + rowoff + dx];
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) Elem<T>::mma(a_cur[dx], b[vs], acc[0][vs]);
+        }
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) a_cur[dx] = a_nxt[dx];
+        dz = dzn;
+        dy = dyn;
+      }
+    } else {
+      u32x4 a_cur[CW], a_nxt[CW];
+#pragma unroll
+      for (int cs = 0; cs < CW; ++cs) a_cur[cs] = wfrag(cs, (dz * 5 + dy) * 5);
+      for (int row = 0; row < nrows; ++row) {
+        int dzn = dz, dyn = dy + 1;
+        if (dyn > dy_hi) { dyn = dy_lo; dzn = dz + 1; }
+        const int rowoff = (dz * BYH + dy) * BXH;
+        const int tap0 = (dz * 5 + dy) * 5;
+        // the tap after dx = 4 is the first tap of the next row (clamped on the last row: harmless reload)
+        const int tap_next_row = (row + 1 < nrows) ? (dzn * 5 + dyn) * 5 : tap0;
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          const int tapn = (dx < 4) ? tap0 + dx + 1 : tap_next_row;
+#pragma unroll
+          for (int cs = 0; cs < CW; ++cs) a_nxt[cs] = wfrag(cs, tapn);
+          u32x4 b[VW];
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) b[vs] = lds[vbase[vs] + rowoff + dx];
+#pragma unroll
+          for (int cs = 0; cs < CW; ++cs)
+#pragma unroll
+            for (int vs = 0; vs < VW; ++vs) Elem<T>::mma(a_cur[cs], b[vs], acc[cs][vs]);
+#pragma unroll
+          for (int cs = 0; cs < CW; ++cs) a_cur[cs] = a_nxt[cs];
+        }
+        dz = dzn;
+        dy = dyn;
+      }
+    }
+  }
+
+  // ---- epilogue.  32x32 C/D layout: column (voxel) = lane & 31, row (channel) =
+  // (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int vs = 0; vs < VW; ++vs) {
+    const int m = (wv * VW + vs) * 32 + l31;
+    const int lx = m % BX, ly = (m / BX) % BY, lz = m / (BX * BY);
+    const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
+    if (gz >= D || gy >= H || gx >= W) continue;
+    const size_t vox = ((size_t)(n * D + gz) * H + gy) * W + gx;
+#pragma unroll
+    for (int cs = 0; cs < CW; ++cs) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = cot * C::COT + (wc * CW + cs) * 32 + 8 * q + 4 * khalf;
+        if (co >= Cout) continue;
+        const float v0 = acc[cs][vs][4 * q + 0], v1 = acc[cs][vs][4 * q + 1];
+        const float v2 = acc[cs][vs][4 * q + 2], v3 = acc[cs][vs][4 * q + 3];
+        if (a.out_f32) {
+          float* yp = static_cast<float*>(a.y) + vox * Cout + co;
+          if (a.ksplit > 1) {
+            unsafeAtomicAdd(yp, v0);
+            if (co + 1 < Cout) unsafeAtomicAdd(yp + 1, v1);
+            if (co + 2 < Cout) unsafeAtomicAdd(yp + 2, v2);
+            if (co + 3 < Cout) unsafeAtomicAdd(yp + 3, v3);
+          } else if ((Cout & 3) == 0) {
+            *reinterpret_cast<f32x4*>(yp) = f32x4{v0, v1, v2, v3};
+          } else {
+            yp[0] = v0;
+            if (co + 1 < Cout) yp[1] = v1;
+            if (co + 2 < Cout) yp[2] = v2;
+            if (co + 3 < Cout) yp[3] = v3;
+          }
+        } else if constexpr (sizeof(T) == 4) {
+          float* yp = static_cast<float*>(a.y) + vox * Cout + co;
+          if ((Cout & 3) == 0) {
+            *reinterpret_cast<f32x4*>(yp) = f32x4{v0, v1, v2, v3};
+          } else {
+            yp[0] = v0;
+            if (co + 1 < Cout) yp[1] = v1;
+            if (co + 2 < Cout) yp[2] = v2;
+            if (co + 3 < Cout) yp[3] = v3;
+          }
+        } else {
+          bf16_t* yp = static_cast<bf16_t*>(a.y) + vox * Cout + co;
+          if ((Cout & 3) == 0) {
+            *reinterpret_cast<u32x2*>(yp) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+          } else {
+            yp[0] = f32_to_bf16(v0);
+            if (co + 1 < Cout) yp[1] = f32_to_bf16(v1);
+            if (co + 2 < Cout) yp[2] = f32_to_bf16(v2);
+            if (co + 3 < Cout) yp[3] = f32_to_bf16(v3);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, typename C>
+int launch_cfg(ConvArgs a, hipStream_t stream) {
+  a.nbz = ceil_div(a.D, C::BZ);
+  a.nby = ceil_div(a.H, C::BY);
+  a.nbx = ceil_div(a.W, C::BX);
+  a.ncot = ceil_div(a.CoutP, C::COT);
+  // split the input-channel reduction when the grid would leave most CUs idle
+  const int nchunks = a.CinP / (2 * Elem<T>::KV);
+  long base = (long)a.N * a.nbz * a.nby * a.nbx * a.ncot;
+  int ks = 1;
+  if (a.out_f32) {
+    while (ks * 2 <= nchunks && base * ks < 768 && ks < 32) ks *= 2;
+  }
+  a.ksplit = ks;
+  const long grid = base * ks;
+  RM_REQUIRE(grid > 0 && grid < (1L << 31), "conv5: grid %ld out of range", grid);
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set) {
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_igemm_kernel<T, C>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    attr_set = true;
+  }
+  if (ks > 1) {
+    RM_HIP(hipMemsetAsync(a.y, 0, (size_t)a.N * a.D * a.H * a.W * a.Cout * sizeof(float), stream));
+  }
+  hipLaunchKernelGGL((conv5_igemm_kernel<T, C>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
+  RM_LAUNCH_CHECK("conv5_igemm");
+  return REPMODE_OK;
+}
+
+// Tile menu.           BZ BY BX  WV WC VW CW
+using CfgX32C32 = Cfg<4, 4, 32, 4, 1, 4, 1>;   // 512 voxels x 32 channels   (level 0, Cout <= 32)
+using CfgX32C64 = Cfg<4, 4, 32, 4, 1, 4, 2>;   // 512 voxels x 64 channels   (level 1)
+using CfgX16C64 = Cfg<4, 4, 16, 2, 2, 4, 1>;   // 256 voxels x 64 channels   (level 2)
+using CfgX8C64  = Cfg<4, 8, 8, 2, 2, 4, 1>;    // 256 voxels x 64 channels   (level 3)
+using CfgX4C128 = Cfg<2, 4, 4, 1, 4, 1, 1>;    // 32 voxels x 128 channels   (level 4)
+
+template <typename T>
+int dispatch(ConvArgs a, hipStream_t stream) {
+  if (a.W >= 32) {
+    if (a.CoutP >= 64) return launch_cfg<T, CfgX32C64>(a, stream);
+    return launch_cfg<T, CfgX32C32>(a, stream);
+  }
+  if (a.W >= 16) return launch_cfg<T, CfgX16C64>(a, stream);
+  if (a.W >= 8) return launch_cfg<T, CfgX8C64>(a, stream);
+  return launch_cfg<T, CfgX4C128>(a, stream);
+}
+
+}  // namespace
+
+extern "C" int repmode_padded_channels(int channels, int dtype, int is_reduction_dim) {
+  if (channels <= 0) return 0;
+  if (!is_reduction_dim) return round_up(channels, 32);
+  return round_up(channels, dtype == REPMODE_BF16 ? 16 : 8);
+}
+
+extern "C" int repmode_conv5(const void* x, const void* w, const int32_t* sample_slot, void* y, int n,
+                             int d, int h, int wdim, int cin, int cout, int dtype, int out_f32,
+                             void* stream) {
+  RM_REQUIRE(x && w && sample_slot && y, "conv5: null pointer");
+  RM_REQUIRE(n > 0 && d > 0 && h > 0 && wdim > 0 && cin > 0 && cout > 0, "conv5: bad shape");
+  RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "conv5: bad dtype %d", dtype);
+  RM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0,
+             "conv5: pointers must be 16-byte aligned");
+  ConvArgs a{};
+  a.x = x; a.w = w; a.sample_slot = sample_slot; a.y = y;
+  a.N = n; a.D = d; a.H = h; a.W = wdim; a.Cin = cin; a.Cout = cout;
+  a.CinP = repmode_padded_channels(cin, dtype, 1);
+  a.CoutP = repmode_padded_channels(cout, dtype, 0);
+  a.out_f32 = (out_f32 != 0) || dtype == REPMODE_F32;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == REPMODE_F32) return dispatch<float>(a, s);
+  return dispatch<bf16_t>(a, s);
+}

@@ -1,0 +1,210 @@
+"""MI355X-native counterpart of the reference plug-in ``fnet/nn_modules/RepMode.py``.
+
+Same boundary as the reference module:
+  * ``Net(opts, mult_chan=32, in_channels=1, out_channels=1)`` -- RepMode.py:8-15; ``opts`` needs
+    ``.adopted_datasets`` (len = number of tasks) and ``.gpu_ids``;
+  * ``net(signal[N,1,D,H,W] float, task int64[N]) -> [N,1,D,H,W]`` -- RepMode.py:51-71;
+  * the same module tree / parameter names, hence the same 309-key ``state_dict``: reference
+    checkpoints load unchanged.
+
+Different inside: activations are channels-last (NDHWC) in HBM, tasks are grouped into slots and the
+gate/GatRep/convolution (forward and backward) of every MoDE block run in the HIP kernels of
+``librepmode_hip.so`` through ``repmode_amd.ops``.  No CPU path: a CPU tensor raises.
+"""
+import math
+import os
+
+import torch
+
+from .. import ops
+
+NUM_EXPERTS = 5
+
+
+def _resolve_dtype(x, override):
+    """float32 (exact-f32 MFMA, parity mode) or bfloat16 (throughput mode).
+
+    An explicit override (ctor argument or REPMODE_AMD_DTYPE) wins; inside ``torch.autocast`` the
+    block computes in bfloat16 (the reference trains under fp16 autocast, fnet_model.py:106; bf16
+    needs no loss scaling); otherwise the input's dtype.
+    """
+    if override is not None:
+        return override
+    env = os.environ.get('REPMODE_AMD_DTYPE')
+    if env:
+        return {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, 'f32': torch.float32, 'float32': torch.float32}[env]
+    if torch.is_autocast_enabled():
+        return torch.bfloat16
+    return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
+
+
+def _to_cl(x):
+    """logical NCDHW (any strides) -> contiguous NDHWC; free when x is already channels_last_3d."""
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _from_cl(x_cl):
+    """contiguous NDHWC -> logical NCDHW view (channels_last_3d strides)."""
+    return x_cl.permute(0, 4, 1, 2, 3)
+
+
+def _kaiming_param(*shape):
+    w = torch.nn.Parameter(torch.empty(*shape))
+    torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))          # RepMode.py:156-159
+    return w
+
+
+class MoDEConv(torch.nn.Module):
+    """RepMode.py:123-214.  ``t`` may be a ``TaskPlan``, int task ids [N] or one-hot rows [N, T]."""
+
+    def __init__(self, num_experts, num_tasks, in_chan, out_chan, kernel_size=5, stride=1, padding='same',
+                 conv_type='normal', dtype=None):
+        super().__init__()
+        if num_experts != NUM_EXPERTS or kernel_size != 5 or stride != 1 or padding != 'same':
+            raise ValueError('the MoDE block is 5 experts on a 5x5x5 stride-1 same-padded filter (RepMode.py:22,114)')
+        assert conv_type in ['normal', 'final']
+        self.num_experts, self.num_tasks = num_experts, num_tasks
+        self.in_chan, self.out_chan = in_chan, out_chan
+        self.kernel_size, self.stride, self.padding, self.conv_type = kernel_size, stride, padding, conv_type
+        self.compute_dtype = dtype
+        self.expert_conv5x5_conv = _kaiming_param(out_chan, in_chan, 5, 5, 5)
+        self.expert_conv3x3_conv = _kaiming_param(out_chan, in_chan, 3, 3, 3)
+        self.expert_conv1x1_conv = _kaiming_param(out_chan, in_chan, 1, 1, 1)
+        self.register_buffer('expert_avg3x3_pool', torch.full((3, 3, 3), 1.0 / 27))
+        self.expert_avg3x3_conv = _kaiming_param(out_chan, in_chan, 1, 1, 1)
+        self.register_buffer('expert_avg5x5_pool', torch.full((5, 5, 5), 1.0 / 125))
+        self.expert_avg5x5_conv = _kaiming_param(out_chan, in_chan, 1, 1, 1)
+        if conv_type == 'normal':
+            self.subsequent_layer = torch.nn.Sequential(
+                torch.nn.BatchNorm3d(out_chan), torch.nn.ReLU(inplace=True))
+        else:
+            self.subsequent_layer = torch.nn.Identity()
+        self.gate = torch.nn.Linear(num_tasks, num_experts * out_chan, bias=True)
+
+    def forward(self, x, t):
+        plan = t if isinstance(t, ops.TaskPlan) else ops.TaskPlan(t, self.num_tasks, x.device, self.training)
+        dtype = _resolve_dtype(x, self.compute_dtype)
+        x_cl = _to_cl(x.to(dtype))
+        # float output where a later stage reduces it in f32 anyway: the final layer, and the deep
+        # levels whose reduction is split over workgroups (f32 atomics)
+        out_f32 = self.conv_type == 'final' or x.shape[-1] < 16
+        y_cl = ops.mode_conv3d(x_cl, self.expert_conv5x5_conv, self.expert_conv3x3_conv, self.expert_conv1x1_conv,
+                               self.expert_avg3x3_conv, self.expert_avg5x5_conv, self.gate.weight, self.gate.bias,
+                               plan, out_f32=out_f32)
+        y = self.subsequent_layer(_from_cl(y_cl))              # RepMode.py:212
+        if self.conv_type == 'normal' and y.dtype != dtype:
+            y = y.to(dtype)
+        return y
+
+
+class MoDESubNet2Conv(torch.nn.Module):                        # RepMode.py:111-120
+    def __init__(self, num_experts, num_tasks, n_in, n_out, dtype=None):
+        super().__init__()
+        self.conv1 = MoDEConv(num_experts, num_tasks, n_in, n_out, kernel_size=5, padding='same', dtype=dtype)
+        self.conv2 = MoDEConv(num_experts, num_tasks, n_out, n_out, kernel_size=5, padding='same', dtype=dtype)
+
+    def forward(self, x, t):
+        return self.conv2(self.conv1(x, t), t)
+
+
+class Down2(torch.nn.Module):
+    """``Conv3d(C, C, kernel_size=2, stride=2, bias=False)`` (RepMode.py:81) on channels-last data:
+    non-overlapping 2x2x2 patches make it one plain GEMM [voxels/8, 8C] x [8C, C]."""
+
+    def __init__(self, chan):
+        super().__init__()
+        self.weight = _kaiming_param(chan, chan, 2, 2, 2)      # same shape / init as nn.Conv3d
+
+    def forward(self, x):
+        x_cl = _to_cl(x)
+        n, d, h, w, c = x_cl.shape
+        a = x_cl.view(n, d // 2, 2, h // 2, 2, w // 2, 2, c).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(-1, 8 * c)
+        wm = self.weight.permute(2, 3, 4, 1, 0).reshape(8 * c, -1).to(x_cl.dtype)
+        return _from_cl((a @ wm).view(n, d // 2, h // 2, w // 2, -1))
+
+
+class Up2(torch.nn.Module):
+    """``ConvTranspose3d(Ci, Co, kernel_size=2, stride=2, bias=False)`` (RepMode.py:98): every input
+    voxel emits a disjoint 2x2x2 output patch -> one plain GEMM [voxels, Ci] x [Ci, 8Co]."""
+
+    def __init__(self, in_chan, out_chan):
+        super().__init__()
+        self.weight = _kaiming_param(in_chan, out_chan, 2, 2, 2)   # same shape / init as nn.ConvTranspose3d
+
+    def forward(self, x):
+        x_cl = _to_cl(x)
+        n, d, h, w, c = x_cl.shape
+        co = self.weight.shape[1]
+        wm = self.weight.permute(0, 2, 3, 4, 1).reshape(c, 8 * co).to(x_cl.dtype)
+        y = (x_cl.reshape(-1, c) @ wm).view(n, d, h, w, 2, 2, 2, co)
+        y = y.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(n, 2 * d, 2 * h, 2 * w, co)
+        return _from_cl(y)
+
+
+class MoDEEncoderBlock(torch.nn.Module):                       # RepMode.py:74-89
+    def __init__(self, num_experts, num_tasks, in_chan, out_chan, dtype=None):
+        super().__init__()
+        self.in_chan, self.out_chan = in_chan, out_chan
+        self.conv_more = MoDESubNet2Conv(num_experts, num_tasks, in_chan, out_chan, dtype=dtype)
+        self.conv_down = torch.nn.Sequential(Down2(out_chan), torch.nn.BatchNorm3d(out_chan),
+                                             torch.nn.ReLU(inplace=True))
+
+    def forward(self, x, t):
+        x_skip = self.conv_more(x, t)
+        y = self.conv_down(x_skip)
+        return y.to(x_skip.dtype), x_skip
+
+
+class MoDEDecoderBlock(torch.nn.Module):                       # RepMode.py:92-108
+    def __init__(self, num_experts, num_tasks, in_chan, out_chan, dtype=None):
+        super().__init__()
+        self.in_chan, self.out_chan = in_chan, out_chan
+        self.convt = torch.nn.Sequential(Up2(in_chan, out_chan), torch.nn.BatchNorm3d(out_chan),
+                                         torch.nn.ReLU(inplace=True))
+        self.conv_less = MoDESubNet2Conv(num_experts, num_tasks, in_chan, out_chan, dtype=dtype)
+
+    def forward(self, x, x_skip, t):
+        up = self.convt(x).to(x_skip.dtype)
+        return self.conv_less(torch.cat((x_skip, up), 1), t)   # skip first, RepMode.py:106
+
+
+class Net(torch.nn.Module):
+    """RepMode.py:8-71.  ``dtype``: None (follow autocast / input), torch.float32 or torch.bfloat16."""
+
+    def __init__(self, opts, mult_chan=32, in_channels=1, out_channels=1, dtype=None):
+        super().__init__()
+        self.opts = opts
+        self.mult_chan, self.in_channels, self.out_channels = mult_chan, in_channels, out_channels
+        self.num_tasks = len(self.opts.adopted_datasets)       # RepMode.py:21
+        self.num_experts = NUM_EXPERTS
+        self.gpu_ids = [self.opts.gpu_ids] if isinstance(self.opts.gpu_ids, int) else self.opts.gpu_ids
+        self.compute_dtype = dtype
+        e, t, m = self.num_experts, self.num_tasks, in_channels * mult_chan
+        self.encoder_block1 = MoDEEncoderBlock(e, t, in_channels, m, dtype)
+        self.encoder_block2 = MoDEEncoderBlock(e, t, m, m * 2, dtype)
+        self.encoder_block3 = MoDEEncoderBlock(e, t, m * 2, m * 4, dtype)
+        self.encoder_block4 = MoDEEncoderBlock(e, t, m * 4, m * 8, dtype)
+        self.bottle_block = MoDESubNet2Conv(e, t, m * 8, m * 16, dtype)
+        self.decoder_block4 = MoDEDecoderBlock(e, t, m * 16, m * 8, dtype)
+        self.decoder_block3 = MoDEDecoderBlock(e, t, m * 8, m * 4, dtype)
+        self.decoder_block2 = MoDEDecoderBlock(e, t, m * 4, m * 2, dtype)
+        self.decoder_block1 = MoDEDecoderBlock(e, t, m * 2, m, dtype)
+        self.conv_out = MoDEConv(e, t, mult_chan, out_channels, kernel_size=5, padding='same', conv_type='final',
+                                 dtype=dtype)
+
+    def forward(self, x, t):
+        if any(s % 16 for s in x.shape[-3:]):
+            raise ValueError('patch dims must be multiples of 16 (4 stride-2 levels), got %s' % (tuple(x.shape[-3:]),))
+        # integer task ids -> slot plan, built once and shared by the 19 MoDE blocks (replaces the
+        # one-hot embedding of RepMode.py:44-49,53)
+        plan = t if isinstance(t, ops.TaskPlan) else ops.TaskPlan(t, self.num_tasks, x.device, self.training)
+        x, s1 = self.encoder_block1(x, plan)
+        x, s2 = self.encoder_block2(x, plan)
+        x, s3 = self.encoder_block3(x, plan)
+        x, s4 = self.encoder_block4(x, plan)
+        x = self.bottle_block(x, plan)
+        x = self.decoder_block4(x, s4, plan)
+        x = self.decoder_block3(x, s3, plan)
+        x = self.decoder_block2(x, s2, plan)
+        x = self.decoder_block1(x, s1, plan)
+        return self.conv_out(x, plan).float()

@@ -1,0 +1,273 @@
+"""Parity of the HIP path (through the C ABI, librepmode_hip.so) against the CPU oracle and the
+golden vectors captured from the reference.  Needs a real MI355X: every test is marked ``gpu``.
+
+Tolerances (max|a-b| / max|b|, the 'relative fp32' measure of BASELINE.json):
+  * float32 path (exact-f32 MFMA): 1e-3 as the north star states; observed ~1e-6.
+  * bfloat16 path, float output: inputs are rounded to bf16 first on BOTH sides, so only the
+    accumulation order differs -> 1e-4.
+  * bfloat16 path, bf16 output / whole blocks: one bf16 rounding of the result (2^-9) plus bf16
+    rounding of the merged filter -> 2e-2 relative to the tensor's max.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, Opts
+from oracle import repmode_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+TOL_F32 = 1e-3
+TOL_BF16_ACC = 1e-4
+TOL_BF16 = 2e-2
+
+
+def _ops():
+    from repmode_amd import ops
+    return ops
+
+
+def _rand_experts(co, ci, gen):
+    def u(*shape, fan):
+        b = 1.0 / np.sqrt(fan)
+        return (torch.rand(*shape, generator=gen) * 2 - 1) * b
+    k5 = u(co, ci, 5, 5, 5, fan=ci * 125)
+    k3 = u(co, ci, 3, 3, 3, fan=ci * 27)
+    k1, a3, a5 = (u(co, ci, 1, 1, 1, fan=ci) for _ in range(3))
+    gw = u(5 * co, 12, fan=12)
+    gb = u(5 * co, fan=12)
+    return k5, k3, k1, a3, a5, gw, gb
+
+
+def _layout_wf(w, cop, cip):
+    """oracle merged filter [S,Co,Ci,5,5,5] -> wf [S,125,CoP,CiP]."""
+    s, co, ci = w.shape[:3]
+    out = torch.zeros(s, 125, cop, cip)
+    out[:, :, :co, :ci] = w.reshape(s, co, ci, 125).permute(0, 3, 1, 2)
+    return out
+
+
+def _layout_wd(w, cip_rows, cop_red):
+    """-> wd [S,125 (flipped),CiP,CoP]."""
+    s, co, ci = w.shape[:3]
+    out = torch.zeros(s, 125, cip_rows, cop_red)
+    out[:, :, :ci, :co] = w.reshape(s, co, ci, 125).flip(3).permute(0, 3, 2, 1)
+    return out
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('co,ci', [(32, 1), (16, 8), (1, 16), (32, 32), (64, 48)])
+def test_gate_and_gatrep(co, ci, dtype):
+    ops = _ops()
+    from repmode_amd import _lib
+    gen = torch.Generator().manual_seed(co * 100 + ci)
+    k5, k3, k1, a3, a5, gw, gb = _rand_experts(co, ci, gen)
+    tasks = [7, 2, 7, 11]
+    plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+    assert plan.slot_task_host == [2, 7, 11] and plan.sample_slot.tolist() == [1, 0, 1, 2]
+    d = [t.to(DEV) for t in (k5, k3, k1, a3, a5, gw, gb)]
+    g = ops.gate_softmax(d[5], d[6], plan, co)
+    g_ref = orc.gate_probs(gw, gb, torch.tensor(plan.slot_task_host), co)
+    assert rel_err(g.cpu(), g_ref) < 1e-5
+    wf, wd = ops.gatrep_merge(*d[:5], g, dtype, want_wf=True, want_wd=True)
+    w_ref = orc.merge_filters(orc.expert_bank(k5, k3, k1, a3, a5), g_ref)
+    code = ops.dtype_code(dtype)
+    tol = 1e-5 if dtype == torch.float32 else 5e-3
+    assert rel_err(wf.float().cpu(), _layout_wf(w_ref, _lib.padded_channels(co, code, False), _lib.padded_channels(ci, code, True))) < tol
+    assert rel_err(wd.float().cpu(), _layout_wd(w_ref, _lib.padded_channels(ci, code, False), _lib.padded_channels(co, code, True))) < tol
+
+
+CONV_CASES = [
+    # (N, D, H, W, Cin, Cout)   -- one per tile configuration plus ragged / thin shapes
+    (2, 4, 8, 32, 32, 32),      # W>=32, Cout<=32
+    (1, 8, 8, 64, 16, 32),      # two bricks along x and z
+    (2, 4, 4, 32, 32, 64),      # W>=32, Cout 64 (two channel sub-tiles per wave)
+    (2, 4, 8, 16, 64, 128),     # W 16
+    (2, 4, 8, 8, 32, 64),       # W 8
+    (3, 2, 4, 4, 64, 128),      # W 4 (deepest level), split-K
+    (2, 1, 2, 2, 32, 32),       # smaller than one brick everywhere
+    (1, 5, 7, 19, 8, 16),       # ragged: nothing divides the brick
+    (2, 6, 9, 33, 1, 32),       # thin input (first layer), ragged
+    (2, 4, 8, 32, 32, 1),       # thin output (final layer)
+    (1, 3, 5, 11, 3, 5),        # odd channel counts -> scalar load/store paths
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv5_kernel(case, dtype):
+    ops = _ops()
+    from repmode_amd import _lib
+    n, d, h, w, cin, cout = case
+    gen = torch.Generator().manual_seed(sum(case))
+    nslots = 2
+    slots = torch.tensor([i % nslots for i in range(n)], dtype=torch.int32)
+    x = torch.randn(n, cin, d, h, w, generator=gen).to(dtype).float()          # values exactly representable
+    wt = (torch.randn(nslots, cout, cin, 5, 5, 5, generator=gen) / np.sqrt(cin * 125)).to(dtype).float()
+    y_ref = orc.conv_per_sample(x, wt[slots.long()])
+    code = ops.dtype_code(dtype)
+    wf = _layout_wf(wt, _lib.padded_channels(cout, code, False), _lib.padded_channels(cin, code, True)).to(DEV, dtype)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype)
+    # naive diagnostic kernel first: separates layout mistakes (both fail) from tiling mistakes
+    import ctypes
+    y_naive = torch.empty(n, d, h, w, cout, device=DEV)
+    _lib.call('repmode_debug_conv5_naive', ctypes.c_void_p(x_cl.data_ptr()), ctypes.c_void_p(wf.data_ptr()),
+              ctypes.c_void_p(slots.to(DEV).data_ptr()), ctypes.c_void_p(y_naive.data_ptr()), n, d, h, w, cin, cout,
+              code, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rel_err(y_naive.permute(0, 4, 1, 2, 3).cpu(), y_ref) < TOL_BF16_ACC, 'naive kernel / layout'
+    y = ops.conv5(x_cl, wf, slots.to(DEV), cout, out_f32=True)
+    assert y.dtype == torch.float32
+    assert rel_err(y.permute(0, 4, 1, 2, 3).cpu(), y_ref) < TOL_BF16_ACC, 'MFMA kernel, float output'
+    if dtype == torch.bfloat16:
+        yb = ops.conv5(x_cl, wf, slots.to(DEV), cout, out_f32=False)
+        assert yb.dtype == torch.bfloat16
+        assert rel_err(yb.float().permute(0, 4, 1, 2, 3).cpu(), y_ref) < 6e-3, 'MFMA kernel, bf16 output'
+
+
+WGRAD_CASES = [
+    (2, 4, 8, 32, 32, 32),
+    (3, 2, 4, 16, 64, 32),
+    (2, 4, 8, 8, 16, 48),
+    (3, 2, 4, 4, 64, 64),
+    (1, 5, 7, 19, 8, 16),
+    (2, 6, 9, 33, 1, 32),
+    (2, 4, 8, 32, 32, 1),
+    (1, 3, 5, 11, 3, 5),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', WGRAD_CASES)
+def test_conv5_wgrad_kernel(case, dtype):
+    ops = _ops()
+    n, d, h, w, cin, cout = case
+    gen = torch.Generator().manual_seed(sum(case) + 1)
+    tasks = [5, 9, 5][:n]
+    plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+    x = torch.randn(n, cin, d, h, w, generator=gen).to(dtype).float()
+    dy = torch.randn(n, cout, d, h, w, generator=gen).to(dtype).float()
+    # oracle: autograd of the per-sample conv w.r.t. a per-slot filter
+    wt = torch.zeros(plan.nslots, cout, cin, 5, 5, 5, requires_grad=True)
+    slots = torch.tensor([plan.slot_task_host.index(t) for t in tasks])
+    (orc.conv_per_sample(x, wt[slots]) * dy).sum().backward()
+    dw_ref = wt.grad.reshape(plan.nslots, cout, cin, 125).permute(0, 3, 1, 2)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype)
+    dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype)
+    dw = ops.conv5_wgrad(x_cl, dy_cl, plan, cout)
+    assert rel_err(dw.cpu(), dw_ref) < TOL_BF16_ACC
+
+
+def _load_block(g, dtype):
+    from repmode_amd.nn_modules.RepMode import MoDEConv
+    co, ci = g['p.expert_conv5x5_conv'].shape[:2]
+    final = 'p.subsequent_layer.0.weight' not in g
+    blk = MoDEConv(5, 12, ci, co, conv_type='final' if final else 'normal', dtype=dtype)
+    blk.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('p.')})
+    return blk.to(DEV)
+
+
+BLOCKS = ['g1_config1.npz', 'g1_block_1_32.npz', 'g1_block_8_16.npz',
+          'g1_block_32_32.npz', 'g1_block_16_1_final.npz', 'g1_block_64_32.npz']
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('name', BLOCKS)
+def test_mode_block_golden(name, dtype):
+    """MoDEConv forward/backward against the reference's own outputs (BASELINE config 1 included)."""
+    g = load_golden(name)
+    blk = _load_block(g, dtype)
+    tol = TOL_F32 if dtype == torch.float32 else TOL_BF16
+    x = torch.from_numpy(g['x']).to(DEV).requires_grad_(True)
+    r = torch.from_numpy(g['r']).to(DEV)
+    tasks = torch.from_numpy(g['tasks'])
+    blk.train()
+    y = blk(x, tasks)
+    assert tuple(y.shape) == g['y_train'].shape
+    loss = (y.float() * r).mean()
+    loss.backward()
+    assert rel_err(y.float().detach().cpu(), g['y_train']) < tol
+    assert rel_err(x.grad.cpu(), g['dx']) < tol * 2
+    for k, p in blk.named_parameters():
+        assert p.grad is not None, k
+        assert rel_err(p.grad.cpu(), g['d.' + k]) < tol * 3, k
+    for k, v in blk.state_dict().items():
+        if 'running' in k:
+            assert rel_err(v.cpu(), g['after.' + k]) < tol, k
+    blk.eval()
+    with torch.no_grad():
+        te = torch.full_like(tasks, int(g['tasks'][0]))
+        ye = blk(torch.from_numpy(g['x']).to(DEV), te)
+    assert rel_err(ye.float().cpu(), g['y_eval']) < tol
+
+
+def test_one_hot_task_argument():
+    """The reference's MoDEConv takes one-hot rows (RepMode.py:194-198); ids and rows must agree."""
+    g = load_golden('g1_block_8_16.npz')
+    blk = _load_block(g, torch.float32).eval()
+    x = torch.from_numpy(g['x']).to(DEV)
+    ids = torch.tensor([4, 4, 4])
+    onehot = torch.zeros(3, 12)
+    onehot[:, 4] = 1
+    with torch.no_grad():
+        assert torch.equal(blk(x, ids), blk(x, onehot.to(DEV)))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_net_golden(dtype):
+    from repmode_amd.nn_modules.RepMode import Net
+    g = load_golden('g3_net_mc2.npz')
+    net = Net(Opts(), mult_chan=int(g['mult_chan']), dtype=dtype)
+    net.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('p.')})
+    net.to(DEV).train()
+    x, tgt = torch.from_numpy(g['x']).to(DEV), torch.from_numpy(g['target']).to(DEV)
+    tasks = torch.from_numpy(g['tasks'])
+    y = net(x, tasks)
+    loss = torch.nn.functional.mse_loss(y, tgt)
+    loss.backward()
+    if dtype == torch.float32:
+        assert rel_err(y.detach().cpu(), g['y']) < TOL_F32
+        assert abs(loss.item() - float(g['loss'])) < 1e-4
+        for k, p in net.named_parameters():
+            assert rel_err(p.grad.cpu(), g['d.' + k]) < 5e-3, k
+    else:
+        # 19 chained bf16 blocks with batch-norm in between: compare in norm, not element-wise
+        yr = torch.from_numpy(g['y'])
+        assert (y.detach().cpu() - yr).norm() / yr.norm() < 0.1
+        assert abs(loss.item() - float(g['loss'])) < 0.05
+    net.eval()
+    with torch.no_grad():
+        te = torch.full_like(tasks, int(g['tasks'][0]))
+        ye = net(x, te)
+    if dtype == torch.float32:
+        assert rel_err(ye.cpu(), g['y_eval']) < TOL_F32
+
+
+def test_cpu_tensor_fails_loudly():
+    from repmode_amd import _lib
+    from repmode_amd.nn_modules.RepMode import MoDEConv
+    blk = MoDEConv(5, 12, 4, 8)
+    with pytest.raises(_lib.RepModeHipError):
+        blk(torch.randn(1, 4, 4, 4, 4), torch.tensor([0]))
+
+
+def test_full_size_linearity_and_oracle_sample():
+    """BASELINE size (32x64x64 patch, 32->32 channels): size-independent property (linearity in the
+    gate-merged filter: conv with w1+w2 == conv w1 + conv w2) plus an oracle check on a cropped
+    interior region, which is exact for a 'same' convolution away from the crop border."""
+    ops = _ops()
+    from repmode_amd import _lib
+    gen = torch.Generator().manual_seed(11)
+    n, d, h, w, c = 2, 32, 64, 64, 32
+    x = torch.randn(n, c, d, h, w, generator=gen)
+    w1 = torch.randn(1, c, c, 5, 5, 5, generator=gen) / np.sqrt(c * 125)
+    w2 = torch.randn(1, c, c, 5, 5, 5, generator=gen) / np.sqrt(c * 125)
+    slots = torch.zeros(n, dtype=torch.int32, device=DEV)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    f = lambda wt: ops.conv5(x_cl, _layout_wf(wt, 32, 32).to(DEV), slots, c)
+    y1, y2, y12 = f(w1), f(w2), f(w1 + w2)
+    assert rel_err((y1 + y2).cpu(), y12.cpu()) < 1e-5
+    crop = x[:, :, 8:24, 16:48, 16:48]
+    yc = orc.conv_per_sample(crop, w1.expand(n, -1, -1, -1, -1, -1))[:, :, 2:-2, 2:-2, 2:-2]
+    got = y1.permute(0, 4, 1, 2, 3)[:, :, 10:22, 18:46, 18:46].cpu()
+    assert rel_err(got, yc) < TOL_BF16_ACC
