@@ -95,6 +95,18 @@ int repmode_gatrep_bwd(const float* dw, const float* k5, const float* k3, const 
                        float* dk1, float* da3, float* da5, float* dgate_w, float* dgate_b,
                        float* dg_ws, void* stream);
 
+/* ---- measurement: per-launch HIP-event timing of the library's kernels on their own stream.
+ * repmode_prof_enable(1) clears the records and starts recording, (0) stops.  repmode_prof_summary()
+ * synchronises the recorded events and returns, for one kernel kind, the number of launches, the
+ * summed duration (ms) and the summed algorithmic work (FLOPs for the conv kernels, bytes for GatRep). */
+#define REPMODE_PROF_CONV5 0    /* conv5_igemm (forward and data-gradient launches) */
+#define REPMODE_PROF_WGRAD 1    /* conv5_wgrad                                      */
+#define REPMODE_PROF_GATREP_FWD 2
+#define REPMODE_PROF_GATREP_BWD 3
+#define REPMODE_PROF_KINDS 4
+int repmode_prof_enable(int on);
+int repmode_prof_summary(int kind, int* launches, double* total_ms, double* total_work);
+
 /* ---- diagnostics: naive one-thread-per-output direct kernels (no MFMA, no LDS).  Not on the
  * product path; used by tests to bisect a failure between tiling and arithmetic. */
 int repmode_debug_conv5_naive(const void* x, const void* w, const int32_t* sample_slot, float* y,

@@ -6,6 +6,9 @@ There is NO fallback: if the shared object is missing or a call fails this modul
 import ctypes
 import os
 
+import torch  # noqa: F401  -- FIRST: torch bundles its own libamdhip64.so.7; importing it before dlopen()ing
+# librepmode_hip.so makes that the single HIP runtime of the process (same soname as /opt/rocm's copy).
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librepmode_hip.so')
 
@@ -26,6 +29,8 @@ _SIGNATURES = {
     'repmode_conv5': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_gatrep_bwd': [_P] * 8 + [_I] * 4 + [_P] * 9,
+    'repmode_prof_enable': [_I],
+    'repmode_prof_summary': [_I, _P, _P, _P],
     'repmode_debug_conv5_naive': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_debug_wgrad_naive': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }
@@ -77,3 +82,17 @@ def device_arch(dev=0):
     buf = ctypes.create_string_buffer(64)
     call('repmode_device_arch', dev, buf, 64)
     return buf.value.decode()
+
+
+PROF_KINDS = {'conv5_igemm': 0, 'conv5_wgrad': 1, 'gatrep_fwd': 2, 'gatrep_bwd': 3}
+
+
+def prof_enable(on):
+    call('repmode_prof_enable', 1 if on else 0)
+
+
+def prof_summary(kind):
+    """(launches, total_ms, total_work) of one kernel kind since prof_enable(True)."""
+    n, ms, work = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
+    call('repmode_prof_summary', PROF_KINDS[kind], ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work))
+    return n.value, ms.value, work.value

@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -30,6 +32,66 @@ extern "C" int repmode_device_arch(int dev, char* buf, int buflen) {
     strncpy(buf, prop.gcnArchName, buflen - 1);
     buf[buflen - 1] = 0;
   }
+  return REPMODE_OK;
+}
+
+namespace {
+struct ProfRec {
+  hipEvent_t a, b;
+  double work;
+  int kind;
+};
+std::vector<ProfRec> g_prof;   // event pool, reused across enable() calls
+size_t g_prof_n = 0;           // records in use
+bool g_prof_on = false;
+bool g_prof_open = false;
+}  // namespace
+
+void repmode_prof_begin(int kind, double work, hipStream_t s) {
+  if (!g_prof_on) return;
+  if (g_prof_n == g_prof.size()) {
+    ProfRec r{};
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    g_prof.push_back(r);
+  }
+  ProfRec& r = g_prof[g_prof_n];
+  r.kind = kind;
+  r.work = work;
+  (void)hipEventRecord(r.a, s);
+  g_prof_open = true;
+}
+
+void repmode_prof_end(hipStream_t s) {
+  if (!g_prof_on || !g_prof_open) return;
+  (void)hipEventRecord(g_prof[g_prof_n].b, s);
+  ++g_prof_n;
+  g_prof_open = false;
+}
+
+extern "C" int repmode_prof_enable(int on) {
+  if (on) g_prof_n = 0;
+  g_prof_on = on != 0;
+  g_prof_open = false;
+  return REPMODE_OK;
+}
+
+extern "C" int repmode_prof_summary(int kind, int* launches, double* total_ms, double* total_work) {
+  RM_REQUIRE(launches && total_ms && total_work, "prof_summary: null pointer");
+  RM_REQUIRE(kind >= 0 && kind < REPMODE_PROF_KINDS, "prof_summary: bad kind %d", kind);
+  int n = 0;
+  double ms = 0, work = 0;
+  for (size_t i = 0; i < g_prof_n; ++i) {
+    if (g_prof[i].kind != kind) continue;
+    RM_HIP(hipEventSynchronize(g_prof[i].b));
+    float t = 0.f;
+    RM_HIP(hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b));
+    ms += t;
+    work += g_prof[i].work;
+    ++n;
+  }
+  *launches = n;
+  *total_ms = ms;
+  *total_work = work;
   return REPMODE_OK;
 }
 

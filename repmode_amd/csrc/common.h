@@ -71,5 +71,10 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return base + (orig >> 3);
 }
 
+// Optional per-launch timing (HIP events on the launch stream), switched on by repmode_prof_enable().
+// kind: REPMODE_PROF_* ; work: algorithmic FLOPs (conv kernels) or bytes (GatRep kernels) of the launch.
+void repmode_prof_begin(int kind, double work, hipStream_t s);
+void repmode_prof_end(hipStream_t s);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

@@ -330,7 +330,9 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   if (ks > 1) {
     RM_HIP(hipMemsetAsync(a.y, 0, (size_t)a.N * a.D * a.H * a.W * a.Cout * sizeof(float), stream));
   }
+  repmode_prof_begin(REPMODE_PROF_CONV5, 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, stream);
   hipLaunchKernelGGL((conv5_igemm_kernel<T, C>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
+  repmode_prof_end(stream);
   RM_LAUNCH_CHECK("conv5_igemm");
   return REPMODE_OK;
 }

@@ -167,10 +167,12 @@ extern "C" int repmode_conv5_wgrad(const void* x, const void* dy, const int32_t*
   const long grid = fixed * a.nchunks;
   RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
   RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * REPMODE_TAPS * cout * cin * sizeof(float), s));
+  repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * d * h * wdim * (double)cin * cout * REPMODE_TAPS, s);
   if (dtype == REPMODE_F32)
     hipLaunchKernelGGL(conv5_wgrad_f32c_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL(conv5_wgrad_f32c_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, s, a);
+  repmode_prof_end(s);
   RM_LAUNCH_CHECK("conv5_wgrad");
   return REPMODE_OK;
 }

@@ -209,6 +209,9 @@ extern "C" int repmode_gate_softmax(const float* gate_w, const float* gate_b, co
 template <typename T>
 static int gatrep_fwd_t(const float* k5, const float* k3, const float* k1, const float* a3, const float* a5,
                         const float* g, int nslots, int co, int ci, int dtype, void* wf, void* wd, hipStream_t s) {
+  // algorithmic bytes: 155 expert floats read once + 125 merged elements written per slot and layout
+  const double bytes = (double)co * ci * (155.0 * 4 + 125.0 * nslots * sizeof(T) * ((wf ? 1 : 0) + (wd ? 1 : 0)));
+  repmode_prof_begin(REPMODE_PROF_GATREP_FWD, bytes, s);
   if (wf) {
     // wf[tap][CoP rows (mult of 32)][CiP reduction]
     const int cop = repmode_padded_channels(co, dtype, 0), cip = repmode_padded_channels(ci, dtype, 1);
@@ -226,6 +229,7 @@ static int gatrep_fwd_t(const float* k5, const float* k3, const float* k1, const
                        k1, a3, a5, g, nslots, co, ci, cop, cip, static_cast<T*>(wd));
     RM_LAUNCH_CHECK("gatrep_fwd(wd)");
   }
+  repmode_prof_end(s);
   return REPMODE_OK;
 }
 
@@ -252,11 +256,13 @@ extern "C" int repmode_gatrep_bwd(const float* dw, const float* k5, const float*
   hipStream_t s = static_cast<hipStream_t>(stream);
   RM_HIP(hipMemsetAsync(dg_ws, 0, (size_t)nslots * E * co * sizeof(float), s));
   const int bt = ci >= 256 ? 256 : (ci > 128 ? 256 : (ci > 64 ? 128 : 64));
+  repmode_prof_begin(REPMODE_PROF_GATREP_BWD, (double)co * ci * 4.0 * (125.0 * nslots + 2 * 155.0), s);
   hipLaunchKernelGGL(gatrep_bwd_kernel, dim3(ceil_div(ci, bt), co), dim3(bt), 0, s, dw, k5, k3, k1, a3, a5, g,
                      nslots, co, ci, dk5, dk3, dk1, da3, da5, dg_ws);
   RM_LAUNCH_CHECK("gatrep_bwd");
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(E * co, 128)), dim3(128), 0, s, g, dg_ws, slot_task, nslots,
                      num_tasks, co, dgate_w, dgate_b);
+  repmode_prof_end(s);
   RM_LAUNCH_CHECK("gate_bwd");
   return REPMODE_OK;
 }
