@@ -141,6 +141,188 @@ __global__ __launch_bounds__(256) void conv5_wgrad_f32c_kernel(WgradArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 version on v_mfma_f32_16x16x32_bf16 (16x the f32 rate).
+//
+// For this GEMM both operands are K-major in HBM (K = voxels, activations are channels-last) while
+// the MFMA wants 8 consecutive K values per lane.  Each staged element is reused by 25 taps x 16
+// channels of the other operand, so the operands are transposed once while staging:
+//   dyT[co][voxel]                       (bf16, 16-byte pad per channel row)
+//   xT [ci][z][halo row][8 + TX + 8]     (bf16; a row stores x0-8 .. x0+TX+7 so that every group of
+//                                         8 voxels starting at a multiple of 8 is 16-byte aligned)
+// A lane's B fragment for tap shift s = dx-2 in [-2,2] is the 8-voxel window starting s elements off
+// an aligned block: one ds_read_b128 (the block) + two ds_read_b32 (the dword before / after) give
+// all five windows -- even shifts are register renames, odd shifts five v_alignbit_b32 (shared
+// between s = -1 and s = +1).  So one (dy) row costs 3 LDS reads + 5 VALU for 5 MFMAs.
+// Staging packs two x-adjacent voxels per ds_write_b32 (8 channels each from one 16-byte load).
+template <int TZ, int TY, int TX>
+struct WgTile {
+  static constexpr int TV = TZ * TY * TX;          // voxels per tile (multiple of 32)
+  static constexpr int HY = TY + 4;
+  static constexpr int XS = TX + 16;               // elements per stored halo row
+  static constexpr int NGX = TX / 8;               // 8-voxel groups per row
+  static constexpr int KSTEPS = TV / 32;
+  static constexpr int ROW_C = TZ * HY * XS * 2 + 16;   // bytes per input channel (odd multiple of 16)
+  static constexpr int DYS = TV * 2 + 16;               // bytes per output channel
+  static constexpr int LDS = 32 * ROW_C + 32 * DYS;
+  static_assert(TV % 32 == 0 && TX % 8 == 0, "tile shape");
+  static_assert((ROW_C / 16) % 2 == 1 && (DYS / 16) % 2 == 1, "odd 16-byte strides avoid bank conflicts");
+};
+
+__device__ __forceinline__ u32x4 load8_bf16(const bf16_t* p, int c, int cmax, bool vec_ok) {
+  if (vec_ok) return *reinterpret_cast<const u32x4*>(p);
+  bf16_t e[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = (c + k < cmax) ? p[k] : (bf16_t)0;
+  return *reinterpret_cast<const u32x4*>(e);
+}
+
+// word k (two bf16) of a 16-byte register -> element index 0..7
+__device__ __forceinline__ uint32_t bf16_elem(const u32x4& v, int k) {
+  const uint32_t w = v[k >> 1];
+  return (k & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+template <int TZ, int TY, int TX>
+__global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
+  using G = WgTile<TZ, TY, TX>;
+  constexpr int TV = G::TV, HY = G::HY, XS = G::XS, NGX = G::NGX, ROW_C = G::ROW_C, DYS = G::DYS;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
+  unsigned char* xT = smem;
+  unsigned char* dyT = smem + 32 * ROW_C;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cq = wave & 1, ciq = wave >> 1;
+  const int l15 = lane & 15, kg = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int chunk = bid % a.nchunks; bid /= a.nchunks;
+  const int dz = bid % 5;            bid /= 5;
+  const int cit = bid % a.ncit;      bid /= a.ncit;
+  const int cot = bid % a.ncot;
+  const int n = bid / a.ncot;
+  const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+  const int slot = a.sample_slot[n];
+  const bf16_t* __restrict__ xn = static_cast<const bf16_t*>(a.x) + (size_t)n * D * H * W * Cin;
+  const bf16_t* __restrict__ dyn = static_cast<const bf16_t*>(a.dy) + (size_t)n * D * H * W * Cout;
+  const bool vec_x = (Cin & 7) == 0, vec_dy = (Cout & 7) == 0;
+
+  f32x4 acc[25];
+#pragma unroll
+  for (int t = 0; t < 25; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int t_begin = chunk * a.tiles_per_block;
+  const int t_end = min(a.ntiles, t_begin + a.tiles_per_block);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int txi = tile % a.ntx, t2 = tile / a.ntx;
+    const int tyi = t2 % a.nty, tzi = t2 / a.nty;
+    const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+    // every input plane this tile needs for this dz is padding -> nothing to add (uniform branch)
+    if (z0 + TZ - 1 + dz - 2 < 0 || z0 + dz - 2 >= D) continue;
+    __syncthreads();
+    // ---- stage x (transposed): items = (plane, halo row, x pair, channel group)
+    constexpr int NPAIR = TX / 2 + 2;              // pairs covering x0-2 .. x0+TX+1
+    for (int it = tid; it < TZ * HY * NPAIR * 4; it += 256) {
+      const int p = it % NPAIR; int r = it / NPAIR;
+      const int cg = r & 3; r >>= 2;
+      const int hy = r % HY, zz = r / HY;
+      const int zin = z0 + zz + dz - 2, gy = y0 + hy - 2, gx = x0 - 2 + 2 * p;
+      const int c = cit * 32 + cg * 8;
+      u32x4 v0 = u32x4{0u, 0u, 0u, 0u}, v1 = v0;
+      if ((unsigned)zin < (unsigned)D && (unsigned)gy < (unsigned)H && c < Cin) {
+        const bf16_t* rowp = xn + ((size_t)(zin * H + gy) * W) * Cin + c;
+        if ((unsigned)gx < (unsigned)W) v0 = load8_bf16(rowp + (size_t)gx * Cin, c, Cin, vec_x);
+        if ((unsigned)(gx + 1) < (unsigned)W) v1 = load8_bf16(rowp + (size_t)(gx + 1) * Cin, c, Cin, vec_x);
+      }
+      unsigned char* dst = xT + (cg * 8) * ROW_C + ((zz * HY + hy) * XS + 6 + 2 * p) * 2;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        *reinterpret_cast<uint32_t*>(dst + k * ROW_C) = bf16_elem(v0, k) | (bf16_elem(v1, k) << 16);
+    }
+    // ---- stage dy (transposed): items = (voxel pair, channel group)
+    for (int it = tid; it < (TV / 2) * 4; it += 256) {
+      const int q = it % (TV / 2), cg = it / (TV / 2);
+      const int m = 2 * q;
+      const int xx = m % TX, yy = (m / TX) % TY, zz = m / (TX * TY);
+      const int gz = z0 + zz, gy = y0 + yy, gx = x0 + xx;
+      const int c = cot * 32 + cg * 8;
+      u32x4 v0 = u32x4{0u, 0u, 0u, 0u}, v1 = v0;
+      if (gz < D && gy < H && c < Cout) {
+        const bf16_t* rowp = dyn + ((size_t)(gz * H + gy) * W) * Cout + c;
+        if (gx < W) v0 = load8_bf16(rowp + (size_t)gx * Cout, c, Cout, vec_dy);
+        if (gx + 1 < W) v1 = load8_bf16(rowp + (size_t)(gx + 1) * Cout, c, Cout, vec_dy);
+      }
+      unsigned char* dst = dyT + (cg * 8) * DYS + m * 2;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        *reinterpret_cast<uint32_t*>(dst + k * DYS) = bf16_elem(v0, k) | (bf16_elem(v1, k) << 16);
+    }
+    __syncthreads();
+    // ---- K loop: 32 voxels per step = 4 groups of 8 consecutive x; this lane's group = 4*ks + kg
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) {
+      const int g = ks * 4 + kg;
+      const int xg = g % NGX, gr = g / NGX;
+      const int yy = gr % TY, zz = gr / TY;
+      const u32x4 af = *reinterpret_cast<const u32x4*>(dyT + (cq * 16 + l15) * DYS + g * 16);
+      const unsigned char* xb = xT + (ciq * 16 + l15) * ROW_C + ((zz * HY + yy) * XS + 8 + 8 * xg) * 2;
+      const bf16x8 afr = __builtin_bit_cast(bf16x8, af);
+#pragma unroll
+      for (int dyi = 0; dyi < 5; ++dyi) {
+        const unsigned char* p = xb + dyi * XS * 2;
+        const u32x4 c = *reinterpret_cast<const u32x4*>(p);
+        const uint32_t pw = *reinterpret_cast<const uint32_t*>(p - 4);
+        const uint32_t nw = *reinterpret_cast<const uint32_t*>(p + 16);
+        const uint32_t a01 = __builtin_amdgcn_alignbit(c.x, pw, 16);
+        const uint32_t a12 = __builtin_amdgcn_alignbit(c.y, c.x, 16);
+        const uint32_t a23 = __builtin_amdgcn_alignbit(c.z, c.y, 16);
+        const uint32_t a34 = __builtin_amdgcn_alignbit(c.w, c.z, 16);
+        const uint32_t a4n = __builtin_amdgcn_alignbit(nw, c.w, 16);
+        const u32x4 b0 = u32x4{pw, c.x, c.y, c.z};       // shift -2
+        const u32x4 b1 = u32x4{a01, a12, a23, a34};      // shift -1
+        const u32x4 b3 = u32x4{a12, a23, a34, a4n};      // shift +1
+        const u32x4 b4 = u32x4{c.y, c.z, c.w, nw};       // shift +2
+        acc[dyi * 5 + 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, __builtin_bit_cast(bf16x8, b0), acc[dyi * 5 + 0], 0, 0, 0);
+        acc[dyi * 5 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, __builtin_bit_cast(bf16x8, b1), acc[dyi * 5 + 1], 0, 0, 0);
+        acc[dyi * 5 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, __builtin_bit_cast(bf16x8, c), acc[dyi * 5 + 2], 0, 0, 0);
+        acc[dyi * 5 + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, __builtin_bit_cast(bf16x8, b3), acc[dyi * 5 + 3], 0, 0, 0);
+        acc[dyi * 5 + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, __builtin_bit_cast(bf16x8, b4), acc[dyi * 5 + 4], 0, 0, 0);
+      }
+    }
+  }
+  // 16x16 C/D layout: column (ci) = lane & 15, row (co) = (lane >> 4) * 4 + r
+  const int ci = cit * 32 + ciq * 16 + l15;
+  if (ci < Cin) {
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+      const int tap = dz * 25 + t;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cot * 32 + cq * 16 + kg * 4 + r;
+        if (co < Cout) unsafeAtomicAdd(a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * Cin + ci, acc[t][r]);
+      }
+    }
+  }
+}
+
+template <int TZ, int TY, int TX>
+int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
+  a.nty = ceil_div(a.H, TY);
+  a.ntx = ceil_div(a.W, TX);
+  a.ntiles = ceil_div(a.D, TZ) * a.nty * a.ntx;
+  const long fixed = (long)n * a.ncot * a.ncit * 5;
+  long want_chunks = (2048 + fixed - 1) / fixed;
+  if (want_chunks < 1) want_chunks = 1;
+  if (want_chunks > a.ntiles) want_chunks = a.ntiles;
+  a.tiles_per_block = ceil_div(a.ntiles, (int)want_chunks);
+  a.nchunks = ceil_div(a.ntiles, a.tiles_per_block);
+  const long grid = fixed * a.nchunks;
+  RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
+  hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  return REPMODE_OK;
+}
+
 }  // namespace
 
 extern "C" int repmode_conv5_wgrad(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
@@ -155,23 +337,30 @@ extern "C" int repmode_conv5_wgrad(const void* x, const void* dy, const int32_t*
   a.N = n; a.D = d; a.H = h; a.W = wdim; a.Cin = cin; a.Cout = cout;
   a.ncot = ceil_div(cout, 32);
   a.ncit = ceil_div(cin, 32);
-  a.nty = ceil_div(h, TY);
-  a.ntx = ceil_div(wdim, TX);
-  a.ntiles = d * a.nty * a.ntx;
-  const long fixed = (long)n * a.ncot * a.ncit * 5;
-  long want_chunks = (2048 + fixed - 1) / fixed;       // aim at >= 2048 workgroups
-  if (want_chunks < 1) want_chunks = 1;
-  if (want_chunks > a.ntiles) want_chunks = a.ntiles;
-  a.tiles_per_block = ceil_div(a.ntiles, (int)want_chunks);
-  a.nchunks = ceil_div(a.ntiles, a.tiles_per_block);
-  const long grid = fixed * a.nchunks;
-  RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
   RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * REPMODE_TAPS * cout * cin * sizeof(float), s));
   repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * d * h * wdim * (double)cin * cout * REPMODE_TAPS, s);
-  if (dtype == REPMODE_F32)
+  if (dtype == REPMODE_BF16) {
+    RM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv5_wgrad: pointers must be 16-byte aligned");
+    int rc;
+    if (wdim >= 32) rc = launch_wgrad_bf16<1, 4, 32>(a, n, s);
+    else if (wdim >= 16) rc = launch_wgrad_bf16<1, 8, 16>(a, n, s);
+    else if (wdim >= 8) rc = launch_wgrad_bf16<2, 8, 8>(a, n, s);
+    else rc = launch_wgrad_bf16<2, 4, 8>(a, n, s);
+    if (rc != REPMODE_OK) return rc;
+  } else {
+    a.nty = ceil_div(h, TY);
+    a.ntx = ceil_div(wdim, TX);
+    a.ntiles = d * a.nty * a.ntx;
+    const long fixed = (long)n * a.ncot * a.ncit * 5;
+    long want_chunks = (2048 + fixed - 1) / fixed;       // aim at >= 2048 workgroups
+    if (want_chunks < 1) want_chunks = 1;
+    if (want_chunks > a.ntiles) want_chunks = a.ntiles;
+    a.tiles_per_block = ceil_div(a.ntiles, (int)want_chunks);
+    a.nchunks = ceil_div(a.ntiles, a.tiles_per_block);
+    const long grid = fixed * a.nchunks;
+    RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
     hipLaunchKernelGGL(conv5_wgrad_f32c_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(conv5_wgrad_f32c_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, s, a);
+  }
   repmode_prof_end(s);
   RM_LAUNCH_CHECK("conv5_wgrad");
   return REPMODE_OK;

@@ -1,0 +1,127 @@
+"""CPU-only checks of the host side: the C ABI library loads and exports exactly what
+include/repmode_hip.h declares, the slot plan, the module surface (309-key state_dict, parameter
+shapes) and that the product path refuses to run without a HIP device.  No compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, Opts, load_golden
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, 'include', 'repmode_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(repmode_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from repmode_amd import _lib
+    lib = _lib.load()
+    declared = _header_functions()
+    assert declared, 'no declarations parsed'
+    for name in declared:
+        assert hasattr(lib, name), 'librepmode_hip.so does not export %s' % name
+    assert set(declared) == set(_lib.EXPORTS), (set(declared) ^ set(_lib.EXPORTS))
+    assert lib.repmode_abi_version() == 1
+
+
+def test_padded_channels():
+    from repmode_amd import _lib
+    assert _lib.padded_channels(1, _lib.BF16, True) == 16
+    assert _lib.padded_channels(17, _lib.BF16, True) == 32
+    assert _lib.padded_channels(1, _lib.F32, True) == 8
+    assert _lib.padded_channels(1, _lib.BF16, False) == 32
+    assert _lib.padded_channels(33, _lib.F32, False) == 64
+
+
+def test_argument_validation_without_gpu():
+    """Argument errors are reported through the int return code + message, never a crash."""
+    from repmode_amd import _lib
+    with pytest.raises(_lib.RepModeHipError, match='null pointer'):
+        _lib.call('repmode_conv5', None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, None)
+    with pytest.raises(_lib.RepModeHipError, match='null pointer'):
+        _lib.call('repmode_gate_softmax', None, None, None, 1, 12, 4, None, None)
+    buf = ctypes.create_string_buffer(16)
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.RepModeHipError):
+            _lib.call('repmode_device_arch', 0, buf, 16)
+
+
+def test_task_plan_grouping():
+    from repmode_amd.ops import TaskPlan
+    p = TaskPlan(torch.tensor([7, 2, 7, 11, 2]), 12, 'cpu', training=True)
+    assert p.nslots == 3 and p.slot_task_host == [2, 7, 11]
+    assert p.sample_slot.tolist() == [1, 0, 1, 2, 0] and p.slot_task.tolist() == [2, 7, 11]
+    assert p.slot_task.dtype == torch.int32
+    # eval: the first sample's task for the whole batch (RepMode.py:209-210)
+    e = TaskPlan(torch.tensor([5, 5, 9]), 12, 'cpu', training=False)
+    assert e.nslots == 1 and e.slot_task_host == [5] and e.sample_slot.tolist() == [0, 0, 0]
+    # one-hot rows as the reference's MoDEConv receives them
+    oh = torch.zeros(2, 12)
+    oh[0, 3] = oh[1, 8] = 1
+    assert TaskPlan(oh, 12, 'cpu').slot_task_host == [3, 8]
+    with pytest.raises(ValueError):
+        TaskPlan([12], 12, 'cpu')
+    with pytest.raises(ValueError):
+        TaskPlan([-1], 12, 'cpu')
+
+
+def test_module_surface_matches_reference_state_dict():
+    from repmode_amd.nn_modules.RepMode import Net
+    g = load_golden('g3_net_mc2.npz')
+    ref = {k[2:]: v for k, v in g.items() if k.startswith('p.')}
+    net = Net(Opts(), mult_chan=2)
+    sd = net.state_dict()
+    assert len(sd) == 309 and list(sd) == list(ref)
+    for k, v in sd.items():
+        assert tuple(v.shape) == ref[k].shape, k
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in ref.items()})      # reference checkpoint loads
+    with torch.device('meta'):
+        big = Net(Opts(), mult_chan=32)
+    assert sum(p.numel() for p in big.parameters()) == 123_877_633
+    assert len(list(big.parameters())) == 193
+
+
+def test_init_distribution_matches_reference():
+    """kaiming_uniform_(a=sqrt(5)) => U(+-1/sqrt(fan_in)) (RepMode.py:156-159)."""
+    from repmode_amd.nn_modules.RepMode import MoDEConv
+    torch.manual_seed(0)
+    blk = MoDEConv(5, 12, 16, 64)
+    for p, k in [(blk.expert_conv5x5_conv, 5), (blk.expert_conv3x3_conv, 3), (blk.expert_conv1x1_conv, 1)]:
+        bound = 1.0 / (16 * k ** 3) ** 0.5
+        assert p.abs().max() <= bound and p.abs().max() > 0.9 * bound
+    assert torch.allclose(blk.expert_avg3x3_pool, torch.full((3, 3, 3), 1 / 27.))
+    assert torch.allclose(blk.expert_avg5x5_pool, torch.full((5, 5, 5), 1 / 125.))
+    assert blk.gate.weight.shape == (5 * 64, 12)
+
+
+def test_no_cpu_fallback():
+    from repmode_amd import _lib
+    from repmode_amd.nn_modules.RepMode import Net
+    net = Net(Opts(), mult_chan=2)
+    with pytest.raises(_lib.RepModeHipError, match='no CPU fallback'):
+        net(torch.randn(1, 1, 16, 16, 16), torch.tensor([0]))
+    with pytest.raises(ValueError, match='multiples of 16'):
+        net(torch.randn(1, 1, 16, 16, 20), torch.tensor([0]))
+
+
+def test_product_code_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under repmode_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'repmode_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', text, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_predict_helpers_match_golden():
+    from repmode_amd.model import get_gaussian, patch_grid
+    import numpy as np
+    g = load_golden('g5_predict.npz')
+    assert np.array_equal(get_gaussian((16, 32, 32)), g['gauss_16x32x32'])
+    grid = patch_grid((64, 624, 924), (32, 128, 128))
+    assert len(grid) == 378 and int(g['patches_64x624x924_nbatches']) == 48
+    assert grid[0] == ([0, 0, 0], [32, 128, 128]) and grid[-1] == ([32, 496, 796], [64, 624, 924])
