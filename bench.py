@@ -48,7 +48,9 @@ def cpu_baseline(seconds_budget=30.0):
     step of the full-size network on the headline patch (the per-voxel cost does not depend on the
     batch size); a tiny warm-up first so thread pools and allocators are initialised."""
     from oracle import repmode_oracle as orc
-    cores = os.cpu_count() or 1
+    # the oracle's PyTorch-CPU ops stop scaling (and then regress) well before a big host's core
+    # count: 32 threads is the measured sweet spot region; `cores` reports what was actually used
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     net = orc.Net(Opts(), mult_chan=MULT_CHAN)

@@ -52,122 +52,178 @@ __device__ __forceinline__ bool in_centre3(int tap, int& t3) {
   return in;
 }
 
-// One thread per (fast index, slow index) pair of (co, ci); FAST_CI selects which of the two is
-// the fast (lane) index so that the layout being written is coalesced along lanes.
-// MAXS slots are processed per pass with their gate probabilities held in registers.
+// Forward merge.  The expert tensors are [co][ci][taps] (taps contiguous) while the conv kernels want
+// [tap][row][reduction] (channels contiguous), so a workgroup stages a 32-channel x 125-tap slab of
+// every expert in LDS with coalesced reads and writes it back transposed, merged, for every slot:
+//   WRITE_WD == false: block = (one co, 32 ci)  -> wf[s][tap][co][ci0..ci0+31]
+//   WRITE_WD == true : block = (32 co, one ci)  -> wd[s][124-tap][ci][co0..co0+31]
+// Lanes run along the 32-channel axis of the slab in both the LDS reads (stride 125 floats: odd, so
+// conflict-free) and the global writes (contiguous).  Padded rows/columns are pre-zeroed by the host.
+constexpr int GF_CT = 32;      // channels per slab
+constexpr int GF_THREADS = 256;
+
 template <typename T, bool WRITE_WD>
-__global__ __launch_bounds__(256) void gatrep_fwd_kernel(
+__global__ __launch_bounds__(GF_THREADS) void gatrep_fwd_kernel(
     const float* __restrict__ k5, const float* __restrict__ k3, const float* __restrict__ k1,
     const float* __restrict__ a3, const float* __restrict__ a5, const float* __restrict__ g, int nslots,
-    int co_n, int ci_n, int cop, int cip, T* __restrict__ wout) {
-  // WRITE_WD == false: writes wf[s][tap][co][ci], lanes run along ci (padded range cip)
-  // WRITE_WD == true : writes wd[s][124-tap][ci][co], lanes run along co (padded range cop)
-  const int fast_n = WRITE_WD ? cop : cip;
-  const int slow_n = WRITE_WD ? cip : cop;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)fast_n * slow_n) return;
-  const int fast = (int)(idx % fast_n), slow = (int)(idx / fast_n);
-  const int co = WRITE_WD ? fast : slow;
-  const int ci = WRITE_WD ? slow : fast;
-  const bool live = co < co_n && ci < ci_n;
-  const size_t oi = live ? (size_t)co * ci_n + ci : 0;
-  const float e2 = live ? k1[oi] : 0.f;
-  const float e3 = live ? a3[oi] * (1.0f / 27.0f) : 0.f;
-  const float e4 = live ? a5[oi] * (1.0f / 125.0f) : 0.f;
-  const size_t slot_stride = (size_t)TAPS * cop * cip;
-  for (int tap = 0; tap < TAPS; ++tap) {
+    int co_n, int ci_n, int rows_p, int red_p, T* __restrict__ wout) {
+  // rows_p / red_p: padded extents of the output's row and reduction (fastest) dimensions
+  __shared__ float s5[GF_CT * TAPS];
+  __shared__ float s3[GF_CT * 27];
+  __shared__ float s1[GF_CT], sa3[GF_CT], sa5[GF_CT];
+  const int tid = threadIdx.x;
+  // slab: `fixed` is the single channel of the other kind, c0 the first of the 32 slab channels
+  const int fixed = blockIdx.y;
+  const int c0 = blockIdx.x * GF_CT;
+  const int slab_n = WRITE_WD ? co_n : ci_n;          // extent of the slab axis
+  const int nlive = min(GF_CT, slab_n - c0);
+  // element (co, ci) of slab channel c:  wf: (fixed, c0 + c)   wd: (c0 + c, fixed)
+  auto oi_of = [&](int c) -> size_t {
+    return WRITE_WD ? (size_t)(c0 + c) * ci_n + fixed : (size_t)fixed * ci_n + c0 + c;
+  };
+  if (!WRITE_WD) {
+    // the 32 x 125 (and 32 x 27) floats are contiguous in memory
+    const size_t base = oi_of(0);
+    for (int i = tid; i < nlive * TAPS; i += GF_THREADS) s5[i] = k5[base * TAPS + i];
+    for (int i = tid; i < nlive * 27; i += GF_THREADS) s3[i] = k3[base * 27 + i];
+  } else {
+    for (int i = tid; i < nlive * TAPS; i += GF_THREADS) s5[i] = k5[oi_of(i / TAPS) * TAPS + i % TAPS];
+    for (int i = tid; i < nlive * 27; i += GF_THREADS) s3[i] = k3[oi_of(i / 27) * 27 + i % 27];
+  }
+  if (tid < nlive) {
+    const size_t oi = oi_of(tid);
+    s1[tid] = k1[oi];
+    sa3[tid] = a3[oi] * (1.0f / 27.0f);
+    sa5[tid] = a5[oi] * (1.0f / 125.0f);
+  }
+  __syncthreads();
+  const int c = tid & (GF_CT - 1);          // slab channel of this thread (fixed: 256 % 32 == 0)
+  const int tq = tid / GF_CT;               // 0..7: taps tq, tq+8, ...
+  if (c >= nlive) return;
+  const size_t slot_stride = (size_t)TAPS * rows_p * red_p;
+  const int co = WRITE_WD ? c0 + c : fixed;
+  for (int tap = tq; tap < TAPS; tap += GF_THREADS / GF_CT) {
     int t3;
     const bool c3 = in_centre3(tap, t3);
-    const float v0 = live ? k5[oi * TAPS + tap] : 0.f;
-    const float v1 = (live && c3) ? k3[oi * 27 + t3] : 0.f;
-    const float v2 = (tap == 62) ? e2 : 0.f;
-    const float v3 = c3 ? e3 : 0.f;
-    const size_t off = WRITE_WD ? ((size_t)(TAPS - 1 - tap) * cip + ci) * cop + co
-                                : ((size_t)tap * cop + co) * cip + ci;
+    const float v0 = s5[c * TAPS + tap];
+    const float v1 = c3 ? s3[c * 27 + t3] : 0.f;
+    const float v2 = (tap == 62) ? s1[c] : 0.f;
+    const float v3 = c3 ? sa3[c] : 0.f;
+    const float v4 = sa5[c];
+    // wf: [tap][co = fixed][ci = c0 + c]      wd: [124 - tap][ci = fixed][co = c0 + c]
+    const size_t off = WRITE_WD ? ((size_t)(TAPS - 1 - tap) * rows_p + fixed) * red_p + c0 + c
+                                : ((size_t)tap * rows_p + fixed) * red_p + c0 + c;
     for (int s = 0; s < nslots; ++s) {
-      float r = 0.f;
-      if (live) {
-        const float* gs = g + (size_t)s * E * co_n + co;
-        // same association order as RepMode.py:184-188: ((((g0 k5 + g1 k3) + g2 k1) + g3 a3) + g4 a5)
-        r = gs[0] * v0 + gs[co_n] * v1;
-        r = r + gs[2 * co_n] * v2;
-        r = r + gs[3 * co_n] * v3;
-        r = r + gs[4 * co_n] * e4;
-      }
+      const float* gs = g + (size_t)s * E * co_n + co;
+      // same association order as RepMode.py:184-188: ((((g0 k5 + g1 k3) + g2 k1) + g3 a3) + g4 a5)
+      float r = gs[0] * v0 + gs[co_n] * v1;
+      r = r + gs[2 * co_n] * v2;
+      r = r + gs[3 * co_n] * v3;
+      r = r + gs[4 * co_n] * v4;
       wout[s * slot_stride + off] = from_f32<T>(r);
     }
   }
 }
 
-// Expert gradients and gate-probability gradients from the per-slot filter gradient.
-// One thread per (co, ci) with lanes along ci (dw is [s][tap][co][ci]); a block covers one co and
-// up to 256 ci, reduces the 5 gate-probability partials per slot over its ci and adds them to dg.
-__global__ __launch_bounds__(256) void gatrep_bwd_kernel(
+// Expert gradients and gate-probability gradients from the per-slot filter gradient dw[s][tap][co][ci].
+// Block = (one co, 32 ci); thread = (ci = tid % 32, taps tid / 32 + 8k).  Reads of dw are 128-byte
+// rows; expert gradients are accumulated over slots in registers and written back transposed through
+// LDS ([ci][taps] contiguous, the experts' layout); the per-slot gate-probability partial sums are
+// reduced over the block and added to dg[s][e][co] (one atomic per block, slot and expert).
+constexpr int GB_NT = 16;   // taps per thread: ceil(125 / 8)
+
+__global__ __launch_bounds__(GF_THREADS) void gatrep_bwd_kernel(
     const float* __restrict__ dw, const float* __restrict__ k5, const float* __restrict__ k3,
     const float* __restrict__ k1, const float* __restrict__ a3, const float* __restrict__ a5,
     const float* __restrict__ g, int nslots, int co_n, int ci_n, float* __restrict__ dk5,
     float* __restrict__ dk3, float* __restrict__ dk1, float* __restrict__ da3, float* __restrict__ da5,
     float* __restrict__ dg) {
-  __shared__ float red[4][E];
+  __shared__ float s5[GF_CT * TAPS];        // k5 slab, later reused for the dk5 write-back
+  __shared__ float s3[GF_CT * 27];
+  __shared__ float part[5][GF_THREADS];
+  const int tid = threadIdx.x;
   const int co = blockIdx.y;
-  const int ci = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = ci < ci_n;
-  const size_t oi = (size_t)co * ci_n + (live ? ci : 0);
-  const size_t tap_stride = (size_t)co_n * ci_n;
+  const int c0 = blockIdx.x * GF_CT;
+  const int nlive = min(GF_CT, ci_n - c0);
+  const size_t base = (size_t)co * ci_n + c0;
+  for (int i = tid; i < nlive * TAPS; i += GF_THREADS) s5[i] = k5[base * TAPS + i];
+  for (int i = tid; i < nlive * 27; i += GF_THREADS) s3[i] = k3[base * 27 + i];
+  __syncthreads();
+  const int c = tid & (GF_CT - 1), tq = tid / GF_CT;
+  const bool live = c < nlive;
+  const size_t oi = base + (live ? c : 0);
   const float w1 = live ? k1[oi] : 0.f;
   const float w3 = live ? a3[oi] * (1.0f / 27.0f) : 0.f;
   const float w5 = live ? a5[oi] * (1.0f / 125.0f) : 0.f;
-  float acc1 = 0.f, acc3 = 0.f, acc5 = 0.f;
-  // pass over slots outermost for dg (needs per-slot reductions), experts accumulate across slots
+  const size_t tap_stride = (size_t)co_n * ci_n;
+  float acc5[GB_NT], acc3[GB_NT];
+#pragma unroll
+  for (int k = 0; k < GB_NT; ++k) { acc5[k] = 0.f; acc3[k] = 0.f; }
+  float acc1 = 0.f, acca3 = 0.f, acca5 = 0.f;     // meaningful in threads tid < 32 only
   for (int s = 0; s < nslots; ++s) {
     const float* gs = g + (size_t)s * E * co_n + co;
     const float g0 = gs[0], g1 = gs[co_n], g2 = gs[2 * co_n], g3 = gs[3 * co_n], g4 = gs[4 * co_n];
     const float* dws = dw + (size_t)s * TAPS * tap_stride + oi;
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f, s27 = 0.f, s125 = 0.f;
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const float d = live ? dws[(size_t)tap * tap_stride] : 0.f;
-      int t3;
-      const bool c3 = in_centre3(tap, t3);
-      s125 += d;
-      if (live) {
-        const float kv = k5[oi * TAPS + tap];
-        p0 += kv * d;
-        // dk5 is accumulated in place across slots: first slot overwrites
-        float* o5 = dk5 + oi * TAPS + tap;
-        *o5 = (s == 0 ? 0.f : *o5) + g0 * d;
+    float q0 = 0.f, q1 = 0.f, dcen = 0.f, s27 = 0.f, s125 = 0.f;
+#pragma unroll
+    for (int k = 0; k < GB_NT; ++k) {
+      const int tap = tq + 8 * k;
+      if (tap < TAPS && live) {      // dead lanes must not touch the (uninitialised) slab tail
+        const float d = dws[(size_t)tap * tap_stride];
+        int t3;
+        const bool c3 = in_centre3(tap, t3);
+        s125 += d;
+        q0 += s5[c * TAPS + tap] * d;
+        acc5[k] += g0 * d;
         if (c3) {
           s27 += d;
-          p1 += k3[oi * 27 + t3] * d;
-          float* o3 = dk3 + oi * 27 + t3;
-          *o3 = (s == 0 ? 0.f : *o3) + g1 * d;
-          if (tap == 62) { p2 = w1 * d; acc1 += g2 * d; }
+          q1 += s3[c * 27 + t3] * d;
+          acc3[k] += g1 * d;
+          if (tap == 62) dcen = d;
         }
       }
     }
-    acc3 += g3 * s27;
-    acc5 += g4 * s125;
-    float part[E] = {p0, p1, p2, w3 * s27, w5 * s125};
-    // block reduction over ci
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      float v = part[e];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][e] = v;
-    }
+    part[0][tid] = q0; part[1][tid] = q1; part[2][tid] = dcen; part[3][tid] = s27; part[4][tid] = s125;
     __syncthreads();
-    if (threadIdx.x < E) {
-      float v = 0.f;
-      for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) v += red[wv][threadIdx.x];
-      atomicAdd(dg + ((size_t)s * E + threadIdx.x) * co_n + co, v);
+    if (tid < GF_CT) {
+      float r0 = 0.f, r1 = 0.f, rc = 0.f, r27 = 0.f, r125 = 0.f;
+#pragma unroll
+      for (int j = 0; j < GF_THREADS / GF_CT; ++j) {
+        r0 += part[0][tid + j * GF_CT]; r1 += part[1][tid + j * GF_CT]; rc += part[2][tid + j * GF_CT];
+        r27 += part[3][tid + j * GF_CT]; r125 += part[4][tid + j * GF_CT];
+      }
+      acc1 += g2 * rc;
+      acca3 += g3 * r27;
+      acca5 += g4 * r125;
+      float e[E] = {r0, r1, w1 * rc, w3 * r27, w5 * r125};
+#pragma unroll
+      for (int k = 0; k < E; ++k) {
+        float v = e[k];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 32);
+        if (tid == 0) atomicAdd(dg + ((size_t)s * E + k) * co_n + co, v);
+      }
     }
     __syncthreads();
   }
-  if (live) {
+  if (tid < GF_CT && live) {
     dk1[oi] = acc1;
-    da3[oi] = acc3 * (1.0f / 27.0f);
-    da5[oi] = acc5 * (1.0f / 125.0f);
+    da3[oi] = acca3 * (1.0f / 27.0f);
+    da5[oi] = acca5 * (1.0f / 125.0f);
   }
+  // write dk5 / dk3 back in the experts' [ci][taps] layout through LDS (slabs are contiguous)
+#pragma unroll
+  for (int k = 0; k < GB_NT; ++k) {
+    const int tap = tq + 8 * k;
+    if (tap < TAPS) {
+      s5[c * TAPS + tap] = acc5[k];
+      int t3;
+      if (in_centre3(tap, t3)) s3[c * 27 + t3] = acc3[k];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < nlive * TAPS; i += GF_THREADS) dk5[base * TAPS + i] = s5[i];
+  for (int i = tid; i < nlive * 27; i += GF_THREADS) dk3[base * 27 + i] = s3[i];
 }
 
 // softmax Jacobian + gate Linear gradients.  One thread per (e, co); loops over slots.
@@ -215,8 +271,8 @@ static int gatrep_fwd_t(const float* k5, const float* k3, const float* k1, const
   if (wf) {
     // wf[tap][CoP rows (mult of 32)][CiP reduction]
     const int cop = repmode_padded_channels(co, dtype, 0), cip = repmode_padded_channels(ci, dtype, 1);
-    const long total = (long)cop * cip;
-    hipLaunchKernelGGL((gatrep_fwd_kernel<T, false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k5, k3,
+    if (cop != co || cip != ci) RM_HIP(hipMemsetAsync(wf, 0, (size_t)nslots * TAPS * cop * cip * sizeof(T), s));
+    hipLaunchKernelGGL((gatrep_fwd_kernel<T, false>), dim3(ceil_div(ci, GF_CT), co), dim3(GF_THREADS), 0, s, k5, k3,
                        k1, a3, a5, g, nslots, co, ci, cop, cip, static_cast<T*>(wf));
     RM_LAUNCH_CHECK("gatrep_fwd(wf)");
   }
@@ -224,9 +280,9 @@ static int gatrep_fwd_t(const float* k5, const float* k3, const float* k1, const
     // wd[124-tap][CiP' rows (mult of 32)][CoP' reduction]: the data-gradient conv swaps the roles of
     // the two channel counts, so each is padded for its role there
     const int cop = repmode_padded_channels(co, dtype, 1), cip = repmode_padded_channels(ci, dtype, 0);
-    const long total = (long)cop * cip;
-    hipLaunchKernelGGL((gatrep_fwd_kernel<T, true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k5, k3,
-                       k1, a3, a5, g, nslots, co, ci, cop, cip, static_cast<T*>(wd));
+    if (cop != co || cip != ci) RM_HIP(hipMemsetAsync(wd, 0, (size_t)nslots * TAPS * cop * cip * sizeof(T), s));
+    hipLaunchKernelGGL((gatrep_fwd_kernel<T, true>), dim3(ceil_div(co, GF_CT), ci), dim3(GF_THREADS), 0, s, k5, k3,
+                       k1, a3, a5, g, nslots, co, ci, cip, cop, static_cast<T*>(wd));
     RM_LAUNCH_CHECK("gatrep_fwd(wd)");
   }
   repmode_prof_end(s);
@@ -255,10 +311,9 @@ extern "C" int repmode_gatrep_bwd(const float* dw, const float* k5, const float*
   RM_REQUIRE(nslots > 0 && num_tasks > 0 && co > 0 && ci > 0, "gatrep_bwd: bad shape");
   hipStream_t s = static_cast<hipStream_t>(stream);
   RM_HIP(hipMemsetAsync(dg_ws, 0, (size_t)nslots * E * co * sizeof(float), s));
-  const int bt = ci >= 256 ? 256 : (ci > 128 ? 256 : (ci > 64 ? 128 : 64));
   repmode_prof_begin(REPMODE_PROF_GATREP_BWD, (double)co * ci * 4.0 * (125.0 * nslots + 2 * 155.0), s);
-  hipLaunchKernelGGL(gatrep_bwd_kernel, dim3(ceil_div(ci, bt), co), dim3(bt), 0, s, dw, k5, k3, k1, a3, a5, g,
-                     nslots, co, ci, dk5, dk3, dk1, da3, da5, dg_ws);
+  hipLaunchKernelGGL(gatrep_bwd_kernel, dim3(ceil_div(ci, GF_CT), co), dim3(GF_THREADS), 0, s, dw, k5, k3, k1, a3, a5,
+                     g, nslots, co, ci, dk5, dk3, dk1, da3, da5, dg_ws);
   RM_LAUNCH_CHECK("gatrep_bwd");
   hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(E * co, 128)), dim3(128), 0, s, g, dg_ws, slot_task, nslots,
                      num_tasks, co, dgate_w, dgate_b);
