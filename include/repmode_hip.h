@@ -13,11 +13,14 @@
  * Layouts (MI355X-first):
  *   activations   NDHWC ("channels last"): x[n][z][y][x][c], element type = dtype
  *   expert params the reference's own layout and dtype: float [Co][Ci][k][k][k]
- *   merged filter wf[slot][tap][CoP][CiP]  (tap = (dz*5+dy)*5+dx, cross-correlation order)
- *                 wd[slot][124-tap][CiP][CoP] (taps flipped, channels transposed: the filter
- *                 that turns the data-gradient into the same convolution)
- *                 CoP / CiP = channel counts rounded up (zero filled) as given by
- *                 repmode_padded_channels().
+ *   merged filter fragment-major: w[slot][tap][row tile][red chunk][32][KC], KC = 16 (bf16) / 8 (f32);
+ *                 element (row, red) of a tap lives at
+ *                   ((tap * NRT + row / 32) * NKC + red / KC) * 32 * KC + (row % 32) * KC + red % KC
+ *                 with NRT = rowsP / 32, NKC = redP / KC (padded extents from repmode_padded_channels(),
+ *                 zero filled).  Each 32 x KC tile is the 1 KiB one MFMA operand load reads.
+ *                 wf: rows = co, red = ci, tap = (dz*5+dy)*5+dx (cross-correlation order);
+ *                 wd: rows = ci, red = co, taps flipped (124 - tap): the filter that turns the
+ *                 data-gradient into the same convolution.
  *   slots         a "slot" is one distinct task of the batch; slot_task[s] is its task id and
  *                 sample_slot[n] the slot of sample n.  Filters depend on the task only, so they
  *                 are merged once per slot, not once per sample as RepMode.py:182-190 does.
@@ -71,7 +74,7 @@ int repmode_gatrep_fwd(const float* k5, const float* k3, const float* k1, const 
 
 /* ---- conv: RepMode.py:204-208 (train, per-sample filter) and :209-210 (eval, one filter) ----
  * y[n] = cross-correlation of x[n] with w[sample_slot[n]], 5^3, stride 1, zero pad 2, no bias.
- * x: [N][D][H][W][Cin] dtype;  w: [nslots][125][CoutP][CinP] dtype;
+ * x: [N][D][H][W][Cin] dtype;  w: fragment-major merged filter of nslots slots (rows = Cout, red = Cin);
  * y: [N][D][H][W][Cout], dtype, or float when out_f32 != 0.
  * Called with wf for the forward pass and with wd (Cin/Cout swapped) for the data gradient
  * (autograd of RepMode.py:207, aten::convolution_backward input grad). */

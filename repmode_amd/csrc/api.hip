@@ -117,8 +117,10 @@ __global__ void conv5_naive_kernel(const T* __restrict__ x, const T* __restrict_
     const int z = gz + tap / 25 - 2, yy = gy + (tap / 5) % 5 - 2, xx = gx + tap % 5 - 2;
     if ((unsigned)z >= (unsigned)D || (unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
     const T* xp = x + ((((size_t)n * D + z) * H + yy) * W + xx) * Cin;
-    const T* wp = ws + ((size_t)tap * CoutP + co) * CinP;
-    for (int ci = 0; ci < Cin; ++ci) acc += to_f32<T>(xp[ci]) * to_f32<T>(wp[ci]);
+    constexpr int KC = 32 / sizeof(T);     // fragment-major filter layout, see gatrep.hip
+    const int nkc = CinP / KC;
+    const T* wp = ws + (((size_t)tap * (CoutP / 32) + co / 32) * nkc) * (32 * KC) + (co % 32) * KC;
+    for (int ci = 0; ci < Cin; ++ci) acc += to_f32<T>(xp[ci]) * to_f32<T>(wp[(size_t)(ci / KC) * (32 * KC) + ci % KC]);
   }
   y[idx] = acc;
 }

@@ -19,8 +19,8 @@
 //   * LDS image: two planes per chunk, plane p = 16-byte channel group p of every halo voxel,
 //     voxel-linear.  Lane l of a wave reads voxel (l & 31) of plane (l >> 5): 32 consecutive
 //     16-byte slots -> conflict-free ds_read_b128, and a tap shift is a constant byte offset.
-//   * filter fragments come straight from global/L2 (layout [tap][co][ci], 16 B per lane,
-//     1 KiB contiguous per wave load), prefetched one (dz,dy) row = 5 taps ahead.
+//   * filter fragments come straight from global/L2 (fragment-major layout: each 32 x KC tile is
+//     1 KiB contiguous = one fully coalesced wave load), prefetched one (dz,dy) row = 5 taps ahead.
 //   * epilogue: the 32x32 accumulator tile holds 4 consecutive output channels per lane per
 //     register quad -> 8-byte (bf16) / 16-byte (f32) channel-contiguous stores.
 #include "common.h"
@@ -105,8 +105,11 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
 
   const int slot = a.sample_slot[n];
   const T* __restrict__ xn = static_cast<const T*>(a.x) + (size_t)n * D * H * W * Cin;
+  // filter layout (fragment-major): [slot][tap][co tile (32)][ci chunk (KC)][32][KC]; a lane's 16 bytes
+  // of an A fragment are bytes [16 lane, 16 lane + 16) of the 1 KiB tile
   const T* __restrict__ wsl = static_cast<const T*>(a.w) + (size_t)slot * REPMODE_TAPS * CoutP * CinP;
   const size_t tap_stride = (size_t)CoutP * CinP;
+  const int nkc = CinP / KC, nrt = CoutP / 32;
 
   // halo index of this lane's voxel in each of its voxel sub-tiles (tap (0,0,0))
   int vbase[VW];
@@ -120,9 +123,9 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   const T* wrow[CW];
 #pragma unroll
   for (int cs = 0; cs < CW; ++cs) {
-    // rows beyond CoutP (tile wider than the filter) are clamped; their results are never stored
-    const int co = min(cot * C::COT + (wc * CW + cs) * 32 + l31, CoutP - 1);
-    wrow[cs] = wsl + (size_t)co * CinP + khalf * KV;
+    // row tiles beyond CoutP (block tile wider than the filter) are clamped; their results are never stored
+    const int rt = min(cot * (C::COT / 32) + wc * CW + cs, nrt - 1);
+    wrow[cs] = wsl + (size_t)rt * nkc * (32 * KC) + l31 * KC + khalf * KV;
   }
 
   // taps whose input plane/row lies outside the volume for every voxel of the brick are skipped
@@ -187,28 +190,40 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
     // row (5 taps) ahead when one channel sub-tile is held (CW == 1), one tap ahead otherwise
     // (register budget: two waves per SIMD must fit, i.e. <= 256 VGPR+AGPR).
     auto wfrag = [&](int cs, int tap) -> u32x4 {
-      return *reinterpret_cast<const u32x4*>(wrow[cs] + (size_t)tap * tap_stride + ci0);
+      return *reinterpret_cast<const u32x4*>(wrow[cs] + (size_t)tap * tap_stride + (size_t)chunk * (32 * KC));
     };
     int dz = dz_lo, dy = dy_lo;
     if constexpr (CW == 1) {
       u32x4 a_cur[5], a_nxt[5];
 #pragma unroll
       for (int dx = 0; dx < 5; ++dx) a_cur[dx] = wfrag(0, (dz * 5 + dy) * 5 + dx);
+      // voxel fragments are double-buffered one tap ahead so that the LDS latency of tap t+1 hides
+      // under the MFMAs of tap t
+      u32x4 b_cur[VW], b_nxt[VW];
+      {
+        const int rowoff0 = (dz * BYH + dy) * BXH;
+#pragma unroll
+        for (int vs = 0; vs < VW; ++vs) b_cur[vs] = lds[vbase[vs] + rowoff0];
+      }
       for (int row = 0; row < nrows; ++row) {
         int dzn = dz, dyn = dy + 1;
         if (dyn > dy_hi) { dyn = dy_lo; dzn = dz + 1; }
-        if (row + 1 < nrows) {
+        const bool more = row + 1 < nrows;
+        if (more) {
 #pragma unroll
           for (int dx = 0; dx < 5; ++dx) a_nxt[dx] = wfrag(0, (dzn * 5 + dyn) * 5 + dx);
         }
         const int rowoff = (dz * BYH + dy) * BXH;
+        const int rowoff_n = more ? (dzn * BYH + dyn) * BXH : rowoff;
 #pragma unroll
         for (int dx = 0; dx < 5; ++dx) {
-          u32x4 b[VW];
+          const int offn = (dx < 4) ? rowoff + dx + 1 : rowoff_n;
 #pragma unroll
-          for (int vs = 0; vs < VW; ++vs) b[vs] = lds[vbase[vs] + rowoff + dx];
+          for (int vs = 0; vs < VW; ++vs) b_nxt[vs] = lds[vbase[vs] + offn];
 #pragma unroll
-          for (int vs = 0; vs < VW; ++vs) Elem<T>::mma(a_cur[dx], b[vs], acc[0][vs]);
+          for (int vs = 0; vs < VW; ++vs) Elem<T>::mma(a_cur[dx], b_cur[vs], acc[0][vs]);
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) b_cur[vs] = b_nxt[vs];
         }
 #pragma unroll
         for (int dx = 0; dx < 5; ++dx) a_cur[dx] = a_nxt[dx];
@@ -219,27 +234,37 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
       u32x4 a_cur[CW], a_nxt[CW];
 #pragma unroll
       for (int cs = 0; cs < CW; ++cs) a_cur[cs] = wfrag(cs, (dz * 5 + dy) * 5);
+      u32x4 b_cur[VW], b_nxt[VW];
+      {
+        const int rowoff0 = (dz * BYH + dy) * BXH;
+#pragma unroll
+        for (int vs = 0; vs < VW; ++vs) b_cur[vs] = lds[vbase[vs] + rowoff0];
+      }
       for (int row = 0; row < nrows; ++row) {
         int dzn = dz, dyn = dy + 1;
         if (dyn > dy_hi) { dyn = dy_lo; dzn = dz + 1; }
+        const bool more = row + 1 < nrows;
         const int rowoff = (dz * BYH + dy) * BXH;
+        const int rowoff_n = more ? (dzn * BYH + dyn) * BXH : rowoff;
         const int tap0 = (dz * 5 + dy) * 5;
         // the tap after dx = 4 is the first tap of the next row (clamped on the last row: harmless reload)
-        const int tap_next_row = (row + 1 < nrows) ? (dzn * 5 + dyn) * 5 : tap0;
+        const int tap_next_row = more ? (dzn * 5 + dyn) * 5 : tap0;
 #pragma unroll
         for (int dx = 0; dx < 5; ++dx) {
           const int tapn = (dx < 4) ? tap0 + dx + 1 : tap_next_row;
+          const int offn = (dx < 4) ? rowoff + dx + 1 : rowoff_n;
 #pragma unroll
           for (int cs = 0; cs < CW; ++cs) a_nxt[cs] = wfrag(cs, tapn);
-          u32x4 b[VW];
 #pragma unroll
-          for (int vs = 0; vs < VW; ++vs) b[vs] = lds[vbase[vs] + rowoff + dx];
+          for (int vs = 0; vs < VW; ++vs) b_nxt[vs] = lds[vbase[vs] + offn];
 #pragma unroll
           for (int cs = 0; cs < CW; ++cs)
 #pragma unroll
-            for (int vs = 0; vs < VW; ++vs) Elem<T>::mma(a_cur[cs], b[vs], acc[cs][vs]);
+            for (int vs = 0; vs < VW; ++vs) Elem<T>::mma(a_cur[cs], b_cur[vs], acc[cs][vs]);
 #pragma unroll
           for (int cs = 0; cs < CW; ++cs) a_cur[cs] = a_nxt[cs];
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) b_cur[vs] = b_nxt[vs];
         }
         dz = dzn;
         dy = dyn;

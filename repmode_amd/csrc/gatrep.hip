@@ -4,8 +4,8 @@
 // over experts), :165-169 / :173-180 (expert padding, avg-pool-as-kernel) and :182-190 (the
 // per-sample weighted sum).  The merged filter depends on the task only, so it is produced once
 // per distinct task ("slot") of the batch, directly in the layouts the conv kernels read:
-//   wf[slot][tap][CoP][CiP]        forward filter
-//   wd[slot][124-tap][CiP][CoP]    data-gradient filter (taps flipped, channels transposed)
+//   wf[slot][tap][co tile][ci chunk][32][KC]        forward filter (fragment-major, see below)
+//   wd[slot][124-tap][ci tile][co chunk][32][KC]    data-gradient filter (taps flipped, channels transposed)
 // Memory-bound: reads 155 expert floats, writes 125 (x2) merged elements per (co, ci) per slot.
 //
 // Backward is the autograd of the same lines: expert gradients, gate-probability gradients
@@ -52,78 +52,101 @@ __device__ __forceinline__ bool in_centre3(int tap, int& t3) {
   return in;
 }
 
-// Forward merge.  The expert tensors are [co][ci][taps] (taps contiguous) while the conv kernels want
-// [tap][row][reduction] (channels contiguous), so a workgroup stages a 32-channel x 125-tap slab of
-// every expert in LDS with coalesced reads and writes it back transposed, merged, for every slot:
-//   WRITE_WD == false: block = (one co, 32 ci)  -> wf[s][tap][co][ci0..ci0+31]
-//   WRITE_WD == true : block = (32 co, one ci)  -> wd[s][124-tap][ci][co0..co0+31]
-// Lanes run along the 32-channel axis of the slab in both the LDS reads (stride 125 floats: odd, so
-// conflict-free) and the global writes (contiguous).  Padded rows/columns are pre-zeroed by the host.
-constexpr int GF_CT = 32;      // channels per slab
-constexpr int GF_THREADS = 256;
+// Forward merge into the conv kernels' FRAGMENT-MAJOR filter layout:
+//
+//     w[slot][tap][row tile (32 rows)][reduction chunk (KC)][row % 32][red % KC]
+//
+// i.e. every 32 x KC tile one MFMA "A" fragment load reads is 1 KiB contiguous (KC = 16 bf16 / 8 f32
+// reduction channels; lane l of the conv kernel reads bytes [16 l, 16 l + 16) of it).  For the forward
+// filter wf rows = co, reduction = ci; for the data-gradient filter wd rows = ci, reduction = co and
+// the taps are flipped.  The expert tensors are [co][ci][taps] (taps contiguous), so a workgroup owns
+// one tile, walks it in 8 groups of 4 rows, stages the 4 x KC x 125 expert values of a group in LDS
+// (coalesced reads along taps) and writes the merged values of every slot with lanes running along
+// the tile's memory order (4 * KC contiguous elements per tap).  The grid covers the padded tensor,
+// so padding is written as zeros here (no memset).
+template <typename T>
+struct FragGeom {
+  static constexpr int KC = 32 / sizeof(T);      // 16 (bf16) / 8 (f32): reduction channels per chunk
+  static constexpr int PAIRS = 4 * KC;           // (row, red) pairs per group
+  static constexpr int TQ = 256 / PAIRS;         // tap phases
+};
 
 template <typename T, bool WRITE_WD>
-__global__ __launch_bounds__(GF_THREADS) void gatrep_fwd_kernel(
+__global__ __launch_bounds__(256) void gatrep_fwd_kernel(
     const float* __restrict__ k5, const float* __restrict__ k3, const float* __restrict__ k1,
     const float* __restrict__ a3, const float* __restrict__ a5, const float* __restrict__ g, int nslots,
-    int co_n, int ci_n, int rows_p, int red_p, T* __restrict__ wout) {
-  // rows_p / red_p: padded extents of the output's row and reduction (fastest) dimensions
-  __shared__ float s5[GF_CT * TAPS];
-  __shared__ float s3[GF_CT * 27];
-  __shared__ float s1[GF_CT], sa3[GF_CT], sa5[GF_CT];
+    int co_n, int ci_n, int nrt, int nkc, T* __restrict__ wout) {
+  using G = FragGeom<T>;
+  constexpr int KC = G::KC, PAIRS = G::PAIRS, TQ = G::TQ;
+  __shared__ float s5[PAIRS * TAPS];
+  __shared__ float s3[PAIRS * 27];
+  __shared__ float s1[PAIRS], sa3[PAIRS], sa5[PAIRS];
   const int tid = threadIdx.x;
-  // slab: `fixed` is the single channel of the other kind, c0 the first of the 32 slab channels
-  const int fixed = blockIdx.y;
-  const int c0 = blockIdx.x * GF_CT;
-  const int slab_n = WRITE_WD ? co_n : ci_n;          // extent of the slab axis
-  const int nlive = min(GF_CT, slab_n - c0);
-  // element (co, ci) of slab channel c:  wf: (fixed, c0 + c)   wd: (c0 + c, fixed)
-  auto oi_of = [&](int c) -> size_t {
-    return WRITE_WD ? (size_t)(c0 + c) * ci_n + fixed : (size_t)fixed * ci_n + c0 + c;
-  };
-  if (!WRITE_WD) {
-    // the 32 x 125 (and 32 x 27) floats are contiguous in memory
-    const size_t base = oi_of(0);
-    for (int i = tid; i < nlive * TAPS; i += GF_THREADS) s5[i] = k5[base * TAPS + i];
-    for (int i = tid; i < nlive * 27; i += GF_THREADS) s3[i] = k3[base * 27 + i];
-  } else {
-    for (int i = tid; i < nlive * TAPS; i += GF_THREADS) s5[i] = k5[oi_of(i / TAPS) * TAPS + i % TAPS];
-    for (int i = tid; i < nlive * 27; i += GF_THREADS) s3[i] = k3[oi_of(i / 27) * 27 + i % 27];
-  }
-  if (tid < nlive) {
-    const size_t oi = oi_of(tid);
-    s1[tid] = k1[oi];
-    sa3[tid] = a3[oi] * (1.0f / 27.0f);
-    sa5[tid] = a5[oi] * (1.0f / 125.0f);
-  }
-  __syncthreads();
-  const int c = tid & (GF_CT - 1);          // slab channel of this thread (fixed: 256 % 32 == 0)
-  const int tq = tid / GF_CT;               // 0..7: taps tq, tq+8, ...
-  if (c >= nlive) return;
-  const size_t slot_stride = (size_t)TAPS * rows_p * red_p;
-  const int co = WRITE_WD ? c0 + c : fixed;
-  for (int tap = tq; tap < TAPS; tap += GF_THREADS / GF_CT) {
-    int t3;
-    const bool c3 = in_centre3(tap, t3);
-    const float v0 = s5[c * TAPS + tap];
-    const float v1 = c3 ? s3[c * 27 + t3] : 0.f;
-    const float v2 = (tap == 62) ? s1[c] : 0.f;
-    const float v3 = c3 ? sa3[c] : 0.f;
-    const float v4 = sa5[c];
-    // wf: [tap][co = fixed][ci = c0 + c]      wd: [124 - tap][ci = fixed][co = c0 + c]
-    const size_t off = WRITE_WD ? ((size_t)(TAPS - 1 - tap) * rows_p + fixed) * red_p + c0 + c
-                                : ((size_t)tap * rows_p + fixed) * red_p + c0 + c;
-    for (int s = 0; s < nslots; ++s) {
-      const float* gs = g + (size_t)s * E * co_n + co;
-      // same association order as RepMode.py:184-188: ((((g0 k5 + g1 k3) + g2 k1) + g3 a3) + g4 a5)
-      float r = gs[0] * v0 + gs[co_n] * v1;
-      r = r + gs[2 * co_n] * v2;
-      r = r + gs[3 * co_n] * v3;
-      r = r + gs[4 * co_n] * v4;
-      wout[s * slot_stride + off] = from_f32<T>(r);
+  const int kc = blockIdx.x, rt = blockIdx.y;
+  const int pr = tid % PAIRS, tq = tid / PAIRS;        // this thread's pair (memory order of the tile) and tap phase
+  const int r4 = pr / KC, k = pr % KC;
+  const size_t tile_elems = 32 * KC;
+  const size_t tap_stride = (size_t)nrt * nkc * tile_elems;
+  const size_t slot_stride = (size_t)TAPS * tap_stride;
+  for (int grp = 0; grp < 8; ++grp) {
+    __syncthreads();
+    // ---- stage the group's expert values; index i runs in MEMORY order of the expert tensors
+    for (int i = tid; i < PAIRS * TAPS; i += 256) {
+      const int pm = i / TAPS, tap = i - pm * TAPS;
+      // memory-order pair -> (row4, red): wf: pairs of one row are contiguous along ci; wd: along ci too
+      const int rr = WRITE_WD ? pm % 4 : pm / KC;
+      const int kk = WRITE_WD ? pm / 4 : pm % KC;
+      const int row = rt * 32 + grp * 4 + rr, red = kc * KC + kk;
+      const int co = WRITE_WD ? red : row, ci = WRITE_WD ? row : red;
+      s5[(rr * KC + kk) * TAPS + tap] = (co < co_n && ci < ci_n) ? k5[((size_t)co * ci_n + ci) * TAPS + tap] : 0.f;
+    }
+    for (int i = tid; i < PAIRS * 27; i += 256) {
+      const int pm = i / 27, t3 = i - pm * 27;
+      const int rr = WRITE_WD ? pm % 4 : pm / KC;
+      const int kk = WRITE_WD ? pm / 4 : pm % KC;
+      const int row = rt * 32 + grp * 4 + rr, red = kc * KC + kk;
+      const int co = WRITE_WD ? red : row, ci = WRITE_WD ? row : red;
+      s3[(rr * KC + kk) * 27 + t3] = (co < co_n && ci < ci_n) ? k3[((size_t)co * ci_n + ci) * 27 + t3] : 0.f;
+    }
+    const int row = rt * 32 + grp * 4 + r4, red = kc * KC + k;
+    const int co = WRITE_WD ? red : row, ci = WRITE_WD ? row : red;
+    const bool live = co < co_n && ci < ci_n;
+    if (tq == 0) {
+      const size_t oi = live ? (size_t)co * ci_n + ci : 0;
+      s1[pr] = live ? k1[oi] : 0.f;
+      sa3[pr] = live ? a3[oi] * (1.0f / 27.0f) : 0.f;
+      sa5[pr] = live ? a5[oi] * (1.0f / 125.0f) : 0.f;
+    }
+    __syncthreads();
+    const size_t in_tile = (size_t)(grp * 4 + r4) * KC + k;
+    for (int tap = tq; tap < TAPS; tap += TQ) {
+      int t3;
+      const bool c3 = in_centre3(tap, t3);
+      const float v0 = s5[pr * TAPS + tap];
+      const float v1 = c3 ? s3[pr * 27 + t3] : 0.f;
+      const float v2 = (tap == 62) ? s1[pr] : 0.f;
+      const float v3 = c3 ? sa3[pr] : 0.f;
+      const float v4 = sa5[pr];
+      const int tap_out = WRITE_WD ? TAPS - 1 - tap : tap;
+      const size_t off = (size_t)tap_out * tap_stride + ((size_t)rt * nkc + kc) * tile_elems + in_tile;
+      for (int s = 0; s < nslots; ++s) {
+        float r = 0.f;
+        if (live) {
+          const float* gs = g + (size_t)s * E * co_n + co;
+          // same association order as RepMode.py:184-188: ((((g0 k5 + g1 k3) + g2 k1) + g3 a3) + g4 a5)
+          r = gs[0] * v0 + gs[co_n] * v1;
+          r = r + gs[2 * co_n] * v2;
+          r = r + gs[3 * co_n] * v3;
+          r = r + gs[4 * co_n] * v4;
+        }
+        wout[s * slot_stride + off] = from_f32<T>(r);
+      }
     }
   }
 }
+
+constexpr int GF_CT = 32;      // channels per slab (backward kernel)
+constexpr int GF_THREADS = 256;
 
 // Expert gradients and gate-probability gradients from the per-slot filter gradient dw[s][tap][co][ci].
 // Block = (one co, 32 ci); thread = (ci = tid % 32, taps tid / 32 + 8k).  Reads of dw are 128-byte
@@ -265,24 +288,20 @@ extern "C" int repmode_gate_softmax(const float* gate_w, const float* gate_b, co
 template <typename T>
 static int gatrep_fwd_t(const float* k5, const float* k3, const float* k1, const float* a3, const float* a5,
                         const float* g, int nslots, int co, int ci, int dtype, void* wf, void* wd, hipStream_t s) {
+  constexpr int KC = FragGeom<T>::KC;
   // algorithmic bytes: 155 expert floats read once + 125 merged elements written per slot and layout
   const double bytes = (double)co * ci * (155.0 * 4 + 125.0 * nslots * sizeof(T) * ((wf ? 1 : 0) + (wd ? 1 : 0)));
   repmode_prof_begin(REPMODE_PROF_GATREP_FWD, bytes, s);
-  if (wf) {
-    // wf[tap][CoP rows (mult of 32)][CiP reduction]
-    const int cop = repmode_padded_channels(co, dtype, 0), cip = repmode_padded_channels(ci, dtype, 1);
-    if (cop != co || cip != ci) RM_HIP(hipMemsetAsync(wf, 0, (size_t)nslots * TAPS * cop * cip * sizeof(T), s));
-    hipLaunchKernelGGL((gatrep_fwd_kernel<T, false>), dim3(ceil_div(ci, GF_CT), co), dim3(GF_THREADS), 0, s, k5, k3,
-                       k1, a3, a5, g, nslots, co, ci, cop, cip, static_cast<T*>(wf));
+  if (wf) {   // rows = co (padded to 32), reduction = ci (padded to KC)
+    const int nrt = repmode_padded_channels(co, dtype, 0) / 32, nkc = repmode_padded_channels(ci, dtype, 1) / KC;
+    hipLaunchKernelGGL((gatrep_fwd_kernel<T, false>), dim3(nkc, nrt), dim3(256), 0, s, k5, k3, k1, a3, a5, g, nslots,
+                       co, ci, nrt, nkc, static_cast<T*>(wf));
     RM_LAUNCH_CHECK("gatrep_fwd(wf)");
   }
-  if (wd) {
-    // wd[124-tap][CiP' rows (mult of 32)][CoP' reduction]: the data-gradient conv swaps the roles of
-    // the two channel counts, so each is padded for its role there
-    const int cop = repmode_padded_channels(co, dtype, 1), cip = repmode_padded_channels(ci, dtype, 0);
-    if (cop != co || cip != ci) RM_HIP(hipMemsetAsync(wd, 0, (size_t)nslots * TAPS * cop * cip * sizeof(T), s));
-    hipLaunchKernelGGL((gatrep_fwd_kernel<T, true>), dim3(ceil_div(co, GF_CT), ci), dim3(GF_THREADS), 0, s, k5, k3,
-                       k1, a3, a5, g, nslots, co, ci, cip, cop, static_cast<T*>(wd));
+  if (wd) {   // rows = ci (padded to 32), reduction = co (padded to KC), taps flipped
+    const int nrt = repmode_padded_channels(ci, dtype, 0) / 32, nkc = repmode_padded_channels(co, dtype, 1) / KC;
+    hipLaunchKernelGGL((gatrep_fwd_kernel<T, true>), dim3(nkc, nrt), dim3(256), 0, s, k5, k3, k1, a3, a5, g, nslots,
+                       co, ci, nrt, nkc, static_cast<T*>(wd));
     RM_LAUNCH_CHECK("gatrep_fwd(wd)");
   }
   repmode_prof_end(s);
