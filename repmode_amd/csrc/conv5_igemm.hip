@@ -56,7 +56,7 @@ struct ConvArgs {
   void* y;
   int N, D, H, W, Cin, Cout, CinP, CoutP;
   int nbz, nby, nbx, ncot, ksplit;
-  int out_f32;  // 0: store as T; 1: float output (atomicAdd when ksplit > 1)
+  int out_f32;  // 0: store as T; 1: float output (SWAP kernels; atomicAdd when ksplit > 1)
 };
 
 // Tile configuration.  BZ*BY*BX output voxels = 32 * WV * VW; 32 * WC * CW output channels.
@@ -75,7 +75,13 @@ struct Cfg {
   static_assert(NV == 32 * WV * VW, "voxel tile must be WV*VW MFMA columns blocks");
 };
 
-template <typename T, typename C>
+// SWAP selects the MFMA operand roles.  false: A = filter rows, B = voxels -> a lane ends up with 4
+// consecutive output channels of one voxel per register quad (8/16-byte channel-contiguous stores; used
+// for the element-typed output).  true: A = voxels, B = filter rows -> a lane holds ONE output channel
+// for 16 voxels, so the 32 lanes of a half-wave cover 32 consecutive channels of a voxel: 128-byte
+// contiguous float stores / atomics (used for the float output, in particular the split-K atomics,
+// which otherwise touch one cache line per lane).
+template <typename T, typename C, bool SWAP>
 __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   constexpr int KV = Elem<T>::KV;
   constexpr int KC = 2 * KV;
@@ -221,7 +227,10 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
 #pragma unroll
           for (int vs = 0; vs < VW; ++vs) b_nxt[vs] = lds[vbase[vs] + offn];
 #pragma unroll
-          for (int vs = 0; vs < VW; ++vs) Elem<T>::mma(a_cur[dx], b_cur[vs], acc[0][vs]);
+          for (int vs = 0; vs < VW; ++vs) {
+            if constexpr (SWAP) Elem<T>::mma(b_cur[vs], a_cur[dx], acc[0][vs]);
+            else Elem<T>::mma(a_cur[dx], b_cur[vs], acc[0][vs]);
+          }
 #pragma unroll
           for (int vs = 0; vs < VW; ++vs) b_cur[vs] = b_nxt[vs];
         }
@@ -260,7 +269,10 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
 #pragma unroll
           for (int cs = 0; cs < CW; ++cs)
 #pragma unroll
-            for (int vs = 0; vs < VW; ++vs) Elem<T>::mma(a_cur[cs], b_cur[vs], acc[cs][vs]);
+            for (int vs = 0; vs < VW; ++vs) {
+              if constexpr (SWAP) Elem<T>::mma(b_cur[vs], a_cur[cs], acc[cs][vs]);
+              else Elem<T>::mma(a_cur[cs], b_cur[vs], acc[cs][vs]);
+            }
 #pragma unroll
           for (int cs = 0; cs < CW; ++cs) a_cur[cs] = a_nxt[cs];
 #pragma unroll
@@ -272,57 +284,64 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
     }
   }
 
-  // ---- epilogue.  32x32 C/D layout: column (voxel) = lane & 31, row (channel) =
-  // (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-#pragma unroll
-  for (int vs = 0; vs < VW; ++vs) {
-    const int m = (wv * VW + vs) * 32 + l31;
-    const int lx = m % BX, ly = (m / BX) % BY, lz = m / (BX * BY);
-    const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
-    if (gz >= D || gy >= H || gx >= W) continue;
-    const size_t vox = ((size_t)(n * D + gz) * H + gy) * W + gx;
+  // ---- epilogue.  32x32 C/D layout: column j = lane & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  if constexpr (SWAP) {
+    // rows = voxels, column = this lane's output channel; float output (store, or atomicAdd for split-K)
 #pragma unroll
     for (int cs = 0; cs < CW; ++cs) {
+      const int co = cot * C::COT + (wc * CW + cs) * 32 + l31;
+      if (co >= Cout) continue;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = cot * C::COT + (wc * CW + cs) * 32 + 8 * q + 4 * khalf;
-        if (co >= Cout) continue;
-        const float v0 = acc[cs][vs][4 * q + 0], v1 = acc[cs][vs][4 * q + 1];
-        const float v2 = acc[cs][vs][4 * q + 2], v3 = acc[cs][vs][4 * q + 3];
-        if (a.out_f32) {
-          float* yp = static_cast<float*>(a.y) + vox * Cout + co;
-          if (a.ksplit > 1) {
-            unsafeAtomicAdd(yp, v0);
-            if (co + 1 < Cout) unsafeAtomicAdd(yp + 1, v1);
-            if (co + 2 < Cout) unsafeAtomicAdd(yp + 2, v2);
-            if (co + 3 < Cout) unsafeAtomicAdd(yp + 3, v3);
-          } else if ((Cout & 3) == 0) {
-            *reinterpret_cast<f32x4*>(yp) = f32x4{v0, v1, v2, v3};
+      for (int vs = 0; vs < VW; ++vs) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wv * VW + vs) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+          const int lx = m % BX, ly = (m / BX) % BY, lz = m / (BX * BY);
+          const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
+          if (gz >= D || gy >= H || gx >= W) continue;
+          float* yp = static_cast<float*>(a.y) + (((size_t)(n * D + gz) * H + gy) * W + gx) * Cout + co;
+          if (a.ksplit > 1) unsafeAtomicAdd(yp, acc[cs][vs][r]);
+          else *yp = acc[cs][vs][r];
+        }
+      }
+    }
+  } else {
+    // rows = output channels (4 consecutive per register quad), column = this lane's voxel; T output
+#pragma unroll
+    for (int vs = 0; vs < VW; ++vs) {
+      const int m = (wv * VW + vs) * 32 + l31;
+      const int lx = m % BX, ly = (m / BX) % BY, lz = m / (BX * BY);
+      const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
+      if (gz >= D || gy >= H || gx >= W) continue;
+      const size_t vox = ((size_t)(n * D + gz) * H + gy) * W + gx;
+#pragma unroll
+      for (int cs = 0; cs < CW; ++cs) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = cot * C::COT + (wc * CW + cs) * 32 + 8 * q + 4 * khalf;
+          if (co >= Cout) continue;
+          const float v0 = acc[cs][vs][4 * q + 0], v1 = acc[cs][vs][4 * q + 1];
+          const float v2 = acc[cs][vs][4 * q + 2], v3 = acc[cs][vs][4 * q + 3];
+          if constexpr (sizeof(T) == 4) {
+            float* yp = static_cast<float*>(a.y) + vox * Cout + co;
+            if ((Cout & 3) == 0) {
+              *reinterpret_cast<f32x4*>(yp) = f32x4{v0, v1, v2, v3};
+            } else {
+              yp[0] = v0;
+              if (co + 1 < Cout) yp[1] = v1;
+              if (co + 2 < Cout) yp[2] = v2;
+              if (co + 3 < Cout) yp[3] = v3;
+            }
           } else {
-            yp[0] = v0;
-            if (co + 1 < Cout) yp[1] = v1;
-            if (co + 2 < Cout) yp[2] = v2;
-            if (co + 3 < Cout) yp[3] = v3;
-          }
-        } else if constexpr (sizeof(T) == 4) {
-          float* yp = static_cast<float*>(a.y) + vox * Cout + co;
-          if ((Cout & 3) == 0) {
-            *reinterpret_cast<f32x4*>(yp) = f32x4{v0, v1, v2, v3};
-          } else {
-            yp[0] = v0;
-            if (co + 1 < Cout) yp[1] = v1;
-            if (co + 2 < Cout) yp[2] = v2;
-            if (co + 3 < Cout) yp[3] = v3;
-          }
-        } else {
-          bf16_t* yp = static_cast<bf16_t*>(a.y) + vox * Cout + co;
-          if ((Cout & 3) == 0) {
-            *reinterpret_cast<u32x2*>(yp) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
-          } else {
-            yp[0] = f32_to_bf16(v0);
-            if (co + 1 < Cout) yp[1] = f32_to_bf16(v1);
-            if (co + 2 < Cout) yp[2] = f32_to_bf16(v2);
-            if (co + 3 < Cout) yp[3] = f32_to_bf16(v3);
+            bf16_t* yp = static_cast<bf16_t*>(a.y) + vox * Cout + co;
+            if ((Cout & 3) == 0) {
+              *reinterpret_cast<u32x2*>(yp) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+            } else {
+              yp[0] = f32_to_bf16(v0);
+              if (co + 1 < Cout) yp[1] = f32_to_bf16(v1);
+              if (co + 2 < Cout) yp[2] = f32_to_bf16(v2);
+              if (co + 3 < Cout) yp[3] = f32_to_bf16(v3);
+            }
           }
         }
       }
@@ -330,25 +349,26 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   }
 }
 
-template <typename T, typename C>
+template <typename T, typename C, bool SWAP>
 int launch_cfg(ConvArgs a, hipStream_t stream) {
   a.nbz = ceil_div(a.D, C::BZ);
   a.nby = ceil_div(a.H, C::BY);
   a.nbx = ceil_div(a.W, C::BX);
   a.ncot = ceil_div(a.CoutP, C::COT);
-  // split the input-channel reduction when the grid would leave most CUs idle
+  // split the input-channel reduction (float output, f32 atomics) until the grid can fill the chip:
+  // aim at >= 4 workgroups per CU
   const int nchunks = a.CinP / (2 * Elem<T>::KV);
   long base = (long)a.N * a.nbz * a.nby * a.nbx * a.ncot;
   int ks = 1;
-  if (a.out_f32) {
-    while (ks * 2 <= nchunks && base * ks < 768 && ks < 32) ks *= 2;
+  if (SWAP) {
+    while (ks * 2 <= nchunks && base * ks < 1024 && ks < 64) ks *= 2;
   }
   a.ksplit = ks;
   const long grid = base * ks;
   RM_REQUIRE(grid > 0 && grid < (1L << 31), "conv5: grid %ld out of range", grid);
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_igemm_kernel<T, C>),
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_igemm_kernel<T, C, SWAP>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set = true;
   }
@@ -356,28 +376,24 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
     RM_HIP(hipMemsetAsync(a.y, 0, (size_t)a.N * a.D * a.H * a.W * a.Cout * sizeof(float), stream));
   }
   repmode_prof_begin(REPMODE_PROF_CONV5, 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, stream);
-  hipLaunchKernelGGL((conv5_igemm_kernel<T, C>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
   repmode_prof_end(stream);
   RM_LAUNCH_CHECK("conv5_igemm");
   return REPMODE_OK;
 }
 
 // Tile menu.           BZ BY BX  WV WC VW CW
-using CfgX32C32 = Cfg<4, 4, 32, 4, 1, 4, 1>;   // 512 voxels x 32 channels   (level 0, Cout <= 32)
-using CfgX32C64 = Cfg<4, 4, 32, 4, 1, 4, 2>;   // 512 voxels x 64 channels   (level 1)
-using CfgX16C64 = Cfg<4, 4, 16, 2, 2, 4, 1>;   // 256 voxels x 64 channels   (level 2)
-using CfgX8C64  = Cfg<4, 8, 8, 2, 2, 4, 1>;    // 256 voxels x 64 channels   (level 3)
-using CfgX4C128 = Cfg<2, 4, 4, 1, 4, 1, 1>;    // 32 voxels x 128 channels   (level 4)
+using CfgX32 = Cfg<4, 4, 32, 4, 1, 4, 1>;      // 512 voxels x 32 channels   (levels 0-1)
+using CfgX16 = Cfg<4, 4, 16, 2, 2, 4, 1>;      // 256 voxels x 64 channels   (level 2)
+using CfgX8 = Cfg<4, 8, 8, 2, 2, 4, 1>;        // 256 voxels x 64 channels   (level 3)
+using CfgX4 = Cfg<2, 4, 4, 1, 4, 1, 1>;        // 32 voxels x 128 channels   (level 4)
 
-template <typename T>
+template <typename T, bool SWAP>
 int dispatch(ConvArgs a, hipStream_t stream) {
-  if (a.W >= 32) {
-    if (a.CoutP >= 64) return launch_cfg<T, CfgX32C64>(a, stream);
-    return launch_cfg<T, CfgX32C32>(a, stream);
-  }
-  if (a.W >= 16) return launch_cfg<T, CfgX16C64>(a, stream);
-  if (a.W >= 8) return launch_cfg<T, CfgX8C64>(a, stream);
-  return launch_cfg<T, CfgX4C128>(a, stream);
+  if (a.W >= 32) return launch_cfg<T, CfgX32, SWAP>(a, stream);
+  if (a.W >= 16) return launch_cfg<T, CfgX16, SWAP>(a, stream);
+  if (a.W >= 8) return launch_cfg<T, CfgX8, SWAP>(a, stream);
+  return launch_cfg<T, CfgX4, SWAP>(a, stream);
 }
 
 }  // namespace
@@ -403,6 +419,7 @@ extern "C" int repmode_conv5(const void* x, const void* w, const int32_t* sample
   a.CoutP = repmode_padded_channels(cout, dtype, 0);
   a.out_f32 = (out_f32 != 0) || dtype == REPMODE_F32;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == REPMODE_F32) return dispatch<float>(a, s);
-  return dispatch<bf16_t>(a, s);
+  if (dtype == REPMODE_F32) return dispatch<float, true>(a, s);
+  if (a.out_f32) return dispatch<bf16_t, true>(a, s);
+  return dispatch<bf16_t, false>(a, s);
 }

@@ -67,10 +67,22 @@ __device__ __forceinline__ bool in_centre3(int tap, int& t3) {
 template <typename T>
 struct FragGeom {
   static constexpr int KC = 32 / sizeof(T);      // 16 (bf16) / 8 (f32): reduction channels per chunk
-  static constexpr int PAIRS = 4 * KC;           // (row, red) pairs per group
-  static constexpr int TQ = 256 / PAIRS;         // tap phases
+  static constexpr int PAIRS = 4 * KC;           // (row, red) pairs per group of 4 rows
+  static constexpr int TQ = 256 / (PAIRS / 2);   // tap phases (a thread owns two adjacent red channels)
 };
 
+template <typename T>
+__device__ __forceinline__ void store_pair(T* p, float a, float b);
+template <>
+__device__ __forceinline__ void store_pair<float>(float* p, float a, float b) {
+  *reinterpret_cast<f32x2*>(p) = f32x2{a, b};
+}
+template <>
+__device__ __forceinline__ void store_pair<bf16_t>(bf16_t* p, float a, float b) {
+  *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(a, b);
+}
+
+// grid = (reduction chunk, row tile, group of 4 rows); 256 threads = (PAIRS / 2 element pairs) x TQ tap phases
 template <typename T, bool WRITE_WD>
 __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
     const float* __restrict__ k5, const float* __restrict__ k3, const float* __restrict__ k1,
@@ -82,65 +94,70 @@ __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
   __shared__ float s3[PAIRS * 27];
   __shared__ float s1[PAIRS], sa3[PAIRS], sa5[PAIRS];
   const int tid = threadIdx.x;
-  const int kc = blockIdx.x, rt = blockIdx.y;
-  const int pr = tid % PAIRS, tq = tid / PAIRS;        // this thread's pair (memory order of the tile) and tap phase
-  const int r4 = pr / KC, k = pr % KC;
+  const int kc = blockIdx.x, rt = blockIdx.y, grp = blockIdx.z;
   const size_t tile_elems = 32 * KC;
   const size_t tap_stride = (size_t)nrt * nkc * tile_elems;
   const size_t slot_stride = (size_t)TAPS * tap_stride;
-  for (int grp = 0; grp < 8; ++grp) {
-    __syncthreads();
-    // ---- stage the group's expert values; index i runs in MEMORY order of the expert tensors
-    for (int i = tid; i < PAIRS * TAPS; i += 256) {
-      const int pm = i / TAPS, tap = i - pm * TAPS;
-      // memory-order pair -> (row4, red): wf: pairs of one row are contiguous along ci; wd: along ci too
-      const int rr = WRITE_WD ? pm % 4 : pm / KC;
-      const int kk = WRITE_WD ? pm / 4 : pm % KC;
-      const int row = rt * 32 + grp * 4 + rr, red = kc * KC + kk;
-      const int co = WRITE_WD ? red : row, ci = WRITE_WD ? row : red;
-      s5[(rr * KC + kk) * TAPS + tap] = (co < co_n && ci < ci_n) ? k5[((size_t)co * ci_n + ci) * TAPS + tap] : 0.f;
-    }
-    for (int i = tid; i < PAIRS * 27; i += 256) {
-      const int pm = i / 27, t3 = i - pm * 27;
-      const int rr = WRITE_WD ? pm % 4 : pm / KC;
-      const int kk = WRITE_WD ? pm / 4 : pm % KC;
-      const int row = rt * 32 + grp * 4 + rr, red = kc * KC + kk;
-      const int co = WRITE_WD ? red : row, ci = WRITE_WD ? row : red;
-      s3[(rr * KC + kk) * 27 + t3] = (co < co_n && ci < ci_n) ? k3[((size_t)co * ci_n + ci) * 27 + t3] : 0.f;
-    }
-    const int row = rt * 32 + grp * 4 + r4, red = kc * KC + k;
+  // ---- stage the group's expert values; index i runs in MEMORY order of the expert tensors
+  for (int i = tid; i < PAIRS * TAPS; i += 256) {
+    const int pm = i / TAPS, tap = i - pm * TAPS;
+    const int rr = WRITE_WD ? pm % 4 : pm / KC;
+    const int kk = WRITE_WD ? pm / 4 : pm % KC;
+    const int row = rt * 32 + grp * 4 + rr, red = kc * KC + kk;
+    const int co = WRITE_WD ? red : row, ci = WRITE_WD ? row : red;
+    s5[(rr * KC + kk) * TAPS + tap] = (co < co_n && ci < ci_n) ? k5[((size_t)co * ci_n + ci) * TAPS + tap] : 0.f;
+  }
+  for (int i = tid; i < PAIRS * 27; i += 256) {
+    const int pm = i / 27, t3 = i - pm * 27;
+    const int rr = WRITE_WD ? pm % 4 : pm / KC;
+    const int kk = WRITE_WD ? pm / 4 : pm % KC;
+    const int row = rt * 32 + grp * 4 + rr, red = kc * KC + kk;
+    const int co = WRITE_WD ? red : row, ci = WRITE_WD ? row : red;
+    s3[(rr * KC + kk) * 27 + t3] = (co < co_n && ci < ci_n) ? k3[((size_t)co * ci_n + ci) * 27 + t3] : 0.f;
+  }
+  if (tid < PAIRS) {
+    const int rr = tid / KC, kk = tid % KC;
+    const int row = rt * 32 + grp * 4 + rr, red = kc * KC + kk;
     const int co = WRITE_WD ? red : row, ci = WRITE_WD ? row : red;
     const bool live = co < co_n && ci < ci_n;
-    if (tq == 0) {
-      const size_t oi = live ? (size_t)co * ci_n + ci : 0;
-      s1[pr] = live ? k1[oi] : 0.f;
-      sa3[pr] = live ? a3[oi] * (1.0f / 27.0f) : 0.f;
-      sa5[pr] = live ? a5[oi] * (1.0f / 125.0f) : 0.f;
-    }
-    __syncthreads();
-    const size_t in_tile = (size_t)(grp * 4 + r4) * KC + k;
-    for (int tap = tq; tap < TAPS; tap += TQ) {
-      int t3;
-      const bool c3 = in_centre3(tap, t3);
-      const float v0 = s5[pr * TAPS + tap];
-      const float v1 = c3 ? s3[pr * 27 + t3] : 0.f;
-      const float v2 = (tap == 62) ? s1[pr] : 0.f;
-      const float v3 = c3 ? sa3[pr] : 0.f;
-      const float v4 = sa5[pr];
-      const int tap_out = WRITE_WD ? TAPS - 1 - tap : tap;
-      const size_t off = (size_t)tap_out * tap_stride + ((size_t)rt * nkc + kc) * tile_elems + in_tile;
-      for (int s = 0; s < nslots; ++s) {
-        float r = 0.f;
-        if (live) {
-          const float* gs = g + (size_t)s * E * co_n + co;
-          // same association order as RepMode.py:184-188: ((((g0 k5 + g1 k3) + g2 k1) + g3 a3) + g4 a5)
-          r = gs[0] * v0 + gs[co_n] * v1;
-          r = r + gs[2 * co_n] * v2;
-          r = r + gs[3 * co_n] * v3;
-          r = r + gs[4 * co_n] * v4;
-        }
-        wout[s * slot_stride + off] = from_f32<T>(r);
-      }
+    const size_t oi = live ? (size_t)co * ci_n + ci : 0;
+    s1[tid] = live ? k1[oi] : 0.f;
+    sa3[tid] = live ? a3[oi] * (1.0f / 27.0f) : 0.f;
+    sa5[tid] = live ? a5[oi] * (1.0f / 125.0f) : 0.f;
+  }
+  __syncthreads();
+  // ---- merge: this thread owns elements pr and pr + 1 (adjacent reduction channels of one row)
+  const int p2 = tid % (PAIRS / 2), tq = tid / (PAIRS / 2);
+  const int pr = 2 * p2;
+  const int r4 = pr / KC, k = pr % KC;
+  const int row = rt * 32 + grp * 4 + r4, red = kc * KC + k;
+  // gate rows: wf -> both elements share co = row; wd -> co = red, red + 1
+  const int coA = WRITE_WD ? red : row, coB = WRITE_WD ? red + 1 : row;
+  const int gA = min(coA, co_n - 1), gB = min(coB, co_n - 1);    // dead elements are zero in LDS already
+  const size_t in_tile = (size_t)(grp * 4 + r4) * KC + k;
+  for (int tap = tq; tap < TAPS; tap += TQ) {
+    int t3;
+    const bool c3 = in_centre3(tap, t3);
+    const float a0 = s5[pr * TAPS + tap], b0 = s5[(pr + 1) * TAPS + tap];
+    const float a1 = c3 ? s3[pr * 27 + t3] : 0.f, b1 = c3 ? s3[(pr + 1) * 27 + t3] : 0.f;
+    const float a2 = (tap == 62) ? s1[pr] : 0.f, b2 = (tap == 62) ? s1[pr + 1] : 0.f;
+    const float a3v = c3 ? sa3[pr] : 0.f, b3v = c3 ? sa3[pr + 1] : 0.f;
+    const float a4 = sa5[pr], b4 = sa5[pr + 1];
+    const int tap_out = WRITE_WD ? TAPS - 1 - tap : tap;
+    const size_t off = (size_t)tap_out * tap_stride + ((size_t)rt * nkc + kc) * tile_elems + in_tile;
+    for (int s = 0; s < nslots; ++s) {
+      const float* gsA = g + (size_t)s * E * co_n + gA;
+      const float* gsB = g + (size_t)s * E * co_n + gB;
+      // same association order as RepMode.py:184-188: ((((g0 k5 + g1 k3) + g2 k1) + g3 a3) + g4 a5)
+      float ra = gsA[0] * a0 + gsA[co_n] * a1;
+      ra = ra + gsA[2 * co_n] * a2;
+      ra = ra + gsA[3 * co_n] * a3v;
+      ra = ra + gsA[4 * co_n] * a4;
+      float rb = gsB[0] * b0 + gsB[co_n] * b1;
+      rb = rb + gsB[2 * co_n] * b2;
+      rb = rb + gsB[3 * co_n] * b3v;
+      rb = rb + gsB[4 * co_n] * b4;
+      store_pair<T>(wout + s * slot_stride + off, ra, rb);
     }
   }
 }
@@ -294,13 +311,13 @@ static int gatrep_fwd_t(const float* k5, const float* k3, const float* k1, const
   repmode_prof_begin(REPMODE_PROF_GATREP_FWD, bytes, s);
   if (wf) {   // rows = co (padded to 32), reduction = ci (padded to KC)
     const int nrt = repmode_padded_channels(co, dtype, 0) / 32, nkc = repmode_padded_channels(ci, dtype, 1) / KC;
-    hipLaunchKernelGGL((gatrep_fwd_kernel<T, false>), dim3(nkc, nrt), dim3(256), 0, s, k5, k3, k1, a3, a5, g, nslots,
+    hipLaunchKernelGGL((gatrep_fwd_kernel<T, false>), dim3(nkc, nrt, 8), dim3(256), 0, s, k5, k3, k1, a3, a5, g, nslots,
                        co, ci, nrt, nkc, static_cast<T*>(wf));
     RM_LAUNCH_CHECK("gatrep_fwd(wf)");
   }
   if (wd) {   // rows = ci (padded to 32), reduction = co (padded to KC), taps flipped
     const int nrt = repmode_padded_channels(ci, dtype, 0) / 32, nkc = repmode_padded_channels(co, dtype, 1) / KC;
-    hipLaunchKernelGGL((gatrep_fwd_kernel<T, true>), dim3(nkc, nrt), dim3(256), 0, s, k5, k3, k1, a3, a5, g, nslots,
+    hipLaunchKernelGGL((gatrep_fwd_kernel<T, true>), dim3(nkc, nrt, 8), dim3(256), 0, s, k5, k3, k1, a3, a5, g, nslots,
                        co, ci, nrt, nkc, static_cast<T*>(wd));
     RM_LAUNCH_CHECK("gatrep_fwd(wd)");
   }

@@ -87,7 +87,7 @@ class MoDEConv(torch.nn.Module):
         x_cl = _to_cl(x.to(dtype))
         # float output where a later stage reduces it in f32 anyway: the final layer, and the deep
         # levels whose reduction is split over workgroups (f32 atomics)
-        out_f32 = self.conv_type == 'final' or x.shape[-1] < 16
+        out_f32 = self.conv_type == 'final' or x.shape[-1] < 32
         y_cl = ops.mode_conv3d(x_cl, self.expert_conv5x5_conv, self.expert_conv3x3_conv, self.expert_conv1x1_conv,
                                self.expert_avg3x3_conv, self.expert_avg5x5_conv, self.gate.weight, self.gate.bias,
                                plan, out_f32=out_f32)

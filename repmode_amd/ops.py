@@ -145,7 +145,10 @@ class _ModeConv3d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # the filter is re-merged in the data-gradient layout instead of being kept from forward
             _, wd = gatrep_merge(k5, k3, k1, a3, a5, g, x_cl.dtype, want_wf=False, want_wd=True)
-            dx = conv5(dy, wd, plan.sample_slot, ci, out_f32=False)
+            # deep levels (small volumes) split the channel reduction over workgroups -> float output
+            dx = conv5(dy, wd, plan.sample_slot, ci, out_f32=x_cl.shape[3] < 32)
+            if dx.dtype != x_cl.dtype:
+                dx = dx.to(x_cl.dtype)
             del wd
         dw = conv5_wgrad(x_cl, dy, plan, co)
         dk5, dk3, dk1 = torch.empty_like(k5), torch.empty_like(k3), torch.empty_like(k1)
