@@ -163,11 +163,134 @@ class _ModeConv3d(torch.autograd.Function):
         return dx, dk5, dk3, dk1, da3, da5, dgw, dgb, None, None
 
 
-def mode_conv3d(x_cl, k5, k3, k1, a3, a5, gate_w, gate_b, plan, out_f32=False):
+class _SingleSlot:
+    """All samples share one filter: used when the experts themselves are the 'slots'."""
+
+    def __init__(self, n, device, slot=0):
+        self.nslots = 1
+        self.n = n
+        self.sample_slot = torch.full((n,), slot, dtype=torch.int32, device=device)
+
+
+_ONEHOT2 = {}
+
+
+def _expert_selector(co, device):
+    """g for two pseudo-slots that select the raw experts: slot 0 = conv5x5, slot 1 = zero-padded conv3x3."""
+    key = (co, str(device))
+    if key not in _ONEHOT2:
+        g = torch.zeros((2, NUM_EXPERTS, co), dtype=torch.float32, device=device)
+        g[0, 0] = 1.0
+        g[1, 1] = 1.0
+        _ONEHOT2[key] = g
+    return _ONEHOT2[key]
+
+
+def _box(x_cl, k):
+    """Zero-padded k^3 box mean of a channels-last tensor: the avg-pool experts' spatial part
+    (RepMode.py:139-142, 176-180: w1x1 * 1/k^3 broadcast over the k^3 support)."""
+    y = torch.nn.functional.avg_pool3d(x_cl.permute(0, 4, 1, 2, 3), k, stride=1, padding=k // 2,
+                                       count_include_pad=True)
+    return y.permute(0, 2, 3, 4, 1).contiguous()
+
+
+class _ModeConv3dUnmerged(torch.autograd.Function):
+    """The same MoDE block by linearity of the convolution (property 3):
+
+        y[n] = sum_e g[n, e, :] * conv(x[n], K_e)
+
+    The experts are shared by all samples, so nothing is merged per task: the 5^3 and 3^3 experts go
+    once through GatRep's layout pass as two pseudo-slots and the HIP conv kernels run them for the
+    whole batch; the three 1x1 experts (conv1x1, avg3, avg5) are plain GEMMs on x and its box means.
+    Used on the deep levels, where the weights (84 % of the network's parameters) dwarf the
+    activations and the per-task merged filters / filter gradients of the merged path are pure HBM
+    traffic (measured 10 of 25 ms per step at 8 distinct tasks).  Backward needs no per-task filter
+    gradient either: expert gradients come from the gate-scaled output gradient, gate gradients from
+    <dy, P_e>.
+    """
+
+    @staticmethod
+    def forward(ctx, x_cl, k5, k3, k1, a3, a5, gate_w, gate_b, plan):
+        _require_hip(x_cl, 'input')
+        co, ci = k5.shape[0], k5.shape[1]
+        n = x_cl.shape[0]
+        dev = x_cl.device
+        g = gate_softmax(gate_w, gate_b, plan, co)                       # [S, 5, Co]
+        gn = g.index_select(0, plan.sample_slot.long())                  # [N, 5, Co]
+        wf2, _ = gatrep_merge(k5, k3, k1, a3, a5, _expert_selector(co, dev), x_cl.dtype, want_wf=True)
+        s0, s1 = _SingleSlot(n, dev, 0), _SingleSlot(n, dev, 1)
+        p0 = conv5(x_cl, wf2, s0.sample_slot, co, out_f32=True)
+        p1 = conv5(x_cl, wf2, s1.sample_slot, co, out_f32=True)
+        xf = x_cl.float()
+        b3, b5 = _box(xf, 3), _box(xf, 5)
+        shp = p0.shape
+        p2 = (xf.reshape(-1, ci) @ k1.view(co, ci).t()).view(shp)
+        p3 = (b3.reshape(-1, ci) @ a3.view(co, ci).t()).view(shp)
+        p4 = (b5.reshape(-1, ci) @ a5.view(co, ci).t()).view(shp)
+        gv = gn.view(n, NUM_EXPERTS, 1, 1, 1, co)
+        y = gv[:, 0] * p0 + gv[:, 1] * p1 + gv[:, 2] * p2 + gv[:, 3] * p3 + gv[:, 4] * p4
+        ctx.save_for_backward(x_cl, k5, k3, k1, a3, a5, gn, b3, b5, p0, p1, p2, p3, p4)
+        ctx.plan = plan
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, k5, k3, k1, a3, a5, gn, b3, b5, p0, p1, p2, p3, p4 = ctx.saved_tensors
+        plan = ctx.plan
+        co, ci = k5.shape[0], k5.shape[1]
+        n = x_cl.shape[0]
+        dev = x_cl.device
+        dt = x_cl.dtype
+        dy = dy.float().contiguous()
+        # ---- gate: dg[n,e,o] = <dy, P_e>, softmax Jacobian, Linear grads (RepMode.py:198-200)
+        dg = torch.stack([(dy * p).sum(dim=(1, 2, 3)) for p in (p0, p1, p2, p3, p4)], dim=1)      # [N,5,Co]
+        dl = gn * (dg - (gn * dg).sum(dim=1, keepdim=True))
+        dl2 = dl.reshape(n, NUM_EXPERTS * co)
+        dgb = dl2.sum(dim=0)
+        tasks = plan.slot_task.long().index_select(0, plan.sample_slot.long())
+        dgw = torch.zeros((NUM_EXPERTS * co, plan.num_tasks), dtype=torch.float32, device=dev)
+        dgw.index_add_(1, tasks, dl2.t().contiguous())
+        # ---- gate-scaled output gradients, one per expert
+        gv = gn.view(n, NUM_EXPERTS, 1, 1, 1, co)
+        dye = [dy * gv[:, e] for e in range(NUM_EXPERTS)]
+        d0, d1 = dye[0].to(dt).contiguous(), dye[1].to(dt).contiguous()
+        s0, s1 = _SingleSlot(n, dev, 0), _SingleSlot(n, dev, 1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            _, wd2 = gatrep_merge(k5, k3, k1, a3, a5, _expert_selector(co, dev), dt, want_wf=False, want_wd=True)
+            dxf = conv5(d0, wd2, s0.sample_slot, ci, out_f32=True) + conv5(d1, wd2, s1.sample_slot, ci, out_f32=True)
+            shp = dxf.shape
+            dxf = dxf + (dye[2].reshape(-1, co) @ k1.view(co, ci)).view(shp)
+            # the zero-padded box mean is self-adjoint
+            dxf = dxf + _box((dye[3].reshape(-1, co) @ a3.view(co, ci)).view(shp), 3)
+            dxf = dxf + _box((dye[4].reshape(-1, co) @ a5.view(co, ci)).view(shp), 5)
+            dx = dxf.to(dt)
+            del wd2
+        # ---- expert gradients: filter gradients of the gate-scaled dy, all samples in one slot
+        one = _SingleSlot(n, dev, 0)
+        dw5 = conv5_wgrad(x_cl, d0, one, co)[0]                             # [125, Co, Ci]
+        dk5 = dw5.permute(1, 2, 0).reshape(k5.shape)
+        dw3 = conv5_wgrad(x_cl, d1, one, co)[0].view(5, 5, 5, co, ci)[1:4, 1:4, 1:4]
+        dk3 = dw3.permute(3, 4, 0, 1, 2).reshape(k3.shape)
+        xf = x_cl.float().reshape(-1, ci)
+        dk1 = (dye[2].reshape(-1, co).t() @ xf).view(k1.shape)
+        da3 = (dye[3].reshape(-1, co).t() @ b3.reshape(-1, ci)).view(a3.shape)
+        da5 = (dye[4].reshape(-1, co).t() @ b5.reshape(-1, ci)).view(a5.shape)
+        return dx, dk5.contiguous(), dk3.contiguous(), dk1, da3, da5, dgw, dgb, None
+
+
+def use_unmerged(x_cl, plan):
+    """Heuristic: small volumes (levels 3-4) with several distinct tasks in the batch."""
+    return plan.training and plan.nslots > 2 and x_cl.shape[3] <= 8
+
+
+def mode_conv3d(x_cl, k5, k3, k1, a3, a5, gate_w, gate_b, plan, out_f32=False, mode='auto'):
     """The MoDE block up to (not including) BN/ReLU, on a channels-last tensor.
 
     x_cl: [N, D, H, W, Ci] float32 or bfloat16 (HIP).  Expert / gate parameters: float32, the
-    reference's shapes.  Returns [N, D, H, W, Co] in x's dtype (float32 when ``out_f32``).
+    reference's shapes.  Returns [N, D, H, W, Co] in x's dtype (float32 when ``out_f32``, and always
+    float32 from the 'unmerged' formulation).  ``mode``: 'merged' (per-task GatRep + one conv), 'unmerged'
+    (per-expert convs, see _ModeConv3dUnmerged) or 'auto'.
     """
     x_cl = x_cl.contiguous()
     ps = [p.contiguous() for p in (k5, k3, k1, a3, a5, gate_w, gate_b)]
@@ -176,4 +299,8 @@ def mode_conv3d(x_cl, k5, k3, k1, a3, a5, gate_w, gate_b, plan, out_f32=False):
             raise TypeError('MoDE parameters must be float32')
     if plan.n != x_cl.shape[0]:
         raise ValueError('task plan is for %d samples, input has %d' % (plan.n, x_cl.shape[0]))
+    if mode == 'auto':
+        mode = 'unmerged' if use_unmerged(x_cl, plan) else 'merged'
+    if mode == 'unmerged':
+        return _ModeConv3dUnmerged.apply(x_cl, *ps, plan)
     return _ModeConv3d.apply(x_cl, *ps, plan, out_f32)

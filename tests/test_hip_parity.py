@@ -180,12 +180,14 @@ def nrm_err(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
+@pytest.mark.parametrize('mode', ['merged', 'unmerged'])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('ci,co,shape', [(8, 16, (4, 8, 16)), (32, 32, (4, 8, 32)), (1, 32, (8, 16, 16)),
-                                         (16, 1, (4, 8, 16)), (64, 64, (2, 4, 4))])
-def test_mode_conv3d_op(ci, co, shape, dtype):
+                                         (16, 1, (4, 8, 16)), (64, 64, (2, 4, 4)), (48, 64, (4, 8, 8))])
+def test_mode_conv3d_op(ci, co, shape, dtype, mode):
     """The fused op (gate + GatRep + conv, no BN/ReLU) forward and backward against the oracle's
-    autograd, mixed tasks with a repeated one (slot reduction)."""
+    autograd, mixed tasks with a repeated one (slot reduction); both formulations (per-task merged
+    filter / per-expert convs by linearity) must agree with the reference arithmetic."""
     ops = _ops()
     gen = torch.Generator().manual_seed(ci * 7 + co)
     ps = _rand_experts(co, ci, gen)
@@ -199,7 +201,7 @@ def test_mode_conv3d_op(ci, co, shape, dtype):
     dev = [p.to(DEV).requires_grad_(True) for p in ps]
     xd = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype).requires_grad_(True)
     plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
-    y = ops.mode_conv3d(xd, *dev, plan, out_f32=True)
+    y = ops.mode_conv3d(xd, *dev, plan, out_f32=True, mode=mode)
     (y * r.permute(0, 2, 3, 4, 1).to(DEV)).sum().backward()
     tol = 1e-4 if dtype == torch.float32 else TOL_BF16
     assert rel_err(y.detach().permute(0, 4, 1, 2, 3).cpu(), yr.detach()) < tol
