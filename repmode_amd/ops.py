@@ -189,8 +189,10 @@ def _expert_selector(co, device):
 def _box(x_cl, k):
     """Zero-padded k^3 box mean of a channels-last tensor: the avg-pool experts' spatial part
     (RepMode.py:139-142, 176-180: w1x1 * 1/k^3 broadcast over the k^3 support)."""
-    y = torch.nn.functional.avg_pool3d(x_cl.permute(0, 4, 1, 2, 3), k, stride=1, padding=k // 2,
-                                       count_include_pad=True)
+    p = k // 2
+    # explicit zero padding: avg_pool3d refuses volumes smaller than the window even when padded
+    xp = torch.nn.functional.pad(x_cl.permute(0, 4, 1, 2, 3), (p, p, p, p, p, p))
+    y = torch.nn.functional.avg_pool3d(xp, k, stride=1, padding=0)
     return y.permute(0, 2, 3, 4, 1).contiguous()
 
 
