@@ -98,6 +98,12 @@ int repmode_gatrep_bwd(const float* dw, const float* k5, const float* k3, const 
                        float* dk1, float* da3, float* da5, float* dgate_w, float* dgate_b,
                        float* dg_ws, void* stream);
 
+/* ---- box means of the avg-pool experts (RepMode.py:139-142, 161-163, 176-180): by linearity
+ * conv(x, w1x1 (x) 1/k^3) = w1x1 applied to the zero-padded k^3 box mean of x.
+ * out = box3(in3) + box5(in5); float NDHWC tensors; either input may be NULL (not both). */
+int repmode_box_sum(const float* in3, const float* in5, float* out, int n, int d, int h, int w, int c,
+                    void* stream);
+
 /* ---- measurement: per-launch HIP-event timing of the library's kernels on their own stream.
  * repmode_prof_enable(1) clears the records and starts recording, (0) stops.  repmode_prof_summary()
  * synchronises the recorded events and returns, for one kernel kind, the number of launches, the

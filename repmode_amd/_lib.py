@@ -29,6 +29,7 @@ _SIGNATURES = {
     'repmode_conv5': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_gatrep_bwd': [_P] * 8 + [_I] * 4 + [_P] * 9,
+    'repmode_box_sum': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'repmode_prof_enable': [_I],
     'repmode_prof_summary': [_I, _P, _P, _P],
     'repmode_debug_conv5_naive': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

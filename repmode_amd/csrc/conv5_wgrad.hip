@@ -30,6 +30,7 @@ struct WgradArgs {
   float* dw;
   int N, D, H, W, Cin, Cout;
   int ncot, ncit, ntiles, tiles_per_block, nchunks, nty, ntx;
+  int nslots, direct;   // direct: every workgroup owns its output completely -> plain stores, no memset
 };
 
 template <typename T>
@@ -73,11 +74,8 @@ __global__ __launch_bounds__(256) void conv5_wgrad_f32c_kernel(WgradArgs a) {
   const int dz = bid % 5;            bid /= 5;
   const int cit = bid % a.ncit;      bid /= a.ncit;
   const int cot = bid % a.ncot;
-  const int n = bid / a.ncot;
+  const int slot = bid / a.ncot;
   const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
-  const int slot = a.sample_slot[n];
-  const T* __restrict__ xn = static_cast<const T*>(a.x) + (size_t)n * D * H * W * Cin;
-  const T* __restrict__ dyn = static_cast<const T*>(a.dy) + (size_t)n * D * H * W * Cout;
   const bool vec_x = (Cin & 3) == 0, vec_dy = (Cout & 3) == 0;
 
   f32x4 acc[25];
@@ -86,6 +84,10 @@ __global__ __launch_bounds__(256) void conv5_wgrad_f32c_kernel(WgradArgs a) {
 
   const int t_begin = chunk * a.tiles_per_block;
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_block);
+  for (int n = 0; n < a.N; ++n) {
+  if (a.sample_slot[n] != slot) continue;             // the workgroup sums over the samples of its slot
+  const T* __restrict__ xn = static_cast<const T*>(a.x) + (size_t)n * D * H * W * Cin;
+  const T* __restrict__ dyn = static_cast<const T*>(a.dy) + (size_t)n * D * H * W * Cout;
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int tx = tile % a.ntx, t2 = tile / a.ntx;
     const int ty = t2 % a.nty, z = t2 / a.nty;
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(256) void conv5_wgrad_f32c_kernel(WgradArgs a) {
       }
     }
   }
+  }
   // 16x16 C/D layout: column (ci) = lane & 15, row (co) = (lane >> 4) * 4 + r
   const int ci = cit * 32 + ciq * 16 + l15;
   if (ci < Cin) {
@@ -135,7 +138,11 @@ __global__ __launch_bounds__(256) void conv5_wgrad_f32c_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = cot * 32 + cq * 16 + kq * 4 + r;
-        if (co < Cout) unsafeAtomicAdd(a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * Cin + ci, acc[t][r]);
+        if (co < Cout) {
+          float* p = a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * Cin + ci;
+          if (a.direct) *p = acc[t][r];
+          else unsafeAtomicAdd(p, acc[t][r]);
+        }
       }
     }
   }
@@ -201,11 +208,8 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
   const int dz = bid % 5;            bid /= 5;
   const int cit = bid % a.ncit;      bid /= a.ncit;
   const int cot = bid % a.ncot;
-  const int n = bid / a.ncot;
+  const int slot = bid / a.ncot;
   const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
-  const int slot = a.sample_slot[n];
-  const bf16_t* __restrict__ xn = static_cast<const bf16_t*>(a.x) + (size_t)n * D * H * W * Cin;
-  const bf16_t* __restrict__ dyn = static_cast<const bf16_t*>(a.dy) + (size_t)n * D * H * W * Cout;
   const bool vec_x = (Cin & 7) == 0, vec_dy = (Cout & 7) == 0;
 
   f32x4 acc[25];
@@ -214,6 +218,10 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
 
   const int t_begin = chunk * a.tiles_per_block;
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_block);
+  for (int n = 0; n < a.N; ++n) {
+  if (a.sample_slot[n] != slot) continue;             // the workgroup sums over the samples of its slot
+  const bf16_t* __restrict__ xn = static_cast<const bf16_t*>(a.x) + (size_t)n * D * H * W * Cin;
+  const bf16_t* __restrict__ dyn = static_cast<const bf16_t*>(a.dy) + (size_t)n * D * H * W * Cout;
   for (int tile = t_begin; tile < t_end; ++tile) {
     const int txi = tile % a.ntx, t2 = tile / a.ntx;
     const int tyi = t2 % a.nty, tzi = t2 / a.nty;
@@ -291,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
       }
     }
   }
+  }
   // 16x16 C/D layout: column (ci) = lane & 15, row (co) = (lane >> 4) * 4 + r
   const int ci = cit * 32 + ciq * 16 + l15;
   if (ci < Cin) {
@@ -300,7 +309,11 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = cot * 32 + cq * 16 + kg * 4 + r;
-        if (co < Cout) unsafeAtomicAdd(a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * Cin + ci, acc[t][r]);
+        if (co < Cout) {
+          float* p = a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * Cin + ci;
+          if (a.direct) *p = acc[t][r];
+          else unsafeAtomicAdd(p, acc[t][r]);
+        }
       }
     }
   }
@@ -311,14 +324,17 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   a.nty = ceil_div(a.H, TY);
   a.ntx = ceil_div(a.W, TX);
   a.ntiles = ceil_div(a.D, TZ) * a.nty * a.ntx;
-  const long fixed = (long)n * a.ncot * a.ncit * 5;
+  const long fixed = (long)a.nslots * a.ncot * a.ncit * 5;
   long want_chunks = (2048 + fixed - 1) / fixed;
   if (want_chunks < 1) want_chunks = 1;
   if (want_chunks > a.ntiles) want_chunks = a.ntiles;
   a.tiles_per_block = ceil_div(a.ntiles, (int)want_chunks);
   a.nchunks = ceil_div(a.ntiles, a.tiles_per_block);
+  a.direct = a.nchunks == 1;
   const long grid = fixed * a.nchunks;
   RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
+  if (!a.direct) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * REPMODE_TAPS * a.Cout * a.Cin * sizeof(float), s));
+  repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, s);
   hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX>), dim3((unsigned)grid), dim3(256), 0, s, a);
   return REPMODE_OK;
 }
@@ -337,8 +353,7 @@ extern "C" int repmode_conv5_wgrad(const void* x, const void* dy, const int32_t*
   a.N = n; a.D = d; a.H = h; a.W = wdim; a.Cin = cin; a.Cout = cout;
   a.ncot = ceil_div(cout, 32);
   a.ncit = ceil_div(cin, 32);
-  RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * REPMODE_TAPS * cout * cin * sizeof(float), s));
-  repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * d * h * wdim * (double)cin * cout * REPMODE_TAPS, s);
+  a.nslots = nslots;
   if (dtype == REPMODE_BF16) {
     RM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv5_wgrad: pointers must be 16-byte aligned");
     int rc;
@@ -351,14 +366,17 @@ extern "C" int repmode_conv5_wgrad(const void* x, const void* dy, const int32_t*
     a.nty = ceil_div(h, TY);
     a.ntx = ceil_div(wdim, TX);
     a.ntiles = d * a.nty * a.ntx;
-    const long fixed = (long)n * a.ncot * a.ncit * 5;
+    const long fixed = (long)nslots * a.ncot * a.ncit * 5;
     long want_chunks = (2048 + fixed - 1) / fixed;       // aim at >= 2048 workgroups
     if (want_chunks < 1) want_chunks = 1;
     if (want_chunks > a.ntiles) want_chunks = a.ntiles;
     a.tiles_per_block = ceil_div(a.ntiles, (int)want_chunks);
     a.nchunks = ceil_div(a.ntiles, a.tiles_per_block);
+    a.direct = a.nchunks == 1;
     const long grid = fixed * a.nchunks;
     RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
+    if (!a.direct) RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * REPMODE_TAPS * cout * cin * sizeof(float), s));
+    repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * d * h * wdim * (double)cin * cout * REPMODE_TAPS, s);
     hipLaunchKernelGGL(conv5_wgrad_f32c_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, a);
   }
   repmode_prof_end(s);

@@ -101,12 +101,13 @@ def gatrep_merge(k5, k3, k1, a3, a5, g, dtype, want_wf=True, want_wd=False):
     return wf, wd
 
 
-def conv5(x_cl, w, sample_slot, cout, out_f32=False):
+def conv5(x_cl, w, sample_slot, cout, out_f32=False, out=None):
     """y[n] = x[n] (*) w[sample_slot[n]], 5^3 'same' cross-correlation, NDHWC -- RepMode.py:204-210."""
     n, d, h, wd_, cin = x_cl.shape
     code = dtype_code(x_cl.dtype)
     out_dtype = torch.float32 if (out_f32 or x_cl.dtype == torch.float32) else x_cl.dtype
-    y = torch.empty((n, d, h, wd_, cout), dtype=out_dtype, device=x_cl.device)
+    y = out if out is not None else torch.empty((n, d, h, wd_, cout), dtype=out_dtype, device=x_cl.device)
+    assert y.dtype == out_dtype and y.is_contiguous()
     _lib.call('repmode_conv5', _ptr(x_cl), _ptr(w), _ptr(sample_slot), _ptr(y), n, d, h, wd_, cin, cout, code,
               1 if out_dtype == torch.float32 else 0, _stream())
     return y
@@ -186,14 +187,15 @@ def _expert_selector(co, device):
     return _ONEHOT2[key]
 
 
-def _box(x_cl, k):
-    """Zero-padded k^3 box mean of a channels-last tensor: the avg-pool experts' spatial part
-    (RepMode.py:139-142, 176-180: w1x1 * 1/k^3 broadcast over the k^3 support)."""
-    p = k // 2
-    # explicit zero padding: avg_pool3d refuses volumes smaller than the window even when padded
-    xp = torch.nn.functional.pad(x_cl.permute(0, 4, 1, 2, 3), (p, p, p, p, p, p))
-    y = torch.nn.functional.avg_pool3d(xp, k, stride=1, padding=0)
-    return y.permute(0, 2, 3, 4, 1).contiguous()
+def box_sum(in3=None, in5=None):
+    """box3(in3) + box5(in5): zero-padded k^3 box means of float channels-last tensors -- the avg-pool
+    experts' spatial part (RepMode.py:139-142, 176-180: w1x1 * 1/k^3 broadcast over the k^3 support)."""
+    ref = in3 if in3 is not None else in5
+    n, d, h, w, c = ref.shape
+    out = torch.empty_like(ref)
+    _lib.call('repmode_box_sum', _ptr(in3) if in3 is not None else None, _ptr(in5) if in5 is not None else None,
+              _ptr(out), n, d, h, w, c, _stream())
+    return out
 
 
 class _ModeConv3dUnmerged(torch.autograd.Function):
@@ -221,23 +223,24 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         gn = g.index_select(0, plan.sample_slot.long())                  # [N, 5, Co]
         wf2, _ = gatrep_merge(k5, k3, k1, a3, a5, _expert_selector(co, dev), x_cl.dtype, want_wf=True)
         s0, s1 = _SingleSlot(n, dev, 0), _SingleSlot(n, dev, 1)
-        p0 = conv5(x_cl, wf2, s0.sample_slot, co, out_f32=True)
-        p1 = conv5(x_cl, wf2, s1.sample_slot, co, out_f32=True)
+        d, h, w = x_cl.shape[1:4]
+        p = torch.empty((NUM_EXPERTS, n, d, h, w, co), dtype=torch.float32, device=dev)   # expert outputs P_e
+        conv5(x_cl, wf2, s0.sample_slot, co, out_f32=True, out=p[0])
+        conv5(x_cl, wf2, s1.sample_slot, co, out_f32=True, out=p[1])
         xf = x_cl.float()
-        b3, b5 = _box(xf, 3), _box(xf, 5)
-        shp = p0.shape
-        p2 = (xf.reshape(-1, ci) @ k1.view(co, ci).t()).view(shp)
-        p3 = (b3.reshape(-1, ci) @ a3.view(co, ci).t()).view(shp)
-        p4 = (b5.reshape(-1, ci) @ a5.view(co, ci).t()).view(shp)
-        gv = gn.view(n, NUM_EXPERTS, 1, 1, 1, co)
-        y = gv[:, 0] * p0 + gv[:, 1] * p1 + gv[:, 2] * p2 + gv[:, 3] * p3 + gv[:, 4] * p4
-        ctx.save_for_backward(x_cl, k5, k3, k1, a3, a5, gn, b3, b5, p0, p1, p2, p3, p4)
+        b3, b5 = box_sum(in3=xf), box_sum(in5=xf)
+        torch.mm(xf.view(-1, ci), k1.view(co, ci).t(), out=p[2].view(-1, co))
+        torch.mm(b3.view(-1, ci), a3.view(co, ci).t(), out=p[3].view(-1, co))
+        torch.mm(b5.view(-1, ci), a5.view(co, ci).t(), out=p[4].view(-1, co))
+        ge = gn.permute(1, 0, 2).reshape(NUM_EXPERTS, n, 1, 1, 1, co)    # [5, N, 1, 1, 1, Co]
+        y = (p * ge).sum(dim=0)
+        ctx.save_for_backward(x_cl, k5, k3, k1, a3, a5, gn, b3, b5, p)
         ctx.plan = plan
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x_cl, k5, k3, k1, a3, a5, gn, b3, b5, p0, p1, p2, p3, p4 = ctx.saved_tensors
+        x_cl, k5, k3, k1, a3, a5, gn, b3, b5, p = ctx.saved_tensors
         plan = ctx.plan
         co, ci = k5.shape[0], k5.shape[1]
         n = x_cl.shape[0]
@@ -245,39 +248,41 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         dt = x_cl.dtype
         dy = dy.float().contiguous()
         # ---- gate: dg[n,e,o] = <dy, P_e>, softmax Jacobian, Linear grads (RepMode.py:198-200)
-        dg = torch.stack([(dy * p).sum(dim=(1, 2, 3)) for p in (p0, p1, p2, p3, p4)], dim=1)      # [N,5,Co]
+        dg = (p * dy.unsqueeze(0)).sum(dim=(2, 3, 4)).permute(1, 0, 2)                  # [N, 5, Co]
         dl = gn * (dg - (gn * dg).sum(dim=1, keepdim=True))
         dl2 = dl.reshape(n, NUM_EXPERTS * co)
         dgb = dl2.sum(dim=0)
         tasks = plan.slot_task.long().index_select(0, plan.sample_slot.long())
         dgw = torch.zeros((NUM_EXPERTS * co, plan.num_tasks), dtype=torch.float32, device=dev)
         dgw.index_add_(1, tasks, dl2.t().contiguous())
-        # ---- gate-scaled output gradients, one per expert
-        gv = gn.view(n, NUM_EXPERTS, 1, 1, 1, co)
-        dye = [dy * gv[:, e] for e in range(NUM_EXPERTS)]
-        d0, d1 = dye[0].to(dt).contiguous(), dye[1].to(dt).contiguous()
+        # ---- gate-scaled output gradients, one per expert: dye[e] = g[n,e,:] * dy
+        ge = gn.permute(1, 0, 2).reshape(NUM_EXPERTS, n, 1, 1, 1, co)
+        dye = dy.unsqueeze(0) * ge                                                     # [5, N, D, H, W, Co]
+        d01 = dye[:2].to(dt)
         s0, s1 = _SingleSlot(n, dev, 0), _SingleSlot(n, dev, 1)
         dx = None
         if ctx.needs_input_grad[0]:
             _, wd2 = gatrep_merge(k5, k3, k1, a3, a5, _expert_selector(co, dev), dt, want_wf=False, want_wd=True)
-            dxf = conv5(d0, wd2, s0.sample_slot, ci, out_f32=True) + conv5(d1, wd2, s1.sample_slot, ci, out_f32=True)
+            dxf = conv5(d01[0], wd2, s0.sample_slot, ci, out_f32=True)
             shp = dxf.shape
-            dxf = dxf + (dye[2].reshape(-1, co) @ k1.view(co, ci)).view(shp)
+            dxf += conv5(d01[1], wd2, s1.sample_slot, ci, out_f32=True)
+            dxf.view(-1, ci).addmm_(dye[2].view(-1, co), k1.view(co, ci))
             # the zero-padded box mean is self-adjoint
-            dxf = dxf + _box((dye[3].reshape(-1, co) @ a3.view(co, ci)).view(shp), 3)
-            dxf = dxf + _box((dye[4].reshape(-1, co) @ a5.view(co, ci)).view(shp), 5)
+            t3 = (dye[3].view(-1, co) @ a3.view(co, ci)).view(shp)
+            t5 = (dye[4].view(-1, co) @ a5.view(co, ci)).view(shp)
+            dxf += box_sum(in3=t3, in5=t5)
             dx = dxf.to(dt)
             del wd2
         # ---- expert gradients: filter gradients of the gate-scaled dy, all samples in one slot
         one = _SingleSlot(n, dev, 0)
-        dw5 = conv5_wgrad(x_cl, d0, one, co)[0]                             # [125, Co, Ci]
+        dw5 = conv5_wgrad(x_cl, d01[0], one, co)[0]                        # [125, Co, Ci]
         dk5 = dw5.permute(1, 2, 0).reshape(k5.shape)
-        dw3 = conv5_wgrad(x_cl, d1, one, co)[0].view(5, 5, 5, co, ci)[1:4, 1:4, 1:4]
+        dw3 = conv5_wgrad(x_cl, d01[1], one, co)[0].view(5, 5, 5, co, ci)[1:4, 1:4, 1:4]
         dk3 = dw3.permute(3, 4, 0, 1, 2).reshape(k3.shape)
-        xf = x_cl.float().reshape(-1, ci)
-        dk1 = (dye[2].reshape(-1, co).t() @ xf).view(k1.shape)
-        da3 = (dye[3].reshape(-1, co).t() @ b3.reshape(-1, ci)).view(a3.shape)
-        da5 = (dye[4].reshape(-1, co).t() @ b5.reshape(-1, ci)).view(a5.shape)
+        xf = x_cl.float().view(-1, ci)
+        dk1 = (dye[2].view(-1, co).t() @ xf).view(k1.shape)
+        da3 = (dye[3].view(-1, co).t() @ b3.view(-1, ci)).view(a3.shape)
+        da5 = (dye[4].view(-1, co).t() @ b5.view(-1, ci)).view(a5.shape)
         return dx, dk5.contiguous(), dk3.contiguous(), dk1, da3, da5, dgw, dgb, None
 
 

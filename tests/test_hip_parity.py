@@ -302,6 +302,23 @@ def test_net_golden(dtype):
         assert rel_err(ye.cpu(), g['y_eval']) < TOL_F32
 
 
+@pytest.mark.parametrize('shape', [(2, 2, 4, 4, 64), (1, 5, 7, 9, 6), (3, 4, 8, 8, 32)])
+def test_box_sum(shape):
+    ops = _ops()
+    gen = torch.Generator().manual_seed(sum(shape))
+    a, b = torch.randn(*shape, generator=gen), torch.randn(*shape, generator=gen)
+
+    def ref_box(t, k):
+        c = t.shape[-1]
+        w = torch.ones(c, 1, k, k, k) / k ** 3
+        return torch.nn.functional.conv3d(t.permute(0, 4, 1, 2, 3), w, padding=k // 2, groups=c).permute(0, 2, 3, 4, 1)
+
+    ad, bd = a.to(DEV), b.to(DEV)
+    assert rel_err(ops.box_sum(in3=ad).cpu(), ref_box(a, 3)) < 1e-5
+    assert rel_err(ops.box_sum(in5=bd).cpu(), ref_box(b, 5)) < 1e-5
+    assert rel_err(ops.box_sum(in3=ad, in5=bd).cpu(), ref_box(a, 3) + ref_box(b, 5)) < 1e-5
+
+
 def test_cpu_tensor_fails_loudly():
     from repmode_amd import _lib
     from repmode_amd.nn_modules.RepMode import MoDEConv
