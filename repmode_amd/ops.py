@@ -232,7 +232,7 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         torch.mm(xf.view(-1, ci), k1.view(co, ci).t(), out=p[2].view(-1, co))
         torch.mm(b3.view(-1, ci), a3.view(co, ci).t(), out=p[3].view(-1, co))
         torch.mm(b5.view(-1, ci), a5.view(co, ci).t(), out=p[4].view(-1, co))
-        ge = gn.permute(1, 0, 2).reshape(NUM_EXPERTS, n, 1, 1, 1, co)    # [5, N, 1, 1, 1, Co]
+        ge = gn.permute(1, 0, 2).contiguous().view(NUM_EXPERTS, n, 1, 1, 1, co)    # [5, N, 1, 1, 1, Co]
         y = (p * ge).sum(dim=0)
         ctx.save_for_backward(x_cl, k5, k3, k1, a3, a5, gn, b3, b5, p)
         ctx.plan = plan
@@ -256,8 +256,8 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         dgw = torch.zeros((NUM_EXPERTS * co, plan.num_tasks), dtype=torch.float32, device=dev)
         dgw.index_add_(1, tasks, dl2.t().contiguous())
         # ---- gate-scaled output gradients, one per expert: dye[e] = g[n,e,:] * dy
-        ge = gn.permute(1, 0, 2).reshape(NUM_EXPERTS, n, 1, 1, 1, co)
-        dye = dy.unsqueeze(0) * ge                                                     # [5, N, D, H, W, Co]
+        ge = gn.permute(1, 0, 2).contiguous().view(NUM_EXPERTS, n, 1, 1, 1, co)
+        dye = (dy.unsqueeze(0) * ge).contiguous()                                                     # [5, N, D, H, W, Co]
         d01 = dye[:2].to(dt)
         s0, s1 = _SingleSlot(n, dev, 0), _SingleSlot(n, dev, 1)
         dx = None
