@@ -135,29 +135,31 @@ __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
   const int coA = WRITE_WD ? red : row, coB = WRITE_WD ? red + 1 : row;
   const int gA = min(coA, co_n - 1), gB = min(coB, co_n - 1);    // dead elements are zero in LDS already
   const size_t in_tile = (size_t)(grp * 4 + r4) * KC + k;
-  for (int tap = tq; tap < TAPS; tap += TQ) {
-    int t3;
-    const bool c3 = in_centre3(tap, t3);
-    const float a0 = s5[pr * TAPS + tap], b0 = s5[(pr + 1) * TAPS + tap];
-    const float a1 = c3 ? s3[pr * 27 + t3] : 0.f, b1 = c3 ? s3[(pr + 1) * 27 + t3] : 0.f;
-    const float a2 = (tap == 62) ? s1[pr] : 0.f, b2 = (tap == 62) ? s1[pr + 1] : 0.f;
-    const float a3v = c3 ? sa3[pr] : 0.f, b3v = c3 ? sa3[pr + 1] : 0.f;
-    const float a4 = sa5[pr], b4 = sa5[pr + 1];
-    const int tap_out = WRITE_WD ? TAPS - 1 - tap : tap;
-    const size_t off = (size_t)tap_out * tap_stride + ((size_t)rt * nkc + kc) * tile_elems + in_tile;
-    for (int s = 0; s < nslots; ++s) {
-      const float* gsA = g + (size_t)s * E * co_n + gA;
-      const float* gsB = g + (size_t)s * E * co_n + gB;
+  // slots outermost: the ten gate probabilities of a slot live in registers across the tap loop
+  const size_t tile_off = ((size_t)rt * nkc + kc) * tile_elems + in_tile;
+  for (int s = 0; s < nslots; ++s) {
+    const float* gsA = g + (size_t)s * E * co_n + gA;
+    const float* gsB = g + (size_t)s * E * co_n + gB;
+    const float ga0 = gsA[0], ga1 = gsA[co_n], ga2 = gsA[2 * co_n], ga3 = gsA[3 * co_n], ga4 = gsA[4 * co_n];
+    const float gb0 = gsB[0], gb1 = gsB[co_n], gb2 = gsB[2 * co_n], gb3 = gsB[3 * co_n], gb4 = gsB[4 * co_n];
+    T* wslot = wout + s * slot_stride + tile_off;
+    const float ca4 = ga4 * sa5[pr], cb4 = gb4 * sa5[pr + 1];
+    for (int tap = tq; tap < TAPS; tap += TQ) {
+      int t3;
+      const bool c3 = in_centre3(tap, t3);
       // same association order as RepMode.py:184-188: ((((g0 k5 + g1 k3) + g2 k1) + g3 a3) + g4 a5)
-      float ra = gsA[0] * a0 + gsA[co_n] * a1;
-      ra = ra + gsA[2 * co_n] * a2;
-      ra = ra + gsA[3 * co_n] * a3v;
-      ra = ra + gsA[4 * co_n] * a4;
-      float rb = gsB[0] * b0 + gsB[co_n] * b1;
-      rb = rb + gsB[2 * co_n] * b2;
-      rb = rb + gsB[3 * co_n] * b3v;
-      rb = rb + gsB[4 * co_n] * b4;
-      store_pair<T>(wout + s * slot_stride + off, ra, rb);
+      float ra = ga0 * s5[pr * TAPS + tap], rb = gb0 * s5[(pr + 1) * TAPS + tap];
+      if (c3) {
+        ra += ga1 * s3[pr * 27 + t3];
+        rb += gb1 * s3[(pr + 1) * 27 + t3];
+        if (tap == 62) { ra += ga2 * s1[pr]; rb += gb2 * s1[pr + 1]; }
+        ra += ga3 * sa3[pr];
+        rb += gb3 * sa3[pr + 1];
+      }
+      ra += ca4;
+      rb += cb4;
+      const int tap_out = WRITE_WD ? TAPS - 1 - tap : tap;
+      store_pair<T>(wslot + (size_t)tap_out * tap_stride, ra, rb);
     }
   }
 }

@@ -119,6 +119,8 @@ class Model(object):
         module = self.ddp if self.ddp is not None else self.net
         module.train()
         self.optimizer.zero_grad(set_to_none=True)
+        if torch.is_tensor(task) and not task.is_cuda:
+            task = [int(t) for t in task.tolist()]   # plain ints: DDP's input scatter would move a tensor to the GPU
         output = module(signal, task)
         loss_nomean = self.criterion(output, target)
         loss = torch.mean(loss_nomean)

@@ -347,3 +347,60 @@ def test_full_size_linearity_and_oracle_sample():
     yc = orc.conv_per_sample(crop, w1.expand(n, -1, -1, -1, -1, -1))[:, :, 2:-2, 2:-2, 2:-2]
     got = y1.permute(0, 4, 1, 2, 3)[:, :, 10:22, 18:46, 18:46].cpu()
     assert rel_err(got, yc) < TOL_BF16_ACC
+
+
+def _mc2_model(g, dtype, lr):
+    from repmode_amd.model import Model
+    m = Model(Opts(), nn_module='RepMode', lr=lr, gpu_ids=0, mult_chan=int(g['mult_chan']), dtype=dtype)
+    m.net.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('p.')})
+    return m
+
+
+def test_train_iter_matches_reference_loss_sequence():
+    """Model.do_train_iter (counterpart of fnet_model.py:96-132) reproduces the reference's 5-step Adam
+    loss sequence (golden g4, f32).  Adam amplifies summation-order noise, hence 2e-4 after 5 steps."""
+    g = load_golden('g4_train_mc2.npz')
+    m = _mc2_model(g, torch.float32, float(g['lr']))
+    tasks = torch.from_numpy(g['tasks'])
+    for s in range(len(g['losses'])):
+        out, per = m.do_train_iter(torch.from_numpy(g['xs'][s]), torch.from_numpy(g['targets'][s]), tasks, sync=True)
+        assert abs(float(m.last_loss) - g['losses'][s]) < 2e-4, s
+        assert np.allclose(per.numpy(), g['loss_per_sample'][s], atol=2e-4)
+    assert m.count_iter == 5
+
+
+def test_predict_matches_reference_blend():
+    """Model.predict (counterpart of fnet_model.py:149-223): tiling, LIFO batches, Gaussian blend."""
+    g = load_golden('g5_predict.npz')
+    from repmode_amd.model import Model
+    m = Model(Opts(), nn_module='RepMode', lr=1e-4, gpu_ids=0, mult_chan=2, dtype=torch.float32)
+    m.net.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('p.')})
+    pred = m.predict(torch.from_numpy(g['blend_signal']), torch.tensor([int(g['blend_task'])]), (16, 32, 32))
+    assert rel_err(pred, g['blend_pred']) < TOL_F32
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    g = load_golden('g4_train_mc2.npz')
+    m = _mc2_model(g, torch.float32, 1e-4)
+    path = str(tmp_path / 'ckpt' / 'model.p')
+    m.save_state(path)
+    state = torch.load(path, weights_only=False)
+    assert set(state) == {'nn_module', 'opts', 'nn_state', 'optimizer_state', 'count_iter', 'count_epoch'}
+    assert len(state['nn_state']) == 309
+    m2 = _mc2_model(g, torch.float32, 1e-4)
+    m2.load_state(path)
+    for (k, a), (_, b) in zip(m.net.state_dict().items(), m2.net.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_bf16_training_reduces_loss():
+    """End-to-end sanity of the throughput path: a few bf16 steps on a fixed batch lower the loss."""
+    g = load_golden('g4_train_mc2.npz')
+    m = _mc2_model(g, torch.bfloat16, 1e-3)
+    x, t = torch.from_numpy(g['xs'][0]), torch.from_numpy(g['targets'][0])
+    tasks = torch.from_numpy(g['tasks'])
+    losses = []
+    for _ in range(8):
+        m.do_train_iter(x, t, tasks)
+        losses.append(float(m.last_loss))
+    assert losses[-1] < losses[0] and all(np.isfinite(losses))
