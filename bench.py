@@ -152,8 +152,14 @@ def main():
             n, ms, flops = _lib.prof_summary('conv5_igemm')
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             peak = PEAK_TFLOPS[args.dtype]
+            # HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE,
+            # separate runs, gfx950 read-side correction applied by profiles/pmc_summary.py); null if not collected
+            traffic = None
+            pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+            if args.dtype == 'bf16' and b == PER_GPU_BATCH and os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get('conv5_igemm', {}).get('hbm_bytes_per_launch')
             out['roofline'] = {'kernel': 'conv5_igemm_kernel', 'bound': 'mfma', 'achieved': achieved, 'peak': peak,
-                               'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                               'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
                                'launches': n, 'avg_launch_ms': ms / max(n, 1),
                                'flops_per_launch': flops / max(n, 1)}
             out['kernels'] = kinds
