@@ -81,12 +81,24 @@ int repmode_gatrep_fwd(const float* k5, const float* k3, const float* k1, const 
 int repmode_conv5(const void* x, const void* w, const int32_t* sample_slot, void* y, int n, int d,
                   int h, int wdim, int cin, int cout, int dtype, int out_f32, void* stream);
 
+/* Same, with centre3 != 0 restricting the filter planes/rows to dz, dy in [1,3] (a filter whose support is
+ * the centred 3x3x3 -- the zero-padded conv3x3 expert of RepMode.py:174 -- skips the 80 all-zero taps). */
+int repmode_conv5_ex(const void* x, const void* w, const int32_t* sample_slot, void* y, int n, int d,
+                     int h, int wdim, int cin, int cout, int dtype, int out_f32, int centre3,
+                     void* stream);
+
 /* ---- weight gradient of the same conv (aten::convolution_backward weight grad), summed over
  * the samples of each slot:  dw[s][tap][o][i] = sum_{n in s} sum_v dy[n][v][o] * x[n][v+tap][i]
  * dw: float [nslots][125][Cout][Cin], OVERWRITTEN (zeroed inside, then accumulated). */
 int repmode_conv5_wgrad(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
                         float* dw, int n, int d, int h, int wdim, int cin, int cout, int dtype,
                         void* stream);
+
+/* Same, with centre3 != 0 computing only the filter planes dz in [1,3]; the other planes of dw are left
+ * UNTOUCHED (callers that want the gradient of a 3x3x3-support filter read the centre taps only). */
+int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
+                           float* dw, int n, int d, int h, int wdim, int cin, int cout, int dtype,
+                           int centre3, void* stream);
 
 /* ---- GatRep backward (autograd of RepMode.py:171-200): expert, gate-probability and gate
  * parameter gradients from the per-slot filter gradient.  Outputs are OVERWRITTEN.

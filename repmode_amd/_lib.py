@@ -27,7 +27,9 @@ _SIGNATURES = {
     'repmode_gate_softmax': [_P, _P, _P, _I, _I, _I, _P, _P],
     'repmode_gatrep_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     'repmode_conv5': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_conv5_ex': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_conv5_wgrad_ex': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_gatrep_bwd': [_P] * 8 + [_I] * 4 + [_P] * 9,
     'repmode_box_sum': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'repmode_prof_enable': [_I],

@@ -57,6 +57,7 @@ struct ConvArgs {
   int N, D, H, W, Cin, Cout, CinP, CoutP;
   int nbz, nby, nbx, ncot, ksplit;
   int out_f32;  // 0: store as T; 1: float output (SWAP kernels; atomicAdd when ksplit > 1)
+  int tap_lo, tap_hi;  // dz and dy are restricted to [tap_lo, tap_hi] (0..4: full filter; 1..3: a 3x3 support)
 };
 
 // Tile configuration.  BZ*BY*BX output voxels = 32 * WV * VW; 32 * WC * CW output channels.
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   }
 
   // taps whose input plane/row lies outside the volume for every voxel of the brick are skipped
-  const int dz_lo = max(0, 2 - z0 - (BZ - 1)), dz_hi = min(4, D + 1 - z0);
-  const int dy_lo = max(0, 2 - y0 - (BY - 1)), dy_hi = min(4, H + 1 - y0);
+  const int dz_lo = max(a.tap_lo, 2 - z0 - (BZ - 1)), dz_hi = min(a.tap_hi, D + 1 - z0);
+  const int dy_lo = max(a.tap_lo, 2 - y0 - (BY - 1)), dy_hi = min(a.tap_hi, H + 1 - y0);
   const int ndy = dy_hi - dy_lo + 1;
   const int nrows = (dz_hi - dz_lo + 1) * ndy;
 
@@ -375,7 +376,8 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   if (ks > 1) {
     RM_HIP(hipMemsetAsync(a.y, 0, (size_t)a.N * a.D * a.H * a.W * a.Cout * sizeof(float), stream));
   }
-  repmode_prof_begin(REPMODE_PROF_CONV5, 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, stream);
+  // algorithmic FLOPs: 125 taps, or the 27 of a 3x3x3 support when restricted
+  repmode_prof_begin(REPMODE_PROF_CONV5, 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * (a.tap_lo ? 27 : REPMODE_TAPS), stream);
   hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
   repmode_prof_end(stream);
   RM_LAUNCH_CHECK("conv5_igemm");
@@ -404,9 +406,19 @@ extern "C" int repmode_padded_channels(int channels, int dtype, int is_reduction
   return round_up(channels, dtype == REPMODE_BF16 ? 16 : 8);
 }
 
+extern "C" int repmode_conv5_ex(const void* x, const void* w, const int32_t* sample_slot, void* y, int n,
+                                int d, int h, int wdim, int cin, int cout, int dtype, int out_f32,
+                                int centre3, void* stream);
+
 extern "C" int repmode_conv5(const void* x, const void* w, const int32_t* sample_slot, void* y, int n,
                              int d, int h, int wdim, int cin, int cout, int dtype, int out_f32,
                              void* stream) {
+  return repmode_conv5_ex(x, w, sample_slot, y, n, d, h, wdim, cin, cout, dtype, out_f32, 0, stream);
+}
+
+extern "C" int repmode_conv5_ex(const void* x, const void* w, const int32_t* sample_slot, void* y, int n,
+                                int d, int h, int wdim, int cin, int cout, int dtype, int out_f32,
+                                int centre3, void* stream) {
   RM_REQUIRE(x && w && sample_slot && y, "conv5: null pointer");
   RM_REQUIRE(n > 0 && d > 0 && h > 0 && wdim > 0 && cin > 0 && cout > 0, "conv5: bad shape");
   RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "conv5: bad dtype %d", dtype);
@@ -418,6 +430,8 @@ extern "C" int repmode_conv5(const void* x, const void* w, const int32_t* sample
   a.CinP = repmode_padded_channels(cin, dtype, 1);
   a.CoutP = repmode_padded_channels(cout, dtype, 0);
   a.out_f32 = (out_f32 != 0) || dtype == REPMODE_F32;
+  a.tap_lo = centre3 ? 1 : 0;
+  a.tap_hi = centre3 ? 3 : 4;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == REPMODE_F32) return dispatch<float, true>(a, s);
   if (a.out_f32) return dispatch<bf16_t, true>(a, s);

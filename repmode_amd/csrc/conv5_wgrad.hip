@@ -30,6 +30,7 @@ struct WgradArgs {
   float* dw;
   int N, D, H, W, Cin, Cout;
   int ncot, ncit, ntiles, tiles_per_block, nchunks, nty, ntx;
+  int dz_lo, ndz;       // dz planes computed: dz_lo .. dz_lo + ndz - 1 (all five, or 1..3 for a 3x3x3 support)
   int nslots, direct;   // direct: every workgroup owns its output completely -> plain stores, no memset
 };
 
@@ -69,9 +70,11 @@ __global__ __launch_bounds__(256) void conv5_wgrad_f32c_kernel(WgradArgs a) {
   const int cq = wave & 1, ciq = wave >> 1;
   const int l15 = lane & 15, kq = lane >> 4;
 
-  int bid = blockIdx.x;
+  // the five dz workgroups of one voxel chunk read the same dy / x tiles: adjacent logical ids, and
+  // xcd_remap keeps adjacent ids on one XCD, so they share those tiles through one L2
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int dz = a.dz_lo + bid % a.ndz; bid /= a.ndz;
   const int chunk = bid % a.nchunks; bid /= a.nchunks;
-  const int dz = bid % 5;            bid /= 5;
   const int cit = bid % a.ncit;      bid /= a.ncit;
   const int cot = bid % a.ncot;
   const int slot = bid / a.ncot;
@@ -203,9 +206,11 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
   const int cq = wave & 1, ciq = wave >> 1;
   const int l15 = lane & 15, kg = lane >> 4;
 
-  int bid = blockIdx.x;
+  // the five dz workgroups of one voxel chunk read the same dy / x tiles: adjacent logical ids, and
+  // xcd_remap keeps adjacent ids on one XCD, so they share those tiles through one L2
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int dz = a.dz_lo + bid % a.ndz; bid /= a.ndz;
   const int chunk = bid % a.nchunks; bid /= a.nchunks;
-  const int dz = bid % 5;            bid /= 5;
   const int cit = bid % a.ncit;      bid /= a.ncit;
   const int cot = bid % a.ncot;
   const int slot = bid / a.ncot;
@@ -324,7 +329,7 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   a.nty = ceil_div(a.H, TY);
   a.ntx = ceil_div(a.W, TX);
   a.ntiles = ceil_div(a.D, TZ) * a.nty * a.ntx;
-  const long fixed = (long)a.nslots * a.ncot * a.ncit * 5;
+  const long fixed = (long)a.nslots * a.ncot * a.ncit * a.ndz;
   long want_chunks = (2048 + fixed - 1) / fixed;
   if (want_chunks < 1) want_chunks = 1;
   if (want_chunks > a.ntiles) want_chunks = a.ntiles;
@@ -341,9 +346,19 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
+                                      float* dw, int n, int d, int h, int wdim, int cin, int cout, int dtype,
+                                      int centre3, void* stream);
+
 extern "C" int repmode_conv5_wgrad(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
                                    float* dw, int n, int d, int h, int wdim, int cin, int cout, int dtype,
                                    void* stream) {
+  return repmode_conv5_wgrad_ex(x, dy, sample_slot, nslots, dw, n, d, h, wdim, cin, cout, dtype, 0, stream);
+}
+
+extern "C" int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
+                                      float* dw, int n, int d, int h, int wdim, int cin, int cout, int dtype,
+                                      int centre3, void* stream) {
   RM_REQUIRE(x && dy && sample_slot && dw, "conv5_wgrad: null pointer");
   RM_REQUIRE(n > 0 && nslots > 0 && d > 0 && h > 0 && wdim > 0 && cin > 0 && cout > 0, "conv5_wgrad: bad shape");
   RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "conv5_wgrad: bad dtype %d", dtype);
@@ -354,6 +369,8 @@ extern "C" int repmode_conv5_wgrad(const void* x, const void* dy, const int32_t*
   a.ncot = ceil_div(cout, 32);
   a.ncit = ceil_div(cin, 32);
   a.nslots = nslots;
+  a.dz_lo = centre3 ? 1 : 0;
+  a.ndz = centre3 ? 3 : 5;
   if (dtype == REPMODE_BF16) {
     RM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv5_wgrad: pointers must be 16-byte aligned");
     int rc;
@@ -366,7 +383,7 @@ extern "C" int repmode_conv5_wgrad(const void* x, const void* dy, const int32_t*
     a.nty = ceil_div(h, TY);
     a.ntx = ceil_div(wdim, TX);
     a.ntiles = d * a.nty * a.ntx;
-    const long fixed = (long)nslots * a.ncot * a.ncit * 5;
+    const long fixed = (long)nslots * a.ncot * a.ncit * a.ndz;
     long want_chunks = (2048 + fixed - 1) / fixed;       // aim at >= 2048 workgroups
     if (want_chunks < 1) want_chunks = 1;
     if (want_chunks > a.ntiles) want_chunks = a.ntiles;

@@ -98,22 +98,23 @@ __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
   const size_t tile_elems = 32 * KC;
   const size_t tap_stride = (size_t)nrt * nkc * tile_elems;
   const size_t slot_stride = (size_t)TAPS * tap_stride;
-  // ---- stage the group's expert values; index i runs in MEMORY order of the expert tensors
-  for (int i = tid; i < PAIRS * TAPS; i += 256) {
-    const int pm = i / TAPS, tap = i - pm * TAPS;
-    const int rr = WRITE_WD ? pm % 4 : pm / KC;
-    const int kk = WRITE_WD ? pm / 4 : pm % KC;
-    const int row = rt * 32 + grp * 4 + rr, red = kc * KC + kk;
-    const int co = WRITE_WD ? red : row, ci = WRITE_WD ? row : red;
-    s5[(rr * KC + kk) * TAPS + tap] = (co < co_n && ci < ci_n) ? k5[((size_t)co * ci_n + ci) * TAPS + tap] : 0.f;
-  }
-  for (int i = tid; i < PAIRS * 27; i += 256) {
-    const int pm = i / 27, t3 = i - pm * 27;
-    const int rr = WRITE_WD ? pm % 4 : pm / KC;
-    const int kk = WRITE_WD ? pm / 4 : pm % KC;
-    const int row = rt * 32 + grp * 4 + rr, red = kc * KC + kk;
-    const int co = WRITE_WD ? red : row, ci = WRITE_WD ? row : red;
-    s3[(rr * KC + kk) * 27 + t3] = (co < co_n && ci < ci_n) ? k3[((size_t)co * ci_n + ci) * 27 + t3] : 0.f;
+  // ---- stage the group's expert values: one wave copies one (row, red) pair's 125 + 27 contiguous
+  // floats at a time (pairs taken in MEMORY order so that consecutive pairs are adjacent in HBM)
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int pm = wave; pm < PAIRS; pm += 4) {
+      const int rr = WRITE_WD ? pm % 4 : pm / KC;
+      const int kk = WRITE_WD ? pm / 4 : pm % KC;
+      const int row = rt * 32 + grp * 4 + rr, red = kc * KC + kk;
+      const int co = WRITE_WD ? red : row, ci = WRITE_WD ? row : red;
+      const bool live = co < co_n && ci < ci_n;
+      const size_t oi = live ? (size_t)co * ci_n + ci : 0;
+      const float* src5 = k5 + oi * TAPS;
+      float* dst5 = s5 + (rr * KC + kk) * TAPS;
+      dst5[lane] = live ? src5[lane] : 0.f;
+      if (lane + 64 < TAPS) dst5[lane + 64] = live ? src5[lane + 64] : 0.f;
+      if (lane < 27) s3[(rr * KC + kk) * 27 + lane] = live ? k3[oi * 27 + lane] : 0.f;
+    }
   }
   if (tid < PAIRS) {
     const int rr = tid / KC, kk = tid % KC;

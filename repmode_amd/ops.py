@@ -101,24 +101,24 @@ def gatrep_merge(k5, k3, k1, a3, a5, g, dtype, want_wf=True, want_wd=False):
     return wf, wd
 
 
-def conv5(x_cl, w, sample_slot, cout, out_f32=False, out=None):
+def conv5(x_cl, w, sample_slot, cout, out_f32=False, out=None, centre3=False):
     """y[n] = x[n] (*) w[sample_slot[n]], 5^3 'same' cross-correlation, NDHWC -- RepMode.py:204-210."""
     n, d, h, wd_, cin = x_cl.shape
     code = dtype_code(x_cl.dtype)
     out_dtype = torch.float32 if (out_f32 or x_cl.dtype == torch.float32) else x_cl.dtype
     y = out if out is not None else torch.empty((n, d, h, wd_, cout), dtype=out_dtype, device=x_cl.device)
     assert y.dtype == out_dtype and y.is_contiguous()
-    _lib.call('repmode_conv5', _ptr(x_cl), _ptr(w), _ptr(sample_slot), _ptr(y), n, d, h, wd_, cin, cout, code,
-              1 if out_dtype == torch.float32 else 0, _stream())
+    _lib.call('repmode_conv5_ex', _ptr(x_cl), _ptr(w), _ptr(sample_slot), _ptr(y), n, d, h, wd_, cin, cout, code,
+              1 if out_dtype == torch.float32 else 0, 1 if centre3 else 0, _stream())
     return y
 
 
-def conv5_wgrad(x_cl, dy_cl, plan, cout):
+def conv5_wgrad(x_cl, dy_cl, plan, cout, centre3=False):
     """dw[s, tap, o, i] (float32) summed over the samples of each slot."""
     n, d, h, wd_, cin = x_cl.shape
     dw = torch.empty((plan.nslots, TAPS, cout, cin), dtype=torch.float32, device=x_cl.device)
-    _lib.call('repmode_conv5_wgrad', _ptr(x_cl), _ptr(dy_cl), _ptr(plan.sample_slot), plan.nslots, _ptr(dw),
-              n, d, h, wd_, cin, cout, dtype_code(x_cl.dtype), _stream())
+    _lib.call('repmode_conv5_wgrad_ex', _ptr(x_cl), _ptr(dy_cl), _ptr(plan.sample_slot), plan.nslots, _ptr(dw),
+              n, d, h, wd_, cin, cout, dtype_code(x_cl.dtype), 1 if centre3 else 0, _stream())
     return dw
 
 
@@ -226,7 +226,7 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         d, h, w = x_cl.shape[1:4]
         p = torch.empty((NUM_EXPERTS, n, d, h, w, co), dtype=torch.float32, device=dev)   # expert outputs P_e
         conv5(x_cl, wf2, s0.sample_slot, co, out_f32=True, out=p[0])
-        conv5(x_cl, wf2, s1.sample_slot, co, out_f32=True, out=p[1])
+        conv5(x_cl, wf2, s1.sample_slot, co, out_f32=True, out=p[1], centre3=True)      # 3x3x3 support
         xf = x_cl.float()
         b3, b5 = box_sum(in3=xf), box_sum(in5=xf)
         torch.mm(xf.view(-1, ci), k1.view(co, ci).t(), out=p[2].view(-1, co))
@@ -265,7 +265,7 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
             _, wd2 = gatrep_merge(k5, k3, k1, a3, a5, _expert_selector(co, dev), dt, want_wf=False, want_wd=True)
             dxf = conv5(d01[0], wd2, s0.sample_slot, ci, out_f32=True)
             shp = dxf.shape
-            dxf += conv5(d01[1], wd2, s1.sample_slot, ci, out_f32=True)
+            dxf += conv5(d01[1], wd2, s1.sample_slot, ci, out_f32=True, centre3=True)
             dxf.view(-1, ci).addmm_(dye[2].view(-1, co), k1.view(co, ci))
             # the zero-padded box mean is self-adjoint
             t3 = (dye[3].view(-1, co) @ a3.view(co, ci)).view(shp)
@@ -277,7 +277,7 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         one = _SingleSlot(n, dev, 0)
         dw5 = conv5_wgrad(x_cl, d01[0], one, co)[0]                        # [125, Co, Ci]
         dk5 = dw5.permute(1, 2, 0).reshape(k5.shape)
-        dw3 = conv5_wgrad(x_cl, d01[1], one, co)[0].view(5, 5, 5, co, ci)[1:4, 1:4, 1:4]
+        dw3 = conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0].view(5, 5, 5, co, ci)[1:4, 1:4, 1:4]
         dk3 = dw3.permute(3, 4, 0, 1, 2).reshape(k3.shape)
         xf = x_cl.float().view(-1, ci)
         dk1 = (dye[2].view(-1, co).t() @ xf).view(k1.shape)
