@@ -79,6 +79,7 @@ def main():
     ap.add_argument('--batch', type=int, default=PER_GPU_BATCH, help='patches per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events')
+    ap.add_argument('--dump-launches', default=None, help='write per-launch (kind, ms, TFLOP/s or TB/s) of the last timed step as JSON')
     args = ap.parse_args()
 
     from repmode_amd import _lib, distributed as dist_
@@ -163,6 +164,13 @@ def main():
                                'launches': n, 'avg_launch_ms': ms / max(n, 1),
                                'flops_per_launch': flops / max(n, 1)}
             out['kernels'] = kinds
+            if args.dump_launches:
+                recs = _lib.prof_records()
+                per = len(recs) // args.steps
+                last = [{'kind': k, 'us': ms * 1e3, 'rate': (w / (ms * 1e-3) / 1e12) if ms > 0 else None,
+                         'work': w} for k, ms, w in recs[-per:]]
+                with open(args.dump_launches, 'w') as f:
+                    json.dump(last, f, indent=0)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

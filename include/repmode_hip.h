@@ -110,6 +110,20 @@ int repmode_gatrep_bwd(const float* dw, const float* k5, const float* k3, const 
                        float* dk1, float* da3, float* da5, float* dgate_w, float* dgate_b,
                        float* dg_ws, void* stream);
 
+/* ---- BatchNorm3d + ReLU of the MoDE block's `subsequent_layer` (RepMode.py:146-149, :212) and of the
+ * stride-2 down/up stages (RepMode.py:80-84, 97-101), on a channels-last tensor viewed as [m][c].
+ * Training: batch mean / biased variance over the m rows, eps, running statistics updated with `momentum`
+ * and the unbiased variance; eval (training == 0): running statistics.  x has in_dtype, out has out_dtype.
+ * save_mean / save_invstd [c] and sums_ws [2c] are float outputs / workspace.  c <= 512. */
+int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float* save_mean, float* save_invstd, float* sums_ws, long m, int c,
+                        float eps, float momentum, int training, int in_dtype, int out_dtype, void* stream);
+/* Backward of the same: dx (in_dtype) from dy (out_dtype); on return sums_ws[0..c) = dbeta and
+ * sums_ws[c..2c) = dgamma. */
+int repmode_bn_relu_bwd(const void* x, const void* dy, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_invstd, void* dx, float* sums_ws, long m, int c,
+                        int training, int in_dtype, int out_dtype, void* stream);
+
 /* ---- box means of the avg-pool experts (RepMode.py:139-142, 161-163, 176-180): by linearity
  * conv(x, w1x1 (x) 1/k^3) = w1x1 applied to the zero-padded k^3 box mean of x.
  * out = box3(in3) + box5(in5); float NDHWC tensors; either input may be NULL (not both). */
@@ -127,6 +141,9 @@ int repmode_box_sum(const float* in3, const float* in5, float* out, int n, int d
 #define REPMODE_PROF_KINDS 4
 int repmode_prof_enable(int on);
 int repmode_prof_summary(int kind, int* launches, double* total_ms, double* total_work);
+/* individual records, in launch order: number of records, and the kind / duration (ms) / work of record i */
+int repmode_prof_count(void);
+int repmode_prof_record(int i, int* kind, double* ms, double* work);
 
 /* ---- diagnostics: naive one-thread-per-output direct kernels (no MFMA, no LDS).  Not on the
  * product path; used by tests to bisect a failure between tiling and arithmetic. */

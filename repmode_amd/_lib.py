@@ -31,9 +31,13 @@ _SIGNATURES = {
     'repmode_conv5_wgrad': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad_ex': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_gatrep_bwd': [_P] * 8 + [_I] * 4 + [_P] * 9,
+    'repmode_bn_relu_fwd': [_P] * 9 + [_c.c_long, _I, _c.c_float, _c.c_float, _I, _I, _I, _P],
+    'repmode_bn_relu_bwd': [_P] * 8 + [_c.c_long, _I, _I, _I, _I, _P],
     'repmode_box_sum': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'repmode_prof_enable': [_I],
     'repmode_prof_summary': [_I, _P, _P, _P],
+    'repmode_prof_count': [],
+    'repmode_prof_record': [_I, _P, _P, _P],
     'repmode_debug_conv5_naive': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_debug_wgrad_naive': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }
@@ -99,3 +103,15 @@ def prof_summary(kind):
     n, ms, work = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
     call('repmode_prof_summary', PROF_KINDS[kind], ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work))
     return n.value, ms.value, work.value
+
+
+def prof_records():
+    """[(kind_name, ms, work)] of every recorded launch, in launch order."""
+    lib = load()
+    names = {v: k for k, v in PROF_KINDS.items()}
+    out = []
+    for i in range(lib.repmode_prof_count()):
+        kind, ms, work = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
+        call('repmode_prof_record', i, ctypes.byref(kind), ctypes.byref(ms), ctypes.byref(work))
+        out.append((names[kind.value], ms.value, work.value))
+    return out

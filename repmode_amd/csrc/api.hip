@@ -95,6 +95,19 @@ extern "C" int repmode_prof_summary(int kind, int* launches, double* total_ms, d
   return REPMODE_OK;
 }
 
+extern "C" int repmode_prof_count(void) { return (int)g_prof_n; }
+
+extern "C" int repmode_prof_record(int i, int* kind, double* ms, double* work) {
+  RM_REQUIRE(kind && ms && work && i >= 0 && (size_t)i < g_prof_n, "prof_record: bad index %d", i);
+  RM_HIP(hipEventSynchronize(g_prof[i].b));
+  float t = 0.f;
+  RM_HIP(hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b));
+  *kind = g_prof[i].kind;
+  *ms = t;
+  *work = g_prof[i].work;
+  return REPMODE_OK;
+}
+
 namespace {
 
 // one thread per output element y[n][v][co]; f32 accumulate in tap-major, channel-minor order

@@ -1,0 +1,354 @@
+// bnrelu.hip -- BatchNorm3d + ReLU on channels-last activations, forward and backward.
+//
+// Replaces the `subsequent_layer` of the reference's MoDE block (fnet/nn_modules/RepMode.py:146-149, :212:
+// BatchNorm3d(Co) + ReLU(inplace), training: batch mean / biased variance over N*D*H*W per channel,
+// eps 1e-5, running statistics with momentum 0.1 and the UNBIASED variance; eval: running statistics)
+// and the identical BN+ReLU pairs behind the stride-2 down/up convolutions (RepMode.py:80-84, 97-101).
+//
+// The tensor is [M][C] (M = voxels of the whole batch, C contiguous), so a thread owns a fixed group of
+// consecutive channels (one 16-byte load per row) and strides over rows: per-channel sums stay in
+// registers, are combined per workgroup through LDS float atomics and leave the workgroup as one global
+// atomic per channel.  Four memory-bound passes per layer and step:
+//   forward : stats (read x) ; normalise + ReLU + downcast (read x, write out)
+//   backward: reduce (read x, dy) ; apply (read x, dy, write dx)
+// against the six kernels plus separate ReLU / dtype-cast passes of the stock path.
+#include "common.h"
+
+namespace {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_MAXC = 512;
+
+template <typename T>
+struct Vec;
+template <>
+struct Vec<float> {
+  static constexpr int CV = 4;
+  __device__ static __forceinline__ void load(const float* p, float* v) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ static __forceinline__ void store(float* p, const float* v) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+};
+template <>
+struct Vec<bf16_t> {
+  static constexpr int CV = 8;
+  __device__ static __forceinline__ void load(const bf16_t* p, float* v) {
+    const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[2 * k] = __uint_as_float(t[k] << 16);
+      v[2 * k + 1] = __uint_as_float(t[k] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float* v) {
+    *reinterpret_cast<u32x4*>(p) = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                         pack_bf16x2(v[6], v[7])};
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ float load1(const T* p);
+template <>
+__device__ __forceinline__ float load1<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float load1<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <typename T>
+__device__ __forceinline__ void store1(T* p, float v);
+template <>
+__device__ __forceinline__ void store1<float>(float* p, float v) { *p = v; }
+template <>
+__device__ __forceinline__ void store1<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+// generic row loader: CV consecutive channels starting at c (vector when C % CV == 0)
+template <typename T, int CV>
+__device__ __forceinline__ void load_row(const T* row, int c, int C, bool vec, float* v) {
+  if (vec) {
+    if constexpr (CV == Vec<T>::CV) {
+      Vec<T>::load(row + c, v);
+    } else {   // CV == 8 over float: two 16-byte loads
+      Vec<T>::load(row + c, v);
+      Vec<T>::load(row + c + 4, v + 4);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < CV; ++k) v[k] = (c + k < C) ? load1<T>(row + c + k) : 0.f;
+  }
+}
+template <typename T, int CV>
+__device__ __forceinline__ void store_row(T* row, int c, int C, bool vec, const float* v) {
+  if (vec) {
+    if constexpr (CV == Vec<T>::CV) {
+      Vec<T>::store(row + c, v);
+    } else {
+      Vec<T>::store(row + c, v);
+      Vec<T>::store(row + c + 4, v + 4);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < CV; ++k) if (c + k < C) store1<T>(row + c + k, v[k]);
+  }
+}
+
+// All kernels use CV = 8 channels per thread; ngroups = ceil(C / 8) threads cover a row.
+constexpr int CV = 8;
+
+struct Geom {
+  int ngroups, rows_per_iter;
+};
+__device__ __forceinline__ Geom geom(int C) {
+  Geom g;
+  g.ngroups = (C + CV - 1) / CV;
+  g.rows_per_iter = BN_THREADS / g.ngroups;
+  return g;
+}
+
+// sums[c] += sum_rows a(row, c) ; sums[C + c] += sum_rows b(row, c)
+__device__ __forceinline__ void block_commit(float* lds, const float* s, const float* ss, int c0, int C, bool active,
+                                             float* __restrict__ sums) {
+  for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) lds[i] = 0.f;
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < CV; ++k)
+      if (c0 + k < C) {
+        atomicAdd(&lds[c0 + k], s[k]);
+        atomicAdd(&lds[C + c0 + k], ss[k]);
+      }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) atomicAdd(&sums[i], lds[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restrict__ x, long M, int C,
+                                                              float* __restrict__ sums) {
+  __shared__ float lds[2 * BN_MAXC];
+  const Geom g = geom(C);
+  const int cg = threadIdx.x % g.ngroups, r0 = threadIdx.x / g.ngroups;
+  const bool active = r0 < g.rows_per_iter;
+  const int c0 = cg * CV;
+  const bool vec = (C % CV) == 0;
+  float s[CV], ss[CV];
+#pragma unroll
+  for (int k = 0; k < CV; ++k) { s[k] = 0.f; ss[k] = 0.f; }
+  if (active) {
+    for (long r = (long)blockIdx.x * g.rows_per_iter + r0; r < M; r += (long)gridDim.x * g.rows_per_iter) {
+      float v[CV];
+      load_row<T, CV>(x + r * C, c0, C, vec, v);
+#pragma unroll
+      for (int k = 0; k < CV; ++k) { s[k] += v[k]; ss[k] += v[k] * v[k]; }
+    }
+  }
+  block_commit(lds, s, ss, c0, C, active, sums);
+}
+
+// scale / shift of channel c from the batch sums (training) or the running statistics (eval)
+__device__ __forceinline__ void channel_affine(int c, const float* sums, long M, int C, const float* gamma,
+                                               const float* beta, const float* rmean, const float* rvar, float eps,
+                                               int training, float& mean, float& invstd, float& scale, float& shift) {
+  if (training) {
+    mean = sums[c] / (float)M;
+    const float var = fmaxf(sums[C + c] / (float)M - mean * mean, 0.f);
+    invstd = rsqrtf(var + eps);
+  } else {
+    mean = rmean[c];
+    invstd = rsqrtf(rvar[c] + eps);
+  }
+  scale = gamma[c] * invstd;
+  shift = beta[c] - mean * scale;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_relu_kernel(
+    const TI* __restrict__ x, TO* __restrict__ out, const float* __restrict__ sums, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, long M, int C, float eps, float momentum,
+    int training) {
+  const Geom g = geom(C);
+  const int cg = threadIdx.x % g.ngroups, r0 = threadIdx.x / g.ngroups;
+  const int c0 = cg * CV;
+  const bool vec = (C % CV) == 0;
+  float scale[CV], shift[CV];
+#pragma unroll
+  for (int k = 0; k < CV; ++k) {
+    scale[k] = 0.f; shift[k] = 0.f;
+    if (c0 + k < C) {
+      float mean, invstd;
+      channel_affine(c0 + k, sums, M, C, gamma, beta, rmean, rvar, eps, training, mean, invstd, scale[k], shift[k]);
+      if (blockIdx.x == 0 && r0 == 0) {
+        save_mean[c0 + k] = mean;
+        save_invstd[c0 + k] = invstd;
+      }
+    }
+  }
+  if (r0 < g.rows_per_iter) {
+    for (long r = (long)blockIdx.x * g.rows_per_iter + r0; r < M; r += (long)gridDim.x * g.rows_per_iter) {
+      float v[CV];
+      load_row<TI, CV>(x + r * C, c0, C, vec, v);
+#pragma unroll
+      for (int k = 0; k < CV; ++k) v[k] = fmaxf(v[k] * scale[k] + shift[k], 0.f);
+      store_row<TO, CV>(out + r * C, c0, C, vec, v);
+    }
+  }
+}
+
+// running statistics (RepMode's BatchNorm3d defaults): rm = (1-m) rm + m mean ; rv = (1-m) rv + m var * M/(M-1)
+__global__ void bn_running_kernel(const float* __restrict__ sums, long M, int C, float momentum,
+                                  float* __restrict__ rmean, float* __restrict__ rvar) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean = sums[c] / (float)M;
+  const float var = fmaxf(sums[C + c] / (float)M - mean * mean, 0.f);
+  const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+  rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+  rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+}
+
+// backward reduce: dz = dy * [x*scale+shift > 0];  sums[c] += dz, sums[C+c] += dz * xhat
+template <typename TI, typename TO>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
+    const TI* __restrict__ x, const TO* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta, long M, int C,
+    float* __restrict__ sums) {
+  __shared__ float lds[2 * BN_MAXC];
+  const Geom g = geom(C);
+  const int cg = threadIdx.x % g.ngroups, r0 = threadIdx.x / g.ngroups;
+  const bool active = r0 < g.rows_per_iter;
+  const int c0 = cg * CV;
+  const bool vec = (C % CV) == 0;
+  float mu[CV], is[CV], ga[CV], be[CV], s[CV], ss[CV];
+#pragma unroll
+  for (int k = 0; k < CV; ++k) {
+    const bool ok = c0 + k < C;
+    mu[k] = ok ? mean[c0 + k] : 0.f; is[k] = ok ? invstd[c0 + k] : 0.f;
+    ga[k] = ok ? gamma[c0 + k] : 0.f; be[k] = ok ? beta[c0 + k] : 0.f;
+    s[k] = 0.f; ss[k] = 0.f;
+  }
+  if (active) {
+    for (long r = (long)blockIdx.x * g.rows_per_iter + r0; r < M; r += (long)gridDim.x * g.rows_per_iter) {
+      float v[CV], d[CV];
+      load_row<TI, CV>(x + r * C, c0, C, vec, v);
+      load_row<TO, CV>(dy + r * C, c0, C, vec, d);
+#pragma unroll
+      for (int k = 0; k < CV; ++k) {
+        const float xh = (v[k] - mu[k]) * is[k];
+        const float dz = (xh * ga[k] + be[k] > 0.f) ? d[k] : 0.f;
+        s[k] += dz;
+        ss[k] += dz * xh;
+      }
+    }
+  }
+  block_commit(lds, s, ss, c0, C, active, sums);
+}
+
+// backward apply: dx = gamma * invstd * (dz - sum(dz)/M - xhat * sum(dz xhat)/M)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
+    const TI* __restrict__ x, const TO* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ sums, long M, int C, int training, TI* __restrict__ dx) {
+  const Geom g = geom(C);
+  const int cg = threadIdx.x % g.ngroups, r0 = threadIdx.x / g.ngroups;
+  const int c0 = cg * CV;
+  const bool vec = (C % CV) == 0;
+  float mu[CV], is[CV], ga[CV], be[CV], m1[CV], m2[CV];
+#pragma unroll
+  for (int k = 0; k < CV; ++k) {
+    const bool ok = c0 + k < C;
+    mu[k] = ok ? mean[c0 + k] : 0.f; is[k] = ok ? invstd[c0 + k] : 0.f;
+    ga[k] = ok ? gamma[c0 + k] : 0.f; be[k] = ok ? beta[c0 + k] : 0.f;
+    // eval mode: the statistics are constants, only the scale survives
+    m1[k] = (ok && training) ? sums[c0 + k] / (float)M : 0.f;
+    m2[k] = (ok && training) ? sums[C + c0 + k] / (float)M : 0.f;
+  }
+  if (r0 < g.rows_per_iter) {
+    for (long r = (long)blockIdx.x * g.rows_per_iter + r0; r < M; r += (long)gridDim.x * g.rows_per_iter) {
+      float v[CV], d[CV];
+      load_row<TI, CV>(x + r * C, c0, C, vec, v);
+      load_row<TO, CV>(dy + r * C, c0, C, vec, d);
+#pragma unroll
+      for (int k = 0; k < CV; ++k) {
+        const float xh = (v[k] - mu[k]) * is[k];
+        const float dz = (xh * ga[k] + be[k] > 0.f) ? d[k] : 0.f;
+        v[k] = ga[k] * is[k] * (dz - m1[k] - xh * m2[k]);
+      }
+      store_row<TI, CV>(dx + r * C, c0, C, vec, v);
+    }
+  }
+}
+
+int grid_for(long M, int C) {
+  const int ngroups = (C + CV - 1) / CV;
+  const int rows_per_iter = BN_THREADS / ngroups;
+  long blocks = (M + rows_per_iter - 1) / rows_per_iter;
+  if (blocks > 2048) blocks = 2048;   // grid-stride beyond 8 workgroups per CU
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+}  // namespace
+
+// in_dtype: dtype of x (and dx); out_dtype: dtype of out (and dy).  REPMODE_F32 / REPMODE_BF16.
+extern "C" int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float* save_mean, float* save_invstd, float* sums_ws, long m,
+                                   int c, float eps, float momentum, int training, int in_dtype, int out_dtype,
+                                   void* stream) {
+  RM_REQUIRE(x && out && gamma && beta && running_mean && running_var && save_mean && save_invstd && sums_ws,
+             "bn_relu_fwd: null pointer");
+  RM_REQUIRE(m > 0 && c > 0 && c <= BN_MAXC, "bn_relu_fwd: bad shape (C <= %d)", BN_MAXC);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for(m, c);
+  if (training) {
+    RM_HIP(hipMemsetAsync(sums_ws, 0, 2 * (size_t)c * sizeof(float), s));
+    if (in_dtype == REPMODE_F32)
+      hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(grid), dim3(BN_THREADS), 0, s, (const float*)x, m, c, sums_ws);
+    else
+      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid), dim3(BN_THREADS), 0, s, (const bf16_t*)x, m, c, sums_ws);
+    RM_LAUNCH_CHECK("bn_stats");
+  }
+#define RM_BN_APPLY(TI, TO)                                                                                        \
+  hipLaunchKernelGGL((bn_apply_relu_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (TO*)out,   \
+                     sums_ws, gamma, beta, running_mean, running_var, save_mean, save_invstd, m, c, eps, momentum, \
+                     training)
+  if (in_dtype == REPMODE_F32 && out_dtype == REPMODE_F32) RM_BN_APPLY(float, float);
+  else if (in_dtype == REPMODE_F32) RM_BN_APPLY(float, bf16_t);
+  else if (out_dtype == REPMODE_F32) RM_BN_APPLY(bf16_t, float);
+  else RM_BN_APPLY(bf16_t, bf16_t);
+#undef RM_BN_APPLY
+  RM_LAUNCH_CHECK("bn_apply_relu");
+  if (training) {
+    // after the apply pass (which reads the OLD running statistics only in eval mode)
+    hipLaunchKernelGGL(bn_running_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, s, sums_ws, m, c, momentum, running_mean,
+                       running_var);
+    RM_LAUNCH_CHECK("bn_running");
+  }
+  return REPMODE_OK;
+}
+
+// dgamma = sums_ws[c + C] (sum dz xhat), dbeta = sums_ws[c] (sum dz) are left in sums_ws for the caller.
+extern "C" int repmode_bn_relu_bwd(const void* x, const void* dy, const float* gamma, const float* beta,
+                                   const float* save_mean, const float* save_invstd, void* dx, float* sums_ws, long m,
+                                   int c, int training, int in_dtype, int out_dtype, void* stream) {
+  RM_REQUIRE(x && dy && gamma && beta && save_mean && save_invstd && dx && sums_ws, "bn_relu_bwd: null pointer");
+  RM_REQUIRE(m > 0 && c > 0 && c <= BN_MAXC, "bn_relu_bwd: bad shape (C <= %d)", BN_MAXC);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_for(m, c);
+  RM_HIP(hipMemsetAsync(sums_ws, 0, 2 * (size_t)c * sizeof(float), s));
+#define RM_BN_BWD(TI, TO)                                                                                              \
+  do {                                                                                                                 \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy, \
+                       save_mean, save_invstd, gamma, beta, m, c, sums_ws);                                            \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy,  \
+                       save_mean, save_invstd, gamma, beta, sums_ws, m, c, training, (TI*)dx);                         \
+  } while (0)
+  if (in_dtype == REPMODE_F32 && out_dtype == REPMODE_F32) RM_BN_BWD(float, float);
+  else if (in_dtype == REPMODE_F32) RM_BN_BWD(float, bf16_t);
+  else if (out_dtype == REPMODE_F32) RM_BN_BWD(bf16_t, float);
+  else RM_BN_BWD(bf16_t, bf16_t);
+#undef RM_BN_BWD
+  RM_LAUNCH_CHECK("bn_relu_bwd");
+  return REPMODE_OK;
+}

@@ -91,10 +91,9 @@ class MoDEConv(torch.nn.Module):
         y_cl = ops.mode_conv3d(x_cl, self.expert_conv5x5_conv, self.expert_conv3x3_conv, self.expert_conv1x1_conv,
                                self.expert_avg3x3_conv, self.expert_avg5x5_conv, self.gate.weight, self.gate.bias,
                                plan, out_f32=out_f32)
-        y = self.subsequent_layer(_from_cl(y_cl))              # RepMode.py:212
-        if self.conv_type == 'normal' and y.dtype != dtype:
-            y = y.to(dtype)
-        return y
+        if self.conv_type == 'normal':                          # RepMode.py:212: BatchNorm3d + ReLU, fused HIP
+            y_cl = ops.bn_relu(y_cl, self.subsequent_layer[0], self.training, dtype)
+        return _from_cl(y_cl)
 
 
 class MoDESubNet2Conv(torch.nn.Module):                        # RepMode.py:111-120
@@ -151,8 +150,9 @@ class MoDEEncoderBlock(torch.nn.Module):                       # RepMode.py:74-8
 
     def forward(self, x, t):
         x_skip = self.conv_more(x, t)
-        y = self.conv_down(x_skip)
-        return y.to(x_skip.dtype), x_skip
+        y = self.conv_down[0](x_skip)                                           # stride-2 conv as a GEMM
+        y_cl = ops.bn_relu(_to_cl(y), self.conv_down[1], self.training, x_skip.dtype)   # BN + ReLU, RepMode.py:82-83
+        return _from_cl(y_cl), x_skip
 
 
 class MoDEDecoderBlock(torch.nn.Module):                       # RepMode.py:92-108
@@ -164,7 +164,8 @@ class MoDEDecoderBlock(torch.nn.Module):                       # RepMode.py:92-1
         self.conv_less = MoDESubNet2Conv(num_experts, num_tasks, in_chan, out_chan, dtype=dtype)
 
     def forward(self, x, x_skip, t):
-        up = self.convt(x).to(x_skip.dtype)
+        up = self.convt[0](x)
+        up = _from_cl(ops.bn_relu(_to_cl(up), self.convt[1], self.training, x_skip.dtype))   # RepMode.py:99-100
         return self.conv_less(torch.cat((x_skip, up), 1), t)   # skip first, RepMode.py:106
 
 

@@ -164,6 +164,52 @@ class _ModeConv3d(torch.autograd.Function):
         return dx, dk5, dk3, dk1, da3, da5, dgw, dgb, None, None
 
 
+class _BnRelu(torch.autograd.Function):
+    """BatchNorm3d + ReLU on a channels-last tensor [..., C] (RepMode.py:146-149, 212; :80-84; :97-101)."""
+
+    @staticmethod
+    def forward(ctx, x_cl, weight, bias, running_mean, running_var, training, momentum, eps, out_dtype):
+        _require_hip(x_cl, 'input')
+        c = x_cl.shape[-1]
+        m = x_cl.numel() // c
+        out = torch.empty(x_cl.shape, dtype=out_dtype, device=x_cl.device)
+        save_mean = torch.empty(c, dtype=torch.float32, device=x_cl.device)
+        save_invstd = torch.empty_like(save_mean)
+        sums = torch.empty(2 * c, dtype=torch.float32, device=x_cl.device)
+        _lib.call('repmode_bn_relu_fwd', _ptr(x_cl), _ptr(out), _ptr(weight), _ptr(bias), _ptr(running_mean),
+                  _ptr(running_var), _ptr(save_mean), _ptr(save_invstd), _ptr(sums), m, c, float(eps), float(momentum),
+                  1 if training else 0, dtype_code(x_cl.dtype), dtype_code(out_dtype), _stream())
+        ctx.save_for_backward(x_cl, weight, bias, save_mean, save_invstd)
+        ctx.training = training
+        ctx.mark_non_differentiable(running_mean, running_var)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, weight, bias, save_mean, save_invstd = ctx.saved_tensors
+        c = x_cl.shape[-1]
+        m = x_cl.numel() // c
+        dy = dy.contiguous()
+        dx = torch.empty_like(x_cl)
+        sums = torch.empty(2 * c, dtype=torch.float32, device=x_cl.device)
+        _lib.call('repmode_bn_relu_bwd', _ptr(x_cl), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(save_mean),
+                  _ptr(save_invstd), _ptr(dx), _ptr(sums), m, c, 1 if ctx.training else 0, dtype_code(x_cl.dtype),
+                  dtype_code(dy.dtype), _stream())
+        return dx, sums[c:], sums[:c], None, None, None, None, None, None
+
+
+def bn_relu(x_cl, bn, training, out_dtype):
+    """``relu(batch_norm(x))`` with the parameters / running statistics of a ``torch.nn.BatchNorm3d`` module
+    (kept as the parameter container so that the state_dict matches the reference)."""
+    x_cl = x_cl.contiguous()
+    use_batch_stats = training or not bn.track_running_stats
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _BnRelu.apply(x_cl, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats, momentum, bn.eps,
+                         out_dtype)
+
+
 class _SingleSlot:
     """All samples share one filter: used when the experts themselves are the 'slots'."""
 

@@ -319,6 +319,46 @@ def test_box_sum(shape):
     assert rel_err(ops.box_sum(in3=ad, in5=bd).cpu(), ref_box(a, 3) + ref_box(b, 5)) < 1e-5
 
 
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('in_dtype,out_dtype', [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                                (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize('shape', [(2, 4, 8, 8, 32), (3, 2, 3, 5, 6), (1, 2, 2, 2, 512), (2, 8, 16, 16, 64)])
+def test_bn_relu(shape, in_dtype, out_dtype, training):
+    ops = _ops()
+    c = shape[-1]
+    gen = torch.Generator().manual_seed(c + int(training))
+    x = (torch.randn(*shape, generator=gen) * 1.5 + 0.3).to(in_dtype).float()
+    r = torch.randn(*shape, generator=gen).to(out_dtype).float()
+    bn = torch.nn.BatchNorm3d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.2, 0.2)
+        bn.running_var.uniform_(0.5, 1.5)
+    import copy
+    bd = copy.deepcopy(bn).to(DEV)
+    bn.train(training)
+    bd.train(training)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.relu(bn(xr.permute(0, 4, 1, 2, 3))).permute(0, 2, 3, 4, 1)
+    (yr * r).sum().backward()
+    xd = x.to(DEV, in_dtype).requires_grad_(True)
+    y = ops.bn_relu(xd, bd, training, out_dtype)
+    assert y.dtype == out_dtype
+    (y.float() * r.to(DEV)).sum().backward()
+    tol = 1e-4 if out_dtype == torch.float32 else 1e-2
+    assert rel_err(y.float().detach().cpu(), yr.detach()) < tol
+    # gradients: bf16 rounding of the pre-activation flips a few ReLU masks -> norm-wise for bf16 output
+    err = rel_err if in_dtype == torch.float32 else nrm_err
+    gtol = 1e-3 if in_dtype == torch.float32 and out_dtype == torch.float32 else 3e-2
+    assert err(xd.grad.float().cpu(), xr.grad) < gtol
+    assert err(bd.weight.grad.cpu(), bn.weight.grad) < gtol
+    assert err(bd.bias.grad.cpu(), bn.bias.grad) < gtol
+    assert rel_err(bd.running_mean.cpu(), bn.running_mean) < 1e-4
+    assert rel_err(bd.running_var.cpu(), bn.running_var) < 1e-4
+    assert int(bd.num_batches_tracked) == int(bn.num_batches_tracked)
+
+
 def test_cpu_tensor_fails_loudly():
     from repmode_amd import _lib
     from repmode_amd.nn_modules.RepMode import MoDEConv
