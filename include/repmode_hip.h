@@ -114,12 +114,12 @@ int repmode_gatrep_bwd(const float* dw, const float* k5, const float* k3, const 
  * stride-2 down/up stages (RepMode.py:80-84, 97-101), on a channels-last tensor viewed as [m][c].
  * Training: batch mean / biased variance over the m rows, eps, running statistics updated with `momentum`
  * and the unbiased variance; eval (training == 0): running statistics.  x has in_dtype, out has out_dtype.
- * save_mean / save_invstd [c] and sums_ws [2c] are float outputs / workspace.  c <= 512. */
+ * save_mean / save_invstd [c] and sums_ws [16][2c] (partial-sum slices) are float outputs / workspace.  c <= 512. */
 int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, float* save_mean, float* save_invstd, float* sums_ws, long m, int c,
                         float eps, float momentum, int training, int in_dtype, int out_dtype, void* stream);
-/* Backward of the same: dx (in_dtype) from dy (out_dtype); on return sums_ws[0..c) = dbeta and
- * sums_ws[c..2c) = dgamma. */
+/* Backward of the same: dx (in_dtype) from dy (out_dtype); on return sums_ws holds 16 partial slices
+ * [16][2][c]: summed over the slices, row 0 = dbeta, row 1 = dgamma. */
 int repmode_bn_relu_bwd(const void* x, const void* dy, const float* gamma, const float* beta,
                         const float* save_mean, const float* save_invstd, void* dx, float* sums_ws, long m, int c,
                         int training, int in_dtype, int out_dtype, void* stream);

@@ -18,6 +18,7 @@ namespace {
 
 constexpr int BN_THREADS = 256;
 constexpr int BN_MAXC = 512;
+constexpr int BN_SLICES = 16;   // partial-sum slices: workgroup b adds into slice b % 16 (16x less atomic contention)
 
 template <typename T>
 struct Vec;
@@ -119,7 +120,16 @@ __device__ __forceinline__ void block_commit(float* lds, const float* s, const f
       }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) atomicAdd(&sums[i], lds[i]);
+  float* slice = sums + (size_t)(blockIdx.x % BN_SLICES) * 2 * C;
+  for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) atomicAdd(&slice[i], lds[i]);
+}
+
+// total of the BN_SLICES partial sums of entry i (i in [0, 2C))
+__device__ __forceinline__ float slice_total(const float* __restrict__ sums, int i, int C) {
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < BN_SLICES; ++k) t += sums[(size_t)k * 2 * C + i];
+  return t;
 }
 
 template <typename T>
@@ -150,8 +160,8 @@ __device__ __forceinline__ void channel_affine(int c, const float* sums, long M,
                                                const float* beta, const float* rmean, const float* rvar, float eps,
                                                int training, float& mean, float& invstd, float& scale, float& shift) {
   if (training) {
-    mean = sums[c] / (float)M;
-    const float var = fmaxf(sums[C + c] / (float)M - mean * mean, 0.f);
+    mean = slice_total(sums, c, C) / (float)M;
+    const float var = fmaxf(slice_total(sums, C + c, C) / (float)M - mean * mean, 0.f);
     invstd = rsqrtf(var + eps);
   } else {
     mean = rmean[c];
@@ -200,8 +210,8 @@ __global__ void bn_running_kernel(const float* __restrict__ sums, long M, int C,
                                   float* __restrict__ rmean, float* __restrict__ rvar) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float mean = sums[c] / (float)M;
-  const float var = fmaxf(sums[C + c] / (float)M - mean * mean, 0.f);
+  const float mean = slice_total(sums, c, C) / (float)M;
+  const float var = fmaxf(slice_total(sums, C + c, C) / (float)M - mean * mean, 0.f);
   const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
   rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
   rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
@@ -261,8 +271,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     mu[k] = ok ? mean[c0 + k] : 0.f; is[k] = ok ? invstd[c0 + k] : 0.f;
     ga[k] = ok ? gamma[c0 + k] : 0.f; be[k] = ok ? beta[c0 + k] : 0.f;
     // eval mode: the statistics are constants, only the scale survives
-    m1[k] = (ok && training) ? sums[c0 + k] / (float)M : 0.f;
-    m2[k] = (ok && training) ? sums[C + c0 + k] / (float)M : 0.f;
+    m1[k] = (ok && training) ? slice_total(sums, c0 + k, C) / (float)M : 0.f;
+    m2[k] = (ok && training) ? slice_total(sums, C + c0 + k, C) / (float)M : 0.f;
   }
   if (r0 < g.rows_per_iter) {
     for (long r = (long)blockIdx.x * g.rows_per_iter + r0; r < M; r += (long)gridDim.x * g.rows_per_iter) {
@@ -278,6 +288,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
       store_row<TI, CV>(dx + r * C, c0, C, vec, v);
     }
   }
+}
+
+// the two reduction kernels end in 2C global atomics per workgroup: cap them at 2 workgroups per CU
+int grid_for_reduce(long M, int C) {
+  const int ngroups = (C + CV - 1) / CV;
+  const int rows_per_iter = BN_THREADS / ngroups;
+  long blocks = (M + rows_per_iter - 1) / rows_per_iter;
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
 }
 
 int grid_for(long M, int C) {
@@ -302,11 +322,11 @@ extern "C" int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma,
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int grid = grid_for(m, c);
   if (training) {
-    RM_HIP(hipMemsetAsync(sums_ws, 0, 2 * (size_t)c * sizeof(float), s));
+    RM_HIP(hipMemsetAsync(sums_ws, 0, (size_t)BN_SLICES * 2 * c * sizeof(float), s));
     if (in_dtype == REPMODE_F32)
-      hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(grid), dim3(BN_THREADS), 0, s, (const float*)x, m, c, sums_ws);
+      hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const float*)x, m, c, sums_ws);
     else
-      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid), dim3(BN_THREADS), 0, s, (const bf16_t*)x, m, c, sums_ws);
+      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const bf16_t*)x, m, c, sums_ws);
     RM_LAUNCH_CHECK("bn_stats");
   }
 #define RM_BN_APPLY(TI, TO)                                                                                        \
@@ -328,7 +348,7 @@ extern "C" int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma,
   return REPMODE_OK;
 }
 
-// dgamma = sums_ws[c + C] (sum dz xhat), dbeta = sums_ws[c] (sum dz) are left in sums_ws for the caller.
+// dbeta (sum dz) and dgamma (sum dz xhat) are left in sums_ws as 16 partial slices [16][2][c] for the caller to add up.
 extern "C" int repmode_bn_relu_bwd(const void* x, const void* dy, const float* gamma, const float* beta,
                                    const float* save_mean, const float* save_invstd, void* dx, float* sums_ws, long m,
                                    int c, int training, int in_dtype, int out_dtype, void* stream) {
@@ -336,10 +356,10 @@ extern "C" int repmode_bn_relu_bwd(const void* x, const void* dy, const float* g
   RM_REQUIRE(m > 0 && c > 0 && c <= BN_MAXC, "bn_relu_bwd: bad shape (C <= %d)", BN_MAXC);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int grid = grid_for(m, c);
-  RM_HIP(hipMemsetAsync(sums_ws, 0, 2 * (size_t)c * sizeof(float), s));
+  RM_HIP(hipMemsetAsync(sums_ws, 0, (size_t)BN_SLICES * 2 * c * sizeof(float), s));
 #define RM_BN_BWD(TI, TO)                                                                                              \
   do {                                                                                                                 \
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy, \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<TI, TO>), dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy, \
                        save_mean, save_invstd, gamma, beta, m, c, sums_ws);                                            \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy,  \
                        save_mean, save_invstd, gamma, beta, sums_ws, m, c, training, (TI*)dx);                         \

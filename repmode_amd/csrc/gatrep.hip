@@ -132,35 +132,45 @@ __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
   const int pr = 2 * p2;
   const int r4 = pr / KC, k = pr % KC;
   const int row = rt * 32 + grp * 4 + r4, red = kc * KC + k;
-  // gate rows: wf -> both elements share co = row; wd -> co = red, red + 1
-  const int coA = WRITE_WD ? red : row, coB = WRITE_WD ? red + 1 : row;
-  const int gA = min(coA, co_n - 1), gB = min(coB, co_n - 1);    // dead elements are zero in LDS already
   const size_t in_tile = (size_t)(grp * 4 + r4) * KC + k;
-  // slots outermost: the ten gate probabilities of a slot live in registers across the tap loop
+  // gate probabilities of the channels this workgroup touches go through LDS once (chunks of 16 slots):
+  // the merge loop then has no dependent global load in it (it was latency-bound at ~50 us per launch)
+  __shared__ float sg[16][E][KC];
   const size_t tile_off = ((size_t)rt * nkc + kc) * tile_elems + in_tile;
-  for (int s = 0; s < nslots; ++s) {
-    const float* gsA = g + (size_t)s * E * co_n + gA;
-    const float* gsB = g + (size_t)s * E * co_n + gB;
-    const float ga0 = gsA[0], ga1 = gsA[co_n], ga2 = gsA[2 * co_n], ga3 = gsA[3 * co_n], ga4 = gsA[4 * co_n];
-    const float gb0 = gsB[0], gb1 = gsB[co_n], gb2 = gsB[2 * co_n], gb3 = gsB[3 * co_n], gb4 = gsB[4 * co_n];
-    T* wslot = wout + s * slot_stride + tile_off;
-    const float ca4 = ga4 * sa5[pr], cb4 = gb4 * sa5[pr + 1];
-    for (int tap = tq; tap < TAPS; tap += TQ) {
-      int t3;
-      const bool c3 = in_centre3(tap, t3);
-      // same association order as RepMode.py:184-188: ((((g0 k5 + g1 k3) + g2 k1) + g3 a3) + g4 a5)
-      float ra = ga0 * s5[pr * TAPS + tap], rb = gb0 * s5[(pr + 1) * TAPS + tap];
-      if (c3) {
-        ra += ga1 * s3[pr * 27 + t3];
-        rb += gb1 * s3[(pr + 1) * 27 + t3];
-        if (tap == 62) { ra += ga2 * s1[pr]; rb += gb2 * s1[pr + 1]; }
-        ra += ga3 * sa3[pr];
-        rb += gb3 * sa3[pr + 1];
+  // LDS column of this thread's two elements: wf -> the row's co (column r4), wd -> the reduction co (columns k, k+1)
+  const int colA = WRITE_WD ? k : r4, colB = WRITE_WD ? k + 1 : r4;
+  for (int s0 = 0; s0 < nslots; s0 += 16) {
+    const int ns = min(16, nslots - s0);
+    __syncthreads();
+    for (int i = tid; i < ns * E * KC; i += 256) {
+      const int col = i % KC, e = (i / KC) % E, sl = i / (KC * E);
+      // column -> co: wf: rows grp*4 + col (col < 4), wd: reduction channels kc*KC + col
+      const int co = WRITE_WD ? kc * KC + col : rt * 32 + grp * 4 + (col & 3);
+      sg[sl][e][col] = g[((size_t)(s0 + sl) * E + e) * co_n + min(co, co_n - 1)];
+    }
+    __syncthreads();
+    for (int sl = 0; sl < ns; ++sl) {
+      const float ga0 = sg[sl][0][colA], ga1 = sg[sl][1][colA], ga2 = sg[sl][2][colA], ga3 = sg[sl][3][colA], ga4 = sg[sl][4][colA];
+      const float gb0 = sg[sl][0][colB], gb1 = sg[sl][1][colB], gb2 = sg[sl][2][colB], gb3 = sg[sl][3][colB], gb4 = sg[sl][4][colB];
+      T* wslot = wout + (size_t)(s0 + sl) * slot_stride + tile_off;
+      const float ca4 = ga4 * sa5[pr], cb4 = gb4 * sa5[pr + 1];
+      for (int tap = tq; tap < TAPS; tap += TQ) {
+        int t3;
+        const bool c3 = in_centre3(tap, t3);
+        // same association order as RepMode.py:184-188: ((((g0 k5 + g1 k3) + g2 k1) + g3 a3) + g4 a5)
+        float ra = ga0 * s5[pr * TAPS + tap], rb = gb0 * s5[(pr + 1) * TAPS + tap];
+        if (c3) {
+          ra += ga1 * s3[pr * 27 + t3];
+          rb += gb1 * s3[(pr + 1) * 27 + t3];
+          if (tap == 62) { ra += ga2 * s1[pr]; rb += gb2 * s1[pr + 1]; }
+          ra += ga3 * sa3[pr];
+          rb += gb3 * sa3[pr + 1];
+        }
+        ra += ca4;
+        rb += cb4;
+        const int tap_out = WRITE_WD ? TAPS - 1 - tap : tap;
+        store_pair<T>(wslot + (size_t)tap_out * tap_stride, ra, rb);
       }
-      ra += ca4;
-      rb += cb4;
-      const int tap_out = WRITE_WD ? TAPS - 1 - tap : tap;
-      store_pair<T>(wslot + (size_t)tap_out * tap_stride, ra, rb);
     }
   }
 }
@@ -203,9 +213,15 @@ __global__ __launch_bounds__(GF_THREADS) void gatrep_bwd_kernel(
 #pragma unroll
   for (int k = 0; k < GB_NT; ++k) { acc5[k] = 0.f; acc3[k] = 0.f; }
   float acc1 = 0.f, acca3 = 0.f, acca5 = 0.f;     // meaningful in threads tid < 32 only
+  // this output channel's gate probabilities for every slot, once, through LDS (up to 64 slots)
+  __shared__ float sgb[64][E];
+  for (int i = tid; i < min(nslots, 64) * E; i += GF_THREADS) sgb[i / E][i % E] = g[((size_t)(i / E) * E + i % E) * co_n + co];
+  __syncthreads();
   for (int s = 0; s < nslots; ++s) {
     const float* gs = g + (size_t)s * E * co_n + co;
-    const float g0 = gs[0], g1 = gs[co_n], g2 = gs[2 * co_n], g3 = gs[3 * co_n], g4 = gs[4 * co_n];
+    const bool in_lds = s < 64;
+    const float g0 = in_lds ? sgb[s][0] : gs[0], g1 = in_lds ? sgb[s][1] : gs[co_n], g2 = in_lds ? sgb[s][2] : gs[2 * co_n],
+                g3 = in_lds ? sgb[s][3] : gs[3 * co_n], g4 = in_lds ? sgb[s][4] : gs[4 * co_n];
     const float* dws = dw + (size_t)s * TAPS * tap_stride + oi;
     float q0 = 0.f, q1 = 0.f, dcen = 0.f, s27 = 0.f, s125 = 0.f;
 #pragma unroll

@@ -13,6 +13,7 @@ from . import _lib
 
 NUM_EXPERTS = 5
 TAPS = 125
+BN_SLICES = 16      # partial-sum slices of the BatchNorm reductions (bnrelu.hip)
 
 _DTYPE_CODE = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 
@@ -175,7 +176,7 @@ class _BnRelu(torch.autograd.Function):
         out = torch.empty(x_cl.shape, dtype=out_dtype, device=x_cl.device)
         save_mean = torch.empty(c, dtype=torch.float32, device=x_cl.device)
         save_invstd = torch.empty_like(save_mean)
-        sums = torch.empty(2 * c, dtype=torch.float32, device=x_cl.device)
+        sums = torch.empty(BN_SLICES * 2 * c, dtype=torch.float32, device=x_cl.device)
         _lib.call('repmode_bn_relu_fwd', _ptr(x_cl), _ptr(out), _ptr(weight), _ptr(bias), _ptr(running_mean),
                   _ptr(running_var), _ptr(save_mean), _ptr(save_invstd), _ptr(sums), m, c, float(eps), float(momentum),
                   1 if training else 0, dtype_code(x_cl.dtype), dtype_code(out_dtype), _stream())
@@ -191,11 +192,12 @@ class _BnRelu(torch.autograd.Function):
         m = x_cl.numel() // c
         dy = dy.contiguous()
         dx = torch.empty_like(x_cl)
-        sums = torch.empty(2 * c, dtype=torch.float32, device=x_cl.device)
+        sums = torch.empty(BN_SLICES * 2 * c, dtype=torch.float32, device=x_cl.device)
         _lib.call('repmode_bn_relu_bwd', _ptr(x_cl), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(save_mean),
                   _ptr(save_invstd), _ptr(dx), _ptr(sums), m, c, 1 if ctx.training else 0, dtype_code(x_cl.dtype),
                   dtype_code(dy.dtype), _stream())
-        return dx, sums[c:], sums[:c], None, None, None, None, None, None
+        tot = sums.view(BN_SLICES, 2, c).sum(dim=0)          # row 0 = dbeta, row 1 = dgamma
+        return dx, tot[1], tot[0], None, None, None, None, None, None
 
 
 def bn_relu(x_cl, bn, training, out_dtype):
