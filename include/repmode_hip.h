@@ -118,8 +118,8 @@ int repmode_gatrep_bwd(const float* dw, const float* k5, const float* k3, const 
 int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, float* save_mean, float* save_invstd, float* sums_ws, long m, int c,
                         float eps, float momentum, int training, int in_dtype, int out_dtype, void* stream);
-/* Backward of the same: dx (in_dtype) from dy (out_dtype); on return sums_ws holds 16 partial slices
- * [16][2][c]: summed over the slices, row 0 = dbeta, row 1 = dgamma. */
+/* Backward of the same: dx (in_dtype) from dy (out_dtype).  sums_ws: (16 + 1) * 2c floats; on return its last
+ * 2c floats are the totals: [0..c) = dbeta, [c..2c) = dgamma. */
 int repmode_bn_relu_bwd(const void* x, const void* dy, const float* gamma, const float* beta,
                         const float* save_mean, const float* save_invstd, void* dx, float* sums_ws, long m, int c,
                         int training, int in_dtype, int out_dtype, void* stream);

@@ -155,28 +155,38 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
   block_commit(lds, s, ss, c0, C, active, sums);
 }
 
-// scale / shift of channel c from the batch sums (training) or the running statistics (eval)
-__device__ __forceinline__ void channel_affine(int c, const float* sums, long M, int C, const float* gamma,
-                                               const float* beta, const float* rmean, const float* rvar, float eps,
-                                               int training, float& mean, float& invstd, float& scale, float& shift) {
+// forward finalize (one thread per channel): consolidate the partial-sum slices into mean / invstd (saved
+// for backward) and update the running statistics (RepMode's BatchNorm3d defaults):
+// rm = (1-m) rm + m mean ; rv = (1-m) rv + m var * M/(M-1).  Eval mode: mean / invstd from the running stats.
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, long M, int C, float eps, float momentum,
+                                   int training, float* __restrict__ rmean, float* __restrict__ rvar,
+                                   float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
   if (training) {
-    mean = slice_total(sums, c, C) / (float)M;
+    const float mean = slice_total(sums, c, C) / (float)M;
     const float var = fmaxf(slice_total(sums, C + c, C) / (float)M - mean * mean, 0.f);
-    invstd = rsqrtf(var + eps);
+    save_mean[c] = mean;
+    save_invstd[c] = rsqrtf(var + eps);
+    const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
   } else {
-    mean = rmean[c];
-    invstd = rsqrtf(rvar[c] + eps);
+    save_mean[c] = rmean[c];
+    save_invstd[c] = rsqrtf(rvar[c] + eps);
   }
-  scale = gamma[c] * invstd;
-  shift = beta[c] - mean * scale;
+}
+
+// backward finalize: totals[c] = sum dz (= dbeta), totals[C + c] = sum dz * xhat (= dgamma)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, float* __restrict__ totals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * C) totals[i] = slice_total(sums, i, C);
 }
 
 template <typename TI, typename TO>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_relu_kernel(
-    const TI* __restrict__ x, TO* __restrict__ out, const float* __restrict__ sums, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
-    float* __restrict__ save_mean, float* __restrict__ save_invstd, long M, int C, float eps, float momentum,
-    int training) {
+    const TI* __restrict__ x, TO* __restrict__ out, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ save_mean, const float* __restrict__ save_invstd, long M, int C) {
   const Geom g = geom(C);
   const int cg = threadIdx.x % g.ngroups, r0 = threadIdx.x / g.ngroups;
   const int c0 = cg * CV;
@@ -186,12 +196,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_relu_kernel(
   for (int k = 0; k < CV; ++k) {
     scale[k] = 0.f; shift[k] = 0.f;
     if (c0 + k < C) {
-      float mean, invstd;
-      channel_affine(c0 + k, sums, M, C, gamma, beta, rmean, rvar, eps, training, mean, invstd, scale[k], shift[k]);
-      if (blockIdx.x == 0 && r0 == 0) {
-        save_mean[c0 + k] = mean;
-        save_invstd[c0 + k] = invstd;
-      }
+      scale[k] = gamma[c0 + k] * save_invstd[c0 + k];
+      shift[k] = beta[c0 + k] - save_mean[c0 + k] * scale[k];
     }
   }
   if (r0 < g.rows_per_iter) {
@@ -203,18 +209,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_relu_kernel(
       store_row<TO, CV>(out + r * C, c0, C, vec, v);
     }
   }
-}
-
-// running statistics (RepMode's BatchNorm3d defaults): rm = (1-m) rm + m mean ; rv = (1-m) rv + m var * M/(M-1)
-__global__ void bn_running_kernel(const float* __restrict__ sums, long M, int C, float momentum,
-                                  float* __restrict__ rmean, float* __restrict__ rvar) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float mean = slice_total(sums, c, C) / (float)M;
-  const float var = fmaxf(slice_total(sums, C + c, C) / (float)M - mean * mean, 0.f);
-  const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
-  rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-  rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
 }
 
 // backward reduce: dz = dy * [x*scale+shift > 0];  sums[c] += dz, sums[C+c] += dz * xhat
@@ -259,7 +253,7 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     const TI* __restrict__ x, const TO* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ sums, long M, int C, int training, TI* __restrict__ dx) {
+    const float* __restrict__ totals, long M, int C, int training, TI* __restrict__ dx) {
   const Geom g = geom(C);
   const int cg = threadIdx.x % g.ngroups, r0 = threadIdx.x / g.ngroups;
   const int c0 = cg * CV;
@@ -271,8 +265,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     mu[k] = ok ? mean[c0 + k] : 0.f; is[k] = ok ? invstd[c0 + k] : 0.f;
     ga[k] = ok ? gamma[c0 + k] : 0.f; be[k] = ok ? beta[c0 + k] : 0.f;
     // eval mode: the statistics are constants, only the scale survives
-    m1[k] = (ok && training) ? slice_total(sums, c0 + k, C) / (float)M : 0.f;
-    m2[k] = (ok && training) ? slice_total(sums, C + c0 + k, C) / (float)M : 0.f;
+    m1[k] = (ok && training) ? totals[c0 + k] / (float)M : 0.f;
+    m2[k] = (ok && training) ? totals[C + c0 + k] / (float)M : 0.f;
   }
   if (r0 < g.rows_per_iter) {
     for (long r = (long)blockIdx.x * g.rows_per_iter + r0; r < M; r += (long)gridDim.x * g.rows_per_iter) {
@@ -329,26 +323,23 @@ extern "C" int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma,
       hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const bf16_t*)x, m, c, sums_ws);
     RM_LAUNCH_CHECK("bn_stats");
   }
-#define RM_BN_APPLY(TI, TO)                                                                                        \
-  hipLaunchKernelGGL((bn_apply_relu_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (TO*)out,   \
-                     sums_ws, gamma, beta, running_mean, running_var, save_mean, save_invstd, m, c, eps, momentum, \
-                     training)
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, s, sums_ws, m, c, eps, momentum, training,
+                     running_mean, running_var, save_mean, save_invstd);
+  RM_LAUNCH_CHECK("bn_finalize");
+#define RM_BN_APPLY(TI, TO)                                                                                      \
+  hipLaunchKernelGGL((bn_apply_relu_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (TO*)out, \
+                     gamma, beta, save_mean, save_invstd, m, c)
   if (in_dtype == REPMODE_F32 && out_dtype == REPMODE_F32) RM_BN_APPLY(float, float);
   else if (in_dtype == REPMODE_F32) RM_BN_APPLY(float, bf16_t);
   else if (out_dtype == REPMODE_F32) RM_BN_APPLY(bf16_t, float);
   else RM_BN_APPLY(bf16_t, bf16_t);
 #undef RM_BN_APPLY
   RM_LAUNCH_CHECK("bn_apply_relu");
-  if (training) {
-    // after the apply pass (which reads the OLD running statistics only in eval mode)
-    hipLaunchKernelGGL(bn_running_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, s, sums_ws, m, c, momentum, running_mean,
-                       running_var);
-    RM_LAUNCH_CHECK("bn_running");
-  }
   return REPMODE_OK;
 }
 
-// dbeta (sum dz) and dgamma (sum dz xhat) are left in sums_ws as 16 partial slices [16][2][c] for the caller to add up.
+// On return sums_ws[16*2c .. 16*2c + 2c) holds the totals: [0..c) = dbeta (sum dz), [c..2c) = dgamma (sum dz xhat);
+// sums_ws must hold (16 + 1) * 2c floats.
 extern "C" int repmode_bn_relu_bwd(const void* x, const void* dy, const float* gamma, const float* beta,
                                    const float* save_mean, const float* save_invstd, void* dx, float* sums_ws, long m,
                                    int c, int training, int in_dtype, int out_dtype, void* stream) {
@@ -357,12 +348,14 @@ extern "C" int repmode_bn_relu_bwd(const void* x, const void* dy, const float* g
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int grid = grid_for(m, c);
   RM_HIP(hipMemsetAsync(sums_ws, 0, (size_t)BN_SLICES * 2 * c * sizeof(float), s));
+  float* totals = sums_ws + (size_t)BN_SLICES * 2 * c;
 #define RM_BN_BWD(TI, TO)                                                                                              \
   do {                                                                                                                 \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<TI, TO>), dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy, \
                        save_mean, save_invstd, gamma, beta, m, c, sums_ws);                                            \
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(2 * c, 128)), dim3(128), 0, s, sums_ws, c, totals);          \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy,  \
-                       save_mean, save_invstd, gamma, beta, sums_ws, m, c, training, (TI*)dx);                         \
+                       save_mean, save_invstd, gamma, beta, totals, m, c, training, (TI*)dx);                          \
   } while (0)
   if (in_dtype == REPMODE_F32 && out_dtype == REPMODE_F32) RM_BN_BWD(float, float);
   else if (in_dtype == REPMODE_F32) RM_BN_BWD(float, bf16_t);

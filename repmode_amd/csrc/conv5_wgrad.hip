@@ -329,8 +329,11 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   a.nty = ceil_div(a.H, TY);
   a.ntx = ceil_div(a.W, TX);
   a.ntiles = ceil_div(a.D, TZ) * a.nty * a.ntx;
+  // split the voxel range over workgroups only as far as needed to fill the chip (>= 2 workgroups per
+  // CU): every extra chunk costs one more f32 atomic per output element, which dominates on levels
+  // with few voxels and many channels
   const long fixed = (long)a.nslots * a.ncot * a.ncit * a.ndz;
-  long want_chunks = (2048 + fixed - 1) / fixed;
+  long want_chunks = fixed >= 512 ? 1 : (1024 + fixed - 1) / fixed;
   if (want_chunks < 1) want_chunks = 1;
   if (want_chunks > a.ntiles) want_chunks = a.ntiles;
   a.tiles_per_block = ceil_div(a.ntiles, (int)want_chunks);
@@ -374,7 +377,8 @@ extern "C" int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32
   if (dtype == REPMODE_BF16) {
     RM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv5_wgrad: pointers must be 16-byte aligned");
     int rc;
-    if (wdim >= 32) rc = launch_wgrad_bf16<1, 4, 32>(a, n, s);
+    if (wdim >= 32 && h >= 8) rc = launch_wgrad_bf16<1, 8, 32>(a, n, s);
+    else if (wdim >= 32) rc = launch_wgrad_bf16<1, 4, 32>(a, n, s);
     else if (wdim >= 16) rc = launch_wgrad_bf16<1, 8, 16>(a, n, s);
     else if (wdim >= 8) rc = launch_wgrad_bf16<2, 8, 8>(a, n, s);
     else rc = launch_wgrad_bf16<2, 4, 8>(a, n, s);

@@ -101,19 +101,33 @@ __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
   // ---- stage the group's expert values: one wave copies one (row, red) pair's 125 + 27 contiguous
   // floats at a time (pairs taken in MEMORY order so that consecutive pairs are adjacent in HBM)
   {
+    // all global loads of the workgroup are issued before the first LDS store (a load -> store loop
+    // serialises on memory latency: ~50 us per launch on the small layers)
     const int lane = tid & 63, wave = tid >> 6;
-    for (int pm = wave; pm < PAIRS; pm += 4) {
+    constexpr int NIT = PAIRS / 4;
+    float va[NIT], vb[NIT], vc[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pm = wave + 4 * it;
       const int rr = WRITE_WD ? pm % 4 : pm / KC;
       const int kk = WRITE_WD ? pm / 4 : pm % KC;
       const int row = rt * 32 + grp * 4 + rr, red = kc * KC + kk;
       const int co = WRITE_WD ? red : row, ci = WRITE_WD ? row : red;
       const bool live = co < co_n && ci < ci_n;
       const size_t oi = live ? (size_t)co * ci_n + ci : 0;
-      const float* src5 = k5 + oi * TAPS;
+      va[it] = live ? k5[oi * TAPS + lane] : 0.f;
+      vb[it] = (live && lane + 64 < TAPS) ? k5[oi * TAPS + lane + 64] : 0.f;
+      vc[it] = (live && lane < 27) ? k3[oi * 27 + lane] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int pm = wave + 4 * it;
+      const int rr = WRITE_WD ? pm % 4 : pm / KC;
+      const int kk = WRITE_WD ? pm / 4 : pm % KC;
       float* dst5 = s5 + (rr * KC + kk) * TAPS;
-      dst5[lane] = live ? src5[lane] : 0.f;
-      if (lane + 64 < TAPS) dst5[lane + 64] = live ? src5[lane + 64] : 0.f;
-      if (lane < 27) s3[(rr * KC + kk) * 27 + lane] = live ? k3[oi * 27 + lane] : 0.f;
+      dst5[lane] = va[it];
+      if (lane + 64 < TAPS) dst5[lane + 64] = vb[it];
+      if (lane < 27) s3[(rr * KC + kk) * 27 + lane] = vc[it];
     }
   }
   if (tid < PAIRS) {
@@ -199,8 +213,18 @@ __global__ __launch_bounds__(GF_THREADS) void gatrep_bwd_kernel(
   const int c0 = blockIdx.x * GF_CT;
   const int nlive = min(GF_CT, ci_n - c0);
   const size_t base = (size_t)co * ci_n + c0;
-  for (int i = tid; i < nlive * TAPS; i += GF_THREADS) s5[i] = k5[base * TAPS + i];
-  for (int i = tid; i < nlive * 27; i += GF_THREADS) s3[i] = k3[base * 27 + i];
+  {
+    // issue all loads first (see gatrep_fwd_kernel): 32 * 125 / 256 -> 16 + 4 loads per thread
+    float v5[16], v3[4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const int i = tid + j * GF_THREADS; v5[j] = i < nlive * TAPS ? k5[base * TAPS + i] : 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int i = tid + j * GF_THREADS; v3[j] = i < nlive * 27 ? k3[base * 27 + i] : 0.f; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const int i = tid + j * GF_THREADS; if (i < GF_CT * TAPS) s5[i] = v5[j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int i = tid + j * GF_THREADS; if (i < GF_CT * 27) s3[i] = v3[j]; }
+  }
   __syncthreads();
   const int c = tid & (GF_CT - 1), tq = tid / GF_CT;
   const bool live = c < nlive;

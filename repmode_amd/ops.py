@@ -192,12 +192,12 @@ class _BnRelu(torch.autograd.Function):
         m = x_cl.numel() // c
         dy = dy.contiguous()
         dx = torch.empty_like(x_cl)
-        sums = torch.empty(BN_SLICES * 2 * c, dtype=torch.float32, device=x_cl.device)
+        sums = torch.empty((BN_SLICES + 1) * 2 * c, dtype=torch.float32, device=x_cl.device)
         _lib.call('repmode_bn_relu_bwd', _ptr(x_cl), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(save_mean),
                   _ptr(save_invstd), _ptr(dx), _ptr(sums), m, c, 1 if ctx.training else 0, dtype_code(x_cl.dtype),
                   dtype_code(dy.dtype), _stream())
-        tot = sums.view(BN_SLICES, 2, c).sum(dim=0)          # row 0 = dbeta, row 1 = dgamma
-        return dx, tot[1], tot[0], None, None, None, None, None, None
+        tot = sums[BN_SLICES * 2 * c:]                           # [0:c) = dbeta, [c:2c) = dgamma
+        return dx, tot[c:], tot[:c], None, None, None, None, None, None
 
 
 def bn_relu(x_cl, bn, training, out_dtype):
