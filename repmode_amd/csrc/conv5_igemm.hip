@@ -159,7 +159,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
     __syncthreads();  // all waves finished reading the previous chunk's halo image
     // ---- stage the halo brick: item = (halo voxel, plane), two 16-byte items per voxel
     constexpr int NITEMS = 2 * VH;
-    constexpr int UNR = 4;
+    constexpr int UNR = (NITEMS + NT - 1) / NT >= 9 ? 9 : 4;   // loads in flight per thread per batch (latency-bound phase)
     for (int it0 = 0; it0 < NITEMS; it0 += NT * UNR) {
       u32x4 v[UNR];
 #pragma unroll

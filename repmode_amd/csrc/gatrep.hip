@@ -87,14 +87,14 @@ template <typename T, bool WRITE_WD>
 __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
     const float* __restrict__ k5, const float* __restrict__ k3, const float* __restrict__ k1,
     const float* __restrict__ a3, const float* __restrict__ a5, const float* __restrict__ g, int nslots,
-    int co_n, int ci_n, int nrt, int nkc, T* __restrict__ wout) {
+    int co_n, int ci_n, int nrt, int nkc, int tsplit, T* __restrict__ wout) {
   using G = FragGeom<T>;
   constexpr int KC = G::KC, PAIRS = G::PAIRS, TQ = G::TQ;
   __shared__ float s5[PAIRS * TAPS];
   __shared__ float s3[PAIRS * 27];
   __shared__ float s1[PAIRS], sa3[PAIRS], sa5[PAIRS];
   const int tid = threadIdx.x;
-  const int kc = blockIdx.x, rt = blockIdx.y, grp = blockIdx.z;
+  const int kc = blockIdx.x, rt = blockIdx.y, grp = blockIdx.z / tsplit, part = blockIdx.z % tsplit;
   const size_t tile_elems = 32 * KC;
   const size_t tap_stride = (size_t)nrt * nkc * tile_elems;
   const size_t slot_stride = (size_t)TAPS * tap_stride;
@@ -153,6 +153,27 @@ __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
   const size_t tile_off = ((size_t)rt * nkc + kc) * tile_elems + in_tile;
   // LDS column of this thread's two elements: wf -> the row's co (column r4), wd -> the reduction co (columns k, k+1)
   const int colA = WRITE_WD ? k : r4, colB = WRITE_WD ? k + 1 : r4;
+  // slot-independent values of this thread's taps, hoisted out of the slot loop.  The workgroups of one
+  // tile group may split the taps between them (blockIdx.z = grp * tsplit + part): small layers would
+  // otherwise run as a handful of long, latency-bound single-wave loops.
+  constexpr int MAXT = (TAPS + TQ - 1) / TQ;
+  int tapj[MAXT];
+  bool c3j[MAXT];
+  float v5a[MAXT], v5b[MAXT], v3a[MAXT], v3b[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int phase = tq + TQ * j;                 // tap phase index; phases are dealt round-robin to the parts
+    const int tap = phase;
+    const bool mine = tap < TAPS && (j % tsplit) == part;
+    tapj[j] = mine ? tap : -1;
+    int t3 = 0;
+    c3j[j] = mine && in_centre3(tap, t3);
+    v5a[j] = mine ? s5[pr * TAPS + tap] : 0.f;
+    v5b[j] = mine ? s5[(pr + 1) * TAPS + tap] : 0.f;
+    v3a[j] = c3j[j] ? s3[pr * 27 + t3] : 0.f;
+    v3b[j] = c3j[j] ? s3[(pr + 1) * 27 + t3] : 0.f;
+  }
+  const float e2a = s1[pr], e2b = s1[pr + 1], e3a = sa3[pr], e3b = sa3[pr + 1], e4a = sa5[pr], e4b = sa5[pr + 1];
   for (int s0 = 0; s0 < nslots; s0 += 16) {
     const int ns = min(16, nslots - s0);
     __syncthreads();
@@ -167,22 +188,22 @@ __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
       const float ga0 = sg[sl][0][colA], ga1 = sg[sl][1][colA], ga2 = sg[sl][2][colA], ga3 = sg[sl][3][colA], ga4 = sg[sl][4][colA];
       const float gb0 = sg[sl][0][colB], gb1 = sg[sl][1][colB], gb2 = sg[sl][2][colB], gb3 = sg[sl][3][colB], gb4 = sg[sl][4][colB];
       T* wslot = wout + (size_t)(s0 + sl) * slot_stride + tile_off;
-      const float ca4 = ga4 * sa5[pr], cb4 = gb4 * sa5[pr + 1];
-      for (int tap = tq; tap < TAPS; tap += TQ) {
-        int t3;
-        const bool c3 = in_centre3(tap, t3);
-        // same association order as RepMode.py:184-188: ((((g0 k5 + g1 k3) + g2 k1) + g3 a3) + g4 a5)
-        float ra = ga0 * s5[pr * TAPS + tap], rb = gb0 * s5[(pr + 1) * TAPS + tap];
-        if (c3) {
-          ra += ga1 * s3[pr * 27 + t3];
-          rb += gb1 * s3[(pr + 1) * 27 + t3];
-          if (tap == 62) { ra += ga2 * s1[pr]; rb += gb2 * s1[pr + 1]; }
-          ra += ga3 * sa3[pr];
-          rb += gb3 * sa3[pr + 1];
+      // same association order as RepMode.py:184-188: ((((g0 k5 + g1 k3) + g2 k1) + g3 a3) + g4 a5)
+      const float ca3 = ga3 * e3a, cb3 = gb3 * e3b, ca4 = ga4 * e4a, cb4 = gb4 * e4b;
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        if (tapj[j] < 0) continue;
+        float ra = ga0 * v5a[j], rb = gb0 * v5b[j];
+        if (c3j[j]) {
+          ra += ga1 * v3a[j];
+          rb += gb1 * v3b[j];
+          if (tapj[j] == 62) { ra += ga2 * e2a; rb += gb2 * e2b; }
+          ra += ca3;
+          rb += cb3;
         }
         ra += ca4;
         rb += cb4;
-        const int tap_out = WRITE_WD ? TAPS - 1 - tap : tap;
+        const int tap_out = WRITE_WD ? TAPS - 1 - tapj[j] : tapj[j];
         store_pair<T>(wslot + (size_t)tap_out * tap_stride, ra, rb);
       }
     }
@@ -354,14 +375,16 @@ static int gatrep_fwd_t(const float* k5, const float* k3, const float* k1, const
   repmode_prof_begin(REPMODE_PROF_GATREP_FWD, bytes, s);
   if (wf) {   // rows = co (padded to 32), reduction = ci (padded to KC)
     const int nrt = repmode_padded_channels(co, dtype, 0) / 32, nkc = repmode_padded_channels(ci, dtype, 1) / KC;
-    hipLaunchKernelGGL((gatrep_fwd_kernel<T, false>), dim3(nkc, nrt, 8), dim3(256), 0, s, k5, k3, k1, a3, a5, g, nslots,
-                       co, ci, nrt, nkc, static_cast<T*>(wf));
+    const int ts = (long)nkc * nrt * 8 < 512 ? 4 : 1;   // small layers: split the taps over 4x more workgroups
+    hipLaunchKernelGGL((gatrep_fwd_kernel<T, false>), dim3(nkc, nrt, 8 * ts), dim3(256), 0, s, k5, k3, k1, a3, a5, g,
+                       nslots, co, ci, nrt, nkc, ts, static_cast<T*>(wf));
     RM_LAUNCH_CHECK("gatrep_fwd(wf)");
   }
   if (wd) {   // rows = ci (padded to 32), reduction = co (padded to KC), taps flipped
     const int nrt = repmode_padded_channels(ci, dtype, 0) / 32, nkc = repmode_padded_channels(co, dtype, 1) / KC;
-    hipLaunchKernelGGL((gatrep_fwd_kernel<T, true>), dim3(nkc, nrt, 8), dim3(256), 0, s, k5, k3, k1, a3, a5, g, nslots,
-                       co, ci, nrt, nkc, static_cast<T*>(wd));
+    const int ts = (long)nkc * nrt * 8 < 512 ? 4 : 1;
+    hipLaunchKernelGGL((gatrep_fwd_kernel<T, true>), dim3(nkc, nrt, 8 * ts), dim3(256), 0, s, k5, k3, k1, a3, a5, g,
+                       nslots, co, ci, nrt, nkc, ts, static_cast<T*>(wd));
     RM_LAUNCH_CHECK("gatrep_fwd(wd)");
   }
   repmode_prof_end(s);
