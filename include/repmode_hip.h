@@ -100,6 +100,14 @@ int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32_t* sample_
                            float* dw, int n, int d, int h, int wdim, int cin, int cout, int dtype,
                            int centre3, void* stream);
 
+/* ---- the same filter gradient when one channel count is 1 (first layer Cin = 1, last layer Cout = 1): the
+ * 125 taps take the place of the missing channel dimension.  bf16 only.  a: [N][D][H][W][C], b: [N][D][H][W],
+ * dw: float [nslots][125][C] (== the general layout with the unit dimension dropped), overwritten.
+ *   flip == 0: dw[tap][c] = sum_v a[v][c] * b[v + tap]     (Cin  == 1: a = dy, b = x)
+ *   flip != 0: dw[tap][c] = sum_v a[v][c] * b[v - tap]     (Cout == 1: a = x,  b = dy) */
+int repmode_conv5_wgrad_thin(const void* a, const void* b, const int32_t* sample_slot, int nslots, float* dw,
+                             int n, int d, int h, int wdim, int c, int flip, void* stream);
+
 /* ---- GatRep backward (autograd of RepMode.py:171-200): expert, gate-probability and gate
  * parameter gradients from the per-slot filter gradient.  Outputs are OVERWRITTEN.
  * dk5 [Co][Ci][125], dk3 [Co][Ci][27], dk1/da3/da5 [Co][Ci], dgate_w [5*Co][T], dgate_b [5*Co].
@@ -138,7 +146,8 @@ int repmode_box_sum(const float* in3, const float* in5, float* out, int n, int d
 #define REPMODE_PROF_WGRAD 1    /* conv5_wgrad                                      */
 #define REPMODE_PROF_GATREP_FWD 2
 #define REPMODE_PROF_GATREP_BWD 3
-#define REPMODE_PROF_KINDS 4
+#define REPMODE_PROF_WGRAD_THIN 4 /* conv5_wgrad_thin */
+#define REPMODE_PROF_KINDS 5
 int repmode_prof_enable(int on);
 int repmode_prof_summary(int kind, int* launches, double* total_ms, double* total_work);
 /* individual records, in launch order: number of records, and the kind / duration (ms) / work of record i */

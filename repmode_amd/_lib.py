@@ -30,6 +30,7 @@ _SIGNATURES = {
     'repmode_conv5_ex': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad_ex': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_conv5_wgrad_thin': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     'repmode_gatrep_bwd': [_P] * 8 + [_I] * 4 + [_P] * 9,
     'repmode_bn_relu_fwd': [_P] * 9 + [_c.c_long, _I, _c.c_float, _c.c_float, _I, _I, _I, _P],
     'repmode_bn_relu_bwd': [_P] * 8 + [_c.c_long, _I, _I, _I, _I, _P],
@@ -91,7 +92,7 @@ def device_arch(dev=0):
     return buf.value.decode()
 
 
-PROF_KINDS = {'conv5_igemm': 0, 'conv5_wgrad': 1, 'gatrep_fwd': 2, 'gatrep_bwd': 3}
+PROF_KINDS = {'conv5_igemm': 0, 'conv5_wgrad': 1, 'gatrep_fwd': 2, 'gatrep_bwd': 3, 'conv5_wgrad_thin': 4}
 
 
 def prof_enable(on):

@@ -404,3 +404,172 @@ extern "C" int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32
   RM_LAUNCH_CHECK("conv5_wgrad");
   return REPMODE_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Thin filter gradient: one of the two channel counts is 1 (first layer: Cin = 1; last layer: Cout = 1).
+//
+//   Cin  == 1:  dw[tap][co] = sum_v dy[v][co] * x[v + tap]          (A = dy, b = x, shift +tap)
+//   Cout == 1:  dw[tap][ci] = sum_v dy[v] * x[v + tap][ci]
+//                           = sum_u x[u][ci] * dy[u - tap]          (A = x,  b = dy, shift -tap)
+//
+// The general kernel would spend a 32x32 channel tile on a 32x1 problem.  Here the 125 taps take the
+// place of the missing channel dimension: GEMM rows = taps (8 tiles of 16), columns = the 32 channels of
+// the multi-channel tensor A, K = voxels.  The single-channel tensor b becomes a Toeplitz operand: the
+// fragment of tap row t and voxel group v0..v0+7 is the 8-element window of b starting at v0 + shift(t),
+// read from a halo tile of b in LDS with five ds_read_b32 and four v_alignbit_b32 (2-byte alignment
+// differs per lane).  A is transposed to [c][voxel] while staging, exactly as in the general kernel.
+namespace {
+
+constexpr int TH_TY = 8, TH_TX = 32;                 // voxel tile: one z plane, 8 rows of 32
+constexpr int TH_RL = 48;                            // stored b row: x0-2 .. x0+45 (window reads stay inside)
+constexpr int TH_HY = TH_TY + 4;
+constexpr int TH_BPL = TH_HY * TH_RL;                // elements per b plane
+constexpr int TH_AS = TH_TY * TH_TX * 2 + 16;        // bytes per channel row of A^T (odd multiple of 16)
+
+struct ThinArgs {
+  const bf16_t* a;      // multi-channel tensor [N][D][H][W][C]
+  const bf16_t* b;      // single-channel tensor [N][D][H][W]
+  const int32_t* sample_slot;
+  float* dw;            // [nslots][125][C]
+  int N, D, H, W, C, flip, nty, ntx, ntiles, tiles_per_block, nchunks, nct;
+};
+
+__global__ __launch_bounds__(256) void conv5_wgrad_thin_kernel(ThinArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[32 * TH_AS + 5 * TH_BPL * 2];
+  unsigned char* aT = smem;                                        // [32 c][TY*TX] bf16
+  bf16_t* bh = reinterpret_cast<bf16_t*>(smem + 32 * TH_AS);       // [5 planes][HY][RL] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  int bid = blockIdx.x;
+  const int chunk = bid % a.nchunks; bid /= a.nchunks;
+  const int ct = bid % a.nct;
+  const int slot = bid / a.nct;
+  const int D = a.D, H = a.H, W = a.W, C = a.C;
+  const bool vec = (C & 7) == 0;
+
+  // this wave's two tap tiles (16 rows each); per lane the tap of its row and the element shift it implies
+  int shift[2];
+  int tapi[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int tap = (wave * 2 + t) * 16 + l15;
+    tapi[t] = tap;
+    const int te = min(tap, REPMODE_TAPS - 1);
+    const int tf = a.flip ? REPMODE_TAPS - 1 - te : te;             // Cout == 1: shift by -tap == flipped tap
+    const int dz = tf / 25, dy = (tf / 5) % 5, dx = tf % 5;
+    shift[t] = dz * TH_BPL + dy * TH_RL + dx;                      // relative to (z-2, y-2, x-2) = halo origin
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int t_begin = chunk * a.tiles_per_block;
+  const int t_end = min(a.ntiles, t_begin + a.tiles_per_block);
+  for (int n = 0; n < a.N; ++n) {
+    if (a.sample_slot[n] != slot) continue;
+    const bf16_t* __restrict__ an = a.a + (size_t)n * D * H * W * C;
+    const bf16_t* __restrict__ bn = a.b + (size_t)n * D * H * W;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int txi = tile % a.ntx, t2 = tile / a.ntx;
+      const int tyi = t2 % a.nty, z = t2 / a.nty;
+      const int y0 = tyi * TH_TY, x0 = txi * TH_TX;
+      __syncthreads();
+      // ---- stage A^T: (voxel pair, channel group) items, two x-adjacent voxels per ds_write_b32
+      for (int it = tid; it < (TH_TY * TH_TX / 2) * 4; it += 256) {
+        const int q = it % (TH_TY * TH_TX / 2), cg = it / (TH_TY * TH_TX / 2);
+        const int m = 2 * q, xx = m % TH_TX, yy = m / TH_TX;
+        const int gy = y0 + yy, gx = x0 + xx, c = ct * 32 + cg * 8;
+        u32x4 v0 = u32x4{0u, 0u, 0u, 0u}, v1 = v0;
+        if (gy < H && c < C) {
+          const bf16_t* rowp = an + ((size_t)(z * H + gy) * W) * C + c;
+          if (gx < W) v0 = load8_bf16(rowp + (size_t)gx * C, c, C, vec);
+          if (gx + 1 < W) v1 = load8_bf16(rowp + (size_t)(gx + 1) * C, c, C, vec);
+        }
+        unsigned char* dst = aT + (cg * 8) * TH_AS + m * 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          *reinterpret_cast<uint32_t*>(dst + k * TH_AS) = bf16_elem(v0, k) | (bf16_elem(v1, k) << 16);
+      }
+      // ---- stage the halo of b: planes z-2..z+2, rows y0-2..y0+TY+1, x0-2..x0+RL-3 (zero outside)
+      for (int it = tid; it < 5 * TH_BPL; it += 256) {
+        const int xx = it % TH_RL, r = it / TH_RL;
+        const int yy = r % TH_HY, pz = r / TH_HY;
+        const int gz = z + pz - 2, gy = y0 + yy - 2, gx = x0 + xx - 2;
+        bf16_t v = 0;
+        if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+          v = bn[((size_t)gz * H + gy) * W + gx];
+        bh[it] = v;
+      }
+      __syncthreads();
+      // ---- K loop: one tile row (32 voxels = 4 groups of 8) per step
+#pragma unroll 2
+      for (int ry = 0; ry < TH_TY; ++ry) {
+        u32x4 bf[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          bf[c] = *reinterpret_cast<const u32x4*>(aT + (c * 16 + l15) * TH_AS + (ry * TH_TX + kg * 8) * 2);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          // window of 8 elements of b starting at element e0 (2-byte granularity)
+          const int e0 = ry * TH_RL + kg * 8 + shift[t];
+          const uint32_t* p = reinterpret_cast<const uint32_t*>(bh) + (e0 >> 1);
+          const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
+          const uint32_t sh = (e0 & 1) * 16;
+          const u32x4 af = u32x4{__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
+                                 __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh)};
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af),
+                                                                __builtin_bit_cast(bf16x8, bf[c]), acc[t][c], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // 16x16 C/D layout: column (channel) = lane & 15, row (tap within the tile) = (lane >> 4) * 4 + r
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ch = ct * 32 + c * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tap = (wave * 2 + t) * 16 + kg * 4 + r;
+        if (tap < REPMODE_TAPS && ch < C)
+          unsafeAtomicAdd(a.dw + ((size_t)slot * REPMODE_TAPS + tap) * C + ch, acc[t][c][r]);
+      }
+    }
+}
+
+}  // namespace
+
+// dw[slot][tap][c] (float, overwritten).  a: [N][D][H][W][C] bf16, b: [N][D][H][W] bf16.
+// flip == 0: dw[tap][c] = sum_v a[v][c] * b[v + tap]   (first layer:  a = dy, b = x)
+// flip != 0: dw[tap][c] = sum_v a[v][c] * b[v - tap]   (last layer:   a = x,  b = dy)
+extern "C" int repmode_conv5_wgrad_thin(const void* a_t, const void* b_t, const int32_t* sample_slot, int nslots,
+                                        float* dw, int n, int d, int h, int wdim, int c, int flip, void* stream) {
+  RM_REQUIRE(a_t && b_t && sample_slot && dw, "conv5_wgrad_thin: null pointer");
+  RM_REQUIRE(n > 0 && nslots > 0 && d > 0 && h > 0 && wdim > 0 && c > 0, "conv5_wgrad_thin: bad shape");
+  RM_REQUIRE(((uintptr_t)a_t & 15) == 0, "conv5_wgrad_thin: pointer must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ThinArgs a{};
+  a.a = static_cast<const bf16_t*>(a_t); a.b = static_cast<const bf16_t*>(b_t);
+  a.sample_slot = sample_slot; a.dw = dw;
+  a.N = n; a.D = d; a.H = h; a.W = wdim; a.C = c; a.flip = flip;
+  a.nty = ceil_div(h, TH_TY); a.ntx = ceil_div(wdim, TH_TX);
+  a.ntiles = d * a.nty * a.ntx;
+  a.nct = ceil_div(c, 32);
+  const long fixed = (long)nslots * a.nct;
+  long want = (1024 + fixed - 1) / fixed;
+  if (want > a.ntiles) want = a.ntiles;
+  if (want < 1) want = 1;
+  a.tiles_per_block = ceil_div(a.ntiles, (int)want);
+  a.nchunks = ceil_div(a.ntiles, a.tiles_per_block);
+  RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * REPMODE_TAPS * c * sizeof(float), s));
+  repmode_prof_begin(REPMODE_PROF_WGRAD_THIN, 2.0 * n * d * h * wdim * (double)c * REPMODE_TAPS, s);
+  hipLaunchKernelGGL(conv5_wgrad_thin_kernel, dim3((unsigned)(fixed * a.nchunks)), dim3(256), 0, s, a);
+  repmode_prof_end(s);
+  RM_LAUNCH_CHECK("conv5_wgrad_thin");
+  return REPMODE_OK;
+}

@@ -118,6 +118,12 @@ def conv5_wgrad(x_cl, dy_cl, plan, cout, centre3=False):
     """dw[s, tap, o, i] (float32) summed over the samples of each slot."""
     n, d, h, wd_, cin = x_cl.shape
     dw = torch.empty((plan.nslots, TAPS, cout, cin), dtype=torch.float32, device=x_cl.device)
+    if x_cl.dtype == torch.bfloat16 and (cin == 1) != (cout == 1) and not centre3:
+        # thin layer: taps stand in for the missing channel dimension (conv5_wgrad_thin)
+        a_t, b_t, c, flip = (dy_cl, x_cl, cout, 0) if cin == 1 else (x_cl, dy_cl, cin, 1)
+        _lib.call('repmode_conv5_wgrad_thin', _ptr(a_t), _ptr(b_t), _ptr(plan.sample_slot), plan.nslots, _ptr(dw),
+                  n, d, h, wd_, c, flip, _stream())
+        return dw
     _lib.call('repmode_conv5_wgrad_ex', _ptr(x_cl), _ptr(dy_cl), _ptr(plan.sample_slot), plan.nslots, _ptr(dw),
               n, d, h, wd_, cin, cout, dtype_code(x_cl.dtype), 1 if centre3 else 0, _stream())
     return dw
