@@ -118,6 +118,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model.do_train_iter(signal, target, task)
+    t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (== dt when the host is the limiter)
     barrier()
     dt = time.perf_counter() - t0
     _lib.prof_enable(False)
@@ -141,7 +142,7 @@ def main():
         'config': {'workload': 'RepMode U-Net (mult_chan 32, 12 tasks, 123.9M params) full train step '
                                '(fwd + bwd + Adam), batch %d x 1x32x64x64 per GPU' % b,
                    'global_batch': world * b, 'patch': list(PATCH), 'parallelism': 'dp%d' % world,
-                   'final_loss': loss},
+                   'final_loss': loss, 'host_issue_ms_per_step': 1e3 * t_issue / args.steps},
     }
     if rank == 0:
         if not args.no_prof:

@@ -241,12 +241,13 @@ def _expert_selector(co, device):
     return _ONEHOT2[key]
 
 
-def box_sum(in3=None, in5=None):
+def box_sum(in3=None, in5=None, out=None):
     """box3(in3) + box5(in5): zero-padded k^3 box means of float channels-last tensors -- the avg-pool
     experts' spatial part (RepMode.py:139-142, 176-180: w1x1 * 1/k^3 broadcast over the k^3 support)."""
     ref = in3 if in3 is not None else in5
     n, d, h, w, c = ref.shape
-    out = torch.empty_like(ref)
+    if out is None:
+        out = torch.empty_like(ref)
     _lib.call('repmode_box_sum', _ptr(in3) if in3 is not None else None, _ptr(in5) if in5 is not None else None,
               _ptr(out), n, d, h, w, c, _stream())
     return out
@@ -281,20 +282,22 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         p = torch.empty((NUM_EXPERTS, n, d, h, w, co), dtype=torch.float32, device=dev)   # expert outputs P_e
         conv5(x_cl, wf2, s0.sample_slot, co, out_f32=True, out=p[0])
         conv5(x_cl, wf2, s1.sample_slot, co, out_f32=True, out=p[1], centre3=True)      # 3x3x3 support
-        xf = x_cl.float()
-        b3, b5 = box_sum(in3=xf), box_sum(in5=xf)
-        torch.mm(xf.view(-1, ci), k1.view(co, ci).t(), out=p[2].view(-1, co))
-        torch.mm(b3.view(-1, ci), a3.view(co, ci).t(), out=p[3].view(-1, co))
-        torch.mm(b5.view(-1, ci), a5.view(co, ci).t(), out=p[4].view(-1, co))
+        # the three 1x1 experts as ONE batched GEMM: [x | box3(x) | box5(x)] @ [K1 | A3 | A5]^T  -> P_2..P_4
+        xb = torch.empty((3, n, d, h, w, ci), dtype=torch.float32, device=dev)
+        xb[0].copy_(x_cl)
+        box_sum(in3=xb[0], out=xb[1])
+        box_sum(in5=xb[0], out=xb[2])
+        w1 = torch.stack((k1.view(co, ci), a3.view(co, ci), a5.view(co, ci)))             # [3, Co, Ci]
+        torch.bmm(xb.view(3, -1, ci), w1.transpose(1, 2), out=p[2:].view(3, -1, co))
         ge = gn.permute(1, 0, 2).contiguous().view(NUM_EXPERTS, n, 1, 1, 1, co)    # [5, N, 1, 1, 1, Co]
         y = (p * ge).sum(dim=0)
-        ctx.save_for_backward(x_cl, k5, k3, k1, a3, a5, gn, b3, b5, p)
+        ctx.save_for_backward(x_cl, k5, k3, k1, a3, a5, gn, xb, w1, p)
         ctx.plan = plan
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x_cl, k5, k3, k1, a3, a5, gn, b3, b5, p = ctx.saved_tensors
+        x_cl, k5, k3, k1, a3, a5, gn, xb, w1, p = ctx.saved_tensors
         plan = ctx.plan
         co, ci = k5.shape[0], k5.shape[1]
         n = x_cl.shape[0]
@@ -320,11 +323,11 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
             dxf = conv5(d01[0], wd2, s0.sample_slot, ci, out_f32=True)
             shp = dxf.shape
             dxf += conv5(d01[1], wd2, s1.sample_slot, ci, out_f32=True, centre3=True)
-            dxf.view(-1, ci).addmm_(dye[2].view(-1, co), k1.view(co, ci))
-            # the zero-padded box mean is self-adjoint
-            t3 = (dye[3].view(-1, co) @ a3.view(co, ci)).view(shp)
-            t5 = (dye[4].view(-1, co) @ a5.view(co, ci)).view(shp)
-            dxf += box_sum(in3=t3, in5=t5)
+            # 1x1 experts: one batched GEMM gives the three partial data gradients; the zero-padded box
+            # mean is self-adjoint, so the avg experts' parts go back through box3 / box5
+            t = torch.bmm(dye[2:].view(3, -1, co), w1).view(3, *shp)                     # [3, N, D, H, W, Ci]
+            dxf += t[0]
+            dxf += box_sum(in3=t[1], in5=t[2])
             dx = dxf.to(dt)
             del wd2
         # ---- expert gradients: filter gradients of the gate-scaled dy, all samples in one slot
@@ -333,10 +336,8 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         dk5 = dw5.permute(1, 2, 0).reshape(k5.shape)
         dw3 = conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0].view(5, 5, 5, co, ci)[1:4, 1:4, 1:4]
         dk3 = dw3.permute(3, 4, 0, 1, 2).reshape(k3.shape)
-        xf = x_cl.float().view(-1, ci)
-        dk1 = (dye[2].view(-1, co).t() @ xf).view(k1.shape)
-        da3 = (dye[3].view(-1, co).t() @ b3.view(-1, ci)).view(a3.shape)
-        da5 = (dye[4].view(-1, co).t() @ b5.view(-1, ci)).view(a5.shape)
+        d1 = torch.bmm(dye[2:].view(3, -1, co).transpose(1, 2), xb.view(3, -1, ci))       # [3, Co, Ci]
+        dk1, da3, da5 = d1[0].reshape(k1.shape), d1[1].reshape(a3.shape), d1[2].reshape(a5.shape)
         return dx, dk5.contiguous(), dk3.contiguous(), dk1, da3, da5, dgw, dgb, None
 
 

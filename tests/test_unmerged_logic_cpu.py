@@ -19,7 +19,7 @@ def fake_kernels(monkeypatch):
         w = orc.merge_filters(orc.expert_bank(k5, k3, k1, a3, a5), g)          # [S,Co,Ci,5,5,5], either role
         return (('wf', w) if want_wf else None), (('wd', w) if want_wd else None)
 
-    def conv5(x_cl, w, slot, cout, out_f32=False, out=None):
+    def conv5(x_cl, w, slot, cout, out_f32=False, out=None, centre3=False):
         role, wt = w
         ws = wt[slot.long()]
         if role == 'wd':
@@ -30,7 +30,7 @@ def fake_kernels(monkeypatch):
             return out
         return y
 
-    def wgrad(x_cl, dy_cl, plan, cout):
+    def wgrad(x_cl, dy_cl, plan, cout, centre3=False):
         with torch.enable_grad():
             n, ci = x_cl.shape[0], x_cl.shape[-1]
             wt = torch.zeros(1, cout, ci, 5, 5, 5, requires_grad=True)
@@ -38,18 +38,21 @@ def fake_kernels(monkeypatch):
             (y * dy_cl.detach().float().permute(0, 4, 1, 2, 3)).sum().backward()
         return wt.grad.reshape(1, cout, ci, 125).permute(0, 3, 1, 2).contiguous()
 
-    def box(in3=None, in5=None):
+    def box(in3=None, in5=None, out=None):
         def one(t, k):
             c = t.shape[-1]
             w = torch.ones(c, 1, k, k, k) / k ** 3
             return torch.nn.functional.conv3d(t.permute(0, 4, 1, 2, 3), w, padding=k // 2,
                                               groups=c).permute(0, 2, 3, 4, 1).contiguous()
-        out = 0
+        res = 0
         if in3 is not None:
-            out = out + one(in3, 3)
+            res = res + one(in3, 3)
         if in5 is not None:
-            out = out + one(in5, 5)
-        return out
+            res = res + one(in5, 5)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
     for name, fn in dict(gate_softmax=gate, gatrep_merge=merge, conv5=conv5, conv5_wgrad=wgrad, box_sum=box).items():
         monkeypatch.setattr(ops, name, fn)
