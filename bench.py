@@ -79,6 +79,7 @@ def main():
     ap.add_argument('--batch', type=int, default=PER_GPU_BATCH, help='patches per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events')
+    ap.add_argument('--prof-all', action='store_true', help='record HIP events for every library kernel, not only conv5_igemm')
     ap.add_argument('--dump-launches', default=None, help='write per-launch (kind, ms, TFLOP/s or TB/s) of the last timed step as JSON')
     args = ap.parse_args()
 
@@ -114,7 +115,8 @@ def main():
         model.do_train_iter(signal, target, task)
     barrier()
     if not args.no_prof:
-        _lib.prof_enable(True)
+        # HIP events around the dominant kernel's launches only by default (each pair costs ~4 us of stream time)
+        _lib.prof_enable(1 if (args.prof_all or args.dump_launches) else 2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model.do_train_iter(signal, target, task)

@@ -139,7 +139,8 @@ int repmode_box_sum(const float* in3, const float* in5, float* out, int n, int d
                     void* stream);
 
 /* ---- measurement: per-launch HIP-event timing of the library's kernels on their own stream.
- * repmode_prof_enable(1) clears the records and starts recording, (0) stops.  repmode_prof_summary()
+ * repmode_prof_enable(1) clears the records and starts recording every kind, (2) records conv5_igemm only
+ * (least perturbation of the timed region), (0) stops.  repmode_prof_summary()
  * synchronises the recorded events and returns, for one kernel kind, the number of launches, the
  * summed duration (ms) and the summed algorithmic work (FLOPs for the conv kernels, bytes for GatRep). */
 #define REPMODE_PROF_CONV5 0    /* conv5_igemm (forward and data-gradient launches) */

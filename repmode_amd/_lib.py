@@ -96,7 +96,8 @@ PROF_KINDS = {'conv5_igemm': 0, 'conv5_wgrad': 1, 'gatrep_fwd': 2, 'gatrep_bwd':
 
 
 def prof_enable(on):
-    call('repmode_prof_enable', 1 if on else 0)
+    """False/0: off; True/1: every kernel kind; 2: conv5_igemm only."""
+    call('repmode_prof_enable', int(on))
 
 
 def prof_summary(kind):

@@ -44,11 +44,12 @@ struct ProfRec {
 std::vector<ProfRec> g_prof;   // event pool, reused across enable() calls
 size_t g_prof_n = 0;           // records in use
 bool g_prof_on = false;
+unsigned g_prof_mask = ~0u;   // bit k set: record kernel kind k
 bool g_prof_open = false;
 }  // namespace
 
 void repmode_prof_begin(int kind, double work, hipStream_t s) {
-  if (!g_prof_on) return;
+  if (!g_prof_on || !((g_prof_mask >> kind) & 1u)) return;
   if (g_prof_n == g_prof.size()) {
     ProfRec r{};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
@@ -71,6 +72,7 @@ void repmode_prof_end(hipStream_t s) {
 extern "C" int repmode_prof_enable(int on) {
   if (on) g_prof_n = 0;
   g_prof_on = on != 0;
+  g_prof_mask = (on == 2) ? (1u << REPMODE_PROF_CONV5) : ~0u;   // 2: the dominant kernel only (least perturbation)
   g_prof_open = false;
   return REPMODE_OK;
 }
