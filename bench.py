@@ -151,6 +151,8 @@ def main():
             kinds = {}
             for kind in ('conv5_igemm', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd'):
                 n, ms, work = _lib.prof_summary(kind)
+                if n == 0:
+                    continue          # kind not recorded (default: the dominant kernel only; --prof-all for all)
                 kinds[kind] = {'launches': n, 'ms_per_step': ms / args.steps,
                                'rate': (work / (ms * 1e-3) / 1e12) if ms > 0 else None}   # TFLOP/s or TB/s
             n, ms, flops = _lib.prof_summary('conv5_igemm')

@@ -132,6 +132,15 @@ int repmode_bn_relu_bwd(const void* x, const void* dy, const float* gamma, const
                         const float* save_mean, const float* save_invstd, void* dx, float* sums_ws, long m, int c,
                         int training, int in_dtype, int out_dtype, void* stream);
 
+/* ---- the stride-2 2x2x2 stages (RepMode.py:81 Conv3d k2 s2, :98 ConvTranspose3d k2 s2; both bias-free) as a
+ * gather / scatter GEMM over the 8 disjoint taps p = (pz*2+py)*2+px of every coarse voxel m:
+ *   scatter == 0:  out[m][co]         = sum_p sum_ci in[fine(m,p)][ci] * w[p][co][ci]   (in: fine grid, out: coarse)
+ *   scatter != 0:  out[fine(m,p)][co] = sum_ci       in[m][ci]         * w[p][co][ci]   (in: coarse, out: fine)
+ * (down forward / up data-gradient, and up forward / down data-gradient.)  d, h, wdim = COARSE dims.
+ * w: fragment-major [8][CoutP/32][CinP/KC][32][KC] like the merged filters; in/out channels-last, `dtype`. */
+int repmode_k2s2(const void* in, const void* w, void* out, int n, int d, int h, int wdim, int cin, int cout,
+                 int dtype, int scatter, void* stream);
+
 /* ---- box means of the avg-pool experts (RepMode.py:139-142, 161-163, 176-180): by linearity
  * conv(x, w1x1 (x) 1/k^3) = w1x1 applied to the zero-padded k^3 box mean of x.
  * out = box3(in3) + box5(in5); float NDHWC tensors; either input may be NULL (not both). */

@@ -1,0 +1,190 @@
+// k2s2.hip -- the stride-2 2x2x2 stages of the RepMode U-Net on channels-last activations.
+//
+//   Conv3d(C, C, kernel_size=2, stride=2, bias=False)            fnet/nn_modules/RepMode.py:81   (down)
+//   ConvTranspose3d(Ci, Co, kernel_size=2, stride=2, bias=False) fnet/nn_modules/RepMode.py:98   (up)
+//
+// With kernel == stride the 8 taps of a coarse voxel m touch 8 disjoint fine voxels fine(m, p), so both
+// stages (and each other's data gradients) are plain GEMMs with a gather / scatter of voxel rows:
+//
+//   GATHER : out[m][co]          = sum_p sum_ci in[fine(m,p)][ci] * W[p][co][ci]   (fine -> coarse)
+//   SCATTER: out[fine(m,p)][co]  = sum_ci        in[m][ci]         * W[p][co][ci]   (coarse -> fine)
+//
+//   down forward = GATHER, down data-gradient = SCATTER, up forward = SCATTER, up data-gradient = GATHER.
+//
+// MFMA "A" operand = filter rows (32 output channels) from the fragment-major tensor
+// W[p][row tile][red chunk][32][KC] (1 KiB contiguous per tile, as for the 5x5x5 conv), "B" operand =
+// 32 voxels x KC input channels read straight from HBM/L2 (every input element is used exactly once per
+// output-channel tile, so there is nothing to stage in LDS).  0.55 % of the network's FLOPs: these kernels
+// are bandwidth/latency bound; what they buy is the removal of the permute copies around a library GEMM.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+struct KElem;
+template <>
+struct KElem<float> {
+  static constexpr int KV = 4;
+  __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+template <>
+struct KElem<bf16_t> {
+  static constexpr int KV = 8;
+  __device__ static __forceinline__ void mma(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+struct K2Args {
+  const void* in;
+  const void* w;
+  void* out;
+  long M;                 // coarse voxels (N * d * h * w)
+  int d, h, wd;           // coarse spatial dims
+  int Cin, Cout, CinP, CoutP;
+};
+
+template <typename T>
+__device__ __forceinline__ u32x4 load_chunk(const T* row, int c, int C, bool vec) {
+  constexpr int KV = KElem<T>::KV;
+  if (c >= C) return u32x4{0u, 0u, 0u, 0u};
+  if (vec) return *reinterpret_cast<const u32x4*>(row + c);
+  T e[KV];
+#pragma unroll
+  for (int k = 0; k < KV; ++k) e[k] = (c + k < C) ? row[c + k] : (T)0;
+  return *reinterpret_cast<const u32x4*>(e);
+}
+
+// 4 consecutive output channels (one accumulator quad) of one voxel row
+template <typename T>
+__device__ __forceinline__ void store_quad(T* row, int co, int Cout, float v0, float v1, float v2, float v3) {
+  if (co >= Cout) return;
+  if constexpr (sizeof(T) == 4) {
+    if ((Cout & 3) == 0) { *reinterpret_cast<f32x4*>(row + co) = f32x4{v0, v1, v2, v3}; return; }
+    row[co] = v0;
+    if (co + 1 < Cout) row[co + 1] = v1;
+    if (co + 2 < Cout) row[co + 2] = v2;
+    if (co + 3 < Cout) row[co + 3] = v3;
+  } else {
+    if ((Cout & 3) == 0) { *reinterpret_cast<u32x2*>(row + co) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)}; return; }
+    row[co] = f32_to_bf16(v0);
+    if (co + 1 < Cout) row[co + 1] = f32_to_bf16(v1);
+    if (co + 2 < Cout) row[co + 2] = f32_to_bf16(v2);
+    if (co + 3 < Cout) row[co + 3] = f32_to_bf16(v3);
+  }
+}
+
+// fine-grid row index of tap p = (pz, py, px) of coarse voxel m
+__device__ __forceinline__ size_t fine_row(long m, int p, int d, int h, int w) {
+  const int x = (int)(m % w); long t = m / w;
+  const int y = (int)(t % h); t /= h;
+  const int z = (int)(t % d);
+  const long n = t / d;
+  const int pz = p >> 2, py = (p >> 1) & 1, px = p & 1;
+  return (((size_t)n * (2 * d) + 2 * z + pz) * (2 * h) + 2 * y + py) * (size_t)(2 * w) + 2 * x + px;
+}
+
+// workgroup = 4 waves = 4 x 32 coarse voxels; blockIdx.y = output-channel tile (32)
+template <typename T, bool SCATTER>
+__global__ __launch_bounds__(256) void k2s2_kernel(K2Args a) {
+  constexpr int KV = KElem<T>::KV, KC = 2 * KV;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const long m = ((long)blockIdx.x * 4 + wave) * 32 + l31;
+  const bool mvalid = m < a.M;
+  const long mc = mvalid ? m : a.M - 1;
+  const int rt = blockIdx.y;
+  const int nkc = a.CinP / KC, nrt = a.CoutP / 32;
+  const int Cin = a.Cin, Cout = a.Cout;
+  const bool vec = (Cin % KV) == 0;
+  const T* __restrict__ in = static_cast<const T*>(a.in);
+  const T* __restrict__ wt = static_cast<const T*>(a.w) + ((size_t)rt * nkc) * (32 * KC) + l31 * KC + khalf * KV;
+  const size_t tap_stride = (size_t)nrt * nkc * (32 * KC);
+  T* __restrict__ out = static_cast<T*>(a.out);
+
+  size_t frow[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) frow[p] = fine_row(mc, p, a.d, a.h, a.wd);
+
+  if constexpr (!SCATTER) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kc = 0; kc < nkc; ++kc) {
+      u32x4 b[8], wa[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        b[p] = load_chunk<T>(in + frow[p] * Cin, kc * KC + khalf * KV, Cin, vec);
+        wa[p] = *reinterpret_cast<const u32x4*>(wt + (size_t)p * tap_stride + (size_t)kc * (32 * KC));
+      }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) KElem<T>::mma(wa[p], b[p], acc);
+    }
+    if (mvalid) {
+      T* row = out + (size_t)m * Cout;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        store_quad<T>(row, rt * 32 + 8 * q + 4 * khalf, Cout, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+  } else {
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    for (int kc = 0; kc < nkc; ++kc) {
+      const u32x4 b = load_chunk<T>(in + (size_t)mc * Cin, kc * KC + khalf * KV, Cin, vec);
+      u32x4 wa[8];
+#pragma unroll
+      for (int p = 0; p < 8; ++p)
+        wa[p] = *reinterpret_cast<const u32x4*>(wt + (size_t)p * tap_stride + (size_t)kc * (32 * KC));
+#pragma unroll
+      for (int p = 0; p < 8; ++p) KElem<T>::mma(wa[p], b, acc[p]);
+    }
+    if (mvalid) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        T* row = out + frow[p] * Cout;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          store_quad<T>(row, rt * 32 + 8 * q + 4 * khalf, Cout, acc[p][4 * q], acc[p][4 * q + 1], acc[p][4 * q + 2],
+                        acc[p][4 * q + 3]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// in/out: channels-last, dtype.  scatter == 0: in is the FINE grid [N][2d][2h][2w][Cin], out the coarse grid
+// [N][d][h][w][Cout];  scatter != 0: in coarse, out fine.  w: fragment-major [8][CoutP/32][CinP/KC][32][KC].
+extern "C" int repmode_k2s2(const void* in, const void* w, void* out, int n, int d, int h, int wdim, int cin, int cout,
+                            int dtype, int scatter, void* stream) {
+  RM_REQUIRE(in && w && out, "k2s2: null pointer");
+  RM_REQUIRE(n > 0 && d > 0 && h > 0 && wdim > 0 && cin > 0 && cout > 0, "k2s2: bad shape");
+  RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "k2s2: bad dtype %d", dtype);
+  RM_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)out & 15) == 0,
+             "k2s2: pointers must be 16-byte aligned");
+  K2Args a{};
+  a.in = in; a.w = w; a.out = out;
+  a.M = (long)n * d * h * wdim; a.d = d; a.h = h; a.wd = wdim;
+  a.Cin = cin; a.Cout = cout;
+  a.CinP = repmode_padded_channels(cin, dtype, 1);
+  a.CoutP = repmode_padded_channels(cout, dtype, 0);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.CoutP / 32));
+  if (dtype == REPMODE_F32) {
+    if (scatter) hipLaunchKernelGGL((k2s2_kernel<float, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k2s2_kernel<float, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (scatter) hipLaunchKernelGGL((k2s2_kernel<bf16_t, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k2s2_kernel<bf16_t, false>), grid, dim3(256), 0, s, a);
+  }
+  RM_LAUNCH_CHECK("k2s2");
+  return REPMODE_OK;
+}

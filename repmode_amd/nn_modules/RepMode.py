@@ -108,36 +108,26 @@ class MoDESubNet2Conv(torch.nn.Module):                        # RepMode.py:111-
 
 class Down2(torch.nn.Module):
     """``Conv3d(C, C, kernel_size=2, stride=2, bias=False)`` (RepMode.py:81) on channels-last data:
-    non-overlapping 2x2x2 patches make it one plain GEMM [voxels/8, 8C] x [8C, C]."""
+    non-overlapping 2x2x2 patches make it a gather GEMM (HIP kernel ``repmode_k2s2``)."""
 
     def __init__(self, chan):
         super().__init__()
         self.weight = _kaiming_param(chan, chan, 2, 2, 2)      # same shape / init as nn.Conv3d
 
     def forward(self, x):
-        x_cl = _to_cl(x)
-        n, d, h, w, c = x_cl.shape
-        a = x_cl.view(n, d // 2, 2, h // 2, 2, w // 2, 2, c).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(-1, 8 * c)
-        wm = self.weight.permute(2, 3, 4, 1, 0).reshape(8 * c, -1).to(x_cl.dtype)
-        return _from_cl((a @ wm).view(n, d // 2, h // 2, w // 2, -1))
+        return _from_cl(ops.down2(_to_cl(x), self.weight))
 
 
 class Up2(torch.nn.Module):
     """``ConvTranspose3d(Ci, Co, kernel_size=2, stride=2, bias=False)`` (RepMode.py:98): every input
-    voxel emits a disjoint 2x2x2 output patch -> one plain GEMM [voxels, Ci] x [Ci, 8Co]."""
+    voxel emits a disjoint 2x2x2 output patch -> a scatter GEMM (HIP kernel ``repmode_k2s2``)."""
 
     def __init__(self, in_chan, out_chan):
         super().__init__()
         self.weight = _kaiming_param(in_chan, out_chan, 2, 2, 2)   # same shape / init as nn.ConvTranspose3d
 
     def forward(self, x):
-        x_cl = _to_cl(x)
-        n, d, h, w, c = x_cl.shape
-        co = self.weight.shape[1]
-        wm = self.weight.permute(0, 2, 3, 4, 1).reshape(c, 8 * co).to(x_cl.dtype)
-        y = (x_cl.reshape(-1, c) @ wm).view(n, d, h, w, 2, 2, 2, co)
-        y = y.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(n, 2 * d, 2 * h, 2 * w, co)
-        return _from_cl(y)
+        return _from_cl(ops.up2(_to_cl(x), self.weight))
 
 
 class MoDEEncoderBlock(torch.nn.Module):                       # RepMode.py:74-89

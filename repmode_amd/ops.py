@@ -218,6 +218,92 @@ def bn_relu(x_cl, bn, training, out_dtype):
                          out_dtype)
 
 
+def k2_weight_frags(w3, dtype):
+    """[8, rows, red] tap-major 2x2x2 filter -> fragment-major [8][rowsP/32][redP/KC][32][KC] in ``dtype``."""
+    code = dtype_code(dtype)
+    _, rows, red = w3.shape
+    rp, kp = _lib.padded_channels(rows, code, False), _lib.padded_channels(red, code, True)
+    kc = 16 if dtype == torch.bfloat16 else 8
+    wp = w3.new_zeros((8, rp, kp))
+    wp[:, :rows, :red] = w3
+    return wp.view(8, rp // 32, 32, kp // kc, kc).permute(0, 1, 3, 2, 4).contiguous().to(dtype)
+
+
+def k2s2(in_cl, w_frag, cout, scatter):
+    """Gather (fine -> coarse) or scatter (coarse -> fine) 2x2x2 stride-2 GEMM, see include/repmode_hip.h."""
+    n, a, b, c, cin = in_cl.shape
+    d, h, w = (a, b, c) if scatter else (a // 2, b // 2, c // 2)
+    oshape = (n, 2 * d, 2 * h, 2 * w, cout) if scatter else (n, d, h, w, cout)
+    out = torch.empty(oshape, dtype=in_cl.dtype, device=in_cl.device)
+    _lib.call('repmode_k2s2', _ptr(in_cl), _ptr(w_frag), _ptr(out), n, d, h, w, cin, cout, dtype_code(in_cl.dtype),
+              1 if scatter else 0, _stream())
+    return out
+
+
+def _gather_patches(x_cl):
+    """fine [N,2d,2h,2w,C] -> [N*d*h*w, 8*C], taps ordered (pz, py, px) -- only the weight gradients need it."""
+    n, a, b, c, ch = x_cl.shape
+    return x_cl.view(n, a // 2, 2, b // 2, 2, c // 2, 2, ch).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(-1, 8 * ch)
+
+
+class _Down2(torch.autograd.Function):
+    """Conv3d(C, C, kernel_size=2, stride=2, bias=False) on channels-last data (RepMode.py:81)."""
+
+    @staticmethod
+    def forward(ctx, x_cl, weight):
+        _require_hip(x_cl, 'input')
+        co, ci = weight.shape[:2]
+        wf = k2_weight_frags(weight.permute(2, 3, 4, 0, 1).reshape(8, co, ci), x_cl.dtype)
+        ctx.save_for_backward(x_cl, weight)
+        return k2s2(x_cl, wf, co, scatter=False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, weight = ctx.saved_tensors
+        co, ci = weight.shape[:2]
+        dy = dy.to(x_cl.dtype).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wb = k2_weight_frags(weight.permute(2, 3, 4, 1, 0).reshape(8, ci, co), x_cl.dtype)
+            dx = k2s2(dy, wb, ci, scatter=True)
+        dw2 = dy.view(-1, co).t() @ _gather_patches(x_cl)                 # [Co, 8*Ci], taps outermost
+        dw = dw2.view(co, 2, 2, 2, ci).permute(0, 4, 1, 2, 3).float()
+        return dx, dw
+
+
+class _Up2(torch.autograd.Function):
+    """ConvTranspose3d(Ci, Co, kernel_size=2, stride=2, bias=False) on channels-last data (RepMode.py:98)."""
+
+    @staticmethod
+    def forward(ctx, x_cl, weight):
+        _require_hip(x_cl, 'input')
+        ci, co = weight.shape[:2]
+        wf = k2_weight_frags(weight.permute(2, 3, 4, 1, 0).reshape(8, co, ci), x_cl.dtype)
+        ctx.save_for_backward(x_cl, weight)
+        return k2s2(x_cl, wf, co, scatter=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, weight = ctx.saved_tensors
+        ci, co = weight.shape[:2]
+        dy = dy.to(x_cl.dtype).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wb = k2_weight_frags(weight.permute(2, 3, 4, 0, 1).reshape(8, ci, co), x_cl.dtype)
+            dx = k2s2(dy, wb, ci, scatter=False)
+        dw2 = x_cl.view(-1, ci).t() @ _gather_patches(dy)                 # [Ci, 8*Co]
+        dw = dw2.view(ci, 2, 2, 2, co).permute(0, 4, 1, 2, 3).float()
+        return dx, dw
+
+
+def down2(x_cl, weight):
+    return _Down2.apply(x_cl.contiguous(), weight)
+
+
+def up2(x_cl, weight):
+    return _Up2.apply(x_cl.contiguous(), weight)
+
+
 class _SingleSlot:
     """All samples share one filter: used when the experts themselves are the 'slots'."""
 

@@ -359,6 +359,42 @@ def test_bn_relu(shape, in_dtype, out_dtype, training):
     assert int(bd.num_batches_tracked) == int(bn.num_batches_tracked)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,d,h,w,ci,co', [(2, 4, 4, 8, 32, 32), (1, 2, 3, 5, 6, 4), (2, 2, 2, 2, 64, 128), (1, 1, 1, 1, 2, 2)])
+def test_down_up_k2s2(n, d, h, w, ci, co, dtype):
+    """The stride-2 stages (gather / scatter GEMM kernels) against torch's Conv3d / ConvTranspose3d on CPU,
+    forward and backward.  d, h, w are the COARSE dims."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(ci * 3 + co)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    # down: Conv3d(ci -> co) (the network uses ci == co, the kernel does not care)
+    xf = torch.randn(n, ci, 2 * d, 2 * h, 2 * w, generator=gen).to(dtype).float()
+    wd = (torch.randn(co, ci, 2, 2, 2, generator=gen) / (8 * ci) ** 0.5).to(dtype).float()
+    r = torch.randn(n, co, d, h, w, generator=gen).to(dtype).float()
+    xr, wr = xf.clone().requires_grad_(True), wd.clone().requires_grad_(True)
+    (torch.nn.functional.conv3d(xr, wr, stride=2) * r).sum().backward()
+    xg = xf.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype).requires_grad_(True)
+    wg = wd.to(DEV).requires_grad_(True)
+    y = ops.down2(xg, wg)
+    (y.float() * r.permute(0, 2, 3, 4, 1).to(DEV)).sum().backward()
+    assert rel_err(y.float().detach().permute(0, 4, 1, 2, 3).cpu(), torch.nn.functional.conv3d(xf, wd, stride=2)) < tol
+    assert rel_err(xg.grad.float().permute(0, 4, 1, 2, 3).cpu(), xr.grad) < tol
+    assert rel_err(wg.grad.cpu(), wr.grad) < tol
+    # up: ConvTranspose3d(ci -> co)
+    xc = torch.randn(n, ci, d, h, w, generator=gen).to(dtype).float()
+    wu = (torch.randn(ci, co, 2, 2, 2, generator=gen) / ci ** 0.5).to(dtype).float()
+    r2 = torch.randn(n, co, 2 * d, 2 * h, 2 * w, generator=gen).to(dtype).float()
+    xr, wr = xc.clone().requires_grad_(True), wu.clone().requires_grad_(True)
+    (torch.nn.functional.conv_transpose3d(xr, wr, stride=2) * r2).sum().backward()
+    xg = xc.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype).requires_grad_(True)
+    wg = wu.to(DEV).requires_grad_(True)
+    y = ops.up2(xg, wg)
+    (y.float() * r2.permute(0, 2, 3, 4, 1).to(DEV)).sum().backward()
+    assert rel_err(y.float().detach().permute(0, 4, 1, 2, 3).cpu(), torch.nn.functional.conv_transpose3d(xc, wu, stride=2)) < tol
+    assert rel_err(xg.grad.float().permute(0, 4, 1, 2, 3).cpu(), xr.grad) < tol
+    assert rel_err(wg.grad.cpu(), wr.grad) < tol
+
+
 def test_cpu_tensor_fails_loudly():
     from repmode_amd import _lib
     from repmode_amd.nn_modules.RepMode import MoDEConv
