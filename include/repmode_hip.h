@@ -94,8 +94,9 @@ int repmode_conv5_wgrad(const void* x, const void* dy, const int32_t* sample_slo
                         float* dw, int n, int d, int h, int wdim, int cin, int cout, int dtype,
                         void* stream);
 
-/* Same, with centre3 != 0 computing only the filter planes dz in [1,3]; the other planes of dw are left
- * UNTOUCHED (callers that want the gradient of a 3x3x3-support filter read the centre taps only). */
+/* Same with a mode: 0 = as above; 1 = only the filter planes dz in [1,3] are computed, the other planes of dw
+ * are left UNTOUCHED; 2 (nslots == 1) = all taps, written in the experts' own layout dw[Cout][Cin][125];
+ * 3 (nslots == 1) = the centred 3x3x3 taps only, written as dw[Cout][Cin][27] (RepMode.py:137's shape). */
 int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
                            float* dw, int n, int d, int h, int wdim, int cin, int cout, int dtype,
                            int centre3, void* stream);
@@ -140,6 +141,11 @@ int repmode_bn_relu_bwd(const void* x, const void* dy, const float* gamma, const
  * w: fragment-major [8][CoutP/32][CinP/KC][32][KC] like the merged filters; in/out channels-last, `dtype`. */
 int repmode_k2s2(const void* in, const void* w, void* out, int n, int d, int h, int wdim, int cin, int cout,
                  int dtype, int scatter, void* stream);
+
+/* Weight gradient of both stride-2 stages (bf16):  dw[p][a][b] = sum_m coarse[m][a] * fine[fine(m,p)][b]
+ * (down: coarse = dy, fine = x;  up: coarse = x, fine = dy).  dw: float [8][ca][cb], overwritten. */
+int repmode_k2s2_wgrad(const void* coarse, const void* fine, float* dw, int n, int d, int h, int wdim, int ca,
+                       int cb, void* stream);
 
 /* ---- box means of the avg-pool experts (RepMode.py:139-142, 161-163, 176-180): by linearity
  * conv(x, w1x1 (x) 1/k^3) = w1x1 applied to the zero-padded k^3 box mean of x.

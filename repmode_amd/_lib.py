@@ -35,6 +35,7 @@ _SIGNATURES = {
     'repmode_bn_relu_fwd': [_P] * 9 + [_c.c_long, _I, _c.c_float, _c.c_float, _I, _I, _I, _P],
     'repmode_bn_relu_bwd': [_P] * 8 + [_c.c_long, _I, _I, _I, _I, _P],
     'repmode_k2s2': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_k2s2_wgrad': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'repmode_box_sum': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'repmode_prof_enable': [_I],
     'repmode_prof_summary': [_I, _P, _P, _P],

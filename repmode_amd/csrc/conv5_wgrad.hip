@@ -31,6 +31,8 @@ struct WgradArgs {
   int N, D, H, W, Cin, Cout;
   int ncot, ncit, ntiles, tiles_per_block, nchunks, nty, ntx;
   int dz_lo, ndz;       // dz planes computed: dz_lo .. dz_lo + ndz - 1 (all five, or 1..3 for a 3x3x3 support)
+  int layout;           // 0: dw[slot][tap][co][ci]; 1: dw[co][ci][125] (expert layout, nslots == 1);
+                        // 2: dw[co][ci][27] (expert layout of a centred 3x3x3 filter, nslots == 1)
   int nslots, direct;   // direct: every workgroup owns its output completely -> plain stores, no memset
 };
 
@@ -142,7 +144,16 @@ __global__ __launch_bounds__(256) void conv5_wgrad_f32c_kernel(WgradArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int co = cot * 32 + cq * 16 + kq * 4 + r;
         if (co < Cout) {
-          float* p = a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * Cin + ci;
+          float* p;
+          if (a.layout == 0) {
+            p = a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * Cin + ci;
+          } else if (a.layout == 1) {
+            p = a.dw + ((size_t)co * Cin + ci) * REPMODE_TAPS + tap;
+          } else {
+            const int ty = t / 5, tx = t % 5;            // (dy, dx) of this tap; dz in [1,3] by construction
+            if (ty < 1 || ty > 3 || tx < 1 || tx > 3) continue;
+            p = a.dw + ((size_t)co * Cin + ci) * 27 + ((dz - 1) * 3 + (ty - 1)) * 3 + (tx - 1);
+          }
           if (a.direct) *p = acc[t][r];
           else unsafeAtomicAdd(p, acc[t][r]);
         }
@@ -315,7 +326,16 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int co = cot * 32 + cq * 16 + kg * 4 + r;
         if (co < Cout) {
-          float* p = a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * Cin + ci;
+          float* p;
+          if (a.layout == 0) {
+            p = a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * Cin + ci;
+          } else if (a.layout == 1) {
+            p = a.dw + ((size_t)co * Cin + ci) * REPMODE_TAPS + tap;
+          } else {
+            const int ty = t / 5, tx = t % 5;            // (dy, dx) of this tap; dz in [1,3] by construction
+            if (ty < 1 || ty > 3 || tx < 1 || tx > 3) continue;
+            p = a.dw + ((size_t)co * Cin + ci) * 27 + ((dz - 1) * 3 + (ty - 1)) * 3 + (tx - 1);
+          }
           if (a.direct) *p = acc[t][r];
           else unsafeAtomicAdd(p, acc[t][r]);
         }
@@ -341,7 +361,7 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   a.direct = a.nchunks == 1;
   const long grid = fixed * a.nchunks;
   RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
-  if (!a.direct) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * REPMODE_TAPS * a.Cout * a.Cin * sizeof(float), s));
+  if (!a.direct) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * a.Cout * a.Cin * sizeof(float), s));
   repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, s);
   hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX>), dim3((unsigned)grid), dim3(256), 0, s, a);
   return REPMODE_OK;
@@ -372,8 +392,12 @@ extern "C" int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32
   a.ncot = ceil_div(cout, 32);
   a.ncit = ceil_div(cin, 32);
   a.nslots = nslots;
-  a.dz_lo = centre3 ? 1 : 0;
-  a.ndz = centre3 ? 3 : 5;
+  // centre3: 0 = all taps, slot layout; 1 = planes dz in [1,3] only, slot layout; 2 = all taps written in the
+  // experts' own [co][ci][125] layout; 3 = centred 3x3x3 taps written as [co][ci][27] (2, 3: nslots == 1)
+  RM_REQUIRE(centre3 >= 0 && centre3 <= 3 && (centre3 < 2 || nslots == 1), "conv5_wgrad: bad mode %d", centre3);
+  a.dz_lo = (centre3 == 1 || centre3 == 3) ? 1 : 0;
+  a.ndz = (centre3 == 1 || centre3 == 3) ? 3 : 5;
+  a.layout = centre3 == 2 ? 1 : (centre3 == 3 ? 2 : 0);
   if (dtype == REPMODE_BF16) {
     RM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv5_wgrad: pointers must be 16-byte aligned");
     int rc;
@@ -396,7 +420,7 @@ extern "C" int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32
     a.direct = a.nchunks == 1;
     const long grid = fixed * a.nchunks;
     RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
-    if (!a.direct) RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * REPMODE_TAPS * cout * cin * sizeof(float), s));
+    if (!a.direct) RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * cout * cin * sizeof(float), s));
     repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * d * h * wdim * (double)cin * cout * REPMODE_TAPS, s);
     hipLaunchKernelGGL(conv5_wgrad_f32c_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, a);
   }

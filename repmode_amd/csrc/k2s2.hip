@@ -188,3 +188,130 @@ extern "C" int repmode_k2s2(const void* in, const void* w, void* out, int n, int
   RM_LAUNCH_CHECK("k2s2");
   return REPMODE_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of both stride-2 stages (bf16):
+//     dw[p][a][b] = sum_m coarse[m][a] * fine[fine(m,p)][b]
+// (down: coarse = dy, fine = x -> dW[p][co][ci];  up: coarse = x, fine = dy -> dWt[p][ci][co]).
+// K = voxels and both operands are K-major in HBM (channels-last), so -- as in conv5_wgrad -- they are
+// transposed once into LDS ([channel][voxel], two x-adjacent voxels per ds_write_b32) and consumed by
+// v_mfma_f32_16x16x32_bf16.  A workgroup owns a 32 x 32 (a, b) tile for all 8 taps (8 accumulator tiles per
+// wave quadrant), walks a chunk of 64-voxel tiles and adds its partial sums with f32 atomics.
+namespace {
+
+constexpr int KW_TM = 64;                       // coarse voxels per tile
+constexpr int KW_RS = KW_TM * 2 + 16;           // bytes per channel row in LDS (odd multiple of 16)
+
+struct K2WArgs {
+  const bf16_t* coarse;
+  const bf16_t* fine;
+  float* dw;              // [8][A][B]
+  long M;
+  int d, h, wd, A, B, ntiles, tiles_per_block;
+};
+
+__device__ __forceinline__ u32x4 kw_load8(const bf16_t* row, int c, int C, bool vec) {
+  if (c >= C) return u32x4{0u, 0u, 0u, 0u};
+  if (vec) return *reinterpret_cast<const u32x4*>(row + c);
+  bf16_t e[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) e[k] = (c + k < C) ? row[c + k] : (bf16_t)0;
+  return *reinterpret_cast<const u32x4*>(e);
+}
+
+__device__ __forceinline__ uint32_t kw_elem(const u32x4& v, int k) {
+  const uint32_t w = v[k >> 1];
+  return (k & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+__global__ __launch_bounds__(256) void k2s2_wgrad_kernel(K2WArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(32 + 8 * 32) * KW_RS];
+  unsigned char* cT = smem;                       // [32 a][64 voxels]
+  unsigned char* fT = smem + 32 * KW_RS;          // [8 taps][32 b][64 voxels]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int aq = wave & 1, bq = wave >> 1, l15 = lane & 15, kg = lane >> 4;
+  const int at = blockIdx.y, bt = blockIdx.z;
+  const bool vec_a = (a.A & 7) == 0, vec_b = (a.B & 7) == 0;
+  f32x4 acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int t_begin = blockIdx.x * a.tiles_per_block;
+  const int t_end = min(a.ntiles, t_begin + a.tiles_per_block);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const long m0 = (long)tile * KW_TM;
+    __syncthreads();
+    // coarse^T: items = (voxel pair, channel group of 8)
+    for (int it = tid; it < (KW_TM / 2) * 4; it += 256) {
+      const int q = it % (KW_TM / 2), cg = it / (KW_TM / 2);
+      const long m = m0 + 2 * q;
+      const int c = at * 32 + cg * 8;
+      u32x4 v0 = u32x4{0u, 0u, 0u, 0u}, v1 = v0;
+      if (m < a.M) v0 = kw_load8(a.coarse + (size_t)m * a.A, c, a.A, vec_a);
+      if (m + 1 < a.M) v1 = kw_load8(a.coarse + (size_t)(m + 1) * a.A, c, a.A, vec_a);
+      unsigned char* dst = cT + (cg * 8) * KW_RS + q * 4;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) *reinterpret_cast<uint32_t*>(dst + k * KW_RS) = kw_elem(v0, k) | (kw_elem(v1, k) << 16);
+    }
+    // fine^T per tap: items = (tap, voxel pair, channel group)
+    for (int it = tid; it < 8 * (KW_TM / 2) * 4; it += 256) {
+      const int q = it % (KW_TM / 2); int r = it / (KW_TM / 2);
+      const int cg = r & 3, p = r >> 2;
+      const long m = m0 + 2 * q;
+      const int c = bt * 32 + cg * 8;
+      u32x4 v0 = u32x4{0u, 0u, 0u, 0u}, v1 = v0;
+      if (m < a.M) v0 = kw_load8(a.fine + fine_row(m, p, a.d, a.h, a.wd) * a.B, c, a.B, vec_b);
+      if (m + 1 < a.M) v1 = kw_load8(a.fine + fine_row(m + 1, p, a.d, a.h, a.wd) * a.B, c, a.B, vec_b);
+      unsigned char* dst = fT + ((size_t)p * 32 + cg * 8) * KW_RS + q * 4;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) *reinterpret_cast<uint32_t*>(dst + k * KW_RS) = kw_elem(v0, k) | (kw_elem(v1, k) << 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KW_TM / 32; ++ks) {
+      const u32x4 af = *reinterpret_cast<const u32x4*>(cT + (aq * 16 + l15) * KW_RS + (ks * 32 + kg * 8) * 2);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const u32x4 bf = *reinterpret_cast<const u32x4*>(fT + ((size_t)p * 32 + bq * 16 + l15) * KW_RS + (ks * 32 + kg * 8) * 2);
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf),
+                                                         acc[p], 0, 0, 0);
+      }
+    }
+  }
+  // 16x16 C/D layout: column (b) = lane & 15, row (a) = (lane >> 4) * 4 + r
+  const int bcol = bt * 32 + bq * 16 + l15;
+  if (bcol < a.B) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int arow = at * 32 + aq * 16 + kg * 4 + r;
+        if (arow < a.A) unsafeAtomicAdd(a.dw + ((size_t)p * a.A + arow) * a.B + bcol, acc[p][r]);
+      }
+  }
+}
+
+}  // namespace
+
+// dw[8][A][B] (float, overwritten) = sum_m coarse[m][a] * fine[fine(m,p)][b].  coarse: [N][d][h][w][A] bf16,
+// fine: [N][2d][2h][2w][B] bf16.
+extern "C" int repmode_k2s2_wgrad(const void* coarse, const void* fine, float* dw, int n, int d, int h, int wdim, int ca,
+                                  int cb, void* stream) {
+  RM_REQUIRE(coarse && fine && dw, "k2s2_wgrad: null pointer");
+  RM_REQUIRE(n > 0 && d > 0 && h > 0 && wdim > 0 && ca > 0 && cb > 0, "k2s2_wgrad: bad shape");
+  RM_REQUIRE(((uintptr_t)coarse & 15) == 0 && ((uintptr_t)fine & 15) == 0, "k2s2_wgrad: pointers must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  K2WArgs a{};
+  a.coarse = static_cast<const bf16_t*>(coarse); a.fine = static_cast<const bf16_t*>(fine); a.dw = dw;
+  a.M = (long)n * d * h * wdim; a.d = d; a.h = h; a.wd = wdim; a.A = ca; a.B = cb;
+  a.ntiles = (int)((a.M + KW_TM - 1) / KW_TM);
+  const int nat = ceil_div(ca, 32), nbt = ceil_div(cb, 32);
+  long want = (1024 + (long)nat * nbt - 1) / ((long)nat * nbt);
+  if (want > a.ntiles) want = a.ntiles;
+  if (want < 1) want = 1;
+  a.tiles_per_block = ceil_div(a.ntiles, (int)want);
+  const int nchunks = ceil_div(a.ntiles, a.tiles_per_block);
+  RM_HIP(hipMemsetAsync(dw, 0, (size_t)8 * ca * cb * sizeof(float), s));
+  hipLaunchKernelGGL(k2s2_wgrad_kernel, dim3(nchunks, nat, nbt), dim3(256), 0, s, a);
+  RM_LAUNCH_CHECK("k2s2_wgrad");
+  return REPMODE_OK;
+}

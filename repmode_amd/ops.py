@@ -114,9 +114,16 @@ def conv5(x_cl, w, sample_slot, cout, out_f32=False, out=None, centre3=False):
     return y
 
 
-def conv5_wgrad(x_cl, dy_cl, plan, cout, centre3=False):
+def conv5_wgrad(x_cl, dy_cl, plan, cout, centre3=False, expert_layout=None):
     """dw[s, tap, o, i] (float32) summed over the samples of each slot."""
     n, d, h, wd_, cin = x_cl.shape
+    if expert_layout is not None:
+        # single slot, gradient written directly in the experts' parameter layout: [Co, Ci, 5,5,5] or [Co, Ci, 3,3,3]
+        k = expert_layout
+        dw = torch.empty((cout, cin, k, k, k), dtype=torch.float32, device=x_cl.device)
+        _lib.call('repmode_conv5_wgrad_ex', _ptr(x_cl), _ptr(dy_cl), _ptr(plan.sample_slot), 1, _ptr(dw),
+                  n, d, h, wd_, cin, cout, dtype_code(x_cl.dtype), 2 if k == 5 else 3, _stream())
+        return dw
     dw = torch.empty((plan.nslots, TAPS, cout, cin), dtype=torch.float32, device=x_cl.device)
     if x_cl.dtype == torch.bfloat16 and (cin == 1) != (cout == 1) and not centre3:
         # thin layer: taps stand in for the missing channel dimension (conv5_wgrad_thin)
@@ -240,6 +247,19 @@ def k2s2(in_cl, w_frag, cout, scatter):
     return out
 
 
+def k2s2_wgrad(coarse_cl, fine_cl):
+    """dw[p, a, b] = sum_m coarse[m, a] * fine[fine(m, p), b]  -> float [8, A, B].  bf16: HIP kernel; float32:
+    a library GEMM on gathered patches (parity mode only)."""
+    n, d, h, w, ca = coarse_cl.shape
+    cb = fine_cl.shape[-1]
+    if coarse_cl.dtype == torch.bfloat16:
+        dw = torch.empty((8, ca, cb), dtype=torch.float32, device=coarse_cl.device)
+        _lib.call('repmode_k2s2_wgrad', _ptr(coarse_cl), _ptr(fine_cl), _ptr(dw), n, d, h, w, ca, cb, _stream())
+        return dw
+    g = _gather_patches(fine_cl)                                       # [M, 8*B]
+    return (coarse_cl.view(-1, ca).t() @ g).view(ca, 8, cb).permute(1, 0, 2)
+
+
 def _gather_patches(x_cl):
     """fine [N,2d,2h,2w,C] -> [N*d*h*w, 8*C], taps ordered (pz, py, px) -- only the weight gradients need it."""
     n, a, b, c, ch = x_cl.shape
@@ -266,8 +286,8 @@ class _Down2(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wb = k2_weight_frags(weight.permute(2, 3, 4, 1, 0).reshape(8, ci, co), x_cl.dtype)
             dx = k2s2(dy, wb, ci, scatter=True)
-        dw2 = dy.view(-1, co).t() @ _gather_patches(x_cl)                 # [Co, 8*Ci], taps outermost
-        dw = dw2.view(co, 2, 2, 2, ci).permute(0, 4, 1, 2, 3).float()
+        dw8 = k2s2_wgrad(dy, x_cl)                                        # [8, Co, Ci]
+        dw = dw8.view(2, 2, 2, co, ci).permute(3, 4, 0, 1, 2).contiguous()
         return dx, dw
 
 
@@ -291,8 +311,8 @@ class _Up2(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wb = k2_weight_frags(weight.permute(2, 3, 4, 0, 1).reshape(8, ci, co), x_cl.dtype)
             dx = k2s2(dy, wb, ci, scatter=False)
-        dw2 = x_cl.view(-1, ci).t() @ _gather_patches(dy)                 # [Ci, 8*Co]
-        dw = dw2.view(ci, 2, 2, 2, co).permute(0, 4, 1, 2, 3).float()
+        dw8 = k2s2_wgrad(x_cl, dy)                                        # [8, Ci, Co]
+        dw = dw8.view(2, 2, 2, ci, co).permute(3, 4, 0, 1, 2).contiguous()
         return dx, dw
 
 
@@ -418,13 +438,11 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
             del wd2
         # ---- expert gradients: filter gradients of the gate-scaled dy, all samples in one slot
         one = _SingleSlot(n, dev, 0)
-        dw5 = conv5_wgrad(x_cl, d01[0], one, co)[0]                        # [125, Co, Ci]
-        dk5 = dw5.permute(1, 2, 0).reshape(k5.shape)
-        dw3 = conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0].view(5, 5, 5, co, ci)[1:4, 1:4, 1:4]
-        dk3 = dw3.permute(3, 4, 0, 1, 2).reshape(k3.shape)
+        dk5 = conv5_wgrad(x_cl, d01[0], one, co, expert_layout=5)          # [Co, Ci, 5, 5, 5], no transpose pass
+        dk3 = conv5_wgrad(x_cl, d01[1], one, co, expert_layout=3)          # [Co, Ci, 3, 3, 3]
         d1 = torch.bmm(dye[2:].view(3, -1, co).transpose(1, 2), xb.view(3, -1, ci))       # [3, Co, Ci]
         dk1, da3, da5 = d1[0].reshape(k1.shape), d1[1].reshape(a3.shape), d1[2].reshape(a5.shape)
-        return dx, dk5.contiguous(), dk3.contiguous(), dk1, da3, da5, dgw, dgb, None
+        return dx, dk5, dk3, dk1, da3, da5, dgw, dgb, None
 
 
 def use_unmerged(x_cl, plan):

@@ -30,12 +30,16 @@ def fake_kernels(monkeypatch):
             return out
         return y
 
-    def wgrad(x_cl, dy_cl, plan, cout, centre3=False):
+    def wgrad(x_cl, dy_cl, plan, cout, centre3=False, expert_layout=None):
         with torch.enable_grad():
             n, ci = x_cl.shape[0], x_cl.shape[-1]
             wt = torch.zeros(1, cout, ci, 5, 5, 5, requires_grad=True)
             y = orc.conv_per_sample(x_cl.detach().float().permute(0, 4, 1, 2, 3), wt.expand(n, -1, -1, -1, -1, -1))
             (y * dy_cl.detach().float().permute(0, 4, 1, 2, 3)).sum().backward()
+        if expert_layout == 5:
+            return wt.grad[0].contiguous()
+        if expert_layout == 3:
+            return wt.grad[0][:, :, 1:4, 1:4, 1:4].contiguous()
         return wt.grad.reshape(1, cout, ci, 125).permute(0, 3, 1, 2).contiguous()
 
     def box(in3=None, in5=None, out=None):
