@@ -438,8 +438,12 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
             del wd2
         # ---- expert gradients: filter gradients of the gate-scaled dy, all samples in one slot
         one = _SingleSlot(n, dev, 0)
-        dk5 = conv5_wgrad(x_cl, d01[0], one, co, expert_layout=5)          # [Co, Ci, 5, 5, 5], no transpose pass
-        dk3 = conv5_wgrad(x_cl, d01[1], one, co, expert_layout=3)          # [Co, Ci, 3, 3, 3]
+        # (the kernel can also write the experts' [Co][Ci][taps] layout directly -- expert_layout= -- but that
+        # epilogue's 4-byte stores at a 500-byte lane stride measured 5x slower than tap-major + one transpose)
+        dw5 = conv5_wgrad(x_cl, d01[0], one, co)[0]                        # [125, Co, Ci]
+        dk5 = dw5.permute(1, 2, 0).reshape(k5.shape)
+        dw3 = conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0].view(5, 5, 5, co, ci)[1:4, 1:4, 1:4]
+        dk3 = dw3.permute(3, 4, 0, 1, 2).reshape(k3.shape)
         d1 = torch.bmm(dye[2:].view(3, -1, co).transpose(1, 2), xb.view(3, -1, ci))       # [3, Co, Ci]
         dk1, da3, da5 = d1[0].reshape(k1.shape), d1[1].reshape(a3.shape), d1[2].reshape(a5.shape)
         return dx, dk5, dk3, dk1, da3, da5, dgw, dgb, None

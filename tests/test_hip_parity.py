@@ -480,3 +480,41 @@ def test_bf16_training_reduces_loss():
         m.do_train_iter(x, t, tasks)
         losses.append(float(m.last_loss))
     assert losses[-1] < losses[0] and all(np.isfinite(losses))
+
+
+@pytest.mark.timeout(900)
+def test_full_size_net_vs_oracle():
+    """BASELINE-size parity: the full mult_chan=32 network (123.9 M parameters) on two 32x64x64 patches with
+    different tasks, float32 HIP path against the CPU oracle (fp32, same initial state): forward output and loss
+    within 1e-3 relative (the north star's bound); a sample of parameter gradients within 2e-2 (the batch-norm
+    chain amplifies summation-order noise, see test_net_golden).  Also exercises the per-expert (unmerged)
+    deep-level path through the module heuristics with 3 distinct tasks."""
+    from repmode_amd.nn_modules.RepMode import Net
+    torch.manual_seed(0)
+    ref = orc.Net(Opts(), mult_chan=32)
+    net = Net(Opts(), mult_chan=32, dtype=torch.float32)
+    net.load_state_dict(ref.state_dict())
+    net.to(DEV).train()
+    ref.train()
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 1, 32, 64, 64, generator=gen)
+    tgt = torch.randn(3, 1, 32, 64, 64, generator=gen)
+    tasks = torch.tensor([3, 7, 11])
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    yr = ref(x, tasks)
+    lr = torch.nn.functional.mse_loss(yr, tgt)
+    lr.backward()
+    y = net(x.to(DEV), tasks)
+    l = torch.nn.functional.mse_loss(y, tgt.to(DEV))
+    l.backward()
+    assert rel_err(y.detach().cpu(), yr.detach()) < TOL_F32
+    assert abs(l.item() - lr.item()) < 1e-4 * abs(lr.item()) + 1e-6
+    rp = dict(ref.named_parameters())
+    checked = 0
+    for k, p in net.named_parameters():
+        if any(t in k for t in ('encoder_block1.conv_more.conv2', 'bottle_block.conv1.expert_conv3x3', 'bottle_block.conv2.gate',
+                                'decoder_block1.conv_less.conv1.expert_conv5x5', 'conv_out', 'encoder_block4.conv_down',
+                                'decoder_block2.convt')):
+            assert nrm_err(p.grad.cpu(), rp[k].grad) < 2e-2, k
+            checked += 1
+    assert checked >= 20
