@@ -147,6 +147,15 @@ int repmode_k2s2(const void* in, const void* w, void* out, int n, int d, int h, 
 int repmode_k2s2_wgrad(const void* coarse, const void* fine, float* dw, int n, int d, int h, int wdim, int ca,
                        int cb, void* stream);
 
+/* ---- gate mixing of the per-expert formulation (linearity of RepMode.py:184-188 + :207).  p: float [5][n][v][c]
+ * expert outputs, g: float [n][5][c] gate probabilities per SAMPLE.
+ *   fwd: y[n][v][c] = sum_e g[n][e][c] * p[e][n][v][c]
+ *   bwd: dg[n][e][c] = sum_v dy * p[e]  (overwritten);  dye_lo[e] = g[n][e] * dy for e = 0, 1 in `dtype`,
+ *        dye_hi[e-2] = g[n][e] * dy for e = 2..4 in float.   c <= 512. */
+int repmode_expert_mix_fwd(const float* p, const float* g, float* y, int n, long v, int c, void* stream);
+int repmode_expert_mix_bwd(const float* dy, const float* p, const float* g, float* dg, void* dye_lo,
+                           float* dye_hi, int n, long v, int c, int dtype, void* stream);
+
 /* ---- box means of the avg-pool experts (RepMode.py:139-142, 161-163, 176-180): by linearity
  * conv(x, w1x1 (x) 1/k^3) = w1x1 applied to the zero-padded k^3 box mean of x.
  * out = box3(in3) + box5(in5); float NDHWC tensors; either input may be NULL (not both). */

@@ -145,7 +145,19 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
 #pragma unroll
   for (int k = 0; k < CV; ++k) { s[k] = 0.f; ss[k] = 0.f; }
   if (active) {
-    for (long r = (long)blockIdx.x * g.rows_per_iter + r0; r < M; r += (long)gridDim.x * g.rows_per_iter) {
+    // 4 rows per iteration, loads issued before use: the pass is bandwidth-bound only with enough bytes in flight
+    const long stride = (long)gridDim.x * g.rows_per_iter;
+    long r = (long)blockIdx.x * g.rows_per_iter + r0;
+    for (; r + 3 * stride < M; r += 4 * stride) {
+      float v[4][CV];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) load_row<T, CV>(x + (r + u * stride) * C, c0, C, vec, v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < CV; ++k) { s[k] += v[u][k]; ss[k] += v[u][k] * v[u][k]; }
+    }
+    for (; r < M; r += stride) {
       float v[CV];
       load_row<T, CV>(x + r * C, c0, C, vec, v);
 #pragma unroll
@@ -232,7 +244,26 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
     s[k] = 0.f; ss[k] = 0.f;
   }
   if (active) {
-    for (long r = (long)blockIdx.x * g.rows_per_iter + r0; r < M; r += (long)gridDim.x * g.rows_per_iter) {
+    const long stride = (long)gridDim.x * g.rows_per_iter;
+    long r = (long)blockIdx.x * g.rows_per_iter + r0;
+    for (; r + stride < M; r += 2 * stride) {          // 2 rows (4 loads) in flight per iteration
+      float v[2][CV], d[2][CV];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        load_row<TI, CV>(x + (r + u * stride) * C, c0, C, vec, v[u]);
+        load_row<TO, CV>(dy + (r + u * stride) * C, c0, C, vec, d[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 0; k < CV; ++k) {
+          const float xh = (v[u][k] - mu[k]) * is[k];
+          const float dz = (xh * ga[k] + be[k] > 0.f) ? d[u][k] : 0.f;
+          s[k] += dz;
+          ss[k] += dz * xh;
+        }
+    }
+    for (; r < M; r += stride) {
       float v[CV], d[CV];
       load_row<TI, CV>(x + r * C, c0, C, vec, v);
       load_row<TO, CV>(dy + r * C, c0, C, vec, d);
@@ -284,12 +315,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
   }
 }
 
-// the two reduction kernels end in 2C global atomics per workgroup: cap them at 2 workgroups per CU
+// the two reduction kernels end in 2C global atomics per workgroup: cap them at 4 workgroups per CU
 int grid_for_reduce(long M, int C) {
   const int ngroups = (C + CV - 1) / CV;
   const int rows_per_iter = BN_THREADS / ngroups;
   long blocks = (M + rows_per_iter - 1) / rows_per_iter;
-  if (blocks > 512) blocks = 512;
+  if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }

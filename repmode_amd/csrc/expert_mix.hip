@@ -1,0 +1,144 @@
+// expert_mix.hip -- gate mixing of the per-expert ("unmerged") formulation used on the deep levels:
+//
+//     y[n][v][o] = sum_e g[n][e][o] * P[e][n][v][o]                        (forward,  RepMode.py:184-188 by linearity)
+//     dg[n][e][o] = sum_v dy[n][v][o] * P[e][n][v][o]                      (backward: gate-probability gradients)
+//     dye[e][n][v][o] = g[n][e][o] * dy[n][v][o]                           (backward: gate-scaled output gradients,
+//                        experts 0-1 (the 5^3 / 3^3 convs) in the conv kernels' element type, 2-4 in float)
+//
+// P_e = conv(x, K_e) are the five expert outputs (float, [5][N][V][Co]).  One pass over P in each direction
+// instead of a chain of broadcast-multiply / reduce / cast kernels with [5][N][V][Co] temporaries.
+#include "common.h"
+
+namespace {
+
+constexpr int E = REPMODE_NUM_EXPERTS;
+
+__global__ __launch_bounds__(256) void expert_mix_fwd_kernel(const float* __restrict__ p, const float* __restrict__ g,
+                                                             float* __restrict__ y, int N, long V, int C) {
+  const int c4n = (C + 3) / 4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)N * V * c4n;
+  if (idx >= total) return;
+  const int c = (int)(idx % c4n) * 4;
+  const long nv = idx / c4n;
+  const int n = (int)(nv / V);
+  const size_t estride = (size_t)N * V * C;
+  const size_t off = (size_t)nv * C + c;
+  const bool vec = (C & 3) == 0;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const float* gp = g + ((size_t)n * E + e) * C + c;
+    const float* pp = p + e * estride + off;
+    if (vec) {
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(pp), gv = *reinterpret_cast<const f32x4*>(gp);
+      acc[0] += gv.x * pv.x; acc[1] += gv.y * pv.y; acc[2] += gv.z * pv.z; acc[3] += gv.w * pv.w;
+    } else {
+      for (int k = 0; k < 4; ++k) if (c + k < C) acc[k] += gp[k] * pp[k];
+    }
+  }
+  if (vec) *reinterpret_cast<f32x4*>(y + off) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+  else for (int k = 0; k < 4; ++k) if (c + k < C) y[off + k] = acc[k];
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float* v, int c, int C, bool vec);
+template <>
+__device__ __forceinline__ void store4<float>(float* p, const float* v, int c, int C, bool vec) {
+  if (vec) *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  else for (int k = 0; k < 4; ++k) if (c + k < C) p[k] = v[k];
+}
+template <>
+__device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float* v, int c, int C, bool vec) {
+  if (vec) *reinterpret_cast<u32x2*>(p) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  else for (int k = 0; k < 4; ++k) if (c + k < C) p[k] = f32_to_bf16(v[k]);
+}
+
+// grid = (voxel chunks, N).  A thread owns 4 channels and strides over the voxels of its chunk; the 5 x 4 partial
+// gate gradients are reduced over the workgroup through LDS atomics, one global atomic per (e, channel) and workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void expert_mix_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ p,
+                                                             const float* __restrict__ g, float* __restrict__ dg,
+                                                             T* __restrict__ dye_lo, float* __restrict__ dye_hi, int N,
+                                                             long V, int C, long vchunk) {
+  __shared__ float red[E * 512];
+  const int c4n = (C + 3) / 4;
+  const int n = blockIdx.y;
+  const int cg = threadIdx.x % c4n, r0 = threadIdx.x / c4n;
+  const int rows = 256 / c4n;                       // voxel rows covered per iteration (C <= 512 -> c4n <= 128)
+  const int c = cg * 4;
+  const bool vec = (C & 3) == 0;
+  const bool active = r0 < rows;
+  const size_t estride = (size_t)N * V * C;
+  float gv[E][4], part[E][4];
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gv[e][k] = (c + k < C) ? g[((size_t)n * E + e) * C + c + k] : 0.f;
+      part[e][k] = 0.f;
+    }
+  const long v_begin = (long)blockIdx.x * vchunk, v_end = min(V, v_begin + vchunk);
+  if (active) {
+    for (long v = v_begin + r0; v < v_end; v += rows) {
+      const size_t off = ((size_t)n * V + v) * C + c;
+      float d[4];
+      if (vec) { const f32x4 t = *reinterpret_cast<const f32x4*>(dy + off); d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; }
+      else for (int k = 0; k < 4; ++k) d[k] = (c + k < C) ? dy[off + k] : 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        float pv[4], o[4];
+        if (vec) { const f32x4 t = *reinterpret_cast<const f32x4*>(p + e * estride + off); pv[0] = t.x; pv[1] = t.y; pv[2] = t.z; pv[3] = t.w; }
+        else for (int k = 0; k < 4; ++k) pv[k] = (c + k < C) ? p[e * estride + off + k] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { part[e][k] += d[k] * pv[k]; o[k] = gv[e][k] * d[k]; }
+        if (e < 2) store4<T>(dye_lo + e * estride + off, o, c, C, vec);
+        else store4<float>(dye_hi + (e - 2) * estride + off, o, c, C, vec);
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < E * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (c + k < C) atomicAdd(&red[e * C + c + k], part[e][k]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < E * C; i += 256) atomicAdd(dg + (size_t)n * E * C + i, red[i]);
+}
+
+}  // namespace
+
+extern "C" int repmode_expert_mix_fwd(const float* p, const float* g, float* y, int n, long v, int c, void* stream) {
+  RM_REQUIRE(p && g && y && n > 0 && v > 0 && c > 0, "expert_mix_fwd: bad argument");
+  const long total = (long)n * v * ((c + 3) / 4);
+  hipLaunchKernelGGL(expert_mix_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p, g, y, n, v, c);
+  RM_LAUNCH_CHECK("expert_mix_fwd");
+  return REPMODE_OK;
+}
+
+// dg [N][5][C] (overwritten), dye_lo [2][N][V][C] in `dtype`, dye_hi [3][N][V][C] float.
+extern "C" int repmode_expert_mix_bwd(const float* dy, const float* p, const float* g, float* dg, void* dye_lo,
+                                      float* dye_hi, int n, long v, int c, int dtype, void* stream) {
+  RM_REQUIRE(dy && p && g && dg && dye_lo && dye_hi && n > 0 && v > 0 && c > 0 && c <= 512, "expert_mix_bwd: bad argument");
+  RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "expert_mix_bwd: bad dtype %d", dtype);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  RM_HIP(hipMemsetAsync(dg, 0, (size_t)n * E * c * sizeof(float), s));
+  const int rows = 256 / ((c + 3) / 4);
+  long chunks = (v + rows * 4 - 1) / (rows * 4);          // >= 4 rows iterations per workgroup
+  if (chunks > 256) chunks = 256;
+  if (chunks < 1) chunks = 1;
+  const long vchunk = (v + chunks - 1) / chunks;
+  const dim3 grid((unsigned)((v + vchunk - 1) / vchunk), (unsigned)n);
+  if (dtype == REPMODE_F32)
+    hipLaunchKernelGGL(expert_mix_bwd_kernel<float>, grid, dim3(256), 0, s, dy, p, g, dg, static_cast<float*>(dye_lo), dye_hi,
+                       n, v, c, vchunk);
+  else
+    hipLaunchKernelGGL(expert_mix_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, dy, p, g, dg, static_cast<bf16_t*>(dye_lo),
+                       dye_hi, n, v, c, vchunk);
+  RM_LAUNCH_CHECK("expert_mix_bwd");
+  return REPMODE_OK;
+}

@@ -324,13 +324,19 @@ def up2(x_cl, weight):
     return _Up2.apply(x_cl.contiguous(), weight)
 
 
+_SLOT_IDS = {}
+
+
 class _SingleSlot:
     """All samples share one filter: used when the experts themselves are the 'slots'."""
 
     def __init__(self, n, device, slot=0):
         self.nslots = 1
         self.n = n
-        self.sample_slot = torch.full((n,), slot, dtype=torch.int32, device=device)
+        key = (n, slot, str(device))
+        if key not in _SLOT_IDS:                      # constant index vectors: built once per shape
+            _SLOT_IDS[key] = torch.full((n,), slot, dtype=torch.int32, device=device)
+        self.sample_slot = _SLOT_IDS[key]
 
 
 _ONEHOT2 = {}
@@ -357,6 +363,25 @@ def box_sum(in3=None, in5=None, out=None):
     _lib.call('repmode_box_sum', _ptr(in3) if in3 is not None else None, _ptr(in5) if in5 is not None else None,
               _ptr(out), n, d, h, w, c, _stream())
     return out
+
+
+def expert_mix_fwd(p, gn):
+    """y = sum_e g[n, e, :] * P_e  (P: float [5, N, D, H, W, Co], gn: float [N, 5, Co])."""
+    _, n, d, h, w, co = p.shape
+    y = torch.empty((n, d, h, w, co), dtype=torch.float32, device=p.device)
+    _lib.call('repmode_expert_mix_fwd', _ptr(p), _ptr(gn), _ptr(y), n, d * h * w, co, _stream())
+    return y
+
+
+def expert_mix_bwd(dy, p, gn, dtype):
+    """(dg [N,5,Co], dye_lo [2,N,D,H,W,Co] in ``dtype``, dye_hi [3,...] float) from dy, the expert outputs and g."""
+    _, n, d, h, w, co = p.shape
+    dg = torch.empty((n, NUM_EXPERTS, co), dtype=torch.float32, device=p.device)
+    lo = torch.empty((2, n, d, h, w, co), dtype=dtype, device=p.device)
+    hi = torch.empty((3, n, d, h, w, co), dtype=torch.float32, device=p.device)
+    _lib.call('repmode_expert_mix_bwd', _ptr(dy), _ptr(p), _ptr(gn), _ptr(dg), _ptr(lo), _ptr(hi), n, d * h * w, co,
+              dtype_code(dtype), _stream())
+    return dg, lo, hi
 
 
 class _ModeConv3dUnmerged(torch.autograd.Function):
@@ -395,8 +420,8 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         box_sum(in5=xb[0], out=xb[2])
         w1 = torch.stack((k1.view(co, ci), a3.view(co, ci), a5.view(co, ci)))             # [3, Co, Ci]
         torch.bmm(xb.view(3, -1, ci), w1.transpose(1, 2), out=p[2:].view(3, -1, co))
-        ge = gn.permute(1, 0, 2).contiguous().view(NUM_EXPERTS, n, 1, 1, 1, co)    # [5, N, 1, 1, 1, Co]
-        y = (p * ge).sum(dim=0)
+        gn = gn.contiguous()
+        y = expert_mix_fwd(p, gn)
         ctx.save_for_backward(x_cl, k5, k3, k1, a3, a5, gn, xb, w1, p)
         ctx.plan = plan
         return y
@@ -411,17 +436,13 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         dt = x_cl.dtype
         dy = dy.float().contiguous()
         # ---- gate: dg[n,e,o] = <dy, P_e>, softmax Jacobian, Linear grads (RepMode.py:198-200)
-        dg = (p * dy.unsqueeze(0)).sum(dim=(2, 3, 4)).permute(1, 0, 2)                  # [N, 5, Co]
+        dg, d01, dhi = expert_mix_bwd(dy, p, gn, dt)            # <dy, P_e>, and the gate-scaled dy per expert
         dl = gn * (dg - (gn * dg).sum(dim=1, keepdim=True))
         dl2 = dl.reshape(n, NUM_EXPERTS * co)
         dgb = dl2.sum(dim=0)
         tasks = plan.slot_task.long().index_select(0, plan.sample_slot.long())
         dgw = torch.zeros((NUM_EXPERTS * co, plan.num_tasks), dtype=torch.float32, device=dev)
         dgw.index_add_(1, tasks, dl2.t().contiguous())
-        # ---- gate-scaled output gradients, one per expert: dye[e] = g[n,e,:] * dy
-        ge = gn.permute(1, 0, 2).contiguous().view(NUM_EXPERTS, n, 1, 1, 1, co)
-        dye = (dy.unsqueeze(0) * ge).contiguous()                                                     # [5, N, D, H, W, Co]
-        d01 = dye[:2].to(dt)
         s0, s1 = _SingleSlot(n, dev, 0), _SingleSlot(n, dev, 1)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -431,7 +452,7 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
             dxf += conv5(d01[1], wd2, s1.sample_slot, ci, out_f32=True, centre3=True)
             # 1x1 experts: one batched GEMM gives the three partial data gradients; the zero-padded box
             # mean is self-adjoint, so the avg experts' parts go back through box3 / box5
-            t = torch.bmm(dye[2:].view(3, -1, co), w1).view(3, *shp)                     # [3, N, D, H, W, Ci]
+            t = torch.bmm(dhi.view(3, -1, co), w1).view(3, *shp)                          # [3, N, D, H, W, Ci]
             dxf += t[0]
             dxf += box_sum(in3=t[1], in5=t[2])
             dx = dxf.to(dt)
@@ -444,7 +465,7 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         dk5 = dw5.permute(1, 2, 0).reshape(k5.shape)
         dw3 = conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0].view(5, 5, 5, co, ci)[1:4, 1:4, 1:4]
         dk3 = dw3.permute(3, 4, 0, 1, 2).reshape(k3.shape)
-        d1 = torch.bmm(dye[2:].view(3, -1, co).transpose(1, 2), xb.view(3, -1, ci))       # [3, Co, Ci]
+        d1 = torch.bmm(dhi.view(3, -1, co).transpose(1, 2), xb.view(3, -1, ci))           # [3, Co, Ci]
         dk1, da3, da5 = d1[0].reshape(k1.shape), d1[1].reshape(a3.shape), d1[2].reshape(a5.shape)
         return dx, dk5, dk3, dk1, da3, da5, dgw, dgb, None
 

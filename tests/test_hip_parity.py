@@ -302,6 +302,24 @@ def test_net_golden(dtype):
         assert rel_err(ye.cpu(), g['y_eval']) < TOL_F32
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('n,v,c', [(3, (2, 4, 4), 64), (2, (1, 3, 5), 6), (8, (4, 8, 8), 256)])
+def test_expert_mix(n, v, c, dtype):
+    ops = _ops()
+    gen = torch.Generator().manual_seed(n * 7 + c)
+    p = torch.randn(5, n, *v, c, generator=gen)
+    gn = torch.softmax(torch.randn(n, 5, c, generator=gen), dim=1)
+    dy = torch.randn(n, *v, c, generator=gen)
+    ge = gn.permute(1, 0, 2)[:, :, None, None, None, :]
+    y = ops.expert_mix_fwd(p.to(DEV), gn.to(DEV))
+    assert rel_err(y.cpu(), (p * ge).sum(0)) < 1e-5
+    dg, lo, hi = ops.expert_mix_bwd(dy.to(DEV), p.to(DEV), gn.to(DEV), dtype)
+    assert rel_err(dg.cpu(), (p * dy[None]).sum((2, 3, 4)).permute(1, 0, 2)) < 1e-4
+    dye = dy[None] * ge
+    assert lo.dtype == dtype and rel_err(lo.float().cpu(), dye[:2]) < (1e-6 if dtype == torch.float32 else 5e-3)
+    assert rel_err(hi.cpu(), dye[2:]) < 1e-6
+
+
 @pytest.mark.parametrize('shape', [(2, 2, 4, 4, 64), (1, 5, 7, 9, 6), (3, 4, 8, 8, 32)])
 def test_box_sum(shape):
     ops = _ops()

@@ -58,7 +58,16 @@ def fake_kernels(monkeypatch):
             return out
         return res
 
-    for name, fn in dict(gate_softmax=gate, gatrep_merge=merge, conv5=conv5, conv5_wgrad=wgrad, box_sum=box).items():
+    def mix_fwd(p, gn):
+        return (p * gn.permute(1, 0, 2)[:, :, None, None, None, :]).sum(0)
+
+    def mix_bwd(dy, p, gn, dtype):
+        dg = (p * dy[None]).sum((2, 3, 4)).permute(1, 0, 2).contiguous()
+        dye = dy[None] * gn.permute(1, 0, 2)[:, :, None, None, None, :]
+        return dg, dye[:2].to(dtype).contiguous(), dye[2:].contiguous()
+
+    for name, fn in dict(gate_softmax=gate, gatrep_merge=merge, conv5=conv5, conv5_wgrad=wgrad, box_sum=box,
+                         expert_mix_fwd=mix_fwd, expert_mix_bwd=mix_bwd).items():
         monkeypatch.setattr(ops, name, fn)
     monkeypatch.setattr(ops, '_require_hip', lambda *a: None)
     return ops
