@@ -49,6 +49,19 @@ struct Elem<bf16_t> {
   }
 };
 
+#ifdef RM_CONV_TIMING
+// developer build only (REPMODE_EXTRA_FLAGS=-DRM_CONV_TIMING): shader-clock stamps of the first workgroups'
+// phases, read back with repmode_debug_conv_timing (tools/conv_phase_timing.py)
+__device__ unsigned long long g_conv_timing[64 * 64];
+#define RM_STAMP(slot)                                                                        \
+  do {                                                                                        \
+    if (tid == 0 && blockIdx.x < 64 && (slot) < 64)                                           \
+      g_conv_timing[blockIdx.x * 64 + (slot)] = __builtin_amdgcn_s_memtime();                 \
+  } while (0)
+#else
+#define RM_STAMP(slot) do {} while (0)
+#endif
+
 struct ConvArgs {
   const void* x;
   const void* w;
@@ -156,7 +169,9 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
 
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     const int ci0 = chunk * KC;
+    RM_STAMP((chunk - c_begin) * 4 + 0);
     __syncthreads();  // all waves finished reading the previous chunk's halo image
+    RM_STAMP((chunk - c_begin) * 4 + 1);
     // ---- stage the halo brick: item = (halo voxel, plane), two 16-byte items per voxel
     constexpr int NITEMS = 2 * VH;
     constexpr int UNR = (NITEMS + NT - 1) / NT >= 9 ? 9 : 4;   // loads in flight per thread per batch (latency-bound phase)
@@ -192,6 +207,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
       }
     }
     __syncthreads();
+    RM_STAMP((chunk - c_begin) * 4 + 2);
 
     // ---- 125 taps from the staged image.  Filter fragments are prefetched from L2 one (dz,dy)
     // row (5 taps) ahead when one channel sub-tile is held (CW == 1), one tap ahead otherwise
@@ -283,6 +299,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
         dy = dyn;
       }
     }
+    RM_STAMP((chunk - c_begin) * 4 + 3);
   }
 
   // ---- epilogue.  32x32 C/D layout: column j = lane & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -348,6 +365,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
       }
     }
   }
+  RM_STAMP(60);
 }
 
 template <typename T, typename C, bool SWAP>
@@ -437,3 +455,11 @@ extern "C" int repmode_conv5_ex(const void* x, const void* w, const int32_t* sam
   if (a.out_f32) return dispatch<bf16_t, true>(a, s);
   return dispatch<bf16_t, false>(a, s);
 }
+
+#ifdef RM_CONV_TIMING
+extern "C" int repmode_debug_conv_timing(unsigned long long* out) {
+  RM_HIP(hipDeviceSynchronize());
+  RM_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_timing), sizeof(unsigned long long) * 64 * 64));
+  return 0;
+}
+#endif

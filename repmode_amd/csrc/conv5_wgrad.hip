@@ -205,7 +205,26 @@ __device__ __forceinline__ uint32_t bf16_elem(const u32x4& v, int k) {
   return (k & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
-template <int TZ, int TY, int TX>
+#ifdef RM_CONV_TIMING
+// developer build only (REPMODE_EXTRA_FLAGS=-DRM_CONV_TIMING): shader-clock stamps of the first workgroups'
+// phases, read back with repmode_debug_wgrad_timing (tools/wgrad_phase_timing.py)
+__device__ unsigned long long g_wgrad_timing[64 * 64];
+#define RM_WSTAMP(slot)                                                                       \
+  do {                                                                                        \
+    if (tid == 0 && blockIdx.x < 64 && (slot) < 64)                                           \
+      g_wgrad_timing[blockIdx.x * 64 + (slot)] = __builtin_amdgcn_s_memtime();                \
+  } while (0)
+#else
+#define RM_WSTAMP(slot) do {} while (0)
+#endif
+
+// VEC (both channel counts multiples of 8, every layer of the network but the thin first/last ones, which
+// have their own kernel): the tile sequence of the workgroup is software-pipelined -- the 16-byte loads of the
+// NEXT tile are issued (buffer loads, 32-bit offsets, out-of-volume positions return 0 through the range check)
+// before the MFMAs of the current one and only transposed into LDS after them.  Without it the phase timing
+// (tools/wgrad_phase_timing.py) showed ~7k cycles of serialized load->LDS staging next to ~5k cycles of MFMAs
+// per tile.  !VEC keeps the simple stage-then-compute loop with per-element loads.
+template <int TZ, int TY, int TX, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
   using G = WgTile<TZ, TY, TX>;
   constexpr int TV = G::TV, HY = G::HY, XS = G::XS, NGX = G::NGX, ROW_C = G::ROW_C, DYS = G::DYS;
@@ -226,7 +245,6 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
   const int cot = bid % a.ncot;
   const int slot = bid / a.ncot;
   const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
-  const bool vec_x = (Cin & 7) == 0, vec_dy = (Cout & 7) == 0;
 
   f32x4 acc[25];
 #pragma unroll
@@ -234,56 +252,12 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
 
   const int t_begin = chunk * a.tiles_per_block;
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_block);
-  for (int n = 0; n < a.N; ++n) {
-  if (a.sample_slot[n] != slot) continue;             // the workgroup sums over the samples of its slot
-  const bf16_t* __restrict__ xn = static_cast<const bf16_t*>(a.x) + (size_t)n * D * H * W * Cin;
-  const bf16_t* __restrict__ dyn = static_cast<const bf16_t*>(a.dy) + (size_t)n * D * H * W * Cout;
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    const int txi = tile % a.ntx, t2 = tile / a.ntx;
-    const int tyi = t2 % a.nty, tzi = t2 / a.nty;
-    const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
-    // every input plane this tile needs for this dz is padding -> nothing to add (uniform branch)
-    if (z0 + TZ - 1 + dz - 2 < 0 || z0 + dz - 2 >= D) continue;
-    __syncthreads();
-    // ---- stage x (transposed): items = (plane, halo row, x pair, channel group)
-    constexpr int NPAIR = TX / 2 + 2;              // pairs covering x0-2 .. x0+TX+1
-    for (int it = tid; it < TZ * HY * NPAIR * 4; it += 256) {
-      const int p = it % NPAIR; int r = it / NPAIR;
-      const int cg = r & 3; r >>= 2;
-      const int hy = r % HY, zz = r / HY;
-      const int zin = z0 + zz + dz - 2, gy = y0 + hy - 2, gx = x0 - 2 + 2 * p;
-      const int c = cit * 32 + cg * 8;
-      u32x4 v0 = u32x4{0u, 0u, 0u, 0u}, v1 = v0;
-      if ((unsigned)zin < (unsigned)D && (unsigned)gy < (unsigned)H && c < Cin) {
-        const bf16_t* rowp = xn + ((size_t)(zin * H + gy) * W) * Cin + c;
-        if ((unsigned)gx < (unsigned)W) v0 = load8_bf16(rowp + (size_t)gx * Cin, c, Cin, vec_x);
-        if ((unsigned)(gx + 1) < (unsigned)W) v1 = load8_bf16(rowp + (size_t)(gx + 1) * Cin, c, Cin, vec_x);
-      }
-      unsigned char* dst = xT + (cg * 8) * ROW_C + ((zz * HY + hy) * XS + 6 + 2 * p) * 2;
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        *reinterpret_cast<uint32_t*>(dst + k * ROW_C) = bf16_elem(v0, k) | (bf16_elem(v1, k) << 16);
-    }
-    // ---- stage dy (transposed): items = (voxel pair, channel group)
-    for (int it = tid; it < (TV / 2) * 4; it += 256) {
-      const int q = it % (TV / 2), cg = it / (TV / 2);
-      const int m = 2 * q;
-      const int xx = m % TX, yy = (m / TX) % TY, zz = m / (TX * TY);
-      const int gz = z0 + zz, gy = y0 + yy, gx = x0 + xx;
-      const int c = cot * 32 + cg * 8;
-      u32x4 v0 = u32x4{0u, 0u, 0u, 0u}, v1 = v0;
-      if (gz < D && gy < H && c < Cout) {
-        const bf16_t* rowp = dyn + ((size_t)(gz * H + gy) * W) * Cout + c;
-        if (gx < W) v0 = load8_bf16(rowp + (size_t)gx * Cout, c, Cout, vec_dy);
-        if (gx + 1 < W) v1 = load8_bf16(rowp + (size_t)(gx + 1) * Cout, c, Cout, vec_dy);
-      }
-      unsigned char* dst = dyT + (cg * 8) * DYS + m * 2;
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        *reinterpret_cast<uint32_t*>(dst + k * DYS) = bf16_elem(v0, k) | (bf16_elem(v1, k) << 16);
-    }
-    __syncthreads();
-    // ---- K loop: 32 voxels per step = 4 groups of 8 consecutive x; this lane's group = 4*ks + kg
+  constexpr int NPAIR = TX / 2 + 2;                // x pairs covering x0-2 .. x0+TX+1
+  constexpr int NIT_X = TZ * HY * NPAIR * 4;       // x items: (plane, halo row, x pair, channel group of 8)
+  constexpr int NIT_DY = (TV / 2) * 4;             // dy items: (voxel pair, channel group of 8)
+
+  // ---- K loop over the staged tile: 32 voxels per step = 4 groups of 8 consecutive x; this lane's group = 4*ks + kg
+  auto mma_tile = [&]() {
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
       const int g = ks * 4 + kg;
@@ -314,6 +288,157 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
         acc[dyi * 5 + 4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, __builtin_bit_cast(bf16x8, b4), acc[dyi * 5 + 4], 0, 0, 0);
       }
     }
+  };
+  // two x-adjacent voxels (8 channels each) -> eight 4-byte stores into the transposed tile
+  auto put_pair = [&](unsigned char* dst, int stride, const u32x4& v0, const u32x4& v1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      *reinterpret_cast<uint32_t*>(dst + k * stride) = bf16_elem(v0, k) | (bf16_elem(v1, k) << 16);
+  };
+
+  if constexpr (VEC) {
+    constexpr int NX = (NIT_X + 255) / 256, NDY = (NIT_DY + 255) / 256;
+    constexpr uint32_t OOB = 0x80000000u;
+    u32x4 px0[NX], px1[NX], pd0[NDY], pd1[NDY];
+
+    // work sequence: (sample of this slot, tile of this chunk), skipping tiles whose input planes for this dz are
+    // all padding.  Everything here is wave-uniform (scalar loads of sample_slot).
+    int n = -1, tile = t_end;
+    auto advance = [&]() -> bool {
+      for (;;) {
+        if (++tile >= t_end) {
+          tile = t_begin;
+          do { ++n; } while (n < a.N && a.sample_slot[n] != slot);
+          if (n >= a.N) return false;
+        }
+        const int z0 = (tile / (a.ntx * a.nty)) * TZ;
+        if (!(z0 + TZ - 1 + dz - 2 < 0 || z0 + dz - 2 >= D)) return true;
+      }
+    };
+    auto fetch = [&]() {
+      const int txi = tile % a.ntx, t2 = tile / a.ntx;
+      const int tyi = t2 % a.nty, tzi = t2 / a.nty;
+      const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+      const uint32_t xbytes = (uint32_t)((size_t)D * H * W * Cin * 2), dybytes = (uint32_t)((size_t)D * H * W * Cout * 2);
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<bf16_t*>(static_cast<const bf16_t*>(a.x)) + (size_t)n * D * H * W * Cin, 0, (int)xbytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<bf16_t*>(static_cast<const bf16_t*>(a.dy)) + (size_t)n * D * H * W * Cout, 0, (int)dybytes, 0x00020000);
+      int tid_ = tid;                       // keep the item arithmetic from being hoisted out of the loops
+      asm volatile("" : "+v"(tid_));        // (it would pin registers next to the 100 accumulators)
+#pragma unroll
+      for (int u = 0; u < NX; ++u) {
+        const int it = u * 256 + tid_;
+        const int p = it % NPAIR; int r = it / NPAIR;
+        const int cg = r & 3; r >>= 2;
+        const int hy = r % HY, zz = r / HY;
+        const int zin = z0 + zz + dz - 2, gy = y0 + hy - 2, gx = x0 - 2 + 2 * p;
+        const int c = cit * 32 + cg * 8;
+        const bool row_ok = it < NIT_X && (unsigned)zin < (unsigned)D && (unsigned)gy < (unsigned)H && c < Cin;
+        const uint32_t off = (uint32_t)((((zin * H + gy) * W + gx) * Cin + c) * 2);
+        px0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                     rx, (row_ok && (unsigned)gx < (unsigned)W) ? off : OOB, 0, 0));
+        px1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                     rx, (row_ok && (unsigned)(gx + 1) < (unsigned)W) ? off + (uint32_t)Cin * 2 : OOB, 0, 0));
+      }
+#pragma unroll
+      for (int u = 0; u < NDY; ++u) {
+        const int it = u * 256 + tid_;
+        const int q = it % (TV / 2), cg = it / (TV / 2);
+        const int m = 2 * q;
+        const int xx = m % TX, yy = (m / TX) % TY, zz = m / (TX * TY);
+        const int gz = z0 + zz, gy = y0 + yy, gx = x0 + xx;
+        const int c = cot * 32 + cg * 8;
+        const bool row_ok = it < NIT_DY && gz < D && gy < H && c < Cout;
+        const uint32_t off = (uint32_t)((((gz * H + gy) * W + gx) * Cout + c) * 2);
+        pd0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (row_ok && gx < W) ? off : OOB, 0, 0));
+        pd1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                     rdy, (row_ok && gx + 1 < W) ? off + (uint32_t)Cout * 2 : OOB, 0, 0));
+      }
+    };
+    auto stage = [&]() {
+      int tid_ = tid;
+      asm volatile("" : "+v"(tid_));
+#pragma unroll
+      for (int u = 0; u < NX; ++u) {
+        const int it = u * 256 + tid_;
+        const int p = it % NPAIR; int r = it / NPAIR;
+        const int cg = r & 3; r >>= 2;
+        const int hy = r % HY, zz = r / HY;
+        if (it < NIT_X) put_pair(xT + (cg * 8) * ROW_C + ((zz * HY + hy) * XS + 6 + 2 * p) * 2, ROW_C, px0[u], px1[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < NDY; ++u) {
+        const int it = u * 256 + tid_;
+        const int q = it % (TV / 2), cg = it / (TV / 2);
+        if (it < NIT_DY) put_pair(dyT + (cg * 8) * DYS + q * 4, DYS, pd0[u], pd1[u]);
+      }
+    };
+    bool have = advance();
+    if (have) fetch();
+#ifdef RM_CONV_TIMING
+    int tl_ = 0;
+#endif
+    while (have) {
+      RM_WSTAMP(tl_ * 3 + 0);
+      __syncthreads();     // every wave is done with the previous tile in LDS
+      stage();
+      __syncthreads();
+      RM_WSTAMP(tl_ * 3 + 1);
+      have = advance();
+      if (have) fetch();   // in flight during the MFMAs below
+      mma_tile();
+      RM_WSTAMP(tl_ * 3 + 2);
+#ifdef RM_CONV_TIMING
+      ++tl_;
+#endif
+    }
+  } else {
+  const bool vec_x = (Cin & 7) == 0, vec_dy = (Cout & 7) == 0;
+  for (int n = 0; n < a.N; ++n) {
+  if (a.sample_slot[n] != slot) continue;             // the workgroup sums over the samples of its slot
+  const bf16_t* __restrict__ xn = static_cast<const bf16_t*>(a.x) + (size_t)n * D * H * W * Cin;
+  const bf16_t* __restrict__ dyn = static_cast<const bf16_t*>(a.dy) + (size_t)n * D * H * W * Cout;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int txi = tile % a.ntx, t2 = tile / a.ntx;
+    const int tyi = t2 % a.nty, tzi = t2 / a.nty;
+    const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+    // every input plane this tile needs for this dz is padding -> nothing to add (uniform branch)
+    if (z0 + TZ - 1 + dz - 2 < 0 || z0 + dz - 2 >= D) continue;
+    __syncthreads();
+    // ---- stage x (transposed)
+    for (int it = tid; it < NIT_X; it += 256) {
+      const int p = it % NPAIR; int r = it / NPAIR;
+      const int cg = r & 3; r >>= 2;
+      const int hy = r % HY, zz = r / HY;
+      const int zin = z0 + zz + dz - 2, gy = y0 + hy - 2, gx = x0 - 2 + 2 * p;
+      const int c = cit * 32 + cg * 8;
+      u32x4 v0 = u32x4{0u, 0u, 0u, 0u}, v1 = v0;
+      if ((unsigned)zin < (unsigned)D && (unsigned)gy < (unsigned)H && c < Cin) {
+        const bf16_t* rowp = xn + ((size_t)(zin * H + gy) * W) * Cin + c;
+        if ((unsigned)gx < (unsigned)W) v0 = load8_bf16(rowp + (size_t)gx * Cin, c, Cin, vec_x);
+        if ((unsigned)(gx + 1) < (unsigned)W) v1 = load8_bf16(rowp + (size_t)(gx + 1) * Cin, c, Cin, vec_x);
+      }
+      put_pair(xT + (cg * 8) * ROW_C + ((zz * HY + hy) * XS + 6 + 2 * p) * 2, ROW_C, v0, v1);
+    }
+    // ---- stage dy (transposed)
+    for (int it = tid; it < NIT_DY; it += 256) {
+      const int q = it % (TV / 2), cg = it / (TV / 2);
+      const int m = 2 * q;
+      const int xx = m % TX, yy = (m / TX) % TY, zz = m / (TX * TY);
+      const int gz = z0 + zz, gy = y0 + yy, gx = x0 + xx;
+      const int c = cot * 32 + cg * 8;
+      u32x4 v0 = u32x4{0u, 0u, 0u, 0u}, v1 = v0;
+      if (gz < D && gy < H && c < Cout) {
+        const bf16_t* rowp = dyn + ((size_t)(gz * H + gy) * W) * Cout + c;
+        if (gx < W) v0 = load8_bf16(rowp + (size_t)gx * Cout, c, Cout, vec_dy);
+        if (gx + 1 < W) v1 = load8_bf16(rowp + (size_t)(gx + 1) * Cout, c, Cout, vec_dy);
+      }
+      put_pair(dyT + (cg * 8) * DYS + m * 2, DYS, v0, v1);
+    }
+    __syncthreads();
+    mma_tile();
+  }
   }
   }
   // 16x16 C/D layout: column (ci) = lane & 15, row (co) = (lane >> 4) * 4 + r
@@ -344,6 +469,16 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
   }
 }
 
+#ifdef RM_CONV_TIMING
+}  // namespace
+extern "C" int repmode_debug_wgrad_timing(unsigned long long* out) {
+  RM_HIP(hipDeviceSynchronize());
+  RM_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgrad_timing), sizeof(unsigned long long) * 64 * 64));
+  return 0;
+}
+namespace {
+#endif
+
 template <int TZ, int TY, int TX>
 int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   a.nty = ceil_div(a.H, TY);
@@ -363,7 +498,12 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
   if (!a.direct) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * a.Cout * a.Cin * sizeof(float), s));
   repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, s);
-  hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  const size_t sample_bytes = (size_t)a.D * a.H * a.W * (a.Cin > a.Cout ? a.Cin : a.Cout) * 2;
+  // (levels with W < 16 hand a workgroup only a tile or two per sample: nothing to overlap, and the old loop is ~15 % faster there)
+  if ((a.Cin & 7) == 0 && (a.Cout & 7) == 0 && a.W >= 16 && sample_bytes < ((size_t)1 << 31))
+    hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
   return REPMODE_OK;
 }
 

@@ -7,17 +7,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from repmode_amd import ops, _lib
+if os.environ.get('REPMODE_LIB'):          # A/B against another build of the library
+    _lib.LIB_PATH = os.environ['REPMODE_LIB']
 
 args = [int(a) for a in sys.argv[1:]]
 cin, cout, d, h, w = (args + [32, 32, 32, 64, 64][len(args):])[:5]
-iters = args[5] if len(args) > 5 else 10
+iters = args[5] if len(args) > 5 else 2000
 n = 8
 dev = 'cuda:0'
 code = _lib.BF16
 x = torch.randn(n, d, h, w, cin, device=dev).bfloat16()
 wf = (torch.randn(8, 125, _lib.padded_channels(cout, code, False), _lib.padded_channels(cin, code, True), device=dev) * 0.02).bfloat16()
 slots = torch.arange(n, dtype=torch.int32, device=dev)
-for _ in range(3):
+for _ in range(1500):                        # ~0.4 s: let the clocks settle under load (power-capped part)
     y = ops.conv5(x, wf, slots, cout)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
