@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define REPMODE_ABI_VERSION 1
+#define REPMODE_ABI_VERSION 2
 
 /* element types of activations / merged filters */
 #define REPMODE_F32 0  /* float in, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)          */
@@ -123,14 +123,16 @@ int repmode_gatrep_bwd(const float* dw, const float* k5, const float* k3, const 
  * stride-2 down/up stages (RepMode.py:80-84, 97-101), on a channels-last tensor viewed as [m][c].
  * Training: batch mean / biased variance over the m rows, eps, running statistics updated with `momentum`
  * and the unbiased variance; eval (training == 0): running statistics.  x has in_dtype, out has out_dtype.
- * save_mean / save_invstd [c] and sums_ws [16][2c] (partial-sum slices) are float outputs / workspace.  c <= 512. */
+ * save_mean / save_invstd [c] are float outputs (kept for the backward).  c <= 512.  Two launches: statistics
+ * (partial sums through a library-owned scratch; the last workgroup finalizes and updates the running statistics)
+ * and normalise + ReLU. */
 int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
-                        float* running_var, float* save_mean, float* save_invstd, float* sums_ws, long m, int c,
+                        float* running_var, float* save_mean, float* save_invstd, long m, int c,
                         float eps, float momentum, int training, int in_dtype, int out_dtype, void* stream);
-/* Backward of the same: dx (in_dtype) from dy (out_dtype).  sums_ws: (16 + 1) * 2c floats; on return its last
- * 2c floats are the totals: [0..c) = dbeta, [c..2c) = dgamma. */
+/* Backward of the same: dx (in_dtype) from dy (out_dtype); totals [2c] float output: [0..c) = dbeta,
+ * [c..2c) = dgamma. */
 int repmode_bn_relu_bwd(const void* x, const void* dy, const float* gamma, const float* beta,
-                        const float* save_mean, const float* save_invstd, void* dx, float* sums_ws, long m, int c,
+                        const float* save_mean, const float* save_invstd, void* dx, float* totals, long m, int c,
                         int training, int in_dtype, int out_dtype, void* stream);
 
 /* ---- the stride-2 2x2x2 stages (RepMode.py:81 Conv3d k2 s2, :98 ConvTranspose3d k2 s2; both bias-free) as a

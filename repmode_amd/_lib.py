@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librepmode_hip.so')
 
 F32, BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c = ctypes
 _P = _c.c_void_p
@@ -32,7 +32,7 @@ _SIGNATURES = {
     'repmode_conv5_wgrad_ex': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad_thin': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     'repmode_gatrep_bwd': [_P] * 8 + [_I] * 4 + [_P] * 9,
-    'repmode_bn_relu_fwd': [_P] * 9 + [_c.c_long, _I, _c.c_float, _c.c_float, _I, _I, _I, _P],
+    'repmode_bn_relu_fwd': [_P] * 8 + [_c.c_long, _I, _c.c_float, _c.c_float, _I, _I, _I, _P],
     'repmode_bn_relu_bwd': [_P] * 8 + [_c.c_long, _I, _I, _I, _I, _P],
     'repmode_k2s2': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_k2s2_wgrad': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -6,6 +6,9 @@
 #include <vector>
 
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 static thread_local char g_err[512] = "";
 
@@ -67,6 +70,25 @@ void repmode_prof_end(hipStream_t s) {
   (void)hipEventRecord(g_prof[g_prof_n].b, s);
   ++g_prof_n;
   g_prof_open = false;
+}
+
+namespace {
+std::mutex g_scratch_mu;
+std::map<std::pair<int, hipStream_t>, float*> g_scratch;
+}  // namespace
+
+float* repmode_zero_scratch(hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { repmode_set_error("zero_scratch: hipGetDevice failed"); return nullptr; }
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  auto it = g_scratch.find({dev, s});
+  if (it != g_scratch.end()) return it->second;
+  float* p = nullptr;
+  hipError_t e = hipMalloc(&p, REPMODE_ZERO_SCRATCH_FLOATS * sizeof(float));
+  if (e == hipSuccess) e = hipMemsetAsync(p, 0, REPMODE_ZERO_SCRATCH_FLOATS * sizeof(float), s);
+  if (e != hipSuccess) { repmode_set_error("zero_scratch: %s", hipGetErrorString(e)); return nullptr; }
+  g_scratch[{dev, s}] = p;
+  return p;
 }
 
 extern "C" int repmode_prof_enable(int on) {

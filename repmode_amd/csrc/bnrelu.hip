@@ -18,7 +18,8 @@ namespace {
 
 constexpr int BN_THREADS = 256;
 constexpr int BN_MAXC = 512;
-constexpr int BN_SLICES = 16;   // partial-sum slices: workgroup b adds into slice b % 16 (16x less atomic contention)
+constexpr int BN_SLICES = 16;
+static_assert((size_t)16 * 2 * 512 <= REPMODE_ZERO_SCRATCH_FLOATS, "the slices must fit the zero scratch");   // partial-sum slices: workgroup b adds into slice b % 16 (16x less atomic contention)
 
 template <typename T>
 struct Vec;
@@ -124,11 +125,17 @@ __device__ __forceinline__ void block_commit(float* lds, const float* s, const f
   for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) atomicAdd(&slice[i], lds[i]);
 }
 
-// total of the BN_SLICES partial sums of entry i (i in [0, 2C))
-__device__ __forceinline__ float slice_total(const float* __restrict__ sums, int i, int C) {
+// Total of the BN_SLICES partial sums of entry i (i in [0, 2C)), putting the zeros back: the slices live in the
+// library's zero scratch (repmode_zero_scratch), which every call must leave all zero.  (A "last workgroup
+// finalizes" variant inside the reduction kernels was tried and lost: the device-scope fence it needs writes
+// back and invalidates the XCD's L2 once per workgroup.)
+__device__ __forceinline__ float slice_total_and_clear(float* __restrict__ sums, int i, int C) {
   float t = 0.f;
 #pragma unroll
-  for (int k = 0; k < BN_SLICES; ++k) t += sums[(size_t)k * 2 * C + i];
+  for (int k = 0; k < BN_SLICES; ++k) {
+    t += sums[(size_t)k * 2 * C + i];
+    sums[(size_t)k * 2 * C + i] = 0.f;
+  }
   return t;
 }
 
@@ -167,32 +174,36 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
   block_commit(lds, s, ss, c0, C, active, sums);
 }
 
-// forward finalize (one thread per channel): consolidate the partial-sum slices into mean / invstd (saved
-// for backward) and update the running statistics (RepMode's BatchNorm3d defaults):
-// rm = (1-m) rm + m mean ; rv = (1-m) rv + m var * M/(M-1).  Eval mode: mean / invstd from the running stats.
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, long M, int C, float eps, float momentum,
-                                   int training, float* __restrict__ rmean, float* __restrict__ rvar,
+// forward finalize (one thread per channel): consolidate the partial-sum slices into mean / invstd (saved for
+// backward), update the running statistics (RepMode's BatchNorm3d defaults:
+// rm = (1-m) rm + m mean ; rv = (1-m) rv + m var * M/(M-1)) and hand the scratch back zeroed
+__global__ void bn_finalize_kernel(float* __restrict__ sums, long M, int C, float eps, float momentum,
+                                   float* __restrict__ rmean, float* __restrict__ rvar,
                                    float* __restrict__ save_mean, float* __restrict__ save_invstd) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  if (training) {
-    const float mean = slice_total(sums, c, C) / (float)M;
-    const float var = fmaxf(slice_total(sums, C + c, C) / (float)M - mean * mean, 0.f);
-    save_mean[c] = mean;
-    save_invstd[c] = rsqrtf(var + eps);
-    const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
-    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
-  } else {
-    save_mean[c] = rmean[c];
-    save_invstd[c] = rsqrtf(rvar[c] + eps);
-  }
+  const float mean = slice_total_and_clear(sums, c, C) / (float)M;
+  const float var = fmaxf(slice_total_and_clear(sums, C + c, C) / (float)M - mean * mean, 0.f);
+  save_mean[c] = mean;
+  save_invstd[c] = rsqrtf(var + eps);
+  const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+  rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+  rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
 }
 
-// backward finalize: totals[c] = sum dz (= dbeta), totals[C + c] = sum dz * xhat (= dgamma)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, int C, float* __restrict__ totals) {
+// backward finalize: totals[c] = sum dz (= dbeta), totals[C + c] = sum dz * xhat (= dgamma); scratch zeroed
+__global__ void bn_bwd_finalize_kernel(float* __restrict__ sums, int C, float* __restrict__ totals) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 2 * C) totals[i] = slice_total(sums, i, C);
+  if (i < 2 * C) totals[i] = slice_total_and_clear(sums, i, C);
+}
+
+// eval mode: mean / invstd from the running statistics (one thread per channel)
+__global__ void bn_eval_stats_kernel(int C, float eps, const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                     float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  save_mean[c] = rmean[c];
+  save_invstd[c] = rsqrtf(rvar[c] + eps);
 }
 
 template <typename TI, typename TO>
@@ -338,25 +349,31 @@ int grid_for(long M, int C) {
 
 // in_dtype: dtype of x (and dx); out_dtype: dtype of out (and dy).  REPMODE_F32 / REPMODE_BF16.
 extern "C" int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
-                                   float* running_var, float* save_mean, float* save_invstd, float* sums_ws, long m,
+                                   float* running_var, float* save_mean, float* save_invstd, long m,
                                    int c, float eps, float momentum, int training, int in_dtype, int out_dtype,
                                    void* stream) {
-  RM_REQUIRE(x && out && gamma && beta && running_mean && running_var && save_mean && save_invstd && sums_ws,
+  RM_REQUIRE(x && out && gamma && beta && running_mean && running_var && save_mean && save_invstd,
              "bn_relu_fwd: null pointer");
   RM_REQUIRE(m > 0 && c > 0 && c <= BN_MAXC, "bn_relu_fwd: bad shape (C <= %d)", BN_MAXC);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int grid = grid_for(m, c);
   if (training) {
-    RM_HIP(hipMemsetAsync(sums_ws, 0, (size_t)BN_SLICES * 2 * c * sizeof(float), s));
+    // partial sums go through the library's zero scratch; the finalize kernel puts the zeros back (no memset)
+    float* scratch = repmode_zero_scratch(s);
+    if (!scratch) return REPMODE_ELAUNCH;
     if (in_dtype == REPMODE_F32)
-      hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const float*)x, m, c, sums_ws);
+      hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const float*)x, m, c, scratch);
     else
-      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const bf16_t*)x, m, c, sums_ws);
+      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const bf16_t*)x, m, c, scratch);
     RM_LAUNCH_CHECK("bn_stats");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, s, scratch, m, c, eps, momentum,
+                       running_mean, running_var, save_mean, save_invstd);
+    RM_LAUNCH_CHECK("bn_finalize");
+  } else {
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, s, c, eps, running_mean, running_var,
+                       save_mean, save_invstd);
+    RM_LAUNCH_CHECK("bn_eval_stats");
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, s, sums_ws, m, c, eps, momentum, training,
-                     running_mean, running_var, save_mean, save_invstd);
-  RM_LAUNCH_CHECK("bn_finalize");
 #define RM_BN_APPLY(TI, TO)                                                                                      \
   hipLaunchKernelGGL((bn_apply_relu_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (TO*)out, \
                      gamma, beta, save_mean, save_invstd, m, c)
@@ -369,22 +386,21 @@ extern "C" int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma,
   return REPMODE_OK;
 }
 
-// On return sums_ws[16*2c .. 16*2c + 2c) holds the totals: [0..c) = dbeta (sum dz), [c..2c) = dgamma (sum dz xhat);
-// sums_ws must hold (16 + 1) * 2c floats.
+// On return totals[0..c) = dbeta (sum dz), totals[c..2c) = dgamma (sum dz xhat).
 extern "C" int repmode_bn_relu_bwd(const void* x, const void* dy, const float* gamma, const float* beta,
-                                   const float* save_mean, const float* save_invstd, void* dx, float* sums_ws, long m,
+                                   const float* save_mean, const float* save_invstd, void* dx, float* totals, long m,
                                    int c, int training, int in_dtype, int out_dtype, void* stream) {
-  RM_REQUIRE(x && dy && gamma && beta && save_mean && save_invstd && dx && sums_ws, "bn_relu_bwd: null pointer");
+  RM_REQUIRE(x && dy && gamma && beta && save_mean && save_invstd && dx && totals, "bn_relu_bwd: null pointer");
   RM_REQUIRE(m > 0 && c > 0 && c <= BN_MAXC, "bn_relu_bwd: bad shape (C <= %d)", BN_MAXC);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int grid = grid_for(m, c);
-  RM_HIP(hipMemsetAsync(sums_ws, 0, (size_t)BN_SLICES * 2 * c * sizeof(float), s));
-  float* totals = sums_ws + (size_t)BN_SLICES * 2 * c;
+  float* scratch = repmode_zero_scratch(s);
+  if (!scratch) return REPMODE_ELAUNCH;
 #define RM_BN_BWD(TI, TO)                                                                                              \
   do {                                                                                                                 \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<TI, TO>), dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy, \
-                       save_mean, save_invstd, gamma, beta, m, c, sums_ws);                                            \
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(2 * c, 128)), dim3(128), 0, s, sums_ws, c, totals);          \
+                       save_mean, save_invstd, gamma, beta, m, c, scratch);                                            \
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(2 * c, 128)), dim3(128), 0, s, scratch, c, totals);          \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy,  \
                        save_mean, save_invstd, gamma, beta, totals, m, c, training, (TI*)dx);                          \
   } while (0)

@@ -74,6 +74,11 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 // Optional per-launch timing (HIP events on the launch stream), switched on by repmode_prof_enable().
 // kind: REPMODE_PROF_* ; work: algorithmic FLOPs (conv kernels) or bytes (GatRep kernels) of the launch.
 void repmode_prof_begin(int kind, double work, hipStream_t s);
+// Library-owned, per (device, stream) scratch of REPMODE_ZERO_SCRATCH_FLOATS floats that is ALL ZERO whenever no
+// library call is executing on that stream: kernels that accumulate into it with atomics put the zeros back
+// themselves ("last workgroup cleans up"), so no call pays a memset launch.  nullptr on failure (error string set).
+constexpr size_t REPMODE_ZERO_SCRATCH_FLOATS = 64 * 1024;
+float* repmode_zero_scratch(hipStream_t s);
 void repmode_prof_end(hipStream_t s);
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -213,6 +213,37 @@ __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
 constexpr int GF_CT = 32;      // channels per slab (backward kernel)
 constexpr int GF_THREADS = 256;
 
+// softmax Jacobian + gate Linear gradients.  One thread per output channel o (all five experts' rows); loops over
+// slots.  `clear`: dg lives in the library's zero scratch -- the thread puts the zeros back behind itself.
+__global__ void gate_bwd_kernel(const float* __restrict__ g, float* __restrict__ dg,
+                                const int32_t* __restrict__ slot_task, int nslots, int num_tasks, int co_n,
+                                float* __restrict__ dgate_w, float* __restrict__ dgate_b, int clear) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= co_n) return;
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    for (int t = 0; t < num_tasks; ++t) dgate_w[((size_t)e * co_n + o) * num_tasks + t] = 0.f;
+  float bsum[E] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nslots; ++s) {
+    const float* gs = g + (size_t)s * E * co_n + o;
+    float* ds = dg + (size_t)s * E * co_n + o;
+    float gv[E], dv[E], dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < E; ++k) { gv[k] = gs[k * co_n]; dv[k] = ds[k * co_n]; dot += gv[k] * dv[k]; }
+    const int task = slot_task[s];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float dl = gv[e] * (dv[e] - dot);
+      dgate_w[((size_t)e * co_n + o) * num_tasks + task] += dl;   // slots hold distinct tasks; += keeps duplicates correct too
+      bsum[e] += dl;
+      if (clear) ds[e * co_n] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) dgate_b[e * co_n + o] = bsum[e];
+}
+
+
 // Expert gradients and gate-probability gradients from the per-slot filter gradient dw[s][tap][co][ci].
 // Block = (one co, 32 ci); thread = (ci = tid % 32, taps tid / 32 + 8k).  Reads of dw are 128-byte
 // rows; expert gradients are accumulated over slots in registers and written back transposed through
@@ -228,7 +259,7 @@ __global__ __launch_bounds__(GF_THREADS) void gatrep_bwd_kernel(
     float* __restrict__ dg) {
   __shared__ float s5[GF_CT * TAPS];        // k5 slab, later reused for the dk5 write-back
   __shared__ float s3[GF_CT * 27];
-  __shared__ float part[5][GF_THREADS];
+  __shared__ float part[2][5][GF_THREADS];  // double-buffered over slots: one barrier per slot
   const int tid = threadIdx.x;
   const int co = blockIdx.y;
   const int c0 = blockIdx.x * GF_CT;
@@ -262,18 +293,30 @@ __global__ __launch_bounds__(GF_THREADS) void gatrep_bwd_kernel(
   __shared__ float sgb[64][E];
   for (int i = tid; i < min(nslots, 64) * E; i += GF_THREADS) sgb[i / E][i % E] = g[((size_t)(i / E) * E + i % E) * co_n + co];
   __syncthreads();
+  // the filter-gradient values of slot s+1 are fetched while slot s is reduced (the loop was a chain of
+  // load -> reduce -> barrier round trips: 50-60 us per launch whatever the layer size)
+  float dcur[GB_NT], dnxt[GB_NT];
+  auto load_slot = [&](float* d, int s) {
+    const float* dws = dw + (size_t)s * TAPS * tap_stride + oi;
+#pragma unroll
+    for (int k = 0; k < GB_NT; ++k) {
+      const int tap = tq + 8 * k;
+      d[k] = (tap < TAPS && live) ? dws[(size_t)tap * tap_stride] : 0.f;
+    }
+  };
+  load_slot(dcur, 0);
   for (int s = 0; s < nslots; ++s) {
+    if (s + 1 < nslots) load_slot(dnxt, s + 1);
     const float* gs = g + (size_t)s * E * co_n + co;
     const bool in_lds = s < 64;
     const float g0 = in_lds ? sgb[s][0] : gs[0], g1 = in_lds ? sgb[s][1] : gs[co_n], g2 = in_lds ? sgb[s][2] : gs[2 * co_n],
                 g3 = in_lds ? sgb[s][3] : gs[3 * co_n], g4 = in_lds ? sgb[s][4] : gs[4 * co_n];
-    const float* dws = dw + (size_t)s * TAPS * tap_stride + oi;
     float q0 = 0.f, q1 = 0.f, dcen = 0.f, s27 = 0.f, s125 = 0.f;
 #pragma unroll
     for (int k = 0; k < GB_NT; ++k) {
       const int tap = tq + 8 * k;
       if (tap < TAPS && live) {      // dead lanes must not touch the (uninitialised) slab tail
-        const float d = dws[(size_t)tap * tap_stride];
+        const float d = dcur[k];
         int t3;
         const bool c3 = in_centre3(tap, t3);
         s125 += d;
@@ -287,14 +330,15 @@ __global__ __launch_bounds__(GF_THREADS) void gatrep_bwd_kernel(
         }
       }
     }
-    part[0][tid] = q0; part[1][tid] = q1; part[2][tid] = dcen; part[3][tid] = s27; part[4][tid] = s125;
+    float (*pb)[GF_THREADS] = part[s & 1];
+    pb[0][tid] = q0; pb[1][tid] = q1; pb[2][tid] = dcen; pb[3][tid] = s27; pb[4][tid] = s125;
     __syncthreads();
     if (tid < GF_CT) {
       float r0 = 0.f, r1 = 0.f, rc = 0.f, r27 = 0.f, r125 = 0.f;
 #pragma unroll
       for (int j = 0; j < GF_THREADS / GF_CT; ++j) {
-        r0 += part[0][tid + j * GF_CT]; r1 += part[1][tid + j * GF_CT]; rc += part[2][tid + j * GF_CT];
-        r27 += part[3][tid + j * GF_CT]; r125 += part[4][tid + j * GF_CT];
+        r0 += pb[0][tid + j * GF_CT]; r1 += pb[1][tid + j * GF_CT]; rc += pb[2][tid + j * GF_CT];
+        r27 += pb[3][tid + j * GF_CT]; r125 += pb[4][tid + j * GF_CT];
       }
       acc1 += g2 * rc;
       acca3 += g3 * r27;
@@ -308,8 +352,10 @@ __global__ __launch_bounds__(GF_THREADS) void gatrep_bwd_kernel(
         if (tid == 0) atomicAdd(dg + ((size_t)s * E + k) * co_n + co, v);
       }
     }
-    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GB_NT; ++k) dcur[k] = dnxt[k];
   }
+  __syncthreads();
   if (tid < GF_CT && live) {
     dk1[oi] = acc1;
     da3[oi] = acca3 * (1.0f / 27.0f);
@@ -328,29 +374,6 @@ __global__ __launch_bounds__(GF_THREADS) void gatrep_bwd_kernel(
   __syncthreads();
   for (int i = tid; i < nlive * TAPS; i += GF_THREADS) dk5[base * TAPS + i] = s5[i];
   for (int i = tid; i < nlive * 27; i += GF_THREADS) dk3[base * 27 + i] = s3[i];
-}
-
-// softmax Jacobian + gate Linear gradients.  One thread per (e, co); loops over slots.
-__global__ void gate_bwd_kernel(const float* __restrict__ g, const float* __restrict__ dg,
-                                const int32_t* __restrict__ slot_task, int nslots, int num_tasks, int co_n,
-                                float* __restrict__ dgate_w, float* __restrict__ dgate_b) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= E * co_n) return;
-  const int e = idx / co_n, o = idx % co_n;
-  float* wrow = dgate_w + (size_t)idx * num_tasks;
-  for (int t = 0; t < num_tasks; ++t) wrow[t] = 0.f;
-  float bsum = 0.f;
-  for (int s = 0; s < nslots; ++s) {
-    const float* gs = g + (size_t)s * E * co_n + o;
-    const float* ds = dg + (size_t)s * E * co_n + o;
-    float dot = 0.f;
-#pragma unroll
-    for (int k = 0; k < E; ++k) dot += gs[k * co_n] * ds[k * co_n];
-    const float dl = gs[e * co_n] * (ds[e * co_n] - dot);
-    wrow[slot_task[s]] += dl;   // slots hold distinct tasks; += keeps duplicates correct too
-    bsum += dl;
-  }
-  dgate_b[idx] = bsum;
 }
 
 }  // namespace
@@ -412,13 +435,24 @@ extern "C" int repmode_gatrep_bwd(const float* dw, const float* k5, const float*
   RM_REQUIRE(dk5 && dk3 && dk1 && da3 && da5 && dgate_w && dgate_b && dg_ws, "gatrep_bwd: null output");
   RM_REQUIRE(nslots > 0 && num_tasks > 0 && co > 0 && ci > 0, "gatrep_bwd: bad shape");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  RM_HIP(hipMemsetAsync(dg_ws, 0, (size_t)nslots * E * co * sizeof(float), s));
+  // dg accumulates in the library's zero scratch when it fits (gate_bwd puts the zeros back: no memset launch);
+  // otherwise in the caller's dg_ws
+  const size_t ndg = (size_t)nslots * E * co;
+  float* dg = dg_ws;
+  int clear = 0;
+  if (ndg <= REPMODE_ZERO_SCRATCH_FLOATS) {
+    dg = repmode_zero_scratch(s);
+    if (!dg) return REPMODE_ELAUNCH;
+    clear = 1;
+  } else {
+    RM_HIP(hipMemsetAsync(dg_ws, 0, ndg * sizeof(float), s));
+  }
   repmode_prof_begin(REPMODE_PROF_GATREP_BWD, (double)co * ci * 4.0 * (125.0 * nslots + 2 * 155.0), s);
   hipLaunchKernelGGL(gatrep_bwd_kernel, dim3(ceil_div(ci, GF_CT), co), dim3(GF_THREADS), 0, s, dw, k5, k3, k1, a3, a5,
-                     g, nslots, co, ci, dk5, dk3, dk1, da3, da5, dg_ws);
+                     g, nslots, co, ci, dk5, dk3, dk1, da3, da5, dg);
   RM_LAUNCH_CHECK("gatrep_bwd");
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(E * co, 128)), dim3(128), 0, s, g, dg_ws, slot_task, nslots,
-                     num_tasks, co, dgate_w, dgate_b);
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(co, 64)), dim3(64), 0, s, g, dg, slot_task, nslots, num_tasks, co,
+                     dgate_w, dgate_b, clear);
   repmode_prof_end(s);
   RM_LAUNCH_CHECK("gate_bwd");
   return REPMODE_OK;

@@ -92,7 +92,7 @@ class MoDEConv(torch.nn.Module):
                                self.expert_avg3x3_conv, self.expert_avg5x5_conv, self.gate.weight, self.gate.bias,
                                plan, out_f32=out_f32)
         if self.conv_type == 'normal':                          # RepMode.py:212: BatchNorm3d + ReLU, fused HIP
-            y_cl = ops.bn_relu(y_cl, self.subsequent_layer[0], self.training, dtype)
+            y_cl = ops.bn_relu(y_cl, self.subsequent_layer[0], self.training, dtype, count=not getattr(t, 'bn_counted', False))
         return _from_cl(y_cl)
 
 
@@ -141,7 +141,8 @@ class MoDEEncoderBlock(torch.nn.Module):                       # RepMode.py:74-8
     def forward(self, x, t):
         x_skip = self.conv_more(x, t)
         y = self.conv_down[0](x_skip)                                           # stride-2 conv as a GEMM
-        y_cl = ops.bn_relu(_to_cl(y), self.conv_down[1], self.training, x_skip.dtype)   # BN + ReLU, RepMode.py:82-83
+        y_cl = ops.bn_relu(_to_cl(y), self.conv_down[1], self.training, x_skip.dtype,          # BN + ReLU, RepMode.py:82-83
+                           count=not getattr(t, 'bn_counted', False))
         return _from_cl(y_cl), x_skip
 
 
@@ -155,7 +156,8 @@ class MoDEDecoderBlock(torch.nn.Module):                       # RepMode.py:92-1
 
     def forward(self, x, x_skip, t):
         up = self.convt[0](x)
-        up = _from_cl(ops.bn_relu(_to_cl(up), self.convt[1], self.training, x_skip.dtype))   # RepMode.py:99-100
+        up = _from_cl(ops.bn_relu(_to_cl(up), self.convt[1], self.training, x_skip.dtype,
+                                   count=not getattr(t, 'bn_counted', False)))   # RepMode.py:99-100
         return self.conv_less(torch.cat((x_skip, up), 1), t)   # skip first, RepMode.py:106
 
 
@@ -189,6 +191,13 @@ class Net(torch.nn.Module):
         # integer task ids -> slot plan, built once and shared by the 19 MoDE blocks (replaces the
         # one-hot embedding of RepMode.py:44-49,53)
         plan = t if isinstance(t, ops.TaskPlan) else ops.TaskPlan(t, self.num_tasks, x.device, self.training)
+        if self.training and not plan.bn_counted:
+            # num_batches_tracked of the 26 BatchNorm layers: one multi-tensor launch instead of 26
+            counters = [m.num_batches_tracked for m in self.modules()
+                        if isinstance(m, torch.nn.BatchNorm3d) and m.track_running_stats]
+            if counters:
+                torch._foreach_add_(counters, 1)
+            plan.bn_counted = True
         x, s1 = self.encoder_block1(x, plan)
         x, s2 = self.encoder_block2(x, plan)
         x, s3 = self.encoder_block3(x, plan)

@@ -75,6 +75,7 @@ class TaskPlan:
         self.slot_task_host = uniq
         self.slot_task = torch.tensor(uniq, dtype=torch.int32).to(device, non_blocking=True)
         self.sample_slot = torch.tensor(slots, dtype=torch.int32).to(device, non_blocking=True)
+        self.bn_counted = False     # set by Net.forward once num_batches_tracked of every BN layer is advanced
 
 
 def gate_softmax(gate_w, gate_b, plan, co):
@@ -189,9 +190,8 @@ class _BnRelu(torch.autograd.Function):
         out = torch.empty(x_cl.shape, dtype=out_dtype, device=x_cl.device)
         save_mean = torch.empty(c, dtype=torch.float32, device=x_cl.device)
         save_invstd = torch.empty_like(save_mean)
-        sums = torch.empty(BN_SLICES * 2 * c, dtype=torch.float32, device=x_cl.device)
         _lib.call('repmode_bn_relu_fwd', _ptr(x_cl), _ptr(out), _ptr(weight), _ptr(bias), _ptr(running_mean),
-                  _ptr(running_var), _ptr(save_mean), _ptr(save_invstd), _ptr(sums), m, c, float(eps), float(momentum),
+                  _ptr(running_var), _ptr(save_mean), _ptr(save_invstd), m, c, float(eps), float(momentum),
                   1 if training else 0, dtype_code(x_cl.dtype), dtype_code(out_dtype), _stream())
         ctx.save_for_backward(x_cl, weight, bias, save_mean, save_invstd)
         ctx.training = training
@@ -205,20 +205,20 @@ class _BnRelu(torch.autograd.Function):
         m = x_cl.numel() // c
         dy = dy.contiguous()
         dx = torch.empty_like(x_cl)
-        sums = torch.empty((BN_SLICES + 1) * 2 * c, dtype=torch.float32, device=x_cl.device)
+        tot = torch.empty(2 * c, dtype=torch.float32, device=x_cl.device)    # [0:c) = dbeta, [c:2c) = dgamma
         _lib.call('repmode_bn_relu_bwd', _ptr(x_cl), _ptr(dy), _ptr(weight), _ptr(bias), _ptr(save_mean),
-                  _ptr(save_invstd), _ptr(dx), _ptr(sums), m, c, 1 if ctx.training else 0, dtype_code(x_cl.dtype),
+                  _ptr(save_invstd), _ptr(dx), _ptr(tot), m, c, 1 if ctx.training else 0, dtype_code(x_cl.dtype),
                   dtype_code(dy.dtype), _stream())
-        tot = sums[BN_SLICES * 2 * c:]                           # [0:c) = dbeta, [c:2c) = dgamma
         return dx, tot[c:], tot[:c], None, None, None, None, None, None
 
 
-def bn_relu(x_cl, bn, training, out_dtype):
+def bn_relu(x_cl, bn, training, out_dtype, count=True):
     """``relu(batch_norm(x))`` with the parameters / running statistics of a ``torch.nn.BatchNorm3d`` module
-    (kept as the parameter container so that the state_dict matches the reference)."""
+    (kept as the parameter container so that the state_dict matches the reference).  ``count=False``: the caller
+    has already advanced ``num_batches_tracked`` (the network does it for all its BN layers in one launch)."""
     x_cl = x_cl.contiguous()
     use_batch_stats = training or not bn.track_running_stats
-    if training and bn.track_running_stats:
+    if count and training and bn.track_running_stats:
         bn.num_batches_tracked.add_(1)
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _BnRelu.apply(x_cl, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats, momentum, bn.eps,
