@@ -81,8 +81,9 @@ int repmode_gatrep_fwd(const float* k5, const float* k3, const float* k1, const 
 int repmode_conv5(const void* x, const void* w, const int32_t* sample_slot, void* y, int n, int d,
                   int h, int wdim, int cin, int cout, int dtype, int out_f32, void* stream);
 
-/* Same, with centre3 != 0 restricting the filter planes/rows to dz, dy in [1,3] (a filter whose support is
- * the centred 3x3x3 -- the zero-padded conv3x3 expert of RepMode.py:174 -- skips the 80 all-zero taps). */
+/* Same, with a flag word `centre3`: bit 0 restricts the filter planes/rows to dz, dy in [1,3] (a filter whose
+ * support is the centred 3x3x3 -- the zero-padded conv3x3 expert of RepMode.py:174 -- skips the 80 all-zero
+ * taps); bit 1 (float output only) ADDS the result to y instead of overwriting it. */
 int repmode_conv5_ex(const void* x, const void* w, const int32_t* sample_slot, void* y, int n, int d,
                      int h, int wdim, int cin, int cout, int dtype, int out_f32, int centre3,
                      void* stream);
@@ -148,6 +149,14 @@ int repmode_k2s2(const void* in, const void* w, void* out, int n, int d, int h, 
  * (down: coarse = dy, fine = x;  up: coarse = x, fine = dy).  dw: float [8][ca][cb], overwritten. */
 int repmode_k2s2_wgrad(const void* coarse, const void* fine, float* dw, int n, int d, int h, int wdim, int ca,
                        int cb, void* stream);
+/* Same with the output written in the parameter's own layout (no permute copy afterwards):
+ * param_layout 0: dw[8][A][B]; 1: dw[A][B][2][2][2]; 2: dw[B][A][2][2][2]. */
+int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float* dw, int n, int d, int h, int wdim, int ca,
+                          int cb, int param_layout, void* stream);
+/* The fragment-major, zero-padded filter operand `w` of repmode_k2s2 from a float parameter tensor, one launch:
+ * out[p][rows/32][red/KC][32][KC] = w(row, red, p), with w stored [rows][red][2][2][2] (red_major == 0) or
+ * [red][rows][2][2][2] (red_major != 0).  out: 8 * padded(rows) * padded(red) elements of `dtype`. */
+int repmode_k2_frags(const float* w, int rows, int red, int red_major, int dtype, void* out, void* stream);
 
 /* ---- gate mixing of the per-expert formulation (linearity of RepMode.py:184-188 + :207).  p: float [5][n][v][c]
  * expert outputs, g: float [n][5][c] gate probabilities per SAMPLE.
@@ -163,6 +172,18 @@ int repmode_expert_mix_bwd(const float* dy, const float* p, const float* g, floa
  * out = box3(in3) + box5(in5); float NDHWC tensors; either input may be NULL (not both). */
 int repmode_box_sum(const float* in3, const float* in5, float* out, int n, int d, int h, int w, int c,
                     void* stream);
+/* out = box3(in3) + box5(in5) [+ add0] [+ add1], stored in out_dtype (float inputs; add0 / add1 may be NULL). */
+int repmode_box_sum_ex(const float* in3, const float* in5, const float* add0, const float* add1, void* out,
+                       int out_dtype, int n, int d, int h, int w, int c, void* stream);
+/* Filter gradient from the kernels' tap-major layout to the experts' parameter layout: out[m][t] = in[tap(t)][m]
+ * for the m = Co*Ci channel pairs; ntaps_out = 125 (all taps), 27 (the centred 3x3x3 taps of the [125][m] input)
+ * or 8 (the 2x2x2 stride-2 filters, input [8][m]). */
+int repmode_tap_transpose(const float* in, float* out, long m, int ntaps_out, void* stream);
+/* Softmax Jacobian + gate Linear gradients (autograd of RepMode.py:198-200) from gate-probability gradients
+ * dg[s][5][Co]: dgate_w [5*Co][T], dgate_b [5*Co], overwritten.  (repmode_gatrep_bwd does this itself; the
+ * per-expert formulation calls it with one "slot" per sample.) */
+int repmode_gate_bwd(const float* g, const float* dg, const int32_t* slot_task, int nslots, int num_tasks, int co,
+                     float* dgate_w, float* dgate_b, void* stream);
 
 /* ---- measurement: per-launch HIP-event timing of the library's kernels on their own stream.
  * repmode_prof_enable(1) clears the records and starts recording every kind, (2) records conv5_igemm only

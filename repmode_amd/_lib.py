@@ -36,9 +36,14 @@ _SIGNATURES = {
     'repmode_bn_relu_bwd': [_P] * 8 + [_c.c_long, _I, _I, _I, _I, _P],
     'repmode_k2s2': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_k2s2_wgrad': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_k2s2_wgrad_ex': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_k2_frags': [_P, _I, _I, _I, _I, _P, _P],
     'repmode_expert_mix_fwd': [_P, _P, _P, _I, _c.c_long, _I, _P],
     'repmode_expert_mix_bwd': [_P, _P, _P, _P, _P, _P, _I, _c.c_long, _I, _I, _P],
     'repmode_box_sum': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'repmode_box_sum_ex': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_tap_transpose': [_P, _P, _c.c_long, _I, _P],
+    'repmode_gate_bwd': [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     'repmode_prof_enable': [_I],
     'repmode_prof_summary': [_I, _P, _P, _P],
     'repmode_prof_count': [],

@@ -15,8 +15,11 @@
 
 namespace {
 
+// out = box3(in3) + box5(in5) [+ add0] [+ add1], stored as float or (OUT_BF16) bfloat16
+template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void box_sum_kernel(const float* __restrict__ in3, const float* __restrict__ in5,
-                                                      float* __restrict__ out, int N, int D, int H, int W, int C) {
+                                                      const float* __restrict__ add0, const float* __restrict__ add1,
+                                                      void* __restrict__ out_, int N, int D, int H, int W, int C) {
   const int c4n = (C + 3) / 4;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)N * D * H * W * c4n;
@@ -62,22 +65,87 @@ __global__ __launch_bounds__(256) void box_sum_kernel(const float* __restrict__ 
   const size_t o = ((((size_t)n * D + z) * H + y) * W + x) * C + c;
   float r[4];
   for (int k = 0; k < 4; ++k) r[k] = a3[k] * (1.0f / 27.0f) + a5[k] * (1.0f / 125.0f);
-  if (vec) {
-    *reinterpret_cast<f32x4*>(out + o) = f32x4{r[0], r[1], r[2], r[3]};
+  for (int q = 0; q < 2; ++q) {
+    const float* add = q ? add1 : add0;
+    if (!add) continue;
+    if (vec) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(add + o);
+      r[0] += t.x; r[1] += t.y; r[2] += t.z; r[3] += t.w;
+    } else {
+      for (int k = 0; k < 4; ++k) if (c + k < C) r[k] += add[o + k];
+    }
+  }
+  if constexpr (OUT_BF16) {
+    bf16_t* out = static_cast<bf16_t*>(out_);
+    if (vec) {
+      *reinterpret_cast<u32x2*>(out + o) = u32x2{pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+    } else {
+      for (int k = 0; k < 4; ++k) if (c + k < C) out[o + k] = f32_to_bf16(r[k]);
+    }
   } else {
-    for (int k = 0; k < 4; ++k) if (c + k < C) out[o + k] = r[k];
+    float* out = static_cast<float*>(out_);
+    if (vec) {
+      *reinterpret_cast<f32x4*>(out + o) = f32x4{r[0], r[1], r[2], r[3]};
+    } else {
+      for (int k = 0; k < 4; ++k) if (c + k < C) out[o + k] = r[k];
+    }
   }
 }
 
 }  // namespace
 
-extern "C" int repmode_box_sum(const float* in3, const float* in5, float* out, int n, int d, int h, int w, int c,
-                               void* stream) {
+extern "C" int repmode_box_sum_ex(const float* in3, const float* in5, const float* add0, const float* add1, void* out,
+                                  int out_dtype, int n, int d, int h, int w, int c, void* stream) {
   RM_REQUIRE(out && (in3 || in5), "box_sum: null pointer");
   RM_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && c > 0, "box_sum: bad shape");
+  RM_REQUIRE(out_dtype == REPMODE_F32 || out_dtype == REPMODE_BF16, "box_sum: bad dtype %d", out_dtype);
   const long total = (long)n * d * h * w * ((c + 3) / 4);
-  hipLaunchKernelGGL(box_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     in3, in5, out, n, d, h, w, c);
+  if (out_dtype == REPMODE_BF16)
+    hipLaunchKernelGGL(box_sum_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), in3, in5, add0, add1, out, n, d, h, w, c);
+  else
+    hipLaunchKernelGGL(box_sum_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), in3, in5, add0, add1, out, n, d, h, w, c);
   RM_LAUNCH_CHECK("box_sum");
+  return REPMODE_OK;
+}
+
+extern "C" int repmode_box_sum(const float* in3, const float* in5, float* out, int n, int d, int h, int w, int c,
+                               void* stream) {
+  return repmode_box_sum_ex(in3, in5, nullptr, nullptr, out, REPMODE_F32, n, d, h, w, c, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Filter gradient, tap-major -> the experts' parameter layout: out[m][t] = in[tap(t)][m], m = (co, ci) pairs.
+//   ntaps_out == 125: all taps;  ntaps_out == 27: the centred 3x3x3 taps of the 5x5x5 grid (in is still [125][M]);
+//   ntaps_out == 8: the 2x2x2 stride-2 filters (in is [8][M]).
+// A 64-column strip goes through LDS so that both the reads (64 floats of a tap row) and the writes (64 * ntaps
+// contiguous floats) are whole lines; the generic strided copy it replaces ran at a quarter of that.
+namespace {
+__global__ __launch_bounds__(256) void tap_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, long M,
+                                                            int ntaps_out) {
+  __shared__ float tile[125 * 65];
+  const long m0 = (long)blockIdx.x * 64;
+  const int ncol = (int)min((long)64, M - m0);
+  for (int i = threadIdx.x; i < ntaps_out * 64; i += 256) {
+    const int t = i / 64, col = i % 64;
+    int tap = t;
+    if (ntaps_out == 27) tap = ((t / 9 + 1) * 5 + (t / 3) % 3 + 1) * 5 + t % 3 + 1;
+    if (col < ncol) tile[t * 65 + col] = in[(size_t)tap * M + m0 + col];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ncol * ntaps_out; i += 256) {
+    const int col = i / ntaps_out, t = i % ntaps_out;
+    out[(size_t)m0 * ntaps_out + i] = tile[t * 65 + col];
+  }
+}
+}  // namespace
+
+extern "C" int repmode_tap_transpose(const float* in, float* out, long m, int ntaps_out, void* stream) {
+  RM_REQUIRE(in && out, "tap_transpose: null pointer");
+  RM_REQUIRE(m > 0 && (ntaps_out == 125 || ntaps_out == 27 || ntaps_out == 8), "tap_transpose: bad shape");
+  hipLaunchKernelGGL(tap_transpose_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     in, out, m, ntaps_out);
+  RM_LAUNCH_CHECK("tap_transpose");
   return REPMODE_OK;
 }

@@ -71,6 +71,7 @@ struct ConvArgs {
   int nbz, nby, nbx, ncot, ksplit;
   int out_f32;  // 0: store as T; 1: float output (SWAP kernels; atomicAdd when ksplit > 1)
   int tap_lo, tap_hi;  // dz and dy are restricted to [tap_lo, tap_hi] (0..4: full filter; 1..3: a 3x3 support)
+  int accum;           // float output only: add to y (atomics, y is not cleared) instead of overwriting it
 };
 
 // Tile configuration.  BZ*BY*BX output voxels = 32 * WV * VW; 32 * WC * CW output channels.
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
           const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
           if (gz >= D || gy >= H || gx >= W) continue;
           float* yp = static_cast<float*>(a.y) + (((size_t)(n * D + gz) * H + gy) * W + gx) * Cout + co;
-          if (a.ksplit > 1) unsafeAtomicAdd(yp, acc[cs][vs][r]);
+          if (a.ksplit > 1 || a.accum) unsafeAtomicAdd(yp, acc[cs][vs][r]);
           else *yp = acc[cs][vs][r];
         }
       }
@@ -391,7 +392,7 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set = true;
   }
-  if (ks > 1) {
+  if (ks > 1 && !a.accum) {
     RM_HIP(hipMemsetAsync(a.y, 0, (size_t)a.N * a.D * a.H * a.W * a.Cout * sizeof(float), stream));
   }
   // algorithmic FLOPs: 125 taps, or the 27 of a 3x3x3 support when restricted
@@ -448,8 +449,11 @@ extern "C" int repmode_conv5_ex(const void* x, const void* w, const int32_t* sam
   a.CinP = repmode_padded_channels(cin, dtype, 1);
   a.CoutP = repmode_padded_channels(cout, dtype, 0);
   a.out_f32 = (out_f32 != 0) || dtype == REPMODE_F32;
-  a.tap_lo = centre3 ? 1 : 0;
-  a.tap_hi = centre3 ? 3 : 4;
+  // `centre3` is a flag word: bit 0 = 3x3x3 support, bit 1 = accumulate into a float y
+  a.tap_lo = (centre3 & 1) ? 1 : 0;
+  a.tap_hi = (centre3 & 1) ? 3 : 4;
+  a.accum = (centre3 & 2) ? 1 : 0;
+  RM_REQUIRE(!a.accum || a.out_f32, "conv5: accumulation needs a float output");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == REPMODE_F32) return dispatch<float, true>(a, s);
   if (a.out_f32) return dispatch<bf16_t, true>(a, s);

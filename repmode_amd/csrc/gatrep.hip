@@ -213,34 +213,38 @@ __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
 constexpr int GF_CT = 32;      // channels per slab (backward kernel)
 constexpr int GF_THREADS = 256;
 
-// softmax Jacobian + gate Linear gradients.  One thread per output channel o (all five experts' rows); loops over
-// slots.  `clear`: dg lives in the library's zero scratch -- the thread puts the zeros back behind itself.
-__global__ void gate_bwd_kernel(const float* __restrict__ g, float* __restrict__ dg,
-                                const int32_t* __restrict__ slot_task, int nslots, int num_tasks, int co_n,
-                                float* __restrict__ dgate_w, float* __restrict__ dgate_b, int clear) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= co_n) return;
+// softmax Jacobian + gate Linear gradients.  One thread per (o, e), the five experts of a channel adjacent in one
+// workgroup (160 threads = 32 channels); loops over slots.  `clear`: dg lives in the library's zero scratch --
+// once every thread of the workgroup has read its channel's entries, they are zeroed again.
+constexpr int GATE_BWD_THREADS = 32 * E;
+
+__global__ __launch_bounds__(GATE_BWD_THREADS) void gate_bwd_kernel(
+    const float* __restrict__ g, float* __restrict__ dg, const int32_t* __restrict__ slot_task, int nslots,
+    int num_tasks, int co_n, float* __restrict__ dgate_w, float* __restrict__ dgate_b, int clear) {
+  const int idx = blockIdx.x * GATE_BWD_THREADS + threadIdx.x;
+  const int o = idx / E, e = idx % E;
+  const bool on = o < co_n;
+  if (on) {
+    float* wrow = dgate_w + ((size_t)e * co_n + o) * num_tasks;
+    for (int t = 0; t < num_tasks; ++t) wrow[t] = 0.f;
+    float bsum = 0.f;
+    for (int s = 0; s < nslots; ++s) {
+      const float* gs = g + (size_t)s * E * co_n + o;
+      const float* ds = dg + (size_t)s * E * co_n + o;
+      float dot = 0.f;
 #pragma unroll
-  for (int e = 0; e < E; ++e)
-    for (int t = 0; t < num_tasks; ++t) dgate_w[((size_t)e * co_n + o) * num_tasks + t] = 0.f;
-  float bsum[E] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < nslots; ++s) {
-    const float* gs = g + (size_t)s * E * co_n + o;
-    float* ds = dg + (size_t)s * E * co_n + o;
-    float gv[E], dv[E], dot = 0.f;
-#pragma unroll
-    for (int k = 0; k < E; ++k) { gv[k] = gs[k * co_n]; dv[k] = ds[k * co_n]; dot += gv[k] * dv[k]; }
-    const int task = slot_task[s];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const float dl = gv[e] * (dv[e] - dot);
-      dgate_w[((size_t)e * co_n + o) * num_tasks + task] += dl;   // slots hold distinct tasks; += keeps duplicates correct too
-      bsum[e] += dl;
-      if (clear) ds[e * co_n] = 0.f;
+      for (int k = 0; k < E; ++k) dot += gs[k * co_n] * ds[k * co_n];
+      const float dl = gs[e * co_n] * (ds[e * co_n] - dot);
+      atomicAdd(&wrow[slot_task[s]], dl);   // (atomic only to keep the slot iterations independent)
+      bsum += dl;
     }
+    dgate_b[e * co_n + o] = bsum;
   }
-#pragma unroll
-  for (int e = 0; e < E; ++e) dgate_b[e * co_n + o] = bsum[e];
+  if (clear) {
+    __syncthreads();
+    if (on)
+      for (int s = 0; s < nslots; ++s) dg[((size_t)s * E + e) * co_n + o] = 0.f;
+  }
 }
 
 
@@ -251,7 +255,8 @@ __global__ void gate_bwd_kernel(const float* __restrict__ g, float* __restrict__
 // reduced over the block and added to dg[s][e][co] (one atomic per block, slot and expert).
 constexpr int GB_NT = 16;   // taps per thread: ceil(125 / 8)
 
-__global__ __launch_bounds__(GF_THREADS) void gatrep_bwd_kernel(
+template <int SG>   // slots per reduction round
+__global__ __launch_bounds__(GF_THREADS, SG > 2 ? 1 : 2) void gatrep_bwd_kernel(
     const float* __restrict__ dw, const float* __restrict__ k5, const float* __restrict__ k3,
     const float* __restrict__ k1, const float* __restrict__ a3, const float* __restrict__ a5,
     const float* __restrict__ g, int nslots, int co_n, int ci_n, float* __restrict__ dk5,
@@ -259,7 +264,8 @@ __global__ __launch_bounds__(GF_THREADS) void gatrep_bwd_kernel(
     float* __restrict__ dg) {
   __shared__ float s5[GF_CT * TAPS];        // k5 slab, later reused for the dk5 write-back
   __shared__ float s3[GF_CT * 27];
-  __shared__ float part[2][5][GF_THREADS];  // double-buffered over slots: one barrier per slot
+  __shared__ float part[SG * 5][GF_THREADS];
+  __shared__ float cross[3][SG][GF_CT];     // per-slot contributions to dk1 / da3 / da5 of each ci
   const int tid = threadIdx.x;
   const int co = blockIdx.y;
   const int c0 = blockIdx.x * GF_CT;
@@ -293,67 +299,86 @@ __global__ __launch_bounds__(GF_THREADS) void gatrep_bwd_kernel(
   __shared__ float sgb[64][E];
   for (int i = tid; i < min(nslots, 64) * E; i += GF_THREADS) sgb[i / E][i % E] = g[((size_t)(i / E) * E + i % E) * co_n + co];
   __syncthreads();
-  // the filter-gradient values of slot s+1 are fetched while slot s is reduced (the loop was a chain of
-  // load -> reduce -> barrier round trips: 50-60 us per launch whatever the layer size)
-  float dcur[GB_NT], dnxt[GB_NT];
-  auto load_slot = [&](float* d, int s) {
-    const float* dws = dw + (size_t)s * TAPS * tap_stride + oi;
+  // Slots are taken SG at a time: their filter-gradient loads are independent (all in flight together) and the
+  // per-slot partial sums stay in registers until ONE block reduction per round.  (One load -> reduce -> barrier
+  // round trip per slot made every launch 50-60 us whatever the layer size.)
+  const int rj = tid / GF_CT;               // reduction phase: this thread reduces slot s0 + rj for ci c
+  for (int s0 = 0; s0 < nslots; s0 += SG) {
+    const int ns = min(SG, nslots - s0);
+    float q[SG][5];
 #pragma unroll
-    for (int k = 0; k < GB_NT; ++k) {
-      const int tap = tq + 8 * k;
-      d[k] = (tap < TAPS && live) ? dws[(size_t)tap * tap_stride] : 0.f;
-    }
-  };
-  load_slot(dcur, 0);
-  for (int s = 0; s < nslots; ++s) {
-    if (s + 1 < nslots) load_slot(dnxt, s + 1);
-    const float* gs = g + (size_t)s * E * co_n + co;
-    const bool in_lds = s < 64;
-    const float g0 = in_lds ? sgb[s][0] : gs[0], g1 = in_lds ? sgb[s][1] : gs[co_n], g2 = in_lds ? sgb[s][2] : gs[2 * co_n],
-                g3 = in_lds ? sgb[s][3] : gs[3 * co_n], g4 = in_lds ? sgb[s][4] : gs[4 * co_n];
-    float q0 = 0.f, q1 = 0.f, dcen = 0.f, s27 = 0.f, s125 = 0.f;
+    for (int j = 0; j < SG; ++j) {
 #pragma unroll
-    for (int k = 0; k < GB_NT; ++k) {
-      const int tap = tq + 8 * k;
-      if (tap < TAPS && live) {      // dead lanes must not touch the (uninitialised) slab tail
-        const float d = dcur[k];
-        int t3;
-        const bool c3 = in_centre3(tap, t3);
-        s125 += d;
-        q0 += s5[c * TAPS + tap] * d;
-        acc5[k] += g0 * d;
-        if (c3) {
-          s27 += d;
-          q1 += s3[c * 27 + t3] * d;
-          acc3[k] += g1 * d;
-          if (tap == 62) dcen = d;
+      for (int v = 0; v < 5; ++v) q[j][v] = 0.f;
+      if (j < ns) {
+        const int s = s0 + j;
+        const bool in_lds = s < 64;
+        const float* gs = g + (size_t)s * E * co_n + co;
+        const float g0 = in_lds ? sgb[s][0] : gs[0], g1 = in_lds ? sgb[s][1] : gs[co_n];
+        const float* dws = dw + (size_t)s * TAPS * tap_stride + oi;
+#pragma unroll
+        for (int k = 0; k < GB_NT; ++k) {
+          const int tap = tq + 8 * k;
+          if (tap < TAPS && live) {      // dead lanes must not touch the (uninitialised) slab tail
+            const float d = dws[(size_t)tap * tap_stride];
+            int t3;
+            const bool c3 = in_centre3(tap, t3);
+            q[j][4] += d;
+            q[j][0] += s5[c * TAPS + tap] * d;
+            acc5[k] += g0 * d;
+            if (c3) {
+              q[j][3] += d;
+              q[j][1] += s3[c * 27 + t3] * d;
+              acc3[k] += g1 * d;
+              if (tap == 62) q[j][2] = d;
+            }
+          }
         }
       }
     }
-    float (*pb)[GF_THREADS] = part[s & 1];
-    pb[0][tid] = q0; pb[1][tid] = q1; pb[2][tid] = dcen; pb[3][tid] = s27; pb[4][tid] = s125;
-    __syncthreads();
-    if (tid < GF_CT) {
-      float r0 = 0.f, r1 = 0.f, rc = 0.f, r27 = 0.f, r125 = 0.f;
 #pragma unroll
-      for (int j = 0; j < GF_THREADS / GF_CT; ++j) {
-        r0 += pb[0][tid + j * GF_CT]; r1 += pb[1][tid + j * GF_CT]; rc += pb[2][tid + j * GF_CT];
-        r27 += pb[3][tid + j * GF_CT]; r125 += pb[4][tid + j * GF_CT];
+    for (int j = 0; j < SG; ++j)
+#pragma unroll
+      for (int v = 0; v < 5; ++v) part[j * 5 + v][tid] = q[j][v];
+    __syncthreads();
+    {
+      // thread (c, rj): totals of slot s0 + rj for ci c over the 8 tap groups
+      float r[5];
+#pragma unroll
+      for (int v = 0; v < 5; ++v) {
+        r[v] = 0.f;
+        if (rj < SG) {
+#pragma unroll
+          for (int t = 0; t < GF_THREADS / GF_CT; ++t) r[v] += part[rj * 5 + v][c + t * GF_CT];
+        }
       }
-      acc1 += g2 * rc;
-      acca3 += g3 * r27;
-      acca5 += g4 * r125;
-      float e[E] = {r0, r1, w1 * rc, w3 * r27, w5 * r125};
+      const int s = s0 + rj;
+      const bool on = rj < ns;
+      const bool in_lds = s < 64;
+      const float* gs = g + (size_t)(on ? s : 0) * E * co_n + co;
+      const float g2 = !on ? 0.f : in_lds ? sgb[s][2] : gs[2 * co_n];
+      const float g3 = !on ? 0.f : in_lds ? sgb[s][3] : gs[3 * co_n];
+      const float g4 = !on ? 0.f : in_lds ? sgb[s][4] : gs[4 * co_n];
+      if (rj < SG) {
+        cross[0][rj][c] = g2 * r[2];
+        cross[1][rj][c] = g3 * r[3];
+        cross[2][rj][c] = g4 * r[4];
+      }
+      // dg[s][e][co] += sum over this block's ci (one atomic per block, slot and expert)
+      float e[E] = {r[0], r[1], w1 * r[2], w3 * r[3], w5 * r[4]};
 #pragma unroll
       for (int k = 0; k < E; ++k) {
         float v = e[k];
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 32);
-        if (tid == 0) atomicAdd(dg + ((size_t)s * E + k) * co_n + co, v);
+        if (c == 0 && on) atomicAdd(dg + ((size_t)s * E + k) * co_n + co, v);
       }
     }
+    __syncthreads();
+    if (tid < GF_CT) {
 #pragma unroll
-    for (int k = 0; k < GB_NT; ++k) dcur[k] = dnxt[k];
+      for (int j = 0; j < SG; ++j) { acc1 += cross[0][j][tid]; acca3 += cross[1][j][tid]; acca5 += cross[2][j][tid]; }
+    }
   }
   __syncthreads();
   if (tid < GF_CT && live) {
@@ -426,6 +451,18 @@ extern "C" int repmode_gatrep_fwd(const float* k5, const float* k3, const float*
   return gatrep_fwd_t<bf16_t>(k5, k3, k1, a3, a5, g, nslots, co, ci, dtype, wf, wd, s);
 }
 
+// Softmax-Jacobian + gate Linear gradients alone, from gate-probability gradients dg[s][5][Co] (used by the
+// per-expert formulation, where "slots" are the samples themselves and dg[n][e][o] = <dy[n], P_e[n]>).
+extern "C" int repmode_gate_bwd(const float* g, const float* dg, const int32_t* slot_task, int nslots, int num_tasks,
+                                int co, float* dgate_w, float* dgate_b, void* stream) {
+  RM_REQUIRE(g && dg && slot_task && dgate_w && dgate_b, "gate_bwd: null pointer");
+  RM_REQUIRE(nslots > 0 && num_tasks > 0 && co > 0, "gate_bwd: bad shape");
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(co, 32)), dim3(GATE_BWD_THREADS), 0, static_cast<hipStream_t>(stream), g,
+                     const_cast<float*>(dg), slot_task, nslots, num_tasks, co, dgate_w, dgate_b, 0);
+  RM_LAUNCH_CHECK("gate_bwd");
+  return REPMODE_OK;
+}
+
 extern "C" int repmode_gatrep_bwd(const float* dw, const float* k5, const float* k3, const float* k1,
                                   const float* a3, const float* a5, const float* g, const int32_t* slot_task,
                                   int nslots, int num_tasks, int co, int ci, float* dk5, float* dk3, float* dk1,
@@ -448,11 +485,17 @@ extern "C" int repmode_gatrep_bwd(const float* dw, const float* k5, const float*
     RM_HIP(hipMemsetAsync(dg_ws, 0, ndg * sizeof(float), s));
   }
   repmode_prof_begin(REPMODE_PROF_GATREP_BWD, (double)co * ci * 4.0 * (125.0 * nslots + 2 * 155.0), s);
-  hipLaunchKernelGGL(gatrep_bwd_kernel, dim3(ceil_div(ci, GF_CT), co), dim3(GF_THREADS), 0, s, dw, k5, k3, k1, a3, a5,
-                     g, nslots, co, ci, dk5, dk3, dk1, da3, da5, dg);
+  // small layers are latency-bound: 8 slots' loads in flight per thread (one wave per SIMD); larger ones want
+  // the occupancy of the 2-slot variant
+  if ((long)ceil_div(ci, GF_CT) * co <= 256)
+    hipLaunchKernelGGL(gatrep_bwd_kernel<8>, dim3(ceil_div(ci, GF_CT), co), dim3(GF_THREADS), 0, s, dw, k5, k3, k1, a3, a5,
+                       g, nslots, co, ci, dk5, dk3, dk1, da3, da5, dg);
+  else
+    hipLaunchKernelGGL(gatrep_bwd_kernel<2>, dim3(ceil_div(ci, GF_CT), co), dim3(GF_THREADS), 0, s, dw, k5, k3, k1, a3, a5,
+                       g, nslots, co, ci, dk5, dk3, dk1, da3, da5, dg);
   RM_LAUNCH_CHECK("gatrep_bwd");
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(co, 64)), dim3(64), 0, s, g, dg, slot_task, nslots, num_tasks, co,
-                     dgate_w, dgate_b, clear);
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(co, 32)), dim3(GATE_BWD_THREADS), 0, s, g, dg, slot_task, nslots,
+                     num_tasks, co, dgate_w, dgate_b, clear);
   repmode_prof_end(s);
   RM_LAUNCH_CHECK("gate_bwd");
   return REPMODE_OK;

@@ -205,7 +205,8 @@ constexpr int KW_RS = KW_TM * 2 + 16;           // bytes per channel row in LDS 
 struct K2WArgs {
   const bf16_t* coarse;
   const bf16_t* fine;
-  float* dw;              // [8][A][B]
+  float* dw;              // [8][A][B], or the parameter's own [A][B][8] / [B][A][8] (param_layout 1 / 2)
+  int param_layout;
   long M;
   int d, h, wd, A, B, ntiles, tiles_per_block;
 };
@@ -285,7 +286,12 @@ __global__ __launch_bounds__(256) void k2s2_wgrad_kernel(K2WArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int arow = at * 32 + aq * 16 + kg * 4 + r;
-        if (arow < a.A) unsafeAtomicAdd(a.dw + ((size_t)p * a.A + arow) * a.B + bcol, acc[p][r]);
+        if (arow < a.A) {
+          const size_t at = a.param_layout == 0 ? ((size_t)p * a.A + arow) * a.B + bcol
+                          : a.param_layout == 1 ? ((size_t)arow * a.B + bcol) * 8 + p
+                                                : ((size_t)bcol * a.A + arow) * 8 + p;
+          unsafeAtomicAdd(a.dw + at, acc[p][r]);
+        }
       }
   }
 }
@@ -294,14 +300,26 @@ __global__ __launch_bounds__(256) void k2s2_wgrad_kernel(K2WArgs a) {
 
 // dw[8][A][B] (float, overwritten) = sum_m coarse[m][a] * fine[fine(m,p)][b].  coarse: [N][d][h][w][A] bf16,
 // fine: [N][2d][2h][2w][B] bf16.
+extern "C" int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float* dw, int n, int d, int h, int wdim,
+                                     int ca, int cb, int param_layout, void* stream);
+
 extern "C" int repmode_k2s2_wgrad(const void* coarse, const void* fine, float* dw, int n, int d, int h, int wdim, int ca,
                                   int cb, void* stream) {
+  return repmode_k2s2_wgrad_ex(coarse, fine, dw, n, d, h, wdim, ca, cb, 0, stream);
+}
+
+// param_layout: 0 = dw[8][A][B]; 1 = dw[A][B][2][2][2]; 2 = dw[B][A][2][2][2] (the Conv3d / ConvTranspose3d
+// parameter layouts, so that the gradient needs no permute copy)
+extern "C" int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float* dw, int n, int d, int h, int wdim,
+                                     int ca, int cb, int param_layout, void* stream) {
   RM_REQUIRE(coarse && fine && dw, "k2s2_wgrad: null pointer");
+  RM_REQUIRE(param_layout >= 0 && param_layout <= 2, "k2s2_wgrad: bad layout %d", param_layout);
   RM_REQUIRE(n > 0 && d > 0 && h > 0 && wdim > 0 && ca > 0 && cb > 0, "k2s2_wgrad: bad shape");
   RM_REQUIRE(((uintptr_t)coarse & 15) == 0 && ((uintptr_t)fine & 15) == 0, "k2s2_wgrad: pointers must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   K2WArgs a{};
   a.coarse = static_cast<const bf16_t*>(coarse); a.fine = static_cast<const bf16_t*>(fine); a.dw = dw;
+  a.param_layout = param_layout;
   a.M = (long)n * d * h * wdim; a.d = d; a.h = h; a.wd = wdim; a.A = ca; a.B = cb;
   a.ntiles = (int)((a.M + KW_TM - 1) / KW_TM);
   const int nat = ceil_div(ca, 32), nbt = ceil_div(cb, 32);
@@ -313,5 +331,51 @@ extern "C" int repmode_k2s2_wgrad(const void* coarse, const void* fine, float* d
   RM_HIP(hipMemsetAsync(dw, 0, (size_t)8 * ca * cb * sizeof(float), s));
   hipLaunchKernelGGL(k2s2_wgrad_kernel, dim3(nchunks, nat, nbt), dim3(256), 0, s, a);
   RM_LAUNCH_CHECK("k2s2_wgrad");
+  return REPMODE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2x2 filter -> the fragment-major operand of k2s2_kernel, straight from the parameter tensor:
+//   out[p][row tile][red chunk][32][KC] (dtype, zero padded) = w(row, red, p)
+//   red_major == 0: w is [rows][red][8]   (Conv3d weight [Co][Ci][2][2][2] with rows = Co, ...)
+//   red_major != 0: w is [red][rows][8]
+// One launch instead of the pad / slice-copy / permute / cast chain.
+namespace {
+template <typename T>
+__global__ void k2_frags_kernel(const float* __restrict__ w, int rows, int red, int rowsP, int redP, int red_major,
+                                T* __restrict__ out) {
+  constexpr int KC = sizeof(T) == 2 ? 16 : 8;
+  const long total = 8L * rowsP * redP;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int kk = (int)(i % KC);
+    long t = i / KC;
+    const int r32 = (int)(t % 32); t /= 32;
+    const int nkc = redP / KC;
+    const int kc = (int)(t % nkc); t /= nkc;
+    const int nrt = rowsP / 32;
+    const int rt = (int)(t % nrt);
+    const int p = (int)(t / nrt);
+    const int row = rt * 32 + r32, k = kc * KC + kk;
+    float v = 0.f;
+    if (row < rows && k < red) v = red_major ? w[((size_t)k * rows + row) * 8 + p] : w[((size_t)row * red + k) * 8 + p];
+    if constexpr (sizeof(T) == 2) out[i] = f32_to_bf16(v);
+    else out[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int repmode_k2_frags(const float* w, int rows, int red, int red_major, int dtype, void* out, void* stream) {
+  RM_REQUIRE(w && out, "k2_frags: null pointer");
+  RM_REQUIRE(rows > 0 && red > 0, "k2_frags: bad shape");
+  RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "k2_frags: bad dtype %d", dtype);
+  const int rowsP = repmode_padded_channels(rows, dtype, 0), redP = repmode_padded_channels(red, dtype, 1);
+  const long total = 8L * rowsP * redP;
+  const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == REPMODE_BF16)
+    hipLaunchKernelGGL(k2_frags_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w, rows, red, rowsP, redP, red_major, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(k2_frags_kernel<float>, dim3(grid), dim3(256), 0, s, w, rows, red, rowsP, redP, red_major, (float*)out);
+  RM_LAUNCH_CHECK("k2_frags");
   return REPMODE_OK;
 }

@@ -75,6 +75,7 @@ class TaskPlan:
         self.slot_task_host = uniq
         self.slot_task = torch.tensor(uniq, dtype=torch.int32).to(device, non_blocking=True)
         self.sample_slot = torch.tensor(slots, dtype=torch.int32).to(device, non_blocking=True)
+        self.sample_task = torch.tensor(host, dtype=torch.int32).to(device, non_blocking=True)   # task id per sample
         self.bn_counted = False     # set by Net.forward once num_batches_tracked of every BN layer is advanced
 
 
@@ -83,6 +84,14 @@ def gate_softmax(gate_w, gate_b, plan, co):
     g = torch.empty((plan.nslots, NUM_EXPERTS, co), dtype=torch.float32, device=gate_w.device)
     _lib.call('repmode_gate_softmax', _ptr(gate_w), _ptr(gate_b), _ptr(plan.slot_task), plan.nslots,
               plan.num_tasks, co, _ptr(g), _stream())
+    return g
+
+
+def gate_softmax_samples(gate_w, gate_b, plan, co):
+    """g[n, e, o] per SAMPLE (the same kernel with one "slot" per sample)."""
+    g = torch.empty((plan.n, NUM_EXPERTS, co), dtype=torch.float32, device=gate_w.device)
+    _lib.call('repmode_gate_softmax', _ptr(gate_w), _ptr(gate_b), _ptr(plan.sample_task), plan.n, plan.num_tasks, co,
+              _ptr(g), _stream())
     return g
 
 
@@ -103,15 +112,17 @@ def gatrep_merge(k5, k3, k1, a3, a5, g, dtype, want_wf=True, want_wd=False):
     return wf, wd
 
 
-def conv5(x_cl, w, sample_slot, cout, out_f32=False, out=None, centre3=False):
-    """y[n] = x[n] (*) w[sample_slot[n]], 5^3 'same' cross-correlation, NDHWC -- RepMode.py:204-210."""
+def conv5(x_cl, w, sample_slot, cout, out_f32=False, out=None, centre3=False, accumulate=False):
+    """y[n] = x[n] (*) w[sample_slot[n]], 5^3 'same' cross-correlation, NDHWC -- RepMode.py:204-210.
+    ``accumulate`` (float ``out`` given): add to ``out`` instead of overwriting it."""
     n, d, h, wd_, cin = x_cl.shape
     code = dtype_code(x_cl.dtype)
     out_dtype = torch.float32 if (out_f32 or x_cl.dtype == torch.float32) else x_cl.dtype
     y = out if out is not None else torch.empty((n, d, h, wd_, cout), dtype=out_dtype, device=x_cl.device)
     assert y.dtype == out_dtype and y.is_contiguous()
+    assert not accumulate or (out is not None and out_dtype == torch.float32)
     _lib.call('repmode_conv5_ex', _ptr(x_cl), _ptr(w), _ptr(sample_slot), _ptr(y), n, d, h, wd_, cin, cout, code,
-              1 if out_dtype == torch.float32 else 0, 1 if centre3 else 0, _stream())
+              1 if out_dtype == torch.float32 else 0, (1 if centre3 else 0) | (2 if accumulate else 0), _stream())
     return y
 
 
@@ -145,22 +156,23 @@ class _ModeConv3d(torch.autograd.Function):
         _require_hip(x_cl, 'input')
         co = k5.shape[0]
         g = gate_softmax(gate_w, gate_b, plan, co)
-        wf, _ = gatrep_merge(k5, k3, k1, a3, a5, g, x_cl.dtype, want_wf=True, want_wd=False)
+        # the data-gradient filter comes out of the same pass over the experts (one launch, one read of the
+        # weights); these are the shallow levels, whose merged filters are small next to the activations
+        want_wd = ctx.needs_input_grad[0]
+        wf, wd = gatrep_merge(k5, k3, k1, a3, a5, g, x_cl.dtype, want_wf=True, want_wd=want_wd)
         y = conv5(x_cl, wf, plan.sample_slot, co, out_f32)
-        ctx.save_for_backward(x_cl, k5, k3, k1, a3, a5, g)
+        ctx.save_for_backward(x_cl, k5, k3, k1, a3, a5, g, wd)
         ctx.plan = plan
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x_cl, k5, k3, k1, a3, a5, g = ctx.saved_tensors
+        x_cl, k5, k3, k1, a3, a5, g, wd = ctx.saved_tensors
         plan = ctx.plan
         co, ci = k5.shape[0], k5.shape[1]
         dy = dy.to(x_cl.dtype).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            # the filter is re-merged in the data-gradient layout instead of being kept from forward
-            _, wd = gatrep_merge(k5, k3, k1, a3, a5, g, x_cl.dtype, want_wf=False, want_wd=True)
             # deep levels (small volumes) split the channel reduction over workgroups -> float output
             dx = conv5(dy, wd, plan.sample_slot, ci, out_f32=x_cl.shape[3] < 32)
             if dx.dtype != x_cl.dtype:
@@ -225,15 +237,14 @@ def bn_relu(x_cl, bn, training, out_dtype, count=True):
                          out_dtype)
 
 
-def k2_weight_frags(w3, dtype):
-    """[8, rows, red] tap-major 2x2x2 filter -> fragment-major [8][rowsP/32][redP/KC][32][KC] in ``dtype``."""
+def k2_weight_frags(weight, rows, red, red_major, dtype):
+    """2x2x2 filter parameter (float, [rows][red][2][2][2] or, ``red_major``, [red][rows][2][2][2]) -> the
+    fragment-major operand [8][rowsP/32][redP/KC][32][KC] of the k2s2 kernel in ``dtype`` (one launch)."""
     code = dtype_code(dtype)
-    _, rows, red = w3.shape
     rp, kp = _lib.padded_channels(rows, code, False), _lib.padded_channels(red, code, True)
-    kc = 16 if dtype == torch.bfloat16 else 8
-    wp = w3.new_zeros((8, rp, kp))
-    wp[:, :rows, :red] = w3
-    return wp.view(8, rp // 32, 32, kp // kc, kc).permute(0, 1, 3, 2, 4).contiguous().to(dtype)
+    out = torch.empty((8, rp, kp), dtype=dtype, device=weight.device)
+    _lib.call('repmode_k2_frags', _ptr(weight), rows, red, 1 if red_major else 0, code, _ptr(out), _stream())
+    return out
 
 
 def k2s2(in_cl, w_frag, cout, scatter):
@@ -247,17 +258,34 @@ def k2s2(in_cl, w_frag, cout, scatter):
     return out
 
 
-def k2s2_wgrad(coarse_cl, fine_cl):
-    """dw[p, a, b] = sum_m coarse[m, a] * fine[fine(m, p), b]  -> float [8, A, B].  bf16: HIP kernel; float32:
-    a library GEMM on gathered patches (parity mode only)."""
+def k2s2_wgrad(coarse_cl, fine_cl, param_layout=0):
+    """dw[p, a, b] = sum_m coarse[m, a] * fine[fine(m, p), b] as float [8, A, B] (``param_layout`` 0), or directly in
+    a parameter's layout: 1 -> [A, B, 2, 2, 2], 2 -> [B, A, 2, 2, 2].  bf16: HIP kernel; float32: a library GEMM on
+    gathered patches (parity mode only)."""
     n, d, h, w, ca = coarse_cl.shape
     cb = fine_cl.shape[-1]
+    shape = {0: (8, ca, cb), 1: (ca, cb, 2, 2, 2), 2: (cb, ca, 2, 2, 2)}[param_layout]
+    if coarse_cl.dtype == torch.bfloat16 and param_layout != 2:
+        # the kernel accumulates tap-major (atomics into the parameter layout, 32-byte stride, measured 5x slower);
+        # layout 1 is one small transpose launch behind it
+        dw8 = torch.empty((8, ca, cb), dtype=torch.float32, device=coarse_cl.device)
+        _lib.call('repmode_k2s2_wgrad', _ptr(coarse_cl), _ptr(fine_cl), _ptr(dw8), n, d, h, w, ca, cb, _stream())
+        if param_layout == 0:
+            return dw8
+        dw = torch.empty(shape, dtype=torch.float32, device=coarse_cl.device)
+        _lib.call('repmode_tap_transpose', _ptr(dw8), _ptr(dw), ca * cb, 8, _stream())
+        return dw
     if coarse_cl.dtype == torch.bfloat16:
-        dw = torch.empty((8, ca, cb), dtype=torch.float32, device=coarse_cl.device)
-        _lib.call('repmode_k2s2_wgrad', _ptr(coarse_cl), _ptr(fine_cl), _ptr(dw), n, d, h, w, ca, cb, _stream())
+        dw = torch.empty(shape, dtype=torch.float32, device=coarse_cl.device)
+        _lib.call('repmode_k2s2_wgrad_ex', _ptr(coarse_cl), _ptr(fine_cl), _ptr(dw), n, d, h, w, ca, cb, param_layout,
+                  _stream())
         return dw
     g = _gather_patches(fine_cl)                                       # [M, 8*B]
-    return (coarse_cl.view(-1, ca).t() @ g).view(ca, 8, cb).permute(1, 0, 2)
+    dw8 = (coarse_cl.view(-1, ca).t() @ g).view(ca, 8, cb).permute(1, 0, 2)   # [8, A, B]
+    if param_layout == 0:
+        return dw8
+    dw = dw8.view(2, 2, 2, ca, cb)
+    return (dw.permute(3, 4, 0, 1, 2) if param_layout == 1 else dw.permute(4, 3, 0, 1, 2)).contiguous()
 
 
 def _gather_patches(x_cl):
@@ -273,7 +301,7 @@ class _Down2(torch.autograd.Function):
     def forward(ctx, x_cl, weight):
         _require_hip(x_cl, 'input')
         co, ci = weight.shape[:2]
-        wf = k2_weight_frags(weight.permute(2, 3, 4, 0, 1).reshape(8, co, ci), x_cl.dtype)
+        wf = k2_weight_frags(weight, co, ci, False, x_cl.dtype)
         ctx.save_for_backward(x_cl, weight)
         return k2s2(x_cl, wf, co, scatter=False)
 
@@ -284,10 +312,9 @@ class _Down2(torch.autograd.Function):
         dy = dy.to(x_cl.dtype).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            wb = k2_weight_frags(weight.permute(2, 3, 4, 1, 0).reshape(8, ci, co), x_cl.dtype)
+            wb = k2_weight_frags(weight, ci, co, True, x_cl.dtype)
             dx = k2s2(dy, wb, ci, scatter=True)
-        dw8 = k2s2_wgrad(dy, x_cl)                                        # [8, Co, Ci]
-        dw = dw8.view(2, 2, 2, co, ci).permute(3, 4, 0, 1, 2).contiguous()
+        dw = k2s2_wgrad(dy, x_cl, param_layout=1)                         # [Co, Ci, 2, 2, 2]
         return dx, dw
 
 
@@ -298,7 +325,7 @@ class _Up2(torch.autograd.Function):
     def forward(ctx, x_cl, weight):
         _require_hip(x_cl, 'input')
         ci, co = weight.shape[:2]
-        wf = k2_weight_frags(weight.permute(2, 3, 4, 1, 0).reshape(8, co, ci), x_cl.dtype)
+        wf = k2_weight_frags(weight, co, ci, True, x_cl.dtype)
         ctx.save_for_backward(x_cl, weight)
         return k2s2(x_cl, wf, co, scatter=True)
 
@@ -309,10 +336,9 @@ class _Up2(torch.autograd.Function):
         dy = dy.to(x_cl.dtype).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            wb = k2_weight_frags(weight.permute(2, 3, 4, 0, 1).reshape(8, ci, co), x_cl.dtype)
+            wb = k2_weight_frags(weight, ci, co, False, x_cl.dtype)
             dx = k2s2(dy, wb, ci, scatter=False)
-        dw8 = k2s2_wgrad(x_cl, dy)                                        # [8, Ci, Co]
-        dw = dw8.view(2, 2, 2, ci, co).permute(3, 4, 0, 1, 2).contiguous()
+        dw = k2s2_wgrad(x_cl, dy, param_layout=1)                         # [Ci, Co, 2, 2, 2]
         return dx, dw
 
 
@@ -353,16 +379,37 @@ def _expert_selector(co, device):
     return _ONEHOT2[key]
 
 
-def box_sum(in3=None, in5=None, out=None):
-    """box3(in3) + box5(in5): zero-padded k^3 box means of float channels-last tensors -- the avg-pool
-    experts' spatial part (RepMode.py:139-142, 176-180: w1x1 * 1/k^3 broadcast over the k^3 support)."""
+def box_sum(in3=None, in5=None, out=None, add=(), out_dtype=torch.float32):
+    """box3(in3) + box5(in5) [+ up to two more float tensors ``add``], stored in ``out_dtype``: zero-padded k^3 box
+    means of float channels-last tensors -- the avg-pool experts' spatial part (RepMode.py:139-142, 176-180:
+    w1x1 * 1/k^3 broadcast over the k^3 support)."""
     ref = in3 if in3 is not None else in5
     n, d, h, w, c = ref.shape
     if out is None:
-        out = torch.empty_like(ref)
-    _lib.call('repmode_box_sum', _ptr(in3) if in3 is not None else None, _ptr(in5) if in5 is not None else None,
-              _ptr(out), n, d, h, w, c, _stream())
+        out = torch.empty(ref.shape, dtype=out_dtype, device=ref.device)
+    add = list(add) + [None, None]
+    _lib.call('repmode_box_sum_ex', _ptr(in3) if in3 is not None else None, _ptr(in5) if in5 is not None else None,
+              _ptr(add[0]) if add[0] is not None else None, _ptr(add[1]) if add[1] is not None else None,
+              _ptr(out), dtype_code(out.dtype), n, d, h, w, c, _stream())
     return out
+
+
+def tap_transpose(dw_taps, shape):
+    """Tap-major filter gradient [125, Co, Ci] -> the expert parameter's [Co, Ci, k, k, k] (k = 5: all taps; k = 3:
+    the centred 27)."""
+    co, ci, k = shape[0], shape[1], shape[2]
+    out = torch.empty(shape, dtype=torch.float32, device=dw_taps.device)
+    _lib.call('repmode_tap_transpose', _ptr(dw_taps), _ptr(out), co * ci, k ** 3, _stream())
+    return out
+
+
+def gate_bwd(g, dg, slot_task, num_tasks):
+    """(dgate_w [5*Co, T], dgate_b [5*Co]) from probabilities g and their gradients dg, both [S, 5, Co]."""
+    s_, _, co = g.shape
+    dgw = torch.empty((NUM_EXPERTS * co, num_tasks), dtype=torch.float32, device=g.device)
+    dgb = torch.empty((NUM_EXPERTS * co,), dtype=torch.float32, device=g.device)
+    _lib.call('repmode_gate_bwd', _ptr(g), _ptr(dg), _ptr(slot_task), s_, num_tasks, co, _ptr(dgw), _ptr(dgb), _stream())
+    return dgw, dgb
 
 
 def expert_mix_fwd(p, gn):
@@ -405,9 +452,10 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         co, ci = k5.shape[0], k5.shape[1]
         n = x_cl.shape[0]
         dev = x_cl.device
-        g = gate_softmax(gate_w, gate_b, plan, co)                       # [S, 5, Co]
-        gn = g.index_select(0, plan.sample_slot.long())                  # [N, 5, Co]
-        wf2, _ = gatrep_merge(k5, k3, k1, a3, a5, _expert_selector(co, dev), x_cl.dtype, want_wf=True)
+        gn = gate_softmax_samples(gate_w, gate_b, plan, co)              # g per SAMPLE [N, 5, Co]
+        # (forward and data-gradient layouts of the two raw experts from one pass over the weights)
+        wf2, wd2 = gatrep_merge(k5, k3, k1, a3, a5, _expert_selector(co, dev), x_cl.dtype, want_wf=True,
+                                want_wd=ctx.needs_input_grad[0])
         s0, s1 = _SingleSlot(n, dev, 0), _SingleSlot(n, dev, 1)
         d, h, w = x_cl.shape[1:4]
         p = torch.empty((NUM_EXPERTS, n, d, h, w, co), dtype=torch.float32, device=dev)   # expert outputs P_e
@@ -420,15 +468,14 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         box_sum(in5=xb[0], out=xb[2])
         w1 = torch.stack((k1.view(co, ci), a3.view(co, ci), a5.view(co, ci)))             # [3, Co, Ci]
         torch.bmm(xb.view(3, -1, ci), w1.transpose(1, 2), out=p[2:].view(3, -1, co))
-        gn = gn.contiguous()
         y = expert_mix_fwd(p, gn)
-        ctx.save_for_backward(x_cl, k5, k3, k1, a3, a5, gn, xb, w1, p)
+        ctx.save_for_backward(x_cl, k5, k3, k1, a3, a5, gn, xb, w1, p, wd2)
         ctx.plan = plan
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x_cl, k5, k3, k1, a3, a5, gn, xb, w1, p = ctx.saved_tensors
+        x_cl, k5, k3, k1, a3, a5, gn, xb, w1, p, wd2 = ctx.saved_tensors
         plan = ctx.plan
         co, ci = k5.shape[0], k5.shape[1]
         n = x_cl.shape[0]
@@ -437,34 +484,25 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         dy = dy.float().contiguous()
         # ---- gate: dg[n,e,o] = <dy, P_e>, softmax Jacobian, Linear grads (RepMode.py:198-200)
         dg, d01, dhi = expert_mix_bwd(dy, p, gn, dt)            # <dy, P_e>, and the gate-scaled dy per expert
-        dl = gn * (dg - (gn * dg).sum(dim=1, keepdim=True))
-        dl2 = dl.reshape(n, NUM_EXPERTS * co)
-        dgb = dl2.sum(dim=0)
-        tasks = plan.slot_task.long().index_select(0, plan.sample_slot.long())
-        dgw = torch.zeros((NUM_EXPERTS * co, plan.num_tasks), dtype=torch.float32, device=dev)
-        dgw.index_add_(1, tasks, dl2.t().contiguous())
+        dgw, dgb = gate_bwd(gn, dg, plan.sample_task, plan.num_tasks)       # one "slot" per sample
         s0, s1 = _SingleSlot(n, dev, 0), _SingleSlot(n, dev, 1)
         dx = None
         if ctx.needs_input_grad[0]:
-            _, wd2 = gatrep_merge(k5, k3, k1, a3, a5, _expert_selector(co, dev), dt, want_wf=False, want_wd=True)
             dxf = conv5(d01[0], wd2, s0.sample_slot, ci, out_f32=True)
             shp = dxf.shape
-            dxf += conv5(d01[1], wd2, s1.sample_slot, ci, out_f32=True, centre3=True)
+            conv5(d01[1], wd2, s1.sample_slot, ci, out_f32=True, out=dxf, centre3=True, accumulate=True)
             # 1x1 experts: one batched GEMM gives the three partial data gradients; the zero-padded box
-            # mean is self-adjoint, so the avg experts' parts go back through box3 / box5
+            # mean is self-adjoint, so the avg experts' parts go back through box3 / box5 -- summed with the
+            # two conv parts and cast in the same kernel
             t = torch.bmm(dhi.view(3, -1, co), w1).view(3, *shp)                          # [3, N, D, H, W, Ci]
-            dxf += t[0]
-            dxf += box_sum(in3=t[1], in5=t[2])
-            dx = dxf.to(dt)
+            dx = box_sum(in3=t[1], in5=t[2], add=(dxf, t[0]), out_dtype=dt)
             del wd2
-        # ---- expert gradients: filter gradients of the gate-scaled dy, all samples in one slot
+        # ---- expert gradients: filter gradients of the gate-scaled dy, all samples in one slot, transposed from
+        # the kernel's tap-major layout to the parameters' [Co][Ci][taps].  (The wgrad kernel can also write that
+        # layout directly -- expert_layout= -- but its 4-byte stores at a 500-byte lane stride measured 5x slower.)
         one = _SingleSlot(n, dev, 0)
-        # (the kernel can also write the experts' [Co][Ci][taps] layout directly -- expert_layout= -- but that
-        # epilogue's 4-byte stores at a 500-byte lane stride measured 5x slower than tap-major + one transpose)
-        dw5 = conv5_wgrad(x_cl, d01[0], one, co)[0]                        # [125, Co, Ci]
-        dk5 = dw5.permute(1, 2, 0).reshape(k5.shape)
-        dw3 = conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0].view(5, 5, 5, co, ci)[1:4, 1:4, 1:4]
-        dk3 = dw3.permute(3, 4, 0, 1, 2).reshape(k3.shape)
+        dk5 = tap_transpose(conv5_wgrad(x_cl, d01[0], one, co)[0], k5.shape)
+        dk3 = tap_transpose(conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0], k3.shape)
         d1 = torch.bmm(dhi.view(3, -1, co).transpose(1, 2), xb.view(3, -1, ci))           # [3, Co, Ci]
         dk1, da3, da5 = d1[0].reshape(k1.shape), d1[1].reshape(a3.shape), d1[2].reshape(a5.shape)
         return dx, dk5, dk3, dk1, da3, da5, dgw, dgb, None

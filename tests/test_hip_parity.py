@@ -335,6 +335,65 @@ def test_box_sum(shape):
     assert rel_err(ops.box_sum(in3=ad).cpu(), ref_box(a, 3)) < 1e-5
     assert rel_err(ops.box_sum(in5=bd).cpu(), ref_box(b, 5)) < 1e-5
     assert rel_err(ops.box_sum(in3=ad, in5=bd).cpu(), ref_box(a, 3) + ref_box(b, 5)) < 1e-5
+    # fused tail of the per-expert data gradient: two more addends and the downcast in the same launch
+    c0, c1 = torch.randn(*shape, generator=gen), torch.randn(*shape, generator=gen)
+    want = ref_box(a, 3) + ref_box(b, 5) + c0 + c1
+    assert rel_err(ops.box_sum(in3=ad, in5=bd, add=(c0.to(DEV), c1.to(DEV))).cpu(), want) < 1e-5
+    got = ops.box_sum(in3=ad, in5=bd, add=(c0.to(DEV),), out_dtype=torch.bfloat16)
+    assert got.dtype == torch.bfloat16 and rel_err(got.float().cpu(), want - c1) < 5e-3
+
+
+@pytest.mark.parametrize('co,ci', [(32, 32), (7, 5), (64, 24)])
+def test_tap_transpose(co, ci):
+    ops = _ops()
+    dw = torch.randn(125, co, ci, generator=torch.Generator().manual_seed(co + ci))
+    v = dw.view(5, 5, 5, co, ci)
+    assert torch.equal(ops.tap_transpose(dw.to(DEV), (co, ci, 5, 5, 5)).cpu(), v.permute(3, 4, 0, 1, 2).contiguous())
+    assert torch.equal(ops.tap_transpose(dw.to(DEV), (co, ci, 3, 3, 3)).cpu(),
+                       v[1:4, 1:4, 1:4].permute(3, 4, 0, 1, 2).contiguous())
+
+
+@pytest.mark.parametrize('rows,cols,tasks', [(3, 32, [0, 5, 7]), (8, 40, [1, 1, 4, 0, 4, 4, 11, 2])])
+def test_gate_bwd_rows(rows, cols, tasks):
+    """repmode_gate_bwd with one 'slot' per sample (duplicated tasks accumulate) vs autograd of the oracle's gate."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(rows + cols)
+    gw = torch.randn(5 * cols, 12, generator=gen, requires_grad=True)
+    gb = torch.randn(5 * cols, generator=gen, requires_grad=True)
+    dg = torch.randn(rows, 5, cols, generator=gen)
+    g = orc.gate_probs(gw, gb, torch.tensor(tasks), cols)
+    (g * dg).sum().backward()
+    dgw, dgb = ops.gate_bwd(g.detach().to(DEV).contiguous(), dg.to(DEV), torch.tensor(tasks, dtype=torch.int32, device=DEV), 12)
+    assert rel_err(dgw.cpu(), gw.grad) < 1e-5 and rel_err(dgb.cpu(), gb.grad) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_k2_frags_and_param_layout_wgrad(dtype):
+    ops = _ops()
+    gen = torch.Generator().manual_seed(11)
+    co, ci = 40, 24
+    w = torch.randn(co, ci, 2, 2, 2, generator=gen)
+    kc = 16 if dtype == torch.bfloat16 else 8
+
+    def ref_frags(w3):                       # [8, rows, red] -> fragment-major, zero padded
+        _, rows, red = w3.shape
+        rp, kp = (rows + 31) // 32 * 32, (red + kc - 1) // kc * kc
+        wp = torch.zeros(8, rp, kp)
+        wp[:, :rows, :red] = w3
+        return wp.view(8, rp // 32, 32, kp // kc, kc).permute(0, 1, 3, 2, 4).contiguous().to(dtype)
+
+    got = ops.k2_weight_frags(w.to(DEV), co, ci, False, dtype).cpu()
+    assert torch.equal(got.flatten(), ref_frags(w.permute(2, 3, 4, 0, 1).reshape(8, co, ci)).flatten())
+    got = ops.k2_weight_frags(w.to(DEV), ci, co, True, dtype).cpu()
+    assert torch.equal(got.flatten(), ref_frags(w.permute(2, 3, 4, 1, 0).reshape(8, ci, co)).flatten())
+    if dtype == torch.bfloat16:
+        coarse = torch.randn(2, 2, 4, 4, co, generator=gen).bfloat16().to(DEV)
+        fine = torch.randn(2, 4, 8, 8, ci, generator=gen).bfloat16().to(DEV)
+        d8 = ops.k2s2_wgrad(coarse, fine)                                   # [8, co, ci]
+        d1 = ops.k2s2_wgrad(coarse, fine, param_layout=1)                   # [co, ci, 2, 2, 2]
+        d2 = ops.k2s2_wgrad(coarse, fine, param_layout=2)                   # [ci, co, 2, 2, 2]
+        assert rel_err(d1.cpu(), d8.view(2, 2, 2, co, ci).permute(3, 4, 0, 1, 2).cpu()) < 1e-5
+        assert rel_err(d2.cpu(), d8.view(2, 2, 2, co, ci).permute(4, 3, 0, 1, 2).cpu()) < 1e-5
 
 
 @pytest.mark.parametrize('training', [True, False])

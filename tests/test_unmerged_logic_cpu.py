@@ -15,18 +15,37 @@ def fake_kernels(monkeypatch):
     def gate(gw, gb, plan, co):
         return orc.gate_probs(gw, gb, torch.tensor(plan.slot_task_host), co)
 
-    def merge(k5, k3, k1, a3, a5, g, dtype, want_wf=True, want_wd=False):
-        w = orc.merge_filters(orc.expert_bank(k5, k3, k1, a3, a5), g)          # [S,Co,Ci,5,5,5], either role
-        return (('wf', w) if want_wf else None), (('wd', w) if want_wd else None)
+    def gate_samples(gw, gb, plan, co):
+        return orc.gate_probs(gw, gb, torch.tensor(plan.tasks_host), co)
 
-    def conv5(x_cl, w, slot, cout, out_f32=False, out=None, centre3=False):
-        role, wt = w
-        ws = wt[slot.long()]
-        if role == 'wd':
-            ws = ws.flip(3, 4, 5).transpose(1, 2)
+    def gate_bwd(g, dg, slot_task, num_tasks):
+        # softmax Jacobian + Linear gradients, one "slot" per row of g
+        s_, _, co = g.shape
+        dl = (g * (dg - (g * dg).sum(dim=1, keepdim=True))).reshape(s_, 5 * co)
+        dgw = torch.zeros(5 * co, num_tasks)
+        dgw.index_add_(1, slot_task.long(), dl.t().contiguous())
+        return dgw, dl.sum(dim=0)
+
+    def tap_t(dw_taps, shape):
+        co, ci, k = shape[0], shape[1], shape[2]
+        w = dw_taps.view(5, 5, 5, co, ci)
+        if k == 3:
+            w = w[1:4, 1:4, 1:4]
+        return w.permute(3, 4, 0, 1, 2).contiguous()
+
+    def merge(k5, k3, k1, a3, a5, g, dtype, want_wf=True, want_wd=False):
+        w = orc.merge_filters(orc.expert_bank(k5, k3, k1, a3, a5), g)          # [S,Co,Ci,5,5,5]
+        # the data-gradient filter: taps flipped, channel roles swapped
+        return (w if want_wf else None), (w.flip(3, 4, 5).transpose(1, 2).contiguous() if want_wd else None)
+
+    def conv5(x_cl, w, slot, cout, out_f32=False, out=None, centre3=False, accumulate=False):
+        ws = w[slot.long()]
         y = orc.conv_per_sample(x_cl.float().permute(0, 4, 1, 2, 3), ws).permute(0, 2, 3, 4, 1).contiguous()
         if out is not None:
-            out.copy_(y)
+            if accumulate:
+                out.add_(y)
+            else:
+                out.copy_(y)
             return out
         return y
 
@@ -42,7 +61,7 @@ def fake_kernels(monkeypatch):
             return wt.grad[0][:, :, 1:4, 1:4, 1:4].contiguous()
         return wt.grad.reshape(1, cout, ci, 125).permute(0, 3, 1, 2).contiguous()
 
-    def box(in3=None, in5=None, out=None):
+    def box(in3=None, in5=None, out=None, add=(), out_dtype=torch.float32):
         def one(t, k):
             c = t.shape[-1]
             w = torch.ones(c, 1, k, k, k) / k ** 3
@@ -53,10 +72,12 @@ def fake_kernels(monkeypatch):
             res = res + one(in3, 3)
         if in5 is not None:
             res = res + one(in5, 5)
+        for a in add:
+            res = res + a
         if out is not None:
             out.copy_(res)
             return out
-        return res
+        return res.to(out_dtype)
 
     def mix_fwd(p, gn):
         return (p * gn.permute(1, 0, 2)[:, :, None, None, None, :]).sum(0)
@@ -66,7 +87,8 @@ def fake_kernels(monkeypatch):
         dye = dy[None] * gn.permute(1, 0, 2)[:, :, None, None, None, :]
         return dg, dye[:2].to(dtype).contiguous(), dye[2:].contiguous()
 
-    for name, fn in dict(gate_softmax=gate, gatrep_merge=merge, conv5=conv5, conv5_wgrad=wgrad, box_sum=box,
+    for name, fn in dict(gate_softmax=gate, gate_softmax_samples=gate_samples, gate_bwd=gate_bwd, tap_transpose=tap_t,
+                         gatrep_merge=merge, conv5=conv5, conv5_wgrad=wgrad, box_sum=box,
                          expert_mix_fwd=mix_fwd, expert_mix_bwd=mix_bwd).items():
         monkeypatch.setattr(ops, name, fn)
     monkeypatch.setattr(ops, '_require_hip', lambda *a: None)
