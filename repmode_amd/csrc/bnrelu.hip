@@ -112,12 +112,26 @@ __device__ __forceinline__ void block_commit(float* lds, const float* s, const f
                                              float* __restrict__ sums) {
   for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) lds[i] = 0.f;
   __syncthreads();
-  if (active) {
+  // lanes l, l + ngroups, l + 2 ngroups ... of a wave hold the same channels: butterfly them together first, so
+  // that one lane per (wave, channel group) goes to the LDS atomics instead of up to 64 on one address
+  const int ngroups = (C + CV - 1) / CV;
+  float sv[CV], ssv[CV];
+#pragma unroll
+  for (int k = 0; k < CV; ++k) { sv[k] = active ? s[k] : 0.f; ssv[k] = active ? ss[k] : 0.f; }
+  bool commit = active;
+  if ((ngroups & (ngroups - 1)) == 0 && ngroups < 64) {
+    for (int off = ngroups; off < 64; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < CV; ++k) { sv[k] += __shfl_xor(sv[k], off, 64); ssv[k] += __shfl_xor(ssv[k], off, 64); }
+    }
+    commit = (threadIdx.x & 63) < ngroups;
+  }
+  if (commit) {
 #pragma unroll
     for (int k = 0; k < CV; ++k)
       if (c0 + k < C) {
-        atomicAdd(&lds[c0 + k], s[k]);
-        atomicAdd(&lds[C + c0 + k], ss[k]);
+        atomicAdd(&lds[c0 + k], sv[k]);
+        atomicAdd(&lds[C + c0 + k], ssv[k]);
       }
   }
   __syncthreads();
