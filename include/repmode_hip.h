@@ -4,8 +4,11 @@
  * This is the drop-in boundary.  Every entry point takes plain device pointers, sizes and a
  * HIP stream handle (passed as void*); no torch / C++ types.  All functions return 0 on
  * success and a non-zero REPMODE_E* code otherwise; repmode_last_error() gives the message.
- * Nothing here allocates device memory or synchronises the stream: outputs and workspaces are
- * owned by the caller, kernels are enqueued on `stream` and return immediately.
+ * Nothing here synchronises the stream: outputs and workspaces are owned by the caller, kernels are
+ * enqueued on `stream` and return immediately.  The one piece of library-owned device memory is a
+ * 256 KiB scratch per (device, stream), allocated on first use and kept all zero between calls (the
+ * BatchNorm and gate reductions accumulate into it and clear it themselves instead of paying a
+ * memset launch per call).
  *
  * The reference (Correr-Zhou/RepMode) is pure Python and has no FFI; each function below names
  * the reference lines whose arithmetic it replaces (paths relative to the reference checkout).
