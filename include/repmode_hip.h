@@ -187,6 +187,12 @@ int repmode_tap_transpose(const float* in, float* out, long m, int ntaps_out, vo
  * per-expert formulation calls it with one "slot" per sample.) */
 int repmode_gate_bwd(const float* g, const float* dg, const int32_t* slot_task, int nslots, int num_tasks, int co,
                      float* dgate_w, float* dgate_b, void* stream);
+/* The raw conv5x5 / conv3x3 experts (RepMode.py:131-134) as two un-merged "slots" of the conv kernels' bf16
+ * fragment-major layout, for the per-expert formulation: slot 0 = K5; slot 1 = K3 on its centred support,
+ * of which ONLY the taps with dz, dy in [1,3] are written (what repmode_conv5_ex reads with centre3 set).
+ * wf: [2][125][padded Co][padded Ci] (rows = co), wd: [2][125][padded Ci][padded Co] (rows = ci, taps
+ * flipped); either may be NULL. */
+int repmode_expert_frags(const float* k5, const float* k3, int co, int ci, void* wf, void* wd, void* stream);
 
 /* ---- measurement: per-launch HIP-event timing of the library's kernels on their own stream.
  * repmode_prof_enable(1) clears the records and starts recording every kind, (2) records conv5_igemm only

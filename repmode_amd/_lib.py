@@ -44,6 +44,7 @@ _SIGNATURES = {
     'repmode_box_sum_ex': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'repmode_tap_transpose': [_P, _P, _c.c_long, _I, _P],
     'repmode_gate_bwd': [_P, _P, _P, _I, _I, _I, _P, _P, _P],
+    'repmode_expert_frags': [_P, _P, _I, _I, _P, _P, _P],
     'repmode_prof_enable': [_I],
     'repmode_prof_summary': [_I, _P, _P, _P],
     'repmode_prof_count': [],

@@ -451,6 +451,99 @@ extern "C" int repmode_gatrep_fwd(const float* k5, const float* k3, const float*
   return gatrep_fwd_t<bf16_t>(k5, k3, k1, a3, a5, g, nslots, co, ci, dtype, wf, wd, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The raw 5x5x5 and 3x3x3 experts in the conv kernels' fragment-major bf16 layouts, for the per-expert
+// formulation of the deep levels (ops._ModeConv3dUnmerged): two "slots" that are not merged with anything,
+//   slot 0 = conv5x5 expert (125 taps),
+//   slot 1 = conv3x3 expert on the centred support: ONLY the taps with dz, dy in [1,3] are written (dx = 0 and 4
+//            as zeros) -- exactly what repmode_conv5_ex's centre3 mode reads; the other 80 taps stay untouched.
+// A pure layout pass (f32 [co][ci][taps] -> bf16 tiles), so unlike gatrep_fwd_kernel there is no gate, no slot
+// loop, and the experts are read once for both layouts' worth of 8-row tile quarters: a workgroup stages
+// 8 rows x 16 reduction channels x (125 + 27) taps as packed bf16 pairs in LDS ([tap][pair couple], taps down the
+// lanes while staging) and writes 256 contiguous bytes per tap.
+namespace {
+constexpr int XF_ROWS = 8, XF_KC = 16, XF_COUPLES = XF_ROWS * XF_KC / 2;   // 64 couples of adjacent reduction channels
+constexpr int XF_S5 = XF_COUPLES + 1;                                       // padded LDS row (u32): conflict-free transposed writes
+
+template <bool WRITE_WD>
+__global__ __launch_bounds__(256) void expert_frags_kernel(const float* __restrict__ k5, const float* __restrict__ k3,
+                                                           int co_n, int ci_n, int nrt, int nkc,
+                                                           bf16_t* __restrict__ wout) {
+  __shared__ uint32_t s5[TAPS * XF_S5];
+  __shared__ uint32_t s3[27 * XF_S5];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kc = blockIdx.x, rt = blockIdx.y, q = blockIdx.z;       // q: which 8 rows of the 32-row tile
+  // ---- stage: wave w takes couples w, w+4, ...; a couple = elements (row, red) and (row, red + 1)
+  constexpr int NB = 4;                                             // couples in flight per wave
+  for (int c0 = wave; c0 < XF_COUPLES; c0 += 4 * NB) {
+    float a0[NB], a1[NB], b0[NB], b1[NB], c3a[NB], c3b[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int cp = c0 + 4 * u;
+      const int rr = cp / (XF_KC / 2), kk = (cp % (XF_KC / 2)) * 2;
+      const int row = rt * 32 + q * XF_ROWS + rr, red = kc * XF_KC + kk;
+      const int coA = WRITE_WD ? red : row, ciA = WRITE_WD ? row : red;
+      const int coB = WRITE_WD ? red + 1 : row, ciB = WRITE_WD ? row : red + 1;
+      const bool liveA = coA < co_n && ciA < ci_n, liveB = coB < co_n && ciB < ci_n;
+      const size_t oa = liveA ? (size_t)coA * ci_n + ciA : 0, ob = liveB ? (size_t)coB * ci_n + ciB : 0;
+      a0[u] = liveA ? k5[oa * TAPS + lane] : 0.f;
+      a1[u] = (liveA && lane + 64 < TAPS) ? k5[oa * TAPS + lane + 64] : 0.f;
+      b0[u] = liveB ? k5[ob * TAPS + lane] : 0.f;
+      b1[u] = (liveB && lane + 64 < TAPS) ? k5[ob * TAPS + lane + 64] : 0.f;
+      c3a[u] = (liveA && lane < 27) ? k3[oa * 27 + lane] : 0.f;
+      c3b[u] = (liveB && lane < 27) ? k3[ob * 27 + lane] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int cp = c0 + 4 * u;
+      s5[lane * XF_S5 + cp] = pack_bf16x2(a0[u], b0[u]);
+      if (lane + 64 < TAPS) s5[(lane + 64) * XF_S5 + cp] = pack_bf16x2(a1[u], b1[u]);
+      if (lane < 27) s3[lane * XF_S5 + cp] = pack_bf16x2(c3a[u], c3b[u]);
+    }
+  }
+  __syncthreads();
+  // ---- write: 64 couples (256 bytes) per tap, the tile quarter's memory order; 4 taps per pass of the workgroup
+  const size_t tile_elems = 32 * XF_KC;
+  const size_t tap_stride = (size_t)nrt * nkc * tile_elems;
+  uint32_t* out = reinterpret_cast<uint32_t*>(wout + ((size_t)rt * nkc + kc) * tile_elems + (size_t)q * XF_ROWS * XF_KC);
+  const int cp = tid & 63, tq = tid >> 6;
+  for (int tap = tq; tap < TAPS; tap += 4) {
+    const int tap_out = WRITE_WD ? TAPS - 1 - tap : tap;
+    out[(size_t)tap_out * tap_stride / 2 + cp] = s5[tap * XF_S5 + cp];
+    const int dz = tap / 25, dy = (tap / 5) % 5, dx = tap % 5;
+    if (dz >= 1 && dz <= 3 && dy >= 1 && dy <= 3) {                  // slot 1: the rows centre3 convolutions read
+      const bool in = dx >= 1 && dx <= 3;
+      const int t3 = ((dz - 1) * 3 + (dy - 1)) * 3 + (dx - 1);
+      out[((size_t)TAPS + tap_out) * tap_stride / 2 + cp] = in ? s3[t3 * XF_S5 + cp] : 0u;
+    }
+  }
+}
+}  // namespace
+
+// wf: [2][125][CoP/32][CiP/16][32][16] bf16 (rows = co), wd: [2][125][CiP/32][CoP/16][32][16] (rows = ci, taps
+// flipped); either may be NULL.  Slot 1 is valid on the centre3 rows only (see above).
+extern "C" int repmode_expert_frags(const float* k5, const float* k3, int co, int ci, void* wf, void* wd, void* stream) {
+  RM_REQUIRE(k5 && k3 && (wf || wd), "expert_frags: null pointer");
+  RM_REQUIRE(co > 0 && ci > 0, "expert_frags: bad shape");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const double bytes = (double)co * ci * (152.0 * 4 + (125.0 + 45.0) * 2 * ((wf ? 1 : 0) + (wd ? 1 : 0)));
+  repmode_prof_begin(REPMODE_PROF_GATREP_FWD, bytes, s);
+  if (wf) {
+    const int nrt = repmode_padded_channels(co, REPMODE_BF16, 0) / 32, nkc = repmode_padded_channels(ci, REPMODE_BF16, 1) / 16;
+    hipLaunchKernelGGL(expert_frags_kernel<false>, dim3(nkc, nrt, 4), dim3(256), 0, s, k5, k3, co, ci, nrt, nkc,
+                       static_cast<bf16_t*>(wf));
+    RM_LAUNCH_CHECK("expert_frags(wf)");
+  }
+  if (wd) {
+    const int nrt = repmode_padded_channels(ci, REPMODE_BF16, 0) / 32, nkc = repmode_padded_channels(co, REPMODE_BF16, 1) / 16;
+    hipLaunchKernelGGL(expert_frags_kernel<true>, dim3(nkc, nrt, 4), dim3(256), 0, s, k5, k3, co, ci, nrt, nkc,
+                       static_cast<bf16_t*>(wd));
+    RM_LAUNCH_CHECK("expert_frags(wd)");
+  }
+  repmode_prof_end(s);
+  return REPMODE_OK;
+}
+
 // Softmax-Jacobian + gate Linear gradients alone, from gate-probability gradients dg[s][5][Co] (used by the
 // per-expert formulation, where "slots" are the samples themselves and dg[n][e][o] = <dy[n], P_e[n]>).
 extern "C" int repmode_gate_bwd(const float* g, const float* dg, const int32_t* slot_task, int nslots, int num_tasks,

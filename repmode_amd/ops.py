@@ -87,6 +87,23 @@ def gate_softmax(gate_w, gate_b, plan, co):
     return g
 
 
+def expert_frags(k5, k3, dtype, want_wd=True):
+    """The raw 5^3 / 3^3 experts as two un-merged slots of the conv kernels' layouts (slot 1 = K3, valid for
+    ``centre3`` convolutions only).  bf16: one layout kernel per role; float32 (parity mode): GatRep with one-hot
+    gate probabilities, which writes all taps."""
+    co, ci = k5.shape[0], k5.shape[1]
+    if dtype != torch.bfloat16:
+        return gatrep_merge(k5, k3, k5.new_zeros((co, ci)), k5.new_zeros((co, ci)), k5.new_zeros((co, ci)),
+                            _expert_selector(co, k5.device), dtype, want_wf=True, want_wd=want_wd)
+    code = dtype_code(dtype)
+    wf = torch.empty((2, TAPS, _lib.padded_channels(co, code, False), _lib.padded_channels(ci, code, True)),
+                     dtype=dtype, device=k5.device)
+    wd = torch.empty((2, TAPS, _lib.padded_channels(ci, code, False), _lib.padded_channels(co, code, True)),
+                     dtype=dtype, device=k5.device) if want_wd else None
+    _lib.call('repmode_expert_frags', _ptr(k5), _ptr(k3), co, ci, _ptr(wf), _ptr(wd) if want_wd else None, _stream())
+    return wf, wd
+
+
 def gate_softmax_samples(gate_w, gate_b, plan, co):
     """g[n, e, o] per SAMPLE (the same kernel with one "slot" per sample)."""
     g = torch.empty((plan.n, NUM_EXPERTS, co), dtype=torch.float32, device=gate_w.device)
@@ -454,8 +471,7 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         dev = x_cl.device
         gn = gate_softmax_samples(gate_w, gate_b, plan, co)              # g per SAMPLE [N, 5, Co]
         # (forward and data-gradient layouts of the two raw experts from one pass over the weights)
-        wf2, wd2 = gatrep_merge(k5, k3, k1, a3, a5, _expert_selector(co, dev), x_cl.dtype, want_wf=True,
-                                want_wd=ctx.needs_input_grad[0])
+        wf2, wd2 = expert_frags(k5, k3, x_cl.dtype, want_wd=ctx.needs_input_grad[0])
         s0, s1 = _SingleSlot(n, dev, 0), _SingleSlot(n, dev, 1)
         d, h, w = x_cl.shape[1:4]
         p = torch.empty((NUM_EXPERTS, n, d, h, w, co), dtype=torch.float32, device=dev)   # expert outputs P_e

@@ -343,6 +343,23 @@ def test_box_sum(shape):
     assert got.dtype == torch.bfloat16 and rel_err(got.float().cpu(), want - c1) < 5e-3
 
 
+@pytest.mark.parametrize('co,ci', [(32, 32), (40, 24), (7, 5), (64, 96)])
+def test_expert_frags_vs_gatrep(co, ci):
+    """The per-expert path's layout kernel = GatRep with one-hot gates, on every tap a centre3 convolution reads."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(co * 3 + ci)
+    k5 = torch.randn(co, ci, 5, 5, 5, generator=gen).to(DEV)
+    k3 = torch.randn(co, ci, 3, 3, 3, generator=gen).to(DEV)
+    z = torch.zeros(co, ci, 1, 1, 1, device=DEV)
+    wf_ref, wd_ref = ops.gatrep_merge(k5, k3, z, z, z, ops._expert_selector(co, DEV), torch.bfloat16, want_wf=True, want_wd=True)
+    wf, wd = ops.expert_frags(k5, k3, torch.bfloat16, want_wd=True)
+    assert torch.equal(wf[0], wf_ref[0]) and torch.equal(wd[0], wd_ref[0])
+    rows = [(dz * 5 + dy) * 5 + dx for dz in (1, 2, 3) for dy in (1, 2, 3) for dx in range(5)]
+    assert torch.equal(wf[1][rows], wf_ref[1][rows])
+    rows_d = [124 - t for t in rows]
+    assert torch.equal(wd[1][rows_d], wd_ref[1][rows_d])
+
+
 @pytest.mark.parametrize('co,ci', [(32, 32), (7, 5), (64, 24)])
 def test_tap_transpose(co, ci):
     ops = _ops()

@@ -38,6 +38,14 @@ def fake_kernels(monkeypatch):
         # the data-gradient filter: taps flipped, channel roles swapped
         return (w if want_wf else None), (w.flip(3, 4, 5).transpose(1, 2).contiguous() if want_wd else None)
 
+    def xfrags(k5, k3, dtype, want_wd=True):
+        co, ci = k5.shape[:2]
+        z = torch.zeros(co, ci, 1, 1, 1)
+        g = torch.zeros(2, 5, co)
+        g[0, 0] = 1.0
+        g[1, 1] = 1.0
+        return merge(k5, k3, z, z, z, g, dtype, want_wf=True, want_wd=want_wd)
+
     def conv5(x_cl, w, slot, cout, out_f32=False, out=None, centre3=False, accumulate=False):
         ws = w[slot.long()]
         y = orc.conv_per_sample(x_cl.float().permute(0, 4, 1, 2, 3), ws).permute(0, 2, 3, 4, 1).contiguous()
@@ -88,7 +96,7 @@ def fake_kernels(monkeypatch):
         return dg, dye[:2].to(dtype).contiguous(), dye[2:].contiguous()
 
     for name, fn in dict(gate_softmax=gate, gate_softmax_samples=gate_samples, gate_bwd=gate_bwd, tap_transpose=tap_t,
-                         gatrep_merge=merge, conv5=conv5, conv5_wgrad=wgrad, box_sum=box,
+                         gatrep_merge=merge, expert_frags=xfrags, conv5=conv5, conv5_wgrad=wgrad, box_sum=box,
                          expert_mix_fwd=mix_fwd, expert_mix_bwd=mix_bwd).items():
         monkeypatch.setattr(ops, name, fn)
     monkeypatch.setattr(ops, '_require_hip', lambda *a: None)
