@@ -91,7 +91,7 @@ __device__ __forceinline__ size_t fine_row(long m, int p, int d, int h, int w) {
 
 // workgroup = 4 waves = 4 x 32 coarse voxels; blockIdx.y = output-channel tile (32)
 template <typename T, bool SCATTER>
-__global__ __launch_bounds__(256) void k2s2_kernel(K2Args a) {
+__global__ __launch_bounds__(256, 2) void k2s2_kernel(K2Args a) {
   constexpr int KV = KElem<T>::KV, KC = 2 * KV;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -132,24 +132,28 @@ __global__ __launch_bounds__(256) void k2s2_kernel(K2Args a) {
         store_quad<T>(row, rt * 32 + 8 * q + 4 * khalf, Cout, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
     }
   } else {
-    f32x16 acc[8];
+    // blockIdx.z = pz: the four taps (pz, *, *) -- 64 accumulator registers instead of 128, so that four waves
+    // per SIMD stay resident (with all eight taps the kernel needed > 256 registers: one wave per SIMD, and the
+    // level-0 up-convolution took 54 us for 84 MB); the input row is read by both halves, it is the small side
+    const int p0 = 4 * blockIdx.z;
+    f32x16 acc[4];
 #pragma unroll
-    for (int p = 0; p < 8; ++p)
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
     for (int kc = 0; kc < nkc; ++kc) {
       const u32x4 b = load_chunk<T>(in + (size_t)mc * Cin, kc * KC + khalf * KV, Cin, vec);
-      u32x4 wa[8];
+      u32x4 wa[4];
 #pragma unroll
-      for (int p = 0; p < 8; ++p)
-        wa[p] = *reinterpret_cast<const u32x4*>(wt + (size_t)p * tap_stride + (size_t)kc * (32 * KC));
+      for (int p = 0; p < 4; ++p)
+        wa[p] = *reinterpret_cast<const u32x4*>(wt + (size_t)(p0 + p) * tap_stride + (size_t)kc * (32 * KC));
 #pragma unroll
-      for (int p = 0; p < 8; ++p) KElem<T>::mma(wa[p], b, acc[p]);
+      for (int p = 0; p < 4; ++p) KElem<T>::mma(wa[p], b, acc[p]);
     }
     if (mvalid) {
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        T* row = out + frow[p] * Cout;
+      for (int p = 0; p < 4; ++p) {
+        T* row = out + (blockIdx.z ? frow[4 + p] : frow[p]) * Cout;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           store_quad<T>(row, rt * 32 + 8 * q + 4 * khalf, Cout, acc[p][4 * q], acc[p][4 * q + 1], acc[p][4 * q + 2],
@@ -177,7 +181,7 @@ extern "C" int repmode_k2s2(const void* in, const void* w, void* out, int n, int
   a.CinP = repmode_padded_channels(cin, dtype, 1);
   a.CoutP = repmode_padded_channels(cout, dtype, 0);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.CoutP / 32));
+  const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.CoutP / 32), scatter ? 2u : 1u);   // z: tap half (scatter)
   if (dtype == REPMODE_F32) {
     if (scatter) hipLaunchKernelGGL((k2s2_kernel<float, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k2s2_kernel<float, false>), grid, dim3(256), 0, s, a);
