@@ -206,6 +206,9 @@ namespace {
 constexpr int KW_TM = 64;                       // coarse voxels per tile
 constexpr int KW_RS = KW_TM * 2 + 16;           // bytes per channel row in LDS (odd multiple of 16)
 
+#ifndef K2W_TARGET_BLOCKS
+#define K2W_TARGET_BLOCKS 512   // fewer, longer workgroups: every workgroup ends in 8*32*32 f32 atomics (1024 -> 512: 43 -> 23 us at level 1)
+#endif
 struct K2WArgs {
   const bf16_t* coarse;
   const bf16_t* fine;
@@ -327,7 +330,7 @@ extern "C" int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float
   a.M = (long)n * d * h * wdim; a.d = d; a.h = h; a.wd = wdim; a.A = ca; a.B = cb;
   a.ntiles = (int)((a.M + KW_TM - 1) / KW_TM);
   const int nat = ceil_div(ca, 32), nbt = ceil_div(cb, 32);
-  long want = (1024 + (long)nat * nbt - 1) / ((long)nat * nbt);
+  long want = (K2W_TARGET_BLOCKS + (long)nat * nbt - 1) / ((long)nat * nbt);
   if (want > a.ntiles) want = a.ntiles;
   if (want < 1) want = 1;
   a.tiles_per_block = ceil_div(a.ntiles, (int)want);

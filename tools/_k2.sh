@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-for lib in librepmode_hip_k2base.so librepmode_hip.so; do
+for lib in librepmode_hip.so librepmode_hip_k2w512.so librepmode_hip_k2w256.so; do
 rm -rf /tmp/pk; REPMODE_LIB=$GRAFT_REPO_ROOT/repmode_amd/$lib rocprofv3 --kernel-trace --output-format csv -d /tmp/pk -- python $GRAFT_REPO_ROOT/tools/k2s2_microbench.py > /tmp/pk.log 2>&1
 python - <<PY
 import csv,glob,collections,re
