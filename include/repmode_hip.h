@@ -128,8 +128,8 @@ int repmode_gatrep_bwd(const float* dw, const float* k5, const float* k3, const 
  * Training: batch mean / biased variance over the m rows, eps, running statistics updated with `momentum`
  * and the unbiased variance; eval (training == 0): running statistics.  x has in_dtype, out has out_dtype.
  * save_mean / save_invstd [c] are float outputs (kept for the backward).  c <= 512.  Two launches: statistics
- * (partial sums through a library-owned scratch; the last workgroup finalizes and updates the running statistics)
- * and normalise + ReLU. */
+ * (partial sums into a library-owned scratch) and normalise + ReLU (whose workgroups finish the reduction
+ * themselves; workgroup 0 writes the saved and running statistics). */
 int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, float* save_mean, float* save_invstd, long m, int c,
                         float eps, float momentum, int training, int in_dtype, int out_dtype, void* stream);

@@ -75,6 +75,7 @@ void repmode_prof_end(hipStream_t s) {
 namespace {
 std::mutex g_scratch_mu;
 std::map<std::pair<int, hipStream_t>, float*> g_scratch;
+std::map<std::pair<int, hipStream_t>, int> g_bn_half;
 }  // namespace
 
 float* repmode_zero_scratch(hipStream_t s) {
@@ -89,6 +90,16 @@ float* repmode_zero_scratch(hipStream_t s) {
   if (e != hipSuccess) { repmode_set_error("zero_scratch: %s", hipGetErrorString(e)); return nullptr; }
   g_scratch[{dev, s}] = p;
   return p;
+}
+
+int repmode_bn_scratch_half(hipStream_t s) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  int& h = g_bn_half[{dev, s}];
+  const int mine = h;
+  h ^= 1;
+  return mine;
 }
 
 extern "C" int repmode_prof_enable(int on) {

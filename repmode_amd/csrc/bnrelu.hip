@@ -19,7 +19,7 @@ namespace {
 constexpr int BN_THREADS = 256;
 constexpr int BN_MAXC = 512;
 constexpr int BN_SLICES = 16;
-static_assert((size_t)16 * 2 * 512 <= REPMODE_ZERO_SCRATCH_FLOATS, "the slices must fit the zero scratch");   // partial-sum slices: workgroup b adds into slice b % 16 (16x less atomic contention)
+static_assert((size_t)16 * 2 * 512 <= REPMODE_SCRATCH_BN_HALF, "the slices must fit one BatchNorm half of the scratch");   // partial-sum slices: workgroup b adds into slice b % 16 (16x less atomic contention)
 
 template <typename T>
 struct Vec;
@@ -139,24 +139,30 @@ __device__ __forceinline__ void block_commit(float* lds, const float* s, const f
   for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) atomicAdd(&slice[i], lds[i]);
 }
 
-// Total of the BN_SLICES partial sums of entry i (i in [0, 2C)), putting the zeros back: the slices live in the
-// library's zero scratch (repmode_zero_scratch), which every call must leave all zero.  (A "last workgroup
-// finalizes" variant inside the reduction kernels was tried and lost: the device-scope fence it needs writes
-// back and invalidates the XCD's L2 once per workgroup.)
-__device__ __forceinline__ float slice_total_and_clear(float* __restrict__ sums, int i, int C) {
+// Total of the BN_SLICES partial sums of entry i (i in [0, 2C)).  The slices live in one of the two BatchNorm
+// halves of the library's zero scratch (common.h): the reduction kernel of call k accumulates into half h and
+// clears the OTHER half (used by call k-1, whose readers are done by stream order); the apply kernel of call k
+// reads half h -- every workgroup finishes the reduction for itself, workgroup 0 also writes the saved statistics.
+// So a BatchNorm pass is two launches, with no finalize kernel and no memset.  (A "last workgroup finalizes"
+// variant inside the reduction kernels was tried and lost: the device-scope fence it needs writes back and
+// invalidates the XCD's L2 once per workgroup.)
+__device__ __forceinline__ float slice_total(const float* __restrict__ sums, int i, int C) {
   float t = 0.f;
 #pragma unroll
-  for (int k = 0; k < BN_SLICES; ++k) {
-    t += sums[(size_t)k * 2 * C + i];
-    sums[(size_t)k * 2 * C + i] = 0.f;
-  }
+  for (int k = 0; k < BN_SLICES; ++k) t += sums[(size_t)k * 2 * C + i];
   return t;
+}
+
+__device__ __forceinline__ void clear_other_half(float* __restrict__ other) {
+  for (size_t i = (size_t)blockIdx.x * BN_THREADS + threadIdx.x; i < REPMODE_SCRATCH_BN_HALF; i += (size_t)gridDim.x * BN_THREADS)
+    other[i] = 0.f;
 }
 
 template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restrict__ x, long M, int C,
-                                                              float* __restrict__ sums) {
+                                                              float* __restrict__ sums, float* __restrict__ other) {
   __shared__ float lds[2 * BN_MAXC];
+  clear_other_half(other);
   const Geom g = geom(C);
   const int cg = threadIdx.x % g.ngroups, r0 = threadIdx.x / g.ngroups;
   const bool active = r0 < g.rows_per_iter;
@@ -188,42 +194,37 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
   block_commit(lds, s, ss, c0, C, active, sums);
 }
 
-// forward finalize (one thread per channel): consolidate the partial-sum slices into mean / invstd (saved for
-// backward), update the running statistics (RepMode's BatchNorm3d defaults:
-// rm = (1-m) rm + m mean ; rv = (1-m) rv + m var * M/(M-1)) and hand the scratch back zeroed
-__global__ void bn_finalize_kernel(float* __restrict__ sums, long M, int C, float eps, float momentum,
-                                   float* __restrict__ rmean, float* __restrict__ rvar,
-                                   float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float mean = slice_total_and_clear(sums, c, C) / (float)M;
-  const float var = fmaxf(slice_total_and_clear(sums, C + c, C) / (float)M - mean * mean, 0.f);
-  save_mean[c] = mean;
-  save_invstd[c] = rsqrtf(var + eps);
-  const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
-  rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-  rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
-}
-
-// backward finalize: totals[c] = sum dz (= dbeta), totals[C + c] = sum dz * xhat (= dgamma); scratch zeroed
-__global__ void bn_bwd_finalize_kernel(float* __restrict__ sums, int C, float* __restrict__ totals) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 2 * C) totals[i] = slice_total_and_clear(sums, i, C);
-}
-
-// eval mode: mean / invstd from the running statistics (one thread per channel)
-__global__ void bn_eval_stats_kernel(int C, float eps, const float* __restrict__ rmean, const float* __restrict__ rvar,
-                                     float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  save_mean[c] = rmean[c];
-  save_invstd[c] = rsqrtf(rvar[c] + eps);
-}
-
+// normalise + ReLU.  Prologue (every workgroup, through LDS): mean / invstd of all channels from the partial-sum
+// slices (training) or from the running statistics (eval); workgroup 0 also writes save_mean / save_invstd for
+// the backward pass and updates the running statistics (RepMode's BatchNorm3d defaults:
+// rm = (1-m) rm + m mean ; rv = (1-m) rv + m var * M/(M-1)).
 template <typename TI, typename TO>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_relu_kernel(
     const TI* __restrict__ x, TO* __restrict__ out, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ save_mean, const float* __restrict__ save_invstd, long M, int C) {
+    const float* __restrict__ sums, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ save_mean,
+    float* __restrict__ save_invstd, float eps, float momentum, int training, long M, int C) {
+  __shared__ float sc[BN_MAXC], sh[BN_MAXC];
+  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+    float mean, invstd;
+    if (training) {
+      mean = slice_total(sums, c, C) / (float)M;
+      const float var = fmaxf(slice_total(sums, C + c, C) / (float)M - mean * mean, 0.f);
+      invstd = rsqrtf(var + eps);
+      if (blockIdx.x == 0) {
+        const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+      }
+    } else {
+      mean = rmean[c];
+      invstd = rsqrtf(rvar[c] + eps);
+    }
+    if (blockIdx.x == 0) { save_mean[c] = mean; save_invstd[c] = invstd; }
+    const float a = gamma[c] * invstd;
+    sc[c] = a;
+    sh[c] = beta[c] - mean * a;
+  }
+  __syncthreads();
   const Geom g = geom(C);
   const int cg = threadIdx.x % g.ngroups, r0 = threadIdx.x / g.ngroups;
   const int c0 = cg * CV;
@@ -232,10 +233,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_relu_kernel(
 #pragma unroll
   for (int k = 0; k < CV; ++k) {
     scale[k] = 0.f; shift[k] = 0.f;
-    if (c0 + k < C) {
-      scale[k] = gamma[c0 + k] * save_invstd[c0 + k];
-      shift[k] = beta[c0 + k] - save_mean[c0 + k] * scale[k];
-    }
+    if (c0 + k < C) { scale[k] = sc[c0 + k]; shift[k] = sh[c0 + k]; }
   }
   if (r0 < g.rows_per_iter) {
     for (long r = (long)blockIdx.x * g.rows_per_iter + r0; r < M; r += (long)gridDim.x * g.rows_per_iter) {
@@ -253,8 +251,9 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
     const TI* __restrict__ x, const TO* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta, long M, int C,
-    float* __restrict__ sums) {
+    float* __restrict__ sums, float* __restrict__ other) {
   __shared__ float lds[2 * BN_MAXC];
+  clear_other_half(other);
   const Geom g = geom(C);
   const int cg = threadIdx.x % g.ngroups, r0 = threadIdx.x / g.ngroups;
   const bool active = r0 < g.rows_per_iter;
@@ -304,12 +303,21 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
   block_commit(lds, s, ss, c0, C, active, sums);
 }
 
-// backward apply: dx = gamma * invstd * (dz - sum(dz)/M - xhat * sum(dz xhat)/M)
+// backward apply: dx = gamma * invstd * (dz - sum(dz)/M - xhat * sum(dz xhat)/M).  Prologue: every workgroup
+// totals the slices of the reduction through LDS; workgroup 0 also writes them out: totals[c] = sum dz (= dbeta),
+// totals[C + c] = sum dz * xhat (= dgamma).
 template <typename TI, typename TO>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     const TI* __restrict__ x, const TO* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ totals, long M, int C, int training, TI* __restrict__ dx) {
+    const float* __restrict__ sums, float* __restrict__ totals, long M, int C, int training, TI* __restrict__ dx) {
+  __shared__ float tot[2 * BN_MAXC];
+  for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) {
+    const float t = slice_total(sums, i, C);
+    tot[i] = t;
+    if (blockIdx.x == 0) totals[i] = t;
+  }
+  __syncthreads();
   const Geom g = geom(C);
   const int cg = threadIdx.x % g.ngroups, r0 = threadIdx.x / g.ngroups;
   const int c0 = cg * CV;
@@ -321,8 +329,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     mu[k] = ok ? mean[c0 + k] : 0.f; is[k] = ok ? invstd[c0 + k] : 0.f;
     ga[k] = ok ? gamma[c0 + k] : 0.f; be[k] = ok ? beta[c0 + k] : 0.f;
     // eval mode: the statistics are constants, only the scale survives
-    m1[k] = (ok && training) ? totals[c0 + k] / (float)M : 0.f;
-    m2[k] = (ok && training) ? totals[C + c0 + k] / (float)M : 0.f;
+    m1[k] = (ok && training) ? tot[c0 + k] / (float)M : 0.f;
+    m2[k] = (ok && training) ? tot[C + c0 + k] / (float)M : 0.f;
   }
   if (r0 < g.rows_per_iter) {
     for (long r = (long)blockIdx.x * g.rows_per_iter + r0; r < M; r += (long)gridDim.x * g.rows_per_iter) {
@@ -371,26 +379,23 @@ extern "C" int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma,
   RM_REQUIRE(m > 0 && c > 0 && c <= BN_MAXC, "bn_relu_fwd: bad shape (C <= %d)", BN_MAXC);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int grid = grid_for(m, c);
+  float* own = nullptr;
   if (training) {
-    // partial sums go through the library's zero scratch; the finalize kernel puts the zeros back (no memset)
+    // partial sums: this call's half of the library's zero scratch (see slice_total)
     float* scratch = repmode_zero_scratch(s);
     if (!scratch) return REPMODE_ELAUNCH;
+    const int half = repmode_bn_scratch_half(s);
+    own = scratch + (size_t)half * REPMODE_SCRATCH_BN_HALF;
+    float* other = scratch + (size_t)(1 - half) * REPMODE_SCRATCH_BN_HALF;
     if (in_dtype == REPMODE_F32)
-      hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const float*)x, m, c, scratch);
+      hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const float*)x, m, c, own, other);
     else
-      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const bf16_t*)x, m, c, scratch);
+      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const bf16_t*)x, m, c, own, other);
     RM_LAUNCH_CHECK("bn_stats");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, s, scratch, m, c, eps, momentum,
-                       running_mean, running_var, save_mean, save_invstd);
-    RM_LAUNCH_CHECK("bn_finalize");
-  } else {
-    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(ceil_div(c, 128)), dim3(128), 0, s, c, eps, running_mean, running_var,
-                       save_mean, save_invstd);
-    RM_LAUNCH_CHECK("bn_eval_stats");
   }
 #define RM_BN_APPLY(TI, TO)                                                                                      \
   hipLaunchKernelGGL((bn_apply_relu_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (TO*)out, \
-                     gamma, beta, save_mean, save_invstd, m, c)
+                     gamma, beta, own, running_mean, running_var, save_mean, save_invstd, eps, momentum, training, m, c)
   if (in_dtype == REPMODE_F32 && out_dtype == REPMODE_F32) RM_BN_APPLY(float, float);
   else if (in_dtype == REPMODE_F32) RM_BN_APPLY(float, bf16_t);
   else if (out_dtype == REPMODE_F32) RM_BN_APPLY(bf16_t, float);
@@ -410,13 +415,15 @@ extern "C" int repmode_bn_relu_bwd(const void* x, const void* dy, const float* g
   const int grid = grid_for(m, c);
   float* scratch = repmode_zero_scratch(s);
   if (!scratch) return REPMODE_ELAUNCH;
+  const int half = repmode_bn_scratch_half(s);
+  float* own = scratch + (size_t)half * REPMODE_SCRATCH_BN_HALF;
+  float* other = scratch + (size_t)(1 - half) * REPMODE_SCRATCH_BN_HALF;
 #define RM_BN_BWD(TI, TO)                                                                                              \
   do {                                                                                                                 \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<TI, TO>), dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy, \
-                       save_mean, save_invstd, gamma, beta, m, c, scratch);                                            \
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(2 * c, 128)), dim3(128), 0, s, scratch, c, totals);          \
+                       save_mean, save_invstd, gamma, beta, m, c, own, other);                                         \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy,  \
-                       save_mean, save_invstd, gamma, beta, totals, m, c, training, (TI*)dx);                          \
+                       save_mean, save_invstd, gamma, beta, own, totals, m, c, training, (TI*)dx);                          \
   } while (0)
   if (in_dtype == REPMODE_F32 && out_dtype == REPMODE_F32) RM_BN_BWD(float, float);
   else if (in_dtype == REPMODE_F32) RM_BN_BWD(float, bf16_t);

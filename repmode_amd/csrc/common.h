@@ -79,6 +79,12 @@ void repmode_prof_begin(int kind, double work, hipStream_t s);
 // themselves ("last workgroup cleans up"), so no call pays a memset launch.  nullptr on failure (error string set).
 constexpr size_t REPMODE_ZERO_SCRATCH_FLOATS = 64 * 1024;
 float* repmode_zero_scratch(hipStream_t s);
+// Regions of the scratch: two halves that the BatchNorm reductions use alternately (the reduction kernel of one
+// call clears the half the previous call used, so no kernel is needed to put zeros back), and the gate-gradient
+// accumulator.  repmode_bn_scratch_half returns this call's half index (0/1) and flips the per-stream state.
+constexpr size_t REPMODE_SCRATCH_BN_HALF = 16 * 1024;                       // floats per BatchNorm half
+constexpr size_t REPMODE_SCRATCH_GATE_OFF = 2 * REPMODE_SCRATCH_BN_HALF;    // gate accumulator: the upper 32 K floats
+int repmode_bn_scratch_half(hipStream_t s);
 void repmode_prof_end(hipStream_t s);
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -570,9 +570,10 @@ extern "C" int repmode_gatrep_bwd(const float* dw, const float* k5, const float*
   const size_t ndg = (size_t)nslots * E * co;
   float* dg = dg_ws;
   int clear = 0;
-  if (ndg <= REPMODE_ZERO_SCRATCH_FLOATS) {
+  if (ndg <= REPMODE_ZERO_SCRATCH_FLOATS - REPMODE_SCRATCH_GATE_OFF) {
     dg = repmode_zero_scratch(s);
     if (!dg) return REPMODE_ELAUNCH;
+    dg += REPMODE_SCRATCH_GATE_OFF;
     clear = 1;
   } else {
     RM_HIP(hipMemsetAsync(dg_ws, 0, ndg * sizeof(float), s));
