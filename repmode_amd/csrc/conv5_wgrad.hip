@@ -502,7 +502,8 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
     resident = (long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
   }
   const long fixed = (long)a.nslots * a.ncot * a.ncit * a.ndz;
-  long want_chunks = fixed >= resident ? 1 : (resident * WGRAD_ROUNDS) / fixed;
+  // (from one workgroup per CU-slot-half on, keep whole voxel ranges together: direct stores, no memset, no atomics)
+  long want_chunks = (fixed >= 512 || fixed >= resident) ? 1 : (resident * WGRAD_ROUNDS) / fixed;
   if (want_chunks < 1) want_chunks = 1;
   if (want_chunks > a.ntiles) want_chunks = a.ntiles;
   a.tiles_per_block = ceil_div(a.ntiles, (int)want_chunks);
