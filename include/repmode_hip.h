@@ -86,7 +86,9 @@ int repmode_conv5(const void* x, const void* w, const int32_t* sample_slot, void
 
 /* Same, with a flag word `centre3`: bit 0 restricts the filter planes/rows to dz, dy in [1,3] (a filter whose
  * support is the centred 3x3x3 -- the zero-padded conv3x3 expert of RepMode.py:174 -- skips the 80 all-zero
- * taps); bit 1 (float output only) ADDS the result to y instead of overwriting it. */
+ * taps); bit 1 (float output only) ADDS the result to y instead of overwriting it; bit 2 uses only the centre
+ * x tap (dx = 2) of every (dz, dy) row -- the thin first / last layers with their x taps folded into channels,
+ * see repmode_shift5 / repmode_thin_pack. */
 int repmode_conv5_ex(const void* x, const void* w, const int32_t* sample_slot, void* y, int n, int d,
                      int h, int wdim, int cin, int cout, int dtype, int out_f32, int centre3,
                      void* stream);
@@ -112,6 +114,19 @@ int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32_t* sample_
  *   flip != 0: dw[tap][c] = sum_v a[v][c] * b[v - tap]     (Cout == 1: a = x,  b = dy) */
 int repmode_conv5_wgrad_thin(const void* a, const void* b, const int32_t* sample_slot, int nslots, float* dw,
                              int n, int d, int h, int wdim, int c, int flip, void* stream);
+
+/* ---- the 1-channel ends of the network on the general conv kernel (bf16): the five x taps become channels.
+ * shift5:    x [nrows][w] (float or bf16, one channel) -> x5 [nrows][w][8] bf16, x5[.][x][dx] = x[.][x+dx-2] (0 outside,
+ *            channels 5..7 zero): the input of a 5-"channel" conv in dx-centre mode (first layer; last layer's
+ *            data gradient).
+ * thin_pack: re-packs the merged filter of a thin layer ([slot][125][ntiles][32][16] bf16, fragment-major; the thin
+ *            dimension is one tile wide, ntiles counts the tiles of the other) for that mode:
+ *            to_rows == 0: out(dz,dy,2)[r][red = dx] = w(dz,dy,dx)[r][0];  to_rows != 0: out(dz,dy,2)[row = dx][k] =
+ *            w(dz,dy,dx)[0][k].  Only the 25 taps (dz,dy,2) of out are written.
+ * unshift5:  y [nrows][w] = sum_dx y5[nrows][x+dx-2][dx] from the 5-row float output of the last layer's forward conv. */
+int repmode_shift5(const void* x, int dtype, void* x5, long nrows, int w, void* stream);
+int repmode_thin_pack(const void* w, void* out, int nslots, int ntiles, int to_rows, void* stream);
+int repmode_unshift5(const float* y5, float* y, long nrows, int w, void* stream);
 
 /* ---- GatRep backward (autograd of RepMode.py:171-200): expert, gate-probability and gate
  * parameter gradients from the per-slot filter gradient.  Outputs are OVERWRITTEN.

@@ -31,6 +31,9 @@ _SIGNATURES = {
     'repmode_conv5_wgrad': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad_ex': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad_thin': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_shift5': [_P, _I, _P, _c.c_long, _I, _P],
+    'repmode_thin_pack': [_P, _P, _I, _I, _I, _P],
+    'repmode_unshift5': [_P, _P, _c.c_long, _I, _P],
     'repmode_gatrep_bwd': [_P] * 8 + [_I] * 4 + [_P] * 9,
     'repmode_bn_relu_fwd': [_P] * 8 + [_c.c_long, _I, _c.c_float, _c.c_float, _I, _I, _I, _P],
     'repmode_bn_relu_bwd': [_P] * 8 + [_c.c_long, _I, _I, _I, _I, _P],

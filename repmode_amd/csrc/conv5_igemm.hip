@@ -75,6 +75,7 @@ struct ConvArgs {
   int out_f32;  // 0: store as T; 1: float output (SWAP kernels; atomicAdd when ksplit > 1)
   int tap_lo, tap_hi;  // dz and dy are restricted to [tap_lo, tap_hi] (0..4: full filter; 1..3: a 3x3 support)
   int accum;           // float output only: add to y (atomics, y is not cleared) instead of overwriting it
+  int dxc;             // only the centre x tap (dx = 2) of every (dz, dy) row: see repmode_conv5_ex
 };
 
 // Tile configuration.  BZ*BY*BX output voxels = 32 * WV * VW; 32 * WC * CW output channels.
@@ -220,7 +221,37 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
       return *reinterpret_cast<const u32x4*>(wrow[cs] + (size_t)tap * tap_stride + (size_t)chunk * (32 * KC));
     };
     int dz = dz_lo, dy = dy_lo;
-    if constexpr (CW == 1) {
+    if (a.dxc) {
+      // one tap per (dz, dy) row (the thin first / last layers, whose x taps were folded into channels)
+      u32x4 a_c[CW], a_n[CW], b_c[VW], b_n[VW];
+#pragma unroll
+      for (int cs = 0; cs < CW; ++cs) a_c[cs] = wfrag(cs, (dz * 5 + dy) * 5 + 2);
+#pragma unroll
+      for (int vs = 0; vs < VW; ++vs) b_c[vs] = lds[vbase[vs] + (dz * BYH + dy) * BXH + 2];
+      for (int row = 0; row < nrows; ++row) {
+        int dzn = dz, dyn = dy + 1;
+        if (dyn > dy_hi) { dyn = dy_lo; dzn = dz + 1; }
+        const bool more = row + 1 < nrows;
+        if (!more) { dzn = dz; dyn = dy; }               // harmless reload on the last row
+#pragma unroll
+        for (int cs = 0; cs < CW; ++cs) a_n[cs] = wfrag(cs, (dzn * 5 + dyn) * 5 + 2);
+#pragma unroll
+        for (int vs = 0; vs < VW; ++vs) b_n[vs] = lds[vbase[vs] + (dzn * BYH + dyn) * BXH + 2];
+#pragma unroll
+        for (int cs = 0; cs < CW; ++cs)
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) {
+            if constexpr (SWAP) Elem<T>::mma(b_c[vs], a_c[cs], acc[cs][vs]);
+            else Elem<T>::mma(a_c[cs], b_c[vs], acc[cs][vs]);
+          }
+#pragma unroll
+        for (int cs = 0; cs < CW; ++cs) a_c[cs] = a_n[cs];
+#pragma unroll
+        for (int vs = 0; vs < VW; ++vs) b_c[vs] = b_n[vs];
+        dz = dzn;
+        dy = dyn;
+      }
+    } else if constexpr (CW == 1) {
       u32x4 a_cur[5], a_nxt[5];
 #pragma unroll
       for (int dx = 0; dx < 5; ++dx) a_cur[dx] = wfrag(0, (dz * 5 + dy) * 5 + dx);
@@ -400,7 +431,10 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
     RM_HIP(hipMemsetAsync(a.y, 0, (size_t)a.N * a.D * a.H * a.W * a.Cout * sizeof(float), stream));
   }
   // algorithmic FLOPs: 125 taps, or the 27 of a 3x3x3 support when restricted
-  repmode_prof_begin(REPMODE_PROF_CONV5, 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * (a.tap_lo ? 27 : REPMODE_TAPS), stream);
+  // (dx-centre mode: 25 taps x the 5 folded x taps of the thin dimension = the original layer's 125 taps x 1 channel)
+  const double alg = a.dxc ? 2.0 * a.N * a.D * a.H * a.W * 25.0 * (a.Cin == 8 ? 5.0 * a.Cout : (double)a.Cin * a.Cout)
+                           : 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * (a.tap_lo ? 27 : REPMODE_TAPS);
+  repmode_prof_begin(REPMODE_PROF_CONV5, alg, stream);
   hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
   repmode_prof_end(stream);
   RM_LAUNCH_CHECK("conv5_igemm");
@@ -457,6 +491,7 @@ extern "C" int repmode_conv5_ex(const void* x, const void* w, const int32_t* sam
   a.tap_lo = (centre3 & 1) ? 1 : 0;
   a.tap_hi = (centre3 & 1) ? 3 : 4;
   a.accum = (centre3 & 2) ? 1 : 0;
+  a.dxc = (centre3 & 4) ? 1 : 0;
   RM_REQUIRE(!a.accum || a.out_f32, "conv5: accumulation needs a float output");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == REPMODE_F32) return dispatch<float, true>(a, s);

@@ -129,9 +129,10 @@ def gatrep_merge(k5, k3, k1, a3, a5, g, dtype, want_wf=True, want_wd=False):
     return wf, wd
 
 
-def conv5(x_cl, w, sample_slot, cout, out_f32=False, out=None, centre3=False, accumulate=False):
+def conv5(x_cl, w, sample_slot, cout, out_f32=False, out=None, centre3=False, accumulate=False, dxc=False):
     """y[n] = x[n] (*) w[sample_slot[n]], 5^3 'same' cross-correlation, NDHWC -- RepMode.py:204-210.
-    ``accumulate`` (float ``out`` given): add to ``out`` instead of overwriting it."""
+    ``accumulate`` (float ``out`` given): add to ``out`` instead of overwriting it.  ``dxc``: only the centre x tap
+    of every (dz, dy) row (thin layers with their x taps folded into channels, see ``thin_conv_*``)."""
     n, d, h, wd_, cin = x_cl.shape
     code = dtype_code(x_cl.dtype)
     out_dtype = torch.float32 if (out_f32 or x_cl.dtype == torch.float32) else x_cl.dtype
@@ -139,7 +140,41 @@ def conv5(x_cl, w, sample_slot, cout, out_f32=False, out=None, centre3=False, ac
     assert y.dtype == out_dtype and y.is_contiguous()
     assert not accumulate or (out is not None and out_dtype == torch.float32)
     _lib.call('repmode_conv5_ex', _ptr(x_cl), _ptr(w), _ptr(sample_slot), _ptr(y), n, d, h, wd_, cin, cout, code,
-              1 if out_dtype == torch.float32 else 0, (1 if centre3 else 0) | (2 if accumulate else 0), _stream())
+              1 if out_dtype == torch.float32 else 0, (1 if centre3 else 0) | (2 if accumulate else 0) | (4 if dxc else 0), _stream())
+    return y
+
+
+def _thin_pack(w, to_rows):
+    """Re-pack a thin layer's merged filter [S, 125, rowsP, redP] (bf16) for the conv kernel's dx-centre mode."""
+    s_, _, rp, kp = w.shape
+    assert (kp == 16 and not to_rows) or (rp == 32 and to_rows)
+    out = torch.empty_like(w)             # only the 25 (dz, dy, dx=2) taps are written -- and read
+    _lib.call('repmode_thin_pack', _ptr(w), _ptr(out), s_, (rp // 32) * (kp // 16), 1 if to_rows else 0, _stream())
+    return out
+
+
+def _shift5(t_cl):
+    """[N, D, H, W, 1] (float or bf16) -> [N, D, H, W, 8] bf16 with channel dx = the input shifted by dx - 2 along x."""
+    n, d, h, w_, _ = t_cl.shape
+    out = torch.empty((n, d, h, w_, 8), dtype=torch.bfloat16, device=t_cl.device)
+    _lib.call('repmode_shift5', _ptr(t_cl), dtype_code(t_cl.dtype), _ptr(out), n * d * h, w_, _stream())
+    return out
+
+
+def thin_conv_in1(x_cl, w, sample_slot, cout, out_f32=False):
+    """conv5 for a ONE-channel input (bf16 filter ``w`` [S, 125, CoP, 16]): the five x taps become channels and the
+    general kernel runs 25 instead of 125 taps (csrc/thin.hip).  Used for the first layer's forward and (with the
+    data-gradient filter) for the last layer's data gradient."""
+    return conv5(_shift5(x_cl.contiguous()), _thin_pack(w, False), sample_slot, cout, out_f32, dxc=True)
+
+
+def thin_conv_out1(x_cl, w, sample_slot):
+    """conv5 for ONE output channel (bf16 filter ``w`` [S, 125, 32, CiP]): the five x taps become output rows, then a
+    5-tap diagonal sum (csrc/thin.hip).  Returns float [N, D, H, W, 1]."""
+    n, d, h, w_, _ = x_cl.shape
+    y5 = conv5(x_cl, _thin_pack(w, True), sample_slot, 5, out_f32=True, dxc=True)
+    y = torch.empty((n, d, h, w_, 1), dtype=torch.float32, device=x_cl.device)
+    _lib.call('repmode_unshift5', _ptr(y5), _ptr(y), n * d * h, w_, _stream())
     return y
 
 
@@ -177,7 +212,16 @@ class _ModeConv3d(torch.autograd.Function):
         # weights); these are the shallow levels, whose merged filters are small next to the activations
         want_wd = ctx.needs_input_grad[0]
         wf, wd = gatrep_merge(k5, k3, k1, a3, a5, g, x_cl.dtype, want_wf=True, want_wd=want_wd)
-        y = conv5(x_cl, wf, plan.sample_slot, co, out_f32)
+        ci = k5.shape[1]
+        thin = x_cl.dtype == torch.bfloat16 and (ci == 1) != (co == 1)
+        if thin and ci == 1:                                  # first layer: x taps folded into input channels
+            y = thin_conv_in1(x_cl, wf, plan.sample_slot, co, out_f32)
+        elif thin:                                            # last layer: x taps folded into output rows
+            y = thin_conv_out1(x_cl, wf, plan.sample_slot)
+            if not out_f32:
+                y = y.to(x_cl.dtype)
+        else:
+            y = conv5(x_cl, wf, plan.sample_slot, co, out_f32)
         ctx.save_for_backward(x_cl, k5, k3, k1, a3, a5, g, wd)
         ctx.plan = plan
         return y
@@ -191,7 +235,12 @@ class _ModeConv3d(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             # deep levels (small volumes) split the channel reduction over workgroups -> float output
-            dx = conv5(dy, wd, plan.sample_slot, ci, out_f32=x_cl.shape[3] < 32)
+            if x_cl.dtype == torch.bfloat16 and co == 1 and ci != 1:     # the last layer: dy has one channel
+                dx = thin_conv_in1(dy, wd, plan.sample_slot, ci, out_f32=x_cl.shape[3] < 32)
+            elif x_cl.dtype == torch.bfloat16 and ci == 1 and co != 1:   # (first layer, if its input ever needs a gradient)
+                dx = thin_conv_out1(dy, wd, plan.sample_slot)
+            else:
+                dx = conv5(dy, wd, plan.sample_slot, ci, out_f32=x_cl.shape[3] < 32)
             if dx.dtype != x_cl.dtype:
                 dx = dx.to(x_cl.dtype)
             del wd

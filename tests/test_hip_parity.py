@@ -343,6 +343,38 @@ def test_box_sum(shape):
     assert got.dtype == torch.bfloat16 and rel_err(got.float().cpu(), want - c1) < 5e-3
 
 
+@pytest.mark.parametrize('shape', [(2, 4, 8, 32), (1, 3, 5, 7), (2, 8, 16, 64)])
+def test_thin_convs_match_general_kernel(shape):
+    """The 1-channel ends of the net with their x taps folded into channels / rows (csrc/thin.hip) vs the same merged
+    filters through the general conv kernel."""
+    ops = _ops()
+    n, d, h, w = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    plan = ops.TaskPlan([i % 3 for i in range(n)], 4, DEV)
+    def experts(co, ci):
+        return [torch.randn(co, ci, k, k, k, generator=gen).to(DEV) * 0.2 for k in (5, 3, 1, 1, 1)]
+    # first layer: 1 -> 24
+    e = experts(24, 1)
+    g = torch.softmax(torch.randn(plan.nslots, 5, 24, generator=gen), dim=1).to(DEV)
+    wf, _ = ops.gatrep_merge(*e, g, torch.bfloat16)
+    x = torch.randn(n, d, h, w, 1, generator=gen).bfloat16().to(DEV)
+    ref = ops.conv5(x, wf, plan.sample_slot, 24, out_f32=True)
+    got = ops.thin_conv_in1(x, wf, plan.sample_slot, 24, out_f32=True)
+    assert rel_err(got.cpu(), ref.cpu()) < 1e-5
+    # last layer: 40 -> 1, forward and data gradient
+    e = experts(1, 40)
+    g = torch.softmax(torch.randn(plan.nslots, 5, 1, generator=gen), dim=1).to(DEV)
+    wf, wd = ops.gatrep_merge(*e, g, torch.bfloat16, want_wf=True, want_wd=True)
+    x = torch.randn(n, d, h, w, 40, generator=gen).bfloat16().to(DEV)
+    ref = ops.conv5(x, wf, plan.sample_slot, 1, out_f32=True)
+    got = ops.thin_conv_out1(x, wf, plan.sample_slot)
+    assert rel_err(got.cpu(), ref.cpu()) < 1e-5
+    dy = torch.randn(n, d, h, w, 1, generator=gen).bfloat16().to(DEV)
+    ref = ops.conv5(dy, wd, plan.sample_slot, 40, out_f32=True)
+    got = ops.thin_conv_in1(dy, wd, plan.sample_slot, 40, out_f32=True)
+    assert rel_err(got.cpu(), ref.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize('co,ci', [(32, 32), (40, 24), (7, 5), (64, 96)])
 def test_expert_frags_vs_gatrep(co, ci):
     """The per-expert path's layout kernel = GatRep with one-hot gates, on every tap a centre3 convolution reads."""
