@@ -441,6 +441,40 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
   }
   }
   }
+  if (a.layout != 0 && a.direct) {
+    // The experts' own layout ([co][ci][125] or, K3, [co][ci][27]): a (co, ci) pair's 25 taps of this dz plane are
+    // 100 contiguous bytes.  Straight from the accumulators that is 4-byte stores 500 B apart (measured 5x slower
+    // than tap-major stores); so each wave transposes its tile through the idle staging LDS, one accumulator
+    // register (4 co x 16 ci = 64 pairs) at a time, and stores whole runs.
+    __syncthreads();
+    float* wl = reinterpret_cast<float*>(smem) + wave * (64 * 25);
+    const int nt = a.layout == 1 ? 25 : 9;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int pair = kg * 16 + l15;
+      if (a.layout == 1) {
+#pragma unroll
+        for (int t = 0; t < 25; ++t) wl[pair * 25 + t] = acc[t][r];
+      } else {
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+          const int ty = t / 5, tx = t % 5;
+          if (ty >= 1 && ty <= 3 && tx >= 1 && tx <= 3) wl[pair * 9 + (ty - 1) * 3 + (tx - 1)] = acc[t][r];
+        }
+      }
+      for (int i = lane; i < 64 * nt; i += 64) {
+        const int pr = i / nt, t = i % nt;
+        const int co = cot * 32 + cq * 16 + (pr >> 4) * 4 + r;
+        const int cic = cit * 32 + ciq * 16 + (pr & 15);
+        if (co < Cout && cic < Cin) {
+          float* p = a.layout == 1 ? a.dw + ((size_t)co * Cin + cic) * REPMODE_TAPS + dz * 25 + t
+                                   : a.dw + ((size_t)co * Cin + cic) * 27 + (dz - 1) * 9 + t;
+          *p = wl[i];
+        }
+      }
+    }
+    return;
+  }
   // 16x16 C/D layout: column (ci) = lane & 15, row (co) = (lane >> 4) * 4 + r
   const int ci = cit * 32 + ciq * 16 + l15;
   if (ci < Cin) {

@@ -562,12 +562,19 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
             t = torch.bmm(dhi.view(3, -1, co), w1).view(3, *shp)                          # [3, N, D, H, W, Ci]
             dx = box_sum(in3=t[1], in5=t[2], add=(dxf, t[0]), out_dtype=dt)
             del wd2
-        # ---- expert gradients: filter gradients of the gate-scaled dy, all samples in one slot, transposed from
-        # the kernel's tap-major layout to the parameters' [Co][Ci][taps].  (The wgrad kernel can also write that
-        # layout directly -- expert_layout= -- but its 4-byte stores at a 500-byte lane stride measured 5x slower.)
+        # ---- expert gradients: filter gradients of the gate-scaled dy, all samples in one slot.  Large layers (every
+        # workgroup owns its outputs: no atomics) write the parameters' [Co][Ci][taps] layout directly, each wave
+        # transposing its tile through LDS; the others accumulate tap-major and are transposed by a second launch.
         one = _SingleSlot(n, dev, 0)
-        dk5 = tap_transpose(conv5_wgrad(x_cl, d01[0], one, co)[0], k5.shape)
-        dk3 = tap_transpose(conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0], k3.shape)
+        tiles = ((co + 31) // 32) * ((ci + 31) // 32)
+        if dt == torch.bfloat16 and tiles * 5 >= 512:
+            dk5 = conv5_wgrad(x_cl, d01[0], one, co, expert_layout=5)
+        else:
+            dk5 = tap_transpose(conv5_wgrad(x_cl, d01[0], one, co)[0], k5.shape)
+        if dt == torch.bfloat16 and tiles * 3 >= 512:
+            dk3 = conv5_wgrad(x_cl, d01[1], one, co, expert_layout=3)
+        else:
+            dk3 = tap_transpose(conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0], k3.shape)
         d1 = torch.bmm(dhi.view(3, -1, co).transpose(1, 2), xb.view(3, -1, ci))           # [3, Co, Ci]
         dk1, da3, da5 = d1[0].reshape(k1.shape), d1[1].reshape(a3.shape), d1[2].reshape(a5.shape)
         return dx, dk5, dk3, dk1, da3, da5, dgw, dgb, None

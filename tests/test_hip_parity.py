@@ -392,6 +392,23 @@ def test_expert_frags_vs_gatrep(co, ci):
     assert torch.equal(wd[1][rows_d], wd_ref[1][rows_d])
 
 
+@pytest.mark.parametrize('co,ci', [(352, 352), (416, 344)])
+def test_wgrad_expert_layout_direct(co, ci):
+    """The filter gradient written straight into the experts' [Co][Ci][taps] layout (LDS-transposed epilogue, large
+    layers only) = tap-major accumulation + transpose, for the 5^3 and the centred 3^3 expert."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(co + ci)
+    x = torch.randn(2, 2, 4, 8, ci, generator=gen).bfloat16().to(DEV)
+    dy = torch.randn(2, 2, 4, 8, co, generator=gen).bfloat16().to(DEV)
+    one = ops._SingleSlot(2, DEV, 0)
+    ref5 = ops.tap_transpose(ops.conv5_wgrad(x, dy, one, co)[0], (co, ci, 5, 5, 5))
+    got5 = ops.conv5_wgrad(x, dy, one, co, expert_layout=5)
+    assert torch.equal(got5, ref5)
+    ref3 = ops.tap_transpose(ops.conv5_wgrad(x, dy, one, co, centre3=True)[0], (co, ci, 3, 3, 3))
+    got3 = ops.conv5_wgrad(x, dy, one, co, expert_layout=3)
+    assert torch.equal(got3, ref3)
+
+
 @pytest.mark.parametrize('co,ci', [(32, 32), (7, 5), (64, 24)])
 def test_tap_transpose(co, ci):
     ops = _ops()
