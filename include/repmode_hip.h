@@ -112,6 +112,8 @@ int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32_t* sample_
  * dw: float [nslots][125][C] (== the general layout with the unit dimension dropped), overwritten.
  *   flip == 0: dw[tap][c] = sum_v a[v][c] * b[v + tap]     (Cin  == 1: a = dy, b = x)
  *   flip != 0: dw[tap][c] = sum_v a[v][c] * b[v - tap]     (Cout == 1: a = x,  b = dy) */
+/* (conv5_wgrad_ex: mode bit 3, conv5_wgrad_thin: flip bit 1, k2s2_wgrad_ex: param_layout bit 2 -- "dw is already
+ * all zero": the call skips its own memset; lets a caller clear all its accumulation buffers with one launch.) */
 int repmode_conv5_wgrad_thin(const void* a, const void* b, const int32_t* sample_slot, int nslots, float* dw,
                              int n, int d, int h, int wdim, int c, int flip, void* stream);
 

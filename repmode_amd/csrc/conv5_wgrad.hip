@@ -34,6 +34,7 @@ struct WgradArgs {
   int layout;           // 0: dw[slot][tap][co][ci]; 1: dw[co][ci][125] (expert layout, nslots == 1);
                         // 2: dw[co][ci][27] (expert layout of a centred 3x3x3 filter, nslots == 1)
   int nslots, direct;   // direct: every workgroup owns its output completely -> plain stores, no memset
+  int prezeroed;   // dw is known to be all zero already: no memset before the atomics
 };
 
 template <typename T>
@@ -545,7 +546,7 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   a.direct = a.nchunks == 1;
   const long grid = fixed * a.nchunks;
   RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
-  if (!a.direct) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * a.Cout * a.Cin * sizeof(float), s));
+  if (!a.direct && !a.prezeroed) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * a.Cout * a.Cin * sizeof(float), s));
   repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, s);
   const size_t sample_bytes = (size_t)a.D * a.H * a.W * (a.Cin > a.Cout ? a.Cin : a.Cout) * 2;
   // (levels with W < 16 hand a workgroup only a tile or two per sample: nothing to overlap, and the old loop is ~15 % faster there)
@@ -583,6 +584,9 @@ extern "C" int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32
   a.nslots = nslots;
   // centre3: 0 = all taps, slot layout; 1 = planes dz in [1,3] only, slot layout; 2 = all taps written in the
   // experts' own [co][ci][125] layout; 3 = centred 3x3x3 taps written as [co][ci][27] (2, 3: nslots == 1)
+  // (bit 3 of the mode word: dw has been cleared by the caller -- one pooled memset per step instead of one per call)
+  a.prezeroed = (centre3 & 8) ? 1 : 0;
+  centre3 &= 7;
   RM_REQUIRE(centre3 >= 0 && centre3 <= 3 && (centre3 < 2 || nslots == 1), "conv5_wgrad: bad mode %d", centre3);
   a.dz_lo = (centre3 == 1 || centre3 == 3) ? 1 : 0;
   a.ndz = (centre3 == 1 || centre3 == 3) ? 3 : 5;
@@ -609,7 +613,7 @@ extern "C" int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32
     a.direct = a.nchunks == 1;
     const long grid = fixed * a.nchunks;
     RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
-    if (!a.direct) RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * cout * cin * sizeof(float), s));
+    if (!a.direct && !a.prezeroed) RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * cout * cin * sizeof(float), s));
     repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * d * h * wdim * (double)cin * cout * REPMODE_TAPS, s);
     hipLaunchKernelGGL(conv5_wgrad_f32c_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, a);
   }
@@ -769,7 +773,7 @@ extern "C" int repmode_conv5_wgrad_thin(const void* a_t, const void* b_t, const 
   ThinArgs a{};
   a.a = static_cast<const bf16_t*>(a_t); a.b = static_cast<const bf16_t*>(b_t);
   a.sample_slot = sample_slot; a.dw = dw;
-  a.N = n; a.D = d; a.H = h; a.W = wdim; a.C = c; a.flip = flip;
+  a.N = n; a.D = d; a.H = h; a.W = wdim; a.C = c; a.flip = flip & 1;
   a.nty = ceil_div(h, TH_TY); a.ntx = ceil_div(wdim, TH_TX);
   a.ntiles = d * a.nty * a.ntx;
   a.nct = ceil_div(c, 32);
@@ -779,7 +783,7 @@ extern "C" int repmode_conv5_wgrad_thin(const void* a_t, const void* b_t, const 
   if (want < 1) want = 1;
   a.tiles_per_block = ceil_div(a.ntiles, (int)want);
   a.nchunks = ceil_div(a.ntiles, a.tiles_per_block);
-  RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * REPMODE_TAPS * c * sizeof(float), s));
+  if (!(flip & 2)) RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * REPMODE_TAPS * c * sizeof(float), s));   // flip bit 1: dw already cleared
   repmode_prof_begin(REPMODE_PROF_WGRAD_THIN, 2.0 * n * d * h * wdim * (double)c * REPMODE_TAPS, s);
   hipLaunchKernelGGL(conv5_wgrad_thin_kernel, dim3((unsigned)(fixed * a.nchunks)), dim3(256), 0, s, a);
   repmode_prof_end(s);

@@ -320,6 +320,8 @@ extern "C" int repmode_k2s2_wgrad(const void* coarse, const void* fine, float* d
 extern "C" int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float* dw, int n, int d, int h, int wdim,
                                      int ca, int cb, int param_layout, void* stream) {
   RM_REQUIRE(coarse && fine && dw, "k2s2_wgrad: null pointer");
+  const int prezeroed = param_layout & 4;        // bit 2: dw has been cleared by the caller
+  param_layout &= 3;
   RM_REQUIRE(param_layout >= 0 && param_layout <= 2, "k2s2_wgrad: bad layout %d", param_layout);
   RM_REQUIRE(n > 0 && d > 0 && h > 0 && wdim > 0 && ca > 0 && cb > 0, "k2s2_wgrad: bad shape");
   RM_REQUIRE(((uintptr_t)coarse & 15) == 0 && ((uintptr_t)fine & 15) == 0, "k2s2_wgrad: pointers must be 16-byte aligned");
@@ -335,7 +337,7 @@ extern "C" int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float
   if (want < 1) want = 1;
   a.tiles_per_block = ceil_div(a.ntiles, (int)want);
   const int nchunks = ceil_div(a.ntiles, a.tiles_per_block);
-  RM_HIP(hipMemsetAsync(dw, 0, (size_t)8 * ca * cb * sizeof(float), s));
+  if (!prezeroed) RM_HIP(hipMemsetAsync(dw, 0, (size_t)8 * ca * cb * sizeof(float), s));
   hipLaunchKernelGGL(k2s2_wgrad_kernel, dim3(nchunks, nat, nbt), dim3(256), 0, s, a);
   RM_LAUNCH_CHECK("k2s2_wgrad");
   return REPMODE_OK;

@@ -191,6 +191,11 @@ class Net(torch.nn.Module):
         # integer task ids -> slot plan, built once and shared by the 19 MoDE blocks (replaces the
         # one-hot embedding of RepMode.py:44-49,53)
         plan = t if isinstance(t, ops.TaskPlan) else ops.TaskPlan(t, self.num_tasks, x.device, self.training)
+        if self.training and torch.is_grad_enabled():
+            # one pooled memset per step for the kernels' float accumulation buffers (ops.ZeroPool)
+            ops.ZERO_POOL.begin(('train', tuple(x.shape), plan.nslots, str(x.device)), x.device)
+        else:
+            ops.ZERO_POOL.end()
         if self.training and not plan.bn_counted:
             # num_batches_tracked of the 26 BatchNorm layers: one multi-tensor launch instead of 26
             counters = [m.num_batches_tracked for m in self.modules()

@@ -39,6 +39,58 @@ def _require_hip(t, what):
             '%s is on %s: repmode_amd runs on MI355X (HIP) tensors only and has no CPU fallback' % (what, t.device))
 
 
+class ZeroPool:
+    """One pre-zeroed buffer per train step for the float accumulation targets of the atomics-based kernels (split-K
+    conv outputs, chunked filter gradients): ~60 memset launches per step become one.
+
+    The first step with a given key records the requested sizes in order; later steps allocate the total once
+    (``torch.zeros``), hand out views in the same order and tell the kernels to skip their own clearing.  Any
+    divergence from the recorded sequence falls back to plain allocations for the rest of the step.  A fresh buffer
+    is allocated every step, so views held across steps (saved activations, a returned output) stay valid.
+    """
+
+    ALIGN = 64        # floats (256 bytes)
+
+    def __init__(self):
+        self.plans = {}
+        self.key = None
+        self.req = []
+        self.buf = None
+
+    def begin(self, key, device):
+        self.end()
+        self.key, self.req, self.pos, self.off = key, [], 0, 0
+        plan = self.plans.get(key)
+        self.plan = plan
+        self.buf = None
+        if plan:
+            total = sum(-(-n // self.ALIGN) * self.ALIGN for n in plan)
+            self.buf = torch.zeros(total, dtype=torch.float32, device=device)
+
+    def end(self):
+        if self.key is not None and self.req:
+            self.plans[self.key] = self.req
+        self.key, self.req, self.buf = None, [], None
+
+    def take(self, shape, device):
+        """(float32 tensor of ``shape``, prezeroed?)"""
+        n = 1
+        for v in shape:
+            n *= int(v)
+        if self.key is not None:
+            self.req.append(n)
+            if self.buf is not None and self.pos < len(self.plan) and self.plan[self.pos] == n:
+                t = self.buf[self.off:self.off + n].view(shape)
+                self.off += -(-n // self.ALIGN) * self.ALIGN
+                self.pos += 1
+                return t, True
+            self.buf = None          # sequence differs from the recorded one: plain allocations from here on
+        return torch.empty(shape, dtype=torch.float32, device=device), False
+
+
+ZERO_POOL = ZeroPool()
+
+
 class TaskPlan:
     """Which merged filter each sample uses.
 
@@ -136,9 +188,16 @@ def conv5(x_cl, w, sample_slot, cout, out_f32=False, out=None, centre3=False, ac
     n, d, h, wd_, cin = x_cl.shape
     code = dtype_code(x_cl.dtype)
     out_dtype = torch.float32 if (out_f32 or x_cl.dtype == torch.float32) else x_cl.dtype
-    y = out if out is not None else torch.empty((n, d, h, wd_, cout), dtype=out_dtype, device=x_cl.device)
+    if out is not None:
+        y = out
+    elif out_dtype == torch.float32 and x_cl.dtype == torch.bfloat16:
+        # float output = the kernel may split the reduction and add with atomics: a pre-zeroed pool view saves its memset
+        y, pre = ZERO_POOL.take((n, d, h, wd_, cout), x_cl.device)
+        accumulate = accumulate or pre
+    else:
+        y = torch.empty((n, d, h, wd_, cout), dtype=out_dtype, device=x_cl.device)
     assert y.dtype == out_dtype and y.is_contiguous()
-    assert not accumulate or (out is not None and out_dtype == torch.float32)
+    assert not accumulate or out_dtype == torch.float32
     _lib.call('repmode_conv5_ex', _ptr(x_cl), _ptr(w), _ptr(sample_slot), _ptr(y), n, d, h, wd_, cin, cout, code,
               1 if out_dtype == torch.float32 else 0, (1 if centre3 else 0) | (2 if accumulate else 0) | (4 if dxc else 0), _stream())
     return y
@@ -188,15 +247,15 @@ def conv5_wgrad(x_cl, dy_cl, plan, cout, centre3=False, expert_layout=None):
         _lib.call('repmode_conv5_wgrad_ex', _ptr(x_cl), _ptr(dy_cl), _ptr(plan.sample_slot), 1, _ptr(dw),
                   n, d, h, wd_, cin, cout, dtype_code(x_cl.dtype), 2 if k == 5 else 3, _stream())
         return dw
-    dw = torch.empty((plan.nslots, TAPS, cout, cin), dtype=torch.float32, device=x_cl.device)
+    dw, pre = ZERO_POOL.take((plan.nslots, TAPS, cout, cin), x_cl.device)
     if x_cl.dtype == torch.bfloat16 and (cin == 1) != (cout == 1) and not centre3:
         # thin layer: taps stand in for the missing channel dimension (conv5_wgrad_thin)
         a_t, b_t, c, flip = (dy_cl, x_cl, cout, 0) if cin == 1 else (x_cl, dy_cl, cin, 1)
         _lib.call('repmode_conv5_wgrad_thin', _ptr(a_t), _ptr(b_t), _ptr(plan.sample_slot), plan.nslots, _ptr(dw),
-                  n, d, h, wd_, c, flip, _stream())
+                  n, d, h, wd_, c, flip | (2 if pre else 0), _stream())
         return dw
     _lib.call('repmode_conv5_wgrad_ex', _ptr(x_cl), _ptr(dy_cl), _ptr(plan.sample_slot), plan.nslots, _ptr(dw),
-              n, d, h, wd_, cin, cout, dtype_code(x_cl.dtype), 1 if centre3 else 0, _stream())
+              n, d, h, wd_, cin, cout, dtype_code(x_cl.dtype), (1 if centre3 else 0) | (8 if pre else 0), _stream())
     return dw
 
 
@@ -334,8 +393,9 @@ def k2s2_wgrad(coarse_cl, fine_cl, param_layout=0):
     if coarse_cl.dtype == torch.bfloat16 and param_layout != 2:
         # the kernel accumulates tap-major (atomics into the parameter layout, 32-byte stride, measured 5x slower);
         # layout 1 is one small transpose launch behind it
-        dw8 = torch.empty((8, ca, cb), dtype=torch.float32, device=coarse_cl.device)
-        _lib.call('repmode_k2s2_wgrad', _ptr(coarse_cl), _ptr(fine_cl), _ptr(dw8), n, d, h, w, ca, cb, _stream())
+        dw8, pre = ZERO_POOL.take((8, ca, cb), coarse_cl.device)
+        _lib.call('repmode_k2s2_wgrad_ex', _ptr(coarse_cl), _ptr(fine_cl), _ptr(dw8), n, d, h, w, ca, cb, 4 if pre else 0,
+                  _stream())
         if param_layout == 0:
             return dw8
         dw = torch.empty(shape, dtype=torch.float32, device=coarse_cl.device)
