@@ -123,10 +123,12 @@ extern "C" int repmode_expert_mix_fwd(const float* p, const float* g, float* y, 
 // dg [N][5][C] (overwritten), dye_lo [2][N][V][C] in `dtype`, dye_hi [3][N][V][C] float.
 extern "C" int repmode_expert_mix_bwd(const float* dy, const float* p, const float* g, float* dg, void* dye_lo,
                                       float* dye_hi, int n, long v, int c, int dtype, void* stream) {
+  const int prezeroed = dtype & 16;     // bit 4 of dtype: dg has been cleared by the caller (pooled memset)
+  dtype &= 15;
   RM_REQUIRE(dy && p && g && dg && dye_lo && dye_hi && n > 0 && v > 0 && c > 0 && c <= 512, "expert_mix_bwd: bad argument");
   RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "expert_mix_bwd: bad dtype %d", dtype);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  RM_HIP(hipMemsetAsync(dg, 0, (size_t)n * E * c * sizeof(float), s));
+  if (!prezeroed) RM_HIP(hipMemsetAsync(dg, 0, (size_t)n * E * c * sizeof(float), s));
   const int rows = 256 / ((c + 3) / 4);
   long chunks = (v + rows * 4 - 1) / (rows * 4);          // >= 4 rows iterations per workgroup
   if (chunks > 256) chunks = 256;

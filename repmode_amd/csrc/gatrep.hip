@@ -82,19 +82,28 @@ __device__ __forceinline__ void store_pair<bf16_t>(bf16_t* p, float a, float b) 
   *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(a, b);
 }
 
-// grid = (reduction chunk, row tile, group of 4 rows); 256 threads = (PAIRS / 2 element pairs) x TQ tap phases
+// LDS of one workgroup of the forward merge (shared by both roles)
+template <typename T>
+struct GatrepFwdLds {
+  float s5[FragGeom<T>::PAIRS * TAPS];
+  float s3[FragGeom<T>::PAIRS * 27];
+  float s1[FragGeom<T>::PAIRS], sa3[FragGeom<T>::PAIRS], sa5[FragGeom<T>::PAIRS];
+  float sg[16][E][FragGeom<T>::KC];
+};
+
+// one workgroup: (reduction chunk kc, row tile rt, zidx = group of 4 rows x tap part); 256 threads =
+// (PAIRS / 2 element pairs) x TQ tap phases
 template <typename T, bool WRITE_WD>
-__global__ __launch_bounds__(256) void gatrep_fwd_kernel(
-    const float* __restrict__ k5, const float* __restrict__ k3, const float* __restrict__ k1,
+__device__ __forceinline__ void gatrep_fwd_body(
+    GatrepFwdLds<T>& L, const float* __restrict__ k5, const float* __restrict__ k3, const float* __restrict__ k1,
     const float* __restrict__ a3, const float* __restrict__ a5, const float* __restrict__ g, int nslots,
-    int co_n, int ci_n, int nrt, int nkc, int tsplit, T* __restrict__ wout) {
+    int co_n, int ci_n, int nrt, int nkc, int tsplit, T* __restrict__ wout, int kc, int rt, int zidx) {
   using G = FragGeom<T>;
   constexpr int KC = G::KC, PAIRS = G::PAIRS, TQ = G::TQ;
-  __shared__ float s5[PAIRS * TAPS];
-  __shared__ float s3[PAIRS * 27];
-  __shared__ float s1[PAIRS], sa3[PAIRS], sa5[PAIRS];
+  float* s5 = L.s5; float* s3 = L.s3; float* s1 = L.s1; float* sa3 = L.sa3; float* sa5 = L.sa5;
+  auto& sg = L.sg;
   const int tid = threadIdx.x;
-  const int kc = blockIdx.x, rt = blockIdx.y, grp = blockIdx.z / tsplit, part = blockIdx.z % tsplit;
+  const int grp = zidx / tsplit, part = zidx % tsplit;
   const size_t tile_elems = 32 * KC;
   const size_t tap_stride = (size_t)nrt * nkc * tile_elems;
   const size_t slot_stride = (size_t)TAPS * tap_stride;
@@ -149,7 +158,6 @@ __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
   const size_t in_tile = (size_t)(grp * 4 + r4) * KC + k;
   // gate probabilities of the channels this workgroup touches go through LDS once (chunks of 16 slots):
   // the merge loop then has no dependent global load in it (it was latency-bound at ~50 us per launch)
-  __shared__ float sg[16][E][KC];
   const size_t tile_off = ((size_t)rt * nkc + kc) * tile_elems + in_tile;
   // LDS column of this thread's two elements: wf -> the row's co (column r4), wd -> the reduction co (columns k, k+1)
   const int colA = WRITE_WD ? k : r4, colB = WRITE_WD ? k + 1 : r4;
@@ -207,6 +215,28 @@ __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
         store_pair<T>(wslot + (size_t)tap_out * tap_stride, ra, rb);
       }
     }
+  }
+}
+
+// Both filter roles in ONE launch: workgroups [0, nwf) build wf (rows = co), the rest wd (rows = ci, taps flipped).
+// Either count may be zero.  On the small layers the two halves are latency-bound and simply overlap.
+template <typename T>
+__global__ __launch_bounds__(256) void gatrep_fwd_kernel(
+    const float* __restrict__ k5, const float* __restrict__ k3, const float* __restrict__ k1,
+    const float* __restrict__ a3, const float* __restrict__ a5, const float* __restrict__ g, int nslots,
+    int co_n, int ci_n, int nwf, int nrt_f, int nkc_f, int ts_f, T* __restrict__ wf, int nrt_d, int nkc_d, int ts_d,
+    T* __restrict__ wd) {
+  __shared__ GatrepFwdLds<T> L;
+  int b = blockIdx.x;
+  if (b < nwf) {
+    const int kc = b % nkc_f; b /= nkc_f;
+    const int rt = b % nrt_f;
+    gatrep_fwd_body<T, false>(L, k5, k3, k1, a3, a5, g, nslots, co_n, ci_n, nrt_f, nkc_f, ts_f, wf, kc, rt, b / nrt_f);
+  } else {
+    b -= nwf;
+    const int kc = b % nkc_d; b /= nkc_d;
+    const int rt = b % nrt_d;
+    gatrep_fwd_body<T, true>(L, k5, k3, k1, a3, a5, g, nslots, co_n, ci_n, nrt_d, nkc_d, ts_d, wd, kc, rt, b / nrt_d);
   }
 }
 
@@ -421,20 +451,23 @@ static int gatrep_fwd_t(const float* k5, const float* k3, const float* k1, const
   // algorithmic bytes: 155 expert floats read once + 125 merged elements written per slot and layout
   const double bytes = (double)co * ci * (155.0 * 4 + 125.0 * nslots * sizeof(T) * ((wf ? 1 : 0) + (wd ? 1 : 0)));
   repmode_prof_begin(REPMODE_PROF_GATREP_FWD, bytes, s);
-  if (wf) {   // rows = co (padded to 32), reduction = ci (padded to KC)
-    const int nrt = repmode_padded_channels(co, dtype, 0) / 32, nkc = repmode_padded_channels(ci, dtype, 1) / KC;
-    const int ts = (long)nkc * nrt * 8 < 512 ? 4 : 1;   // small layers: split the taps over 4x more workgroups
-    hipLaunchKernelGGL((gatrep_fwd_kernel<T, false>), dim3(nkc, nrt, 8 * ts), dim3(256), 0, s, k5, k3, k1, a3, a5, g,
-                       nslots, co, ci, nrt, nkc, ts, static_cast<T*>(wf));
-    RM_LAUNCH_CHECK("gatrep_fwd(wf)");
+  // wf: rows = co (padded to 32), reduction = ci (padded to KC); wd: rows = ci, reduction = co, taps flipped
+  int nrt_f = 1, nkc_f = 1, ts_f = 1, nrt_d = 1, nkc_d = 1, ts_d = 1;
+  long nwf = 0, nwd = 0;
+  if (wf) {
+    nrt_f = repmode_padded_channels(co, dtype, 0) / 32; nkc_f = repmode_padded_channels(ci, dtype, 1) / KC;
+    ts_f = (long)nkc_f * nrt_f * 8 < 512 ? 4 : 1;   // small layers: split the taps over 4x more workgroups
+    nwf = (long)nkc_f * nrt_f * 8 * ts_f;
   }
-  if (wd) {   // rows = ci (padded to 32), reduction = co (padded to KC), taps flipped
-    const int nrt = repmode_padded_channels(ci, dtype, 0) / 32, nkc = repmode_padded_channels(co, dtype, 1) / KC;
-    const int ts = (long)nkc * nrt * 8 < 512 ? 4 : 1;
-    hipLaunchKernelGGL((gatrep_fwd_kernel<T, true>), dim3(nkc, nrt, 8 * ts), dim3(256), 0, s, k5, k3, k1, a3, a5, g,
-                       nslots, co, ci, nrt, nkc, ts, static_cast<T*>(wd));
-    RM_LAUNCH_CHECK("gatrep_fwd(wd)");
+  if (wd) {
+    nrt_d = repmode_padded_channels(ci, dtype, 0) / 32; nkc_d = repmode_padded_channels(co, dtype, 1) / KC;
+    ts_d = (long)nkc_d * nrt_d * 8 < 512 ? 4 : 1;
+    nwd = (long)nkc_d * nrt_d * 8 * ts_d;
   }
+  RM_REQUIRE(nwf + nwd < (1L << 31), "gatrep_fwd: grid too large");
+  hipLaunchKernelGGL((gatrep_fwd_kernel<T>), dim3((unsigned)(nwf + nwd)), dim3(256), 0, s, k5, k3, k1, a3, a5, g, nslots, co,
+                     ci, (int)nwf, nrt_f, nkc_f, ts_f, static_cast<T*>(wf), nrt_d, nkc_d, ts_d, static_cast<T*>(wd));
+  RM_LAUNCH_CHECK("gatrep_fwd");
   repmode_prof_end(s);
   return REPMODE_OK;
 }

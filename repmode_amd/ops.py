@@ -80,7 +80,10 @@ class ZeroPool:
         if self.key is not None:
             self.req.append(n)
             if self.buf is not None and self.pos < len(self.plan) and self.plan[self.pos] == n:
-                t = self.buf[self.off:self.off + n].view(shape)
+                # an independent tensor over the pool's storage (not a view: views would share ONE version counter,
+                # and an in-place torch op on any of them would invalidate every saved one for autograd)
+                t = torch.empty(0, dtype=torch.float32, device=device).set_(
+                    self.buf.untyped_storage(), self.off, tuple(int(v) for v in shape))
                 self.off += -(-n // self.ALIGN) * self.ALIGN
                 self.pos += 1
                 return t, True
@@ -549,11 +552,11 @@ def expert_mix_fwd(p, gn):
 def expert_mix_bwd(dy, p, gn, dtype):
     """(dg [N,5,Co], dye_lo [2,N,D,H,W,Co] in ``dtype``, dye_hi [3,...] float) from dy, the expert outputs and g."""
     _, n, d, h, w, co = p.shape
-    dg = torch.empty((n, NUM_EXPERTS, co), dtype=torch.float32, device=p.device)
+    dg, pre = ZERO_POOL.take((n, NUM_EXPERTS, co), p.device)
     lo = torch.empty((2, n, d, h, w, co), dtype=dtype, device=p.device)
     hi = torch.empty((3, n, d, h, w, co), dtype=torch.float32, device=p.device)
     _lib.call('repmode_expert_mix_bwd', _ptr(dy), _ptr(p), _ptr(gn), _ptr(dg), _ptr(lo), _ptr(hi), n, d * h * w, co,
-              dtype_code(dtype), _stream())
+              dtype_code(dtype) | (16 if pre else 0), _stream())
     return dg, lo, hi
 
 
@@ -583,9 +586,9 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         wf2, wd2 = expert_frags(k5, k3, x_cl.dtype, want_wd=ctx.needs_input_grad[0])
         s0, s1 = _SingleSlot(n, dev, 0), _SingleSlot(n, dev, 1)
         d, h, w = x_cl.shape[1:4]
-        p = torch.empty((NUM_EXPERTS, n, d, h, w, co), dtype=torch.float32, device=dev)   # expert outputs P_e
-        conv5(x_cl, wf2, s0.sample_slot, co, out_f32=True, out=p[0])
-        conv5(x_cl, wf2, s1.sample_slot, co, out_f32=True, out=p[1], centre3=True)      # 3x3x3 support
+        p, pre = ZERO_POOL.take((NUM_EXPERTS, n, d, h, w, co), dev)                       # expert outputs P_e
+        conv5(x_cl, wf2, s0.sample_slot, co, out_f32=True, out=p[0], accumulate=pre)
+        conv5(x_cl, wf2, s1.sample_slot, co, out_f32=True, out=p[1], centre3=True, accumulate=pre)   # 3x3x3 support
         # the three 1x1 experts as ONE batched GEMM: [x | box3(x) | box5(x)] @ [K1 | A3 | A5]^T  -> P_2..P_4
         xb = torch.empty((3, n, d, h, w, ci), dtype=torch.float32, device=dev)
         xb[0].copy_(x_cl)
