@@ -149,6 +149,13 @@ __device__ __forceinline__ void gatrep_fwd_body(
     sa3[tid] = live ? a3[oi] * (1.0f / 27.0f) : 0.f;
     sa5[tid] = live ? a5[oi] * (1.0f / 125.0f) : 0.f;
   }
+  // gate probabilities of the first 16 slots: loaded here, with everything else the workgroup needs, before the
+  // first barrier (one round trip to memory instead of two when the inputs are cold)
+  for (int i = tid; i < min(16, nslots) * E * KC; i += 256) {
+    const int col = i % KC, e = (i / KC) % E, sl = i / (KC * E);
+    const int cog = WRITE_WD ? kc * KC + col : rt * 32 + grp * 4 + (col & 3);
+    sg[sl][e][col] = g[((size_t)sl * E + e) * co_n + min(cog, co_n - 1)];
+  }
   __syncthreads();
   // ---- merge: this thread owns elements pr and pr + 1 (adjacent reduction channels of one row)
   const int p2 = tid % (PAIRS / 2), tq = tid / (PAIRS / 2);
@@ -184,14 +191,16 @@ __device__ __forceinline__ void gatrep_fwd_body(
   const float e2a = s1[pr], e2b = s1[pr + 1], e3a = sa3[pr], e3b = sa3[pr + 1], e4a = sa5[pr], e4b = sa5[pr + 1];
   for (int s0 = 0; s0 < nslots; s0 += 16) {
     const int ns = min(16, nslots - s0);
-    __syncthreads();
-    for (int i = tid; i < ns * E * KC; i += 256) {
-      const int col = i % KC, e = (i / KC) % E, sl = i / (KC * E);
-      // column -> co: wf: rows grp*4 + col (col < 4), wd: reduction channels kc*KC + col
-      const int co = WRITE_WD ? kc * KC + col : rt * 32 + grp * 4 + (col & 3);
-      sg[sl][e][col] = g[((size_t)(s0 + sl) * E + e) * co_n + min(co, co_n - 1)];
+    if (s0 > 0) {
+      __syncthreads();
+      for (int i = tid; i < ns * E * KC; i += 256) {
+        const int col = i % KC, e = (i / KC) % E, sl = i / (KC * E);
+        // column -> co: wf: rows grp*4 + col (col < 4), wd: reduction channels kc*KC + col
+        const int co = WRITE_WD ? kc * KC + col : rt * 32 + grp * 4 + (col & 3);
+        sg[sl][e][col] = g[((size_t)(s0 + sl) * E + e) * co_n + min(co, co_n - 1)];
+      }
+      __syncthreads();
     }
-    __syncthreads();
     for (int sl = 0; sl < ns; ++sl) {
       const float ga0 = sg[sl][0][colA], ga1 = sg[sl][1][colA], ga2 = sg[sl][2][colA], ga3 = sg[sl][3][colA], ga4 = sg[sl][4][colA];
       const float gb0 = sg[sl][0][colB], gb1 = sg[sl][1][colB], gb2 = sg[sl][2][colB], gb3 = sg[sl][3][colB], gb4 = sg[sl][4][colB];
@@ -301,33 +310,51 @@ __global__ __launch_bounds__(GF_THREADS, SG > 2 ? 1 : 2) void gatrep_bwd_kernel(
   const int c0 = blockIdx.x * GF_CT;
   const int nlive = min(GF_CT, ci_n - c0);
   const size_t base = (size_t)co * ci_n + c0;
+  const int c = tid & (GF_CT - 1), tq = tid / GF_CT;
+  const bool live = c < nlive;
+  const size_t oi = base + (live ? c : 0);
+  const size_t tap_stride = (size_t)co_n * ci_n;
+  // Every global load this workgroup needs before its first reduction is issued up front, BEFORE anything waits: the
+  // first round's filter gradients (SG x 16 per thread), the expert slabs, the 1x1 experts and the gate
+  // probabilities.  In the train step these are cold (the filter gradient was just written by another kernel): the
+  // prologue used to be three dependent round trips to HBM (50-70 us per launch cold vs 25 us warm).
+  float dpre[SG][GB_NT];
+#pragma unroll
+  for (int j = 0; j < SG; ++j) {
+    const float* dws = dw + (size_t)min(j, nslots - 1) * TAPS * tap_stride + oi;
+#pragma unroll
+    for (int k = 0; k < GB_NT; ++k) {
+      const int tap = tq + 8 * k;
+      dpre[j][k] = (tap < TAPS && live && j < nslots) ? dws[(size_t)tap * tap_stride] : 0.f;
+    }
+  }
+  const float w1 = live ? k1[oi] : 0.f;
+  const float w3 = live ? a3[oi] * (1.0f / 27.0f) : 0.f;
+  const float w5 = live ? a5[oi] * (1.0f / 125.0f) : 0.f;
+  __shared__ float sgb[64][E];
   {
-    // issue all loads first (see gatrep_fwd_kernel): 32 * 125 / 256 -> 16 + 4 loads per thread
-    float v5[16], v3[4];
+    float v5[16], v3[4], vg[2];
 #pragma unroll
     for (int j = 0; j < 16; ++j) { const int i = tid + j * GF_THREADS; v5[j] = i < nlive * TAPS ? k5[base * TAPS + i] : 0.f; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int i = tid + j * GF_THREADS; v3[j] = i < nlive * 27 ? k3[base * 27 + i] : 0.f; }
+    // this output channel's gate probabilities for every slot (up to 64 slots through LDS: 320 values)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = tid + j * GF_THREADS;
+      vg[j] = i < min(nslots, 64) * E ? g[((size_t)(i / E) * E + i % E) * co_n + co] : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) { const int i = tid + j * GF_THREADS; if (i < GF_CT * TAPS) s5[i] = v5[j]; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int i = tid + j * GF_THREADS; if (i < GF_CT * 27) s3[i] = v3[j]; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int i = tid + j * GF_THREADS; if (i < 64 * E) sgb[i / E][i % E] = vg[j]; }
   }
-  __syncthreads();
-  const int c = tid & (GF_CT - 1), tq = tid / GF_CT;
-  const bool live = c < nlive;
-  const size_t oi = base + (live ? c : 0);
-  const float w1 = live ? k1[oi] : 0.f;
-  const float w3 = live ? a3[oi] * (1.0f / 27.0f) : 0.f;
-  const float w5 = live ? a5[oi] * (1.0f / 125.0f) : 0.f;
-  const size_t tap_stride = (size_t)co_n * ci_n;
   float acc5[GB_NT], acc3[GB_NT];
 #pragma unroll
   for (int k = 0; k < GB_NT; ++k) { acc5[k] = 0.f; acc3[k] = 0.f; }
   float acc1 = 0.f, acca3 = 0.f, acca5 = 0.f;     // meaningful in threads tid < 32 only
-  // this output channel's gate probabilities for every slot, once, through LDS (up to 64 slots)
-  __shared__ float sgb[64][E];
-  for (int i = tid; i < min(nslots, 64) * E; i += GF_THREADS) sgb[i / E][i % E] = g[((size_t)(i / E) * E + i % E) * co_n + co];
   __syncthreads();
   // Slots are taken SG at a time: their filter-gradient loads are independent (all in flight together) and the
   // per-slot partial sums stay in registers until ONE block reduction per round.  (One load -> reduce -> barrier
@@ -350,7 +377,7 @@ __global__ __launch_bounds__(GF_THREADS, SG > 2 ? 1 : 2) void gatrep_bwd_kernel(
         for (int k = 0; k < GB_NT; ++k) {
           const int tap = tq + 8 * k;
           if (tap < TAPS && live) {      // dead lanes must not touch the (uninitialised) slab tail
-            const float d = dws[(size_t)tap * tap_stride];
+            const float d = s0 == 0 ? dpre[j][k] : dws[(size_t)tap * tap_stride];
             int t3;
             const bool c3 = in_centre3(tap, t3);
             q[j][4] += d;

@@ -25,11 +25,14 @@ for co, ci in ((32, 32), (64, 64), (128, 128), (256, 128), (512, 512)):
                   ops._ptr(dgw), ops._ptr(dgb), ops._ptr(ws), ops._stream())
     def fwd():
         return ops.gatrep_merge(k5, k3, k1, a3, a5, g, torch.bfloat16, want_wf=True, want_wd=True)
+    flush = torch.empty(128 * 1024 * 1024, device=dev) if os.environ.get('GATREP_COLD') else None   # 512 MB: evicts L2 + MALL
     for name, fn in (('fwd', fwd), ('bwd', bwd)):
         for _ in range(5): fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(50): fn()
+        for _ in range(50):
+            if flush is not None: flush.zero_()
+            fn()
         e1.record(); torch.cuda.synchronize()
         print('gatrep %s co=%d ci=%d: %.1f us/call (host+gpu)' % (name, co, ci, e0.elapsed_time(e1) / 50 * 1e3))
