@@ -174,6 +174,17 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
 
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     const int ci0 = chunk * KC;
+    // The first filter row of the chunk is requested before the halo staging, not behind its barrier: the two
+    // fetches are independent, and after a kernel boundary both come from HBM / MALL, not L2.
+    u32x4 a_first[5];
+    if constexpr (CW == 1) {
+      if (!a.dxc) {
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx)
+          a_first[dx] = *reinterpret_cast<const u32x4*>(wrow[0] + (size_t)((dz_lo * 5 + dy_lo) * 5 + dx) * tap_stride +
+                                                        (size_t)chunk * (32 * KC));
+      }
+    }
     RM_STAMP((chunk - c_begin) * 4 + 0);
     __syncthreads();  // all waves finished reading the previous chunk's halo image
     RM_STAMP((chunk - c_begin) * 4 + 1);
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
     } else if constexpr (CW == 1) {
       u32x4 a_cur[5], a_nxt[5];
 #pragma unroll
-      for (int dx = 0; dx < 5; ++dx) a_cur[dx] = wfrag(0, (dz * 5 + dy) * 5 + dx);
+      for (int dx = 0; dx < 5; ++dx) a_cur[dx] = a_first[dx];
       // voxel fragments are double-buffered one tap ahead so that the LDS latency of tap t+1 hides
       // under the MFMAs of tap t
       u32x4 b_cur[VW], b_nxt[VW];
