@@ -251,6 +251,12 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
   for (int t = 0; t < 25; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // which samples belong to this workgroup's slot: one vector load + ballot for the first 64 samples instead of a
+  // chain of dependent scalar loads (cold after the kernel boundary: ~2 us each before the first tile is fetched)
+  const unsigned long long mine64 =
+      __ballot(lane < a.N && a.sample_slot[min(lane, a.N - 1)] == slot);
+  auto in_slot = [&](int n) -> bool { return n < 64 ? ((mine64 >> n) & 1ull) != 0 : a.sample_slot[n] == slot; };
+
   const int t_begin = chunk * a.tiles_per_block;
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_block);
   constexpr int NPAIR = TX / 2 + 2;                // x pairs covering x0-2 .. x0+TX+1
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
       for (;;) {
         if (++tile >= t_end) {
           tile = t_begin;
-          do { ++n; } while (n < a.N && a.sample_slot[n] != slot);
+          do { ++n; } while (n < a.N && !in_slot(n));
           if (n >= a.N) return false;
         }
         const int z0 = (tile / (a.ntx * a.nty)) * TZ;
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
   } else {
   const bool vec_x = (Cin & 7) == 0, vec_dy = (Cout & 7) == 0;
   for (int n = 0; n < a.N; ++n) {
-  if (a.sample_slot[n] != slot) continue;             // the workgroup sums over the samples of its slot
+  if (!in_slot(n)) continue;                          // the workgroup sums over the samples of its slot
   const bf16_t* __restrict__ xn = static_cast<const bf16_t*>(a.x) + (size_t)n * D * H * W * Cin;
   const bf16_t* __restrict__ dyn = static_cast<const bf16_t*>(a.dy) + (size_t)n * D * H * W * Cout;
   for (int tile = t_begin; tile < t_end; ++tile) {
