@@ -520,6 +520,9 @@ extern "C" int repmode_debug_wgrad_timing(unsigned long long* out) {
 namespace {
 #endif
 
+#ifndef WGRAD_PIPE_MINW
+#define WGRAD_PIPE_MINW 16
+#endif
 #ifndef WGRAD_ROUNDS
 #define WGRAD_ROUNDS 2
 #endif
@@ -556,7 +559,7 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, s);
   const size_t sample_bytes = (size_t)a.D * a.H * a.W * (a.Cin > a.Cout ? a.Cin : a.Cout) * 2;
   // (levels with W < 16 hand a workgroup only a tile or two per sample: nothing to overlap, and the old loop is ~15 % faster there)
-  if ((a.Cin & 7) == 0 && (a.Cout & 7) == 0 && a.W >= 16 && sample_bytes < ((size_t)1 << 31))
+  if ((a.Cin & 7) == 0 && (a.Cout & 7) == 0 && a.W >= WGRAD_PIPE_MINW && sample_bytes < ((size_t)1 << 31))
     hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
