@@ -198,8 +198,13 @@ class Net(torch.nn.Module):
             ops.ZERO_POOL.end()
         if self.training and not plan.bn_counted:
             # num_batches_tracked of the 26 BatchNorm layers: one multi-tensor launch instead of 26
-            counters = [m.num_batches_tracked for m in self.modules()
-                        if isinstance(m, torch.nn.BatchNorm3d) and m.track_running_stats]
+            counters = getattr(self, '_bn_counters', None)
+            # (cached; rebuilt when the buffers were replaced, e.g. by .to(device): the probe is the last BN's buffer)
+            if counters is None or counters[-1] is not self._bn_probe.num_batches_tracked:
+                bns = [m for m in self.modules() if isinstance(m, torch.nn.BatchNorm3d) and m.track_running_stats]
+                counters = [m.num_batches_tracked for m in bns]
+                object.__setattr__(self, '_bn_counters', counters)
+                object.__setattr__(self, '_bn_probe', bns[-1] if bns else None)
             if counters:
                 torch._foreach_add_(counters, 1)
             plan.bn_counted = True

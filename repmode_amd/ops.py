@@ -30,7 +30,8 @@ def _ptr(t):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of the calling thread's current stream (the Stream-object route costs ~10 us per call, 600 calls a step)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _require_hip(t, what):
