@@ -254,8 +254,10 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
   // which samples belong to this workgroup's slot: one vector load + ballot for the first 64 samples instead of a
   // chain of dependent scalar loads (cold after the kernel boundary: ~2 us each before the first tile is fetched)
   const unsigned long long mine64 =
-      __ballot(lane < a.N && a.sample_slot[min(lane, a.N - 1)] == slot);
-  auto in_slot = [&](int n) -> bool { return n < 64 ? ((mine64 >> n) & 1ull) != 0 : a.sample_slot[n] == slot; };
+      a.nslots == 1 ? ~0ull : __ballot(lane < a.N && a.sample_slot[min(lane, a.N - 1)] == slot);   // one slot: every sample
+  auto in_slot = [&](int n) -> bool {
+    return n < 64 ? ((mine64 >> n) & 1ull) != 0 : (a.nslots == 1 || a.sample_slot[n] == slot);
+  };
 
   const int t_begin = chunk * a.tiles_per_block;
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_block);
