@@ -186,6 +186,10 @@ int repmode_k2_frags(const float* w, int rows, int red, int red_major, int dtype
 int repmode_expert_mix_fwd(const float* p, const float* g, float* y, int n, long v, int c, void* stream);
 int repmode_expert_mix_bwd(const float* dy, const float* p, const float* g, float* dg, void* dye_lo,
                            float* dye_hi, int n, long v, int c, int dtype, void* stream);
+/* Same with hi_stride elements (>= n*v*c) between the three float outputs dye_hi[e]: lets the caller pad them (the
+ * batched GEMMs behind them hit a pathological rocBLAS kernel at exactly 256 x 256 outputs). */
+int repmode_expert_mix_bwd_ex(const float* dy, const float* p, const float* g, float* dg, void* dye_lo,
+                              float* dye_hi, long hi_stride, int n, long v, int c, int dtype, void* stream);
 
 /* ---- box means of the avg-pool experts (RepMode.py:139-142, 161-163, 176-180): by linearity
  * conv(x, w1x1 (x) 1/k^3) = w1x1 applied to the zero-padded k^3 box mean of x.

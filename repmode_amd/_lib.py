@@ -43,6 +43,7 @@ _SIGNATURES = {
     'repmode_k2_frags': [_P, _I, _I, _I, _I, _P, _P],
     'repmode_expert_mix_fwd': [_P, _P, _P, _I, _c.c_long, _I, _P],
     'repmode_expert_mix_bwd': [_P, _P, _P, _P, _P, _P, _I, _c.c_long, _I, _I, _P],
+    'repmode_expert_mix_bwd_ex': [_P, _P, _P, _P, _P, _P, _c.c_long, _I, _c.c_long, _I, _I, _P],
     'repmode_box_sum': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'repmode_box_sum_ex': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'repmode_tap_transpose': [_P, _P, _c.c_long, _I, _P],

@@ -60,7 +60,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void expert_mix_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ p,
                                                              const float* __restrict__ g, float* __restrict__ dg,
                                                              T* __restrict__ dye_lo, float* __restrict__ dye_hi, int N,
-                                                             long V, int C, long vchunk) {
+                                                             long V, int C, long vchunk, long hi_stride) {
   __shared__ float red[E * 512];
   const int c4n = (C + 3) / 4;
   const int n = blockIdx.y;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void expert_mix_bwd_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < 4; ++k) { part[e][k] += d[k] * pv[k]; o[k] = gv[e][k] * d[k]; }
         if (e < 2) store4<T>(dye_lo + e * estride + off, o, c, C, vec);
-        else store4<float>(dye_hi + (e - 2) * estride + off, o, c, C, vec);
+        else store4<float>(dye_hi + (e - 2) * (size_t)hi_stride + off, o, c, C, vec);
       }
     }
   }
@@ -121,10 +121,20 @@ extern "C" int repmode_expert_mix_fwd(const float* p, const float* g, float* y, 
 }
 
 // dg [N][5][C] (overwritten), dye_lo [2][N][V][C] in `dtype`, dye_hi [3][N][V][C] float.
+extern "C" int repmode_expert_mix_bwd_ex(const float* dy, const float* p, const float* g, float* dg, void* dye_lo,
+                                         float* dye_hi, long hi_stride, int n, long v, int c, int dtype, void* stream);
+
 extern "C" int repmode_expert_mix_bwd(const float* dy, const float* p, const float* g, float* dg, void* dye_lo,
                                       float* dye_hi, int n, long v, int c, int dtype, void* stream) {
+  return repmode_expert_mix_bwd_ex(dy, p, g, dg, dye_lo, dye_hi, (long)n * v * c, n, v, c, dtype, stream);
+}
+
+// hi_stride: elements between the three float outputs dye_hi[e] (>= n * v * c; lets the caller pad each of them)
+extern "C" int repmode_expert_mix_bwd_ex(const float* dy, const float* p, const float* g, float* dg, void* dye_lo,
+                                         float* dye_hi, long hi_stride, int n, long v, int c, int dtype, void* stream) {
   const int prezeroed = dtype & 16;     // bit 4 of dtype: dg has been cleared by the caller (pooled memset)
   dtype &= 15;
+  RM_REQUIRE(hi_stride >= (long)n * v * c, "expert_mix_bwd: hi_stride too small");
   RM_REQUIRE(dy && p && g && dg && dye_lo && dye_hi && n > 0 && v > 0 && c > 0 && c <= 512, "expert_mix_bwd: bad argument");
   RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "expert_mix_bwd: bad dtype %d", dtype);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -137,10 +147,10 @@ extern "C" int repmode_expert_mix_bwd(const float* dy, const float* p, const flo
   const dim3 grid((unsigned)((v + vchunk - 1) / vchunk), (unsigned)n);
   if (dtype == REPMODE_F32)
     hipLaunchKernelGGL(expert_mix_bwd_kernel<float>, grid, dim3(256), 0, s, dy, p, g, dg, static_cast<float*>(dye_lo), dye_hi,
-                       n, v, c, vchunk);
+                       n, v, c, vchunk, hi_stride);
   else
     hipLaunchKernelGGL(expert_mix_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, dy, p, g, dg, static_cast<bf16_t*>(dye_lo),
-                       dye_hi, n, v, c, vchunk);
+                       dye_hi, n, v, c, vchunk, hi_stride);
   RM_LAUNCH_CHECK("expert_mix_bwd");
   return REPMODE_OK;
 }

@@ -551,13 +551,23 @@ def expert_mix_fwd(p, gn):
 
 
 def expert_mix_bwd(dy, p, gn, dtype):
-    """(dg [N,5,Co], dye_lo [2,N,D,H,W,Co] in ``dtype``, dye_hi [3,...] float) from dy, the expert outputs and g."""
+    """(dg [N,5,Co], dye_lo [2,N,D,H,W,Co] in ``dtype``, dye_hi [3, M(+pad), Co] float) from dy, the expert outputs and
+    g; M = N*D*H*W voxel rows.  dye_hi's three matrices feed batched GEMMs; rocBLAS picks a pathological kernel when
+    such a GEMM has exactly 256 x 256 (or 128 x 256) outputs (118 us instead of 18), so for small M each matrix gets
+    8 rows of zero padding."""
     _, n, d, h, w, co = p.shape
+    m = n * d * h * w
+    pad = 8 if m <= 512 else 0
     dg, pre = ZERO_POOL.take((n, NUM_EXPERTS, co), p.device)
     lo = torch.empty((2, n, d, h, w, co), dtype=dtype, device=p.device)
-    hi = torch.empty((3, n, d, h, w, co), dtype=torch.float32, device=p.device)
-    _lib.call('repmode_expert_mix_bwd', _ptr(dy), _ptr(p), _ptr(gn), _ptr(dg), _ptr(lo), _ptr(hi), n, d * h * w, co,
-              dtype_code(dtype) | (16 if pre else 0), _stream())
+    if pad:
+        hi, hpre = ZERO_POOL.take((3, m + pad, co), p.device)
+        if not hpre:
+            hi[:, m:].zero_()
+    else:
+        hi = torch.empty((3, m, co), dtype=torch.float32, device=p.device)
+    _lib.call('repmode_expert_mix_bwd_ex', _ptr(dy), _ptr(p), _ptr(gn), _ptr(dg), _ptr(lo), _ptr(hi), (m + pad) * co, n,
+              d * h * w, co, dtype_code(dtype) | (16 if pre else 0), _stream())
     return dg, lo, hi
 
 
@@ -623,8 +633,10 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
             # 1x1 experts: one batched GEMM gives the three partial data gradients; the zero-padded box
             # mean is self-adjoint, so the avg experts' parts go back through box3 / box5 -- summed with the
             # two conv parts and cast in the same kernel
-            t = torch.bmm(dhi.view(3, -1, co), w1).view(3, *shp)                          # [3, N, D, H, W, Ci]
-            dx = box_sum(in3=t[1], in5=t[2], add=(dxf, t[0]), out_dtype=dt)
+            m = dxf.numel() // ci
+            t = torch.bmm(dhi, w1)                                                        # [3, M(+pad), Ci]
+            tv = [t[e, :m].view(shp) for e in range(3)]
+            dx = box_sum(in3=tv[1], in5=tv[2], add=(dxf, tv[0]), out_dtype=dt)
             del wd2
         # ---- expert gradients: filter gradients of the gate-scaled dy, all samples in one slot.  Large layers (every
         # workgroup owns its outputs: no atomics) write the parameters' [Co][Ci][taps] layout directly, each wave
@@ -639,7 +651,7 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
             dk3 = conv5_wgrad(x_cl, d01[1], one, co, expert_layout=3)
         else:
             dk3 = tap_transpose(conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0], k3.shape)
-        d1 = torch.bmm(dhi.view(3, -1, co).transpose(1, 2), xb.view(3, -1, ci))           # [3, Co, Ci]
+        d1 = torch.bmm(dhi[:, :xb[0].numel() // ci].transpose(1, 2), xb.view(3, -1, ci))   # [3, Co, Ci]
         dk1, da3, da5 = d1[0].reshape(k1.shape), d1[1].reshape(a3.shape), d1[2].reshape(a5.shape)
         return dx, dk5, dk3, dk1, da3, da5, dgw, dgb, None
 

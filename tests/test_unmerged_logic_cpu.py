@@ -93,7 +93,7 @@ def fake_kernels(monkeypatch):
     def mix_bwd(dy, p, gn, dtype):
         dg = (p * dy[None]).sum((2, 3, 4)).permute(1, 0, 2).contiguous()
         dye = dy[None] * gn.permute(1, 0, 2)[:, :, None, None, None, :]
-        return dg, dye[:2].to(dtype).contiguous(), dye[2:].contiguous()
+        return dg, dye[:2].to(dtype).contiguous(), dye[2:].reshape(3, -1, dye.shape[-1]).contiguous()
 
     for name, fn in dict(gate_softmax=gate, gate_softmax_samples=gate_samples, gate_bwd=gate_bwd, tap_transpose=tap_t,
                          gatrep_merge=merge, expert_frags=xfrags, conv5=conv5, conv5_wgrad=wgrad, box_sum=box,
