@@ -31,6 +31,7 @@ import torch  # noqa: E402
 
 PATCH = (32, 64, 64)
 PER_GPU_BATCH = 8
+PROF_EVERY = 5           # the per-launch HIP events of the roofline are taken on every 5th timed step
 MULT_CHAN = 32
 NUM_TASKS = 12
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
@@ -114,11 +115,18 @@ def main():
     for _ in range(args.warmup):
         model.do_train_iter(signal, target, task)
     barrier()
+    # HIP events around the dominant kernel's launches only by default, and on every PROF_EVERY-th timed step (each
+    # event pair costs ~4 us of stream time: ~0.5 ms per step if every launch of every step were bracketed)
+    sample = 1 if (args.prof_all or args.dump_launches) else PROF_EVERY
     if not args.no_prof:
-        # HIP events around the dominant kernel's launches only by default (each pair costs ~4 us of stream time)
         _lib.prof_enable(1 if (args.prof_all or args.dump_launches) else 2)
+    profiled_steps = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for step in range(args.steps):
+        if not args.no_prof:
+            on = step % sample == 0
+            _lib.prof_pause(not on)
+            profiled_steps += on
         model.do_train_iter(signal, target, task)
     t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (== dt when the host is the limiter)
     barrier()
@@ -153,7 +161,7 @@ def main():
                 n, ms, work = _lib.prof_summary(kind)
                 if n == 0:
                     continue          # kind not recorded (default: the dominant kernel only; --prof-all for all)
-                kinds[kind] = {'launches': n, 'ms_per_step': ms / args.steps,
+                kinds[kind] = {'launches': n, 'ms_per_step': ms / max(profiled_steps, 1),
                                'rate': (work / (ms * 1e-3) / 1e12) if ms > 0 else None}   # TFLOP/s or TB/s
             n, ms, flops = _lib.prof_summary('conv5_igemm')
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -171,7 +179,7 @@ def main():
             out['kernels'] = kinds
             if args.dump_launches:
                 recs = _lib.prof_records()
-                per = len(recs) // args.steps
+                per = len(recs) // max(profiled_steps, 1)
                 last = [{'kind': k, 'us': ms * 1e3, 'rate': (w / (ms * 1e-3) / 1e12) if ms > 0 else None,
                          'work': w} for k, ms, w in recs[-per:]]
                 with open(args.dump_launches, 'w') as f:

@@ -227,6 +227,8 @@ int repmode_expert_frags(const float* k5, const float* k3, int co, int ci, void*
 #define REPMODE_PROF_WGRAD_THIN 4 /* conv5_wgrad_thin */
 #define REPMODE_PROF_KINDS 5
 int repmode_prof_enable(int on);
+/* Suspend (1) / resume (0) recording; the records so far are kept (sampling a subset of the steps). */
+int repmode_prof_pause(int paused);
 int repmode_prof_summary(int kind, int* launches, double* total_ms, double* total_work);
 /* individual records, in launch order: number of records, and the kind / duration (ms) / work of record i */
 int repmode_prof_count(void);

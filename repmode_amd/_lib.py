@@ -50,6 +50,7 @@ _SIGNATURES = {
     'repmode_gate_bwd': [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     'repmode_expert_frags': [_P, _P, _I, _I, _P, _P, _P],
     'repmode_prof_enable': [_I],
+    'repmode_prof_pause': [_I],
     'repmode_prof_summary': [_I, _P, _P, _P],
     'repmode_prof_count': [],
     'repmode_prof_record': [_I, _P, _P, _P],
@@ -112,6 +113,10 @@ PROF_KINDS = {'conv5_igemm': 0, 'conv5_wgrad': 1, 'gatrep_fwd': 2, 'gatrep_bwd':
 def prof_enable(on):
     """False/0: off; True/1: every kernel kind; 2: conv5_igemm only."""
     call('repmode_prof_enable', int(on))
+
+
+def prof_pause(paused):
+    call('repmode_prof_pause', int(bool(paused)))
 
 
 def prof_summary(kind):

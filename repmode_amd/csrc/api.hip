@@ -49,10 +49,11 @@ size_t g_prof_n = 0;           // records in use
 bool g_prof_on = false;
 unsigned g_prof_mask = ~0u;   // bit k set: record kernel kind k
 bool g_prof_open = false;
+bool g_prof_paused = false;
 }  // namespace
 
 void repmode_prof_begin(int kind, double work, hipStream_t s) {
-  if (!g_prof_on || !((g_prof_mask >> kind) & 1u)) return;
+  if (!g_prof_on || g_prof_paused || !((g_prof_mask >> kind) & 1u)) return;
   if (g_prof_n == g_prof.size()) {
     ProfRec r{};
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
@@ -107,6 +108,13 @@ extern "C" int repmode_prof_enable(int on) {
   g_prof_on = on != 0;
   g_prof_mask = (on == 2) ? (1u << REPMODE_PROF_CONV5) : ~0u;   // 2: the dominant kernel only (least perturbation)
   g_prof_open = false;
+  g_prof_paused = false;
+  return REPMODE_OK;
+}
+
+// pause / resume recording without discarding what has been recorded (bench.py samples every few steps)
+extern "C" int repmode_prof_pause(int paused) {
+  g_prof_paused = paused != 0;
   return REPMODE_OK;
 }
 
