@@ -525,6 +525,9 @@ namespace {
 #ifndef WGRAD_PIPE_MINW
 #define WGRAD_PIPE_MINW 16
 #endif
+#ifndef WGRAD_DIRECT_MIN
+#define WGRAD_DIRECT_MIN 512
+#endif
 #ifndef WGRAD_ROUNDS
 #define WGRAD_ROUNDS 2
 #endif
@@ -549,7 +552,7 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   }
   const long fixed = (long)a.nslots * a.ncot * a.ncit * a.ndz;
   // (from one workgroup per CU-slot-half on, keep whole voxel ranges together: direct stores, no memset, no atomics)
-  long want_chunks = (fixed >= 512 || fixed >= resident) ? 1 : (resident * WGRAD_ROUNDS) / fixed;
+  long want_chunks = (fixed >= WGRAD_DIRECT_MIN || fixed >= resident) ? 1 : (resident * WGRAD_ROUNDS) / fixed;
   if (want_chunks < 1) want_chunks = 1;
   if (want_chunks > a.ntiles) want_chunks = a.ntiles;
   a.tiles_per_block = ceil_div(a.ntiles, (int)want_chunks);
