@@ -1,6 +1,6 @@
 # regenerates the artefacts under gpurun_out/r01/ that get copied into profiles/ (run through gpurun)
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01; rm -rf $O; mkdir -p $O   # (gpurun merges into the local gpurun_out/: delete the local copy first too)
 cd $R
 python bench.py > $O/bench_line.json 2> $O/bench.err
 python bench.py --no-cpu-baseline --prof-all --dump-launches $O/launches_last_step.json > $O/bench_profall.json 2>> $O/bench.err
