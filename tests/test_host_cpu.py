@@ -125,3 +125,34 @@ def test_predict_helpers_match_golden():
     grid = patch_grid((64, 624, 924), (32, 128, 128))
     assert len(grid) == 378 and int(g['patches_64x624x924_nbatches']) == 48
     assert grid[0] == ([0, 0, 0], [32, 128, 128]) and grid[-1] == ([32, 496, 796], [64, 624, 924])
+
+
+def test_zero_pool_semantics():
+    """ops.ZeroPool on CPU tensors: the first step of a key records, later steps hand out zeroed, non-overlapping,
+    independently versioned tensors in the recorded order, and any divergence falls back to plain allocations."""
+    import torch
+    from repmode_amd.ops import ZeroPool
+    pool, dev = ZeroPool(), torch.device('cpu')
+    shapes = [(3, 5), (7,), (2, 2, 4)]
+    pool.begin('k', dev)
+    first = [pool.take(s, dev) for s in shapes]
+    assert all(not pre for _, pre in first)                      # recording step: nothing pooled
+    pool.begin('k', dev)                                         # (begin() closes the previous step)
+    got = [pool.take(s, dev) for s in shapes]
+    assert all(pre for _, pre in got)
+    ts = [t for t, _ in got]
+    assert all(float(t.abs().sum()) == 0.0 and tuple(t.shape) == s for t, s in zip(ts, shapes))
+    v1 = ts[1]._version
+    ts[0].fill_(1.0)                                             # in-place op on one tensor ...
+    assert ts[1]._version == v1 and float(ts[1].sum()) == 0.0    # ... neither touches nor re-versions another
+    ptrs = sorted((t.data_ptr(), t.numel() * 4) for t in ts)
+    assert all(a + n <= b for (a, n), (b, _) in zip(ptrs, ptrs[1:]))
+    extra, pre = pool.take((4,), dev)                            # more requests than recorded: plain allocation
+    assert not pre
+    pool.begin('k', dev)
+    _, pre0 = pool.take(shapes[0], dev)
+    _, pre1 = pool.take((9, 9), dev)                             # diverges from the recorded sequence
+    _, pre2 = pool.take(shapes[2], dev)
+    assert pre0 and not pre1 and not pre2
+    pool.end()
+    assert pool.take((3,), dev)[1] is False                      # inactive pool
