@@ -13,7 +13,6 @@ from . import _lib
 
 NUM_EXPERTS = 5
 TAPS = 125
-BN_SLICES = 16      # partial-sum slices of the BatchNorm reductions (bnrelu.hip)
 
 _DTYPE_CODE = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
 
