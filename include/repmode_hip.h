@@ -177,6 +177,10 @@ int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float* dw, int n
  * out[p][rows/32][red/KC][32][KC] = w(row, red, p), with w stored [rows][red][2][2][2] (red_major == 0) or
  * [red][rows][2][2][2] (red_major != 0).  out: 8 * padded(rows) * padded(red) elements of `dtype`. */
 int repmode_k2_frags(const float* w, int rows, int red, int red_major, int dtype, void* out, void* stream);
+/* Same, plus (out_t != NULL) the operand with rows and red exchanged from the same launch: forward and
+ * data-gradient filters of a stride-2 stage together.  out_t: 8 * padded(red) * padded(rows) elements. */
+int repmode_k2_frags2(const float* w, int rows, int red, int red_major, int dtype, void* out, void* out_t,
+                      void* stream);
 
 /* ---- gate mixing of the per-expert formulation (linearity of RepMode.py:184-188 + :207).  p: float [5][n][v][c]
  * expert outputs, g: float [n][5][c] gate probabilities per SAMPLE.

@@ -351,11 +351,11 @@ extern "C" int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float
 // One launch instead of the pad / slice-copy / permute / cast chain.
 namespace {
 template <typename T>
-__global__ void k2_frags_kernel(const float* __restrict__ w, int rows, int red, int rowsP, int redP, int red_major,
-                                T* __restrict__ out) {
+__device__ __forceinline__ void k2_frags_one(const float* __restrict__ w, int rows, int red, int rowsP, int redP,
+                                             int red_major, T* __restrict__ out, long first, long step) {
   constexpr int KC = sizeof(T) == 2 ? 16 : 8;
   const long total = 8L * rowsP * redP;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  for (long i = first; i < total; i += step) {
     const int kk = (int)(i % KC);
     long t = i / KC;
     const int r32 = (int)(t % 32); t /= 32;
@@ -371,20 +371,43 @@ __global__ void k2_frags_kernel(const float* __restrict__ w, int rows, int red, 
     else out[i] = v;
   }
 }
+
+// the operand of one direction, and (out2 != nullptr) of the opposite one (rows <-> red, the other memory order of
+// w): forward and data-gradient filters of a stride-2 stage from one launch
+template <typename T>
+__global__ void k2_frags_kernel(const float* __restrict__ w, int rows, int red, int rowsP, int redP, int red_major,
+                                T* __restrict__ out, int rowsP2, int redP2, T* __restrict__ out2) {
+  const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, step = (long)gridDim.x * blockDim.x;
+  k2_frags_one<T>(w, rows, red, rowsP, redP, red_major, out, first, step);
+  if (out2) k2_frags_one<T>(w, red, rows, rowsP2, redP2, !red_major, out2, first, step);
+}
 }  // namespace
 
+extern "C" int repmode_k2_frags2(const float* w, int rows, int red, int red_major, int dtype, void* out, void* out_t,
+                                 void* stream);
+
 extern "C" int repmode_k2_frags(const float* w, int rows, int red, int red_major, int dtype, void* out, void* stream) {
+  return repmode_k2_frags2(w, rows, red, red_major, dtype, out, nullptr, stream);
+}
+
+// out_t (may be NULL): the operand with the roles of rows and red exchanged (same w): if `out` is the forward filter
+// of a stride-2 stage, out_t is the filter of its data gradient.  8 * padded(red) * padded(rows) elements.
+extern "C" int repmode_k2_frags2(const float* w, int rows, int red, int red_major, int dtype, void* out, void* out_t,
+                                 void* stream) {
   RM_REQUIRE(w && out, "k2_frags: null pointer");
   RM_REQUIRE(rows > 0 && red > 0, "k2_frags: bad shape");
   RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "k2_frags: bad dtype %d", dtype);
   const int rowsP = repmode_padded_channels(rows, dtype, 0), redP = repmode_padded_channels(red, dtype, 1);
+  const int rowsP2 = repmode_padded_channels(red, dtype, 0), redP2 = repmode_padded_channels(rows, dtype, 1);
   const long total = 8L * rowsP * redP;
   const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == REPMODE_BF16)
-    hipLaunchKernelGGL(k2_frags_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w, rows, red, rowsP, redP, red_major, (bf16_t*)out);
+    hipLaunchKernelGGL(k2_frags_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w, rows, red, rowsP, redP, red_major, (bf16_t*)out,
+                       rowsP2, redP2, (bf16_t*)out_t);
   else
-    hipLaunchKernelGGL(k2_frags_kernel<float>, dim3(grid), dim3(256), 0, s, w, rows, red, rowsP, redP, red_major, (float*)out);
+    hipLaunchKernelGGL(k2_frags_kernel<float>, dim3(grid), dim3(256), 0, s, w, rows, red, rowsP, redP, red_major, (float*)out,
+                       rowsP2, redP2, (float*)out_t);
   RM_LAUNCH_CHECK("k2_frags");
   return REPMODE_OK;
 }

@@ -365,14 +365,20 @@ def bn_relu(x_cl, bn, training, out_dtype, count=True):
                          out_dtype)
 
 
-def k2_weight_frags(weight, rows, red, red_major, dtype):
+def k2_weight_frags(weight, rows, red, red_major, dtype, both=False):
     """2x2x2 filter parameter (float, [rows][red][2][2][2] or, ``red_major``, [red][rows][2][2][2]) -> the
-    fragment-major operand [8][rowsP/32][redP/KC][32][KC] of the k2s2 kernel in ``dtype`` (one launch)."""
+    fragment-major operand [8][rowsP/32][redP/KC][32][KC] of the k2s2 kernel in ``dtype`` (one launch).  ``both``:
+    also the operand with rows and red exchanged (the stage's data-gradient filter) from the same launch."""
     code = dtype_code(dtype)
     rp, kp = _lib.padded_channels(rows, code, False), _lib.padded_channels(red, code, True)
     out = torch.empty((8, rp, kp), dtype=dtype, device=weight.device)
-    _lib.call('repmode_k2_frags', _ptr(weight), rows, red, 1 if red_major else 0, code, _ptr(out), _stream())
-    return out
+    if not both:
+        _lib.call('repmode_k2_frags', _ptr(weight), rows, red, 1 if red_major else 0, code, _ptr(out), _stream())
+        return out
+    out_t = torch.empty((8, _lib.padded_channels(red, code, False), _lib.padded_channels(rows, code, True)), dtype=dtype,
+                        device=weight.device)
+    _lib.call('repmode_k2_frags2', _ptr(weight), rows, red, 1 if red_major else 0, code, _ptr(out), _ptr(out_t), _stream())
+    return out, out_t
 
 
 def k2s2(in_cl, w_frag, cout, scatter):
@@ -430,18 +436,20 @@ class _Down2(torch.autograd.Function):
     def forward(ctx, x_cl, weight):
         _require_hip(x_cl, 'input')
         co, ci = weight.shape[:2]
-        wf = k2_weight_frags(weight, co, ci, False, x_cl.dtype)
-        ctx.save_for_backward(x_cl, weight)
+        if ctx.needs_input_grad[0]:
+            wf, wb = k2_weight_frags(weight, co, ci, False, x_cl.dtype, both=True)   # forward + data-gradient filters
+        else:
+            wf, wb = k2_weight_frags(weight, co, ci, False, x_cl.dtype), None
+        ctx.save_for_backward(x_cl, weight, wb)
         return k2s2(x_cl, wf, co, scatter=False)
 
     @staticmethod
     def backward(ctx, dy):
-        x_cl, weight = ctx.saved_tensors
+        x_cl, weight, wb = ctx.saved_tensors
         co, ci = weight.shape[:2]
         dy = dy.to(x_cl.dtype).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            wb = k2_weight_frags(weight, ci, co, True, x_cl.dtype)
             dx = k2s2(dy, wb, ci, scatter=True)
         dw = k2s2_wgrad(dy, x_cl, param_layout=1)                         # [Co, Ci, 2, 2, 2]
         return dx, dw
@@ -454,18 +462,20 @@ class _Up2(torch.autograd.Function):
     def forward(ctx, x_cl, weight):
         _require_hip(x_cl, 'input')
         ci, co = weight.shape[:2]
-        wf = k2_weight_frags(weight, co, ci, True, x_cl.dtype)
-        ctx.save_for_backward(x_cl, weight)
+        if ctx.needs_input_grad[0]:
+            wf, wb = k2_weight_frags(weight, co, ci, True, x_cl.dtype, both=True)
+        else:
+            wf, wb = k2_weight_frags(weight, co, ci, True, x_cl.dtype), None
+        ctx.save_for_backward(x_cl, weight, wb)
         return k2s2(x_cl, wf, co, scatter=True)
 
     @staticmethod
     def backward(ctx, dy):
-        x_cl, weight = ctx.saved_tensors
+        x_cl, weight, wb = ctx.saved_tensors
         ci, co = weight.shape[:2]
         dy = dy.to(x_cl.dtype).contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            wb = k2_weight_frags(weight, ci, co, False, x_cl.dtype)
             dx = k2s2(dy, wb, ci, scatter=False)
         dw = k2s2_wgrad(x_cl, dy, param_layout=1)                         # [Ci, Co, 2, 2, 2]
         return dx, dw

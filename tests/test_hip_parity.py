@@ -481,6 +481,9 @@ def test_k2_frags_and_param_layout_wgrad(dtype):
     assert torch.equal(got.flatten(), ref_frags(w.permute(2, 3, 4, 0, 1).reshape(8, co, ci)).flatten())
     got = ops.k2_weight_frags(w.to(DEV), ci, co, True, dtype).cpu()
     assert torch.equal(got.flatten(), ref_frags(w.permute(2, 3, 4, 1, 0).reshape(8, ci, co)).flatten())
+    a, b = ops.k2_weight_frags(w.to(DEV), co, ci, False, dtype, both=True)          # both roles from one launch
+    assert torch.equal(a.cpu().flatten(), ref_frags(w.permute(2, 3, 4, 0, 1).reshape(8, co, ci)).flatten())
+    assert torch.equal(b.cpu().flatten(), ref_frags(w.permute(2, 3, 4, 1, 0).reshape(8, ci, co)).flatten())
     if dtype == torch.bfloat16:
         coarse = torch.randn(2, 2, 4, 4, co, generator=gen).bfloat16().to(DEV)
         fine = torch.randn(2, 4, 8, 8, ci, generator=gen).bfloat16().to(DEV)
