@@ -90,12 +90,17 @@ def load():
     return lib
 
 
+_FUNCS = {}     # name -> bound foreign function (the hot path makes ~500 calls per train step)
+
+
 def call(name, *args):
     """Call an int-returning entry point; raise with the library's message on failure."""
-    lib = load()
-    rc = getattr(lib, name)(*args)
+    fn = _FUNCS.get(name)
+    if fn is None:
+        fn = _FUNCS[name] = getattr(load(), name)
+    rc = fn(*args)
     if rc != 0:
-        raise RepModeHipError('%s failed (code %d): %s' % (name, rc, lib.repmode_last_error().decode()))
+        raise RepModeHipError('%s failed (code %d): %s' % (name, rc, load().repmode_last_error().decode()))
 
 
 def padded_channels(channels, dtype_code, is_reduction_dim):

@@ -25,12 +25,12 @@ def dtype_code(dtype):
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()            # plain int: ctypes converts it for a c_void_p parameter (no wrapper object)
 
 
 def _stream():
     # raw handle of the calling thread's current stream (the Stream-object route costs ~10 us per call, 600 calls a step)
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _require_hip(t, what):
