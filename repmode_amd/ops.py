@@ -5,8 +5,6 @@ MoDE block runs in the hand-written HIP kernels of librepmode_hip.so.  Tensors h
 library are channels-last (NDHWC) and contiguous.  There is no CPU / eager fallback: calling an
 operator on a non-HIP tensor raises.
 """
-import ctypes
-
 import torch
 
 from . import _lib
@@ -585,8 +583,8 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
 
         y[n] = sum_e g[n, e, :] * conv(x[n], K_e)
 
-    The experts are shared by all samples, so nothing is merged per task: the 5^3 and 3^3 experts go
-    once through GatRep's layout pass as two pseudo-slots and the HIP conv kernels run them for the
+    The experts are shared by all samples, so nothing is merged per task: the 5^3 and 3^3 experts are
+    laid out once as two pseudo-slots (``expert_frags``) and the HIP conv kernels run them for the
     whole batch; the three 1x1 experts (conv1x1, avg3, avg5) are plain GEMMs on x and its box means.
     Used on the deep levels, where the weights (84 % of the network's parameters) dwarf the
     activations and the per-task merged filters / filter gradients of the merged path are pure HBM
