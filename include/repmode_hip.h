@@ -93,6 +93,15 @@ int repmode_conv5_ex(const void* x, const void* w, const int32_t* sample_slot, v
                      int h, int wdim, int cin, int cout, int dtype, int out_f32, int centre3,
                      void* stream);
 
+/* The same convolution with the input and / or the output channels split over two tensors: a U-Net skip connection
+ * without the concatenated copy (RepMode.py:106 torch.cat((x_skip, up), 1)).  Input channels [0, cin1) are read from
+ * x ([N][D][H][W][cin1]), [cin1, cin) from x2; output channels [0, cout1) are written to y ([...][cout1]), the rest
+ * to y2 (the data gradient of such a layer).  cin1 == 0 / cout1 == 0: one tensor (x2 / y2 ignored).  cin1 must be a
+ * multiple of 16 (bf16) / 8 (f32), cout1 of 32.  flags as repmode_conv5_ex's centre3 word. */
+int repmode_conv5_pair(const void* x, const void* x2, int cin1, const void* w, const int32_t* sample_slot, void* y,
+                       void* y2, int cout1, int n, int d, int h, int wdim, int cin, int cout, int dtype, int out_f32,
+                       int flags, void* stream);
+
 /* ---- weight gradient of the same conv (aten::convolution_backward weight grad), summed over
  * the samples of each slot:  dw[s][tap][o][i] = sum_{n in s} sum_v dy[n][v][o] * x[n][v+tap][i]
  * dw: float [nslots][125][Cout][Cin], OVERWRITTEN (zeroed inside, then accumulated). */
@@ -106,6 +115,12 @@ int repmode_conv5_wgrad(const void* x, const void* dy, const int32_t* sample_slo
 int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
                            float* dw, int n, int d, int h, int wdim, int cin, int cout, int dtype,
                            int centre3, void* stream);
+/* Filter gradient of the input channels [ci_off, ci_off + cin) of a layer with cin_total input channels: x holds only
+ * those channels, dw is the whole layer's [nslots][125][cout][cin_total] and must have been cleared by the caller
+ * (mode bit 3 set).  One call per tensor of a skip connection. */
+int repmode_conv5_wgrad_part(const void* x, const void* dy, const int32_t* sample_slot, int nslots, float* dw, int n,
+                             int d, int h, int wdim, int cin, int cin_total, int ci_off, int cout, int dtype,
+                             int centre3, void* stream);
 
 /* ---- the same filter gradient when one channel count is 1 (first layer Cin = 1, last layer Cout = 1): the
  * 125 taps take the place of the missing channel dimension.  bf16 only.  a: [N][D][H][W][C], b: [N][D][H][W],

@@ -76,6 +76,11 @@ struct ConvArgs {
   int tap_lo, tap_hi;  // dz and dy are restricted to [tap_lo, tap_hi] (0..4: full filter; 1..3: a 3x3 support)
   int accum;           // float output only: add to y (atomics, y is not cleared) instead of overwriting it
   int dxc;             // only the centre x tap (dx = 2) of every (dz, dy) row: see repmode_conv5_ex
+  // skip connections without a concatenated tensor (repmode_conv5_pair): channels [0, Cin1) of the input come from
+  // x, [Cin1, Cin) from x2 (Cin1 == 0: one input); output channels [0, Cout1) go to y, the rest to y2 (Cout1 == 0: one)
+  const void* x2;
+  void* y2;
+  int Cin1, Cout1;
 };
 
 // Tile configuration.  BZ*BY*BX output voxels = 32 * WV * VW; 32 * WC * CW output channels.
@@ -100,7 +105,8 @@ struct Cfg {
 // for 16 voxels, so the 32 lanes of a half-wave cover 32 consecutive channels of a voxel: 128-byte
 // contiguous float stores / atomics (used for the float output, in particular the split-K atomics,
 // which otherwise touch one cache line per lane).
-template <typename T, typename C, bool SWAP>
+// PAIR: the two-tensor form (repmode_conv5_pair); a separate instantiation keeps the one-tensor kernels free of its selects
+template <typename T, typename C, bool SWAP, bool PAIR>
 __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   constexpr int KV = Elem<T>::KV;
   constexpr int KC = 2 * KV;
@@ -128,8 +134,10 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   const int z0 = bz * BZ, y0 = by * BY, x0 = bx * BX;
   const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, CinP = a.CinP, CoutP = a.CoutP;
 
+  const int Cin1 = PAIR ? a.Cin1 : 0, Cout1 = PAIR ? a.Cout1 : 0;
   const int slot = a.sample_slot[n];
-  const T* __restrict__ xn = static_cast<const T*>(a.x) + (size_t)n * D * H * W * Cin;
+  const T* __restrict__ xn = static_cast<const T*>(a.x) + (size_t)n * D * H * W * (Cin1 > 0 ? Cin1 : Cin);
+  const T* __restrict__ xn2 = Cin1 > 0 ? static_cast<const T*>(a.x2) + (size_t)n * D * H * W * (Cin - Cin1) : nullptr;
   // filter layout (fragment-major): [slot][tap][co tile (32)][ci chunk (KC)][32][KC]; a lane's 16 bytes
   // of an A fragment are bytes [16 lane, 16 lane + 16) of the 1 KiB tile
   const T* __restrict__ wsl = static_cast<const T*>(a.w) + (size_t)slot * REPMODE_TAPS * CoutP * CinP;
@@ -189,6 +197,10 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
     __syncthreads();  // all waves finished reading the previous chunk's halo image
     RM_STAMP((chunk - c_begin) * 4 + 1);
     // ---- stage the halo brick: item = (halo voxel, plane), two 16-byte items per voxel
+    const bool second = Cin1 > 0 && ci0 >= Cin1;
+    const T* __restrict__ xsrc = second ? xn2 : xn;
+    const int csrc = Cin1 > 0 ? (second ? Cin - Cin1 : Cin1) : Cin;     // channel stride of the source tensor
+    const int cbase = second ? Cin1 : 0;                                     // first channel the source holds
     constexpr int NITEMS = 2 * VH;
     constexpr int UNR = (NITEMS + NT - 1) / NT >= 9 ? 9 : 4;   // loads in flight per thread per batch (latency-bound phase)
     for (int it0 = 0; it0 < NITEMS; it0 += NT * UNR) {
@@ -204,7 +216,8 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
           const int gz = z0 + zz - 2, gy = y0 + yy - 2, gx = x0 + xx - 2;
           const int c = ci0 + pl * KV;
           if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin) {
-            const T* p = xn + ((size_t)(gz * H + gy) * W + gx) * Cin + c;
+            // (two-input mode: this chunk's channels lie entirely in one of the two tensors, Cin1 % KC == 0)
+            const T* p = xsrc + ((size_t)(gz * H + gy) * W + gx) * csrc + (c - cbase);
             if (vec_ok) {
               v[u] = *reinterpret_cast<const u32x4*>(p);
             } else {
@@ -363,7 +376,10 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
           const int lx = m % BX, ly = (m / BX) % BY, lz = m / (BX * BY);
           const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
           if (gz >= D || gy >= H || gx >= W) continue;
-          float* yp = static_cast<float*>(a.y) + (((size_t)(n * D + gz) * H + gy) * W + gx) * Cout + co;
+          const bool out2 = Cout1 > 0 && co >= Cout1;                   // (two-output mode: the data gradient of a pair)
+          const int cw = Cout1 > 0 ? (out2 ? Cout - Cout1 : Cout1) : Cout;
+          float* yp = static_cast<float*>(out2 ? a.y2 : a.y) + (((size_t)(n * D + gz) * H + gy) * W + gx) * cw +
+                      (out2 ? co - Cout1 : co);
           if (a.ksplit > 1 || a.accum) unsafeAtomicAdd(yp, acc[cs][vs][r]);
           else *yp = acc[cs][vs][r];
         }
@@ -382,29 +398,33 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
       for (int cs = 0; cs < CW; ++cs) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int co = cot * C::COT + (wc * CW + cs) * 32 + 8 * q + 4 * khalf;
-          if (co >= Cout) continue;
+          const int co_all = cot * C::COT + (wc * CW + cs) * 32 + 8 * q + 4 * khalf;
+          if (co_all >= Cout) continue;
+          const bool out2 = Cout1 > 0 && co_all >= Cout1;              // (Cout1 is a multiple of 4: a quad never straddles)
+          const int Cout_ = Cout1 > 0 ? (out2 ? Cout - Cout1 : Cout1) : Cout;
+          const int co = out2 ? co_all - Cout1 : co_all;
+          void* ybase = out2 ? a.y2 : a.y;
           const float v0 = acc[cs][vs][4 * q + 0], v1 = acc[cs][vs][4 * q + 1];
           const float v2 = acc[cs][vs][4 * q + 2], v3 = acc[cs][vs][4 * q + 3];
           if constexpr (sizeof(T) == 4) {
-            float* yp = static_cast<float*>(a.y) + vox * Cout + co;
-            if ((Cout & 3) == 0) {
+            float* yp = static_cast<float*>(ybase) + vox * Cout_ + co;
+            if ((Cout_ & 3) == 0) {
               *reinterpret_cast<f32x4*>(yp) = f32x4{v0, v1, v2, v3};
             } else {
               yp[0] = v0;
-              if (co + 1 < Cout) yp[1] = v1;
-              if (co + 2 < Cout) yp[2] = v2;
-              if (co + 3 < Cout) yp[3] = v3;
+              if (co + 1 < Cout_) yp[1] = v1;
+              if (co + 2 < Cout_) yp[2] = v2;
+              if (co + 3 < Cout_) yp[3] = v3;
             }
           } else {
-            bf16_t* yp = static_cast<bf16_t*>(a.y) + vox * Cout + co;
-            if ((Cout & 3) == 0) {
+            bf16_t* yp = static_cast<bf16_t*>(ybase) + vox * Cout_ + co;
+            if ((Cout_ & 3) == 0) {
               *reinterpret_cast<u32x2*>(yp) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
             } else {
               yp[0] = f32_to_bf16(v0);
-              if (co + 1 < Cout) yp[1] = f32_to_bf16(v1);
-              if (co + 2 < Cout) yp[2] = f32_to_bf16(v2);
-              if (co + 3 < Cout) yp[3] = f32_to_bf16(v3);
+              if (co + 1 < Cout_) yp[1] = f32_to_bf16(v1);
+              if (co + 2 < Cout_) yp[2] = f32_to_bf16(v2);
+              if (co + 3 < Cout_) yp[3] = f32_to_bf16(v3);
             }
           }
         }
@@ -414,7 +434,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   RM_STAMP(60);
 }
 
-template <typename T, typename C, bool SWAP>
+template <typename T, typename C, bool SWAP, bool PAIR>
 int launch_cfg(ConvArgs a, hipStream_t stream) {
   a.nbz = ceil_div(a.D, C::BZ);
   a.nby = ceil_div(a.H, C::BY);
@@ -434,19 +454,21 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   RM_REQUIRE(grid > 0 && grid < (1L << 31), "conv5: grid %ld out of range", grid);
   static bool attr_set = false;  // per instantiation
   if (!attr_set) {
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_igemm_kernel<T, C, SWAP>),
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_igemm_kernel<T, C, SWAP, PAIR>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set = true;
   }
   if (ks > 1 && !a.accum) {
-    RM_HIP(hipMemsetAsync(a.y, 0, (size_t)a.N * a.D * a.H * a.W * a.Cout * sizeof(float), stream));
+    const size_t vox = (size_t)a.N * a.D * a.H * a.W;
+    RM_HIP(hipMemsetAsync(a.y, 0, vox * (a.Cout1 > 0 ? a.Cout1 : a.Cout) * sizeof(float), stream));
+    if (a.Cout1 > 0) RM_HIP(hipMemsetAsync(a.y2, 0, vox * (a.Cout - a.Cout1) * sizeof(float), stream));
   }
   // algorithmic FLOPs: 125 taps, or the 27 of a 3x3x3 support when restricted
   // (dx-centre mode: 25 taps x the 5 folded x taps of the thin dimension = the original layer's 125 taps x 1 channel)
   const double alg = a.dxc ? 2.0 * a.N * a.D * a.H * a.W * 25.0 * (a.Cin == 8 ? 5.0 * a.Cout : (double)a.Cin * a.Cout)
                            : 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * (a.tap_lo ? 27 : REPMODE_TAPS);
   repmode_prof_begin(REPMODE_PROF_CONV5, alg, stream);
-  hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP, PAIR>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
   repmode_prof_end(stream);
   RM_LAUNCH_CHECK("conv5_igemm");
   return REPMODE_OK;
@@ -458,12 +480,18 @@ using CfgX16 = Cfg<4, 4, 16, 2, 2, 4, 1>;      // 256 voxels x 64 channels   (le
 using CfgX8 = Cfg<4, 8, 8, 2, 2, 4, 1>;        // 256 voxels x 64 channels   (level 3)
 using CfgX4 = Cfg<2, 4, 4, 1, 4, 1, 1>;        // 32 voxels x 128 channels   (level 4)
 
+template <typename T, bool SWAP, bool PAIR>
+int dispatch_tile(ConvArgs a, hipStream_t stream) {
+  if (a.W >= 32) return launch_cfg<T, CfgX32, SWAP, PAIR>(a, stream);
+  if (a.W >= 16) return launch_cfg<T, CfgX16, SWAP, PAIR>(a, stream);
+  if (a.W >= 8) return launch_cfg<T, CfgX8, SWAP, PAIR>(a, stream);
+  return launch_cfg<T, CfgX4, SWAP, PAIR>(a, stream);
+}
+
 template <typename T, bool SWAP>
 int dispatch(ConvArgs a, hipStream_t stream) {
-  if (a.W >= 32) return launch_cfg<T, CfgX32, SWAP>(a, stream);
-  if (a.W >= 16) return launch_cfg<T, CfgX16, SWAP>(a, stream);
-  if (a.W >= 8) return launch_cfg<T, CfgX8, SWAP>(a, stream);
-  return launch_cfg<T, CfgX4, SWAP>(a, stream);
+  if (a.Cin1 > 0 || a.Cout1 > 0) return dispatch_tile<T, SWAP, true>(a, stream);
+  return dispatch_tile<T, SWAP, false>(a, stream);
 }
 
 }  // namespace
@@ -484,25 +512,49 @@ extern "C" int repmode_conv5(const void* x, const void* w, const int32_t* sample
   return repmode_conv5_ex(x, w, sample_slot, y, n, d, h, wdim, cin, cout, dtype, out_f32, 0, stream);
 }
 
+extern "C" int repmode_conv5_pair(const void* x, const void* x2, int cin1, const void* w, const int32_t* sample_slot,
+                                  void* y, void* y2, int cout1, int n, int d, int h, int wdim, int cin, int cout,
+                                  int dtype, int out_f32, int flags, void* stream);
+
 extern "C" int repmode_conv5_ex(const void* x, const void* w, const int32_t* sample_slot, void* y, int n,
                                 int d, int h, int wdim, int cin, int cout, int dtype, int out_f32,
                                 int centre3, void* stream) {
+  return repmode_conv5_pair(x, nullptr, 0, w, sample_slot, y, nullptr, 0, n, d, h, wdim, cin, cout, dtype, out_f32,
+                            centre3, stream);
+}
+
+// The same convolution with the input and / or the output channels split over two tensors -- a U-Net skip
+// connection without the concatenated copy (RepMode.py:106 `torch.cat((x_skip, up), 1)`): input channels
+// [0, cin1) are read from x ([N][D][H][W][cin1]), [cin1, cin) from x2; output channels [0, cout1) are written to y
+// ([...][cout1]), the rest to y2 (the data gradient of such a layer).  cin1 == 0 / cout1 == 0: one tensor.
+// cin1 must be a multiple of 16 (bf16) / 8 (f32) and cin - cin1 of 8 / 4; cout1 of 32.
+extern "C" int repmode_conv5_pair(const void* x, const void* x2, int cin1, const void* w, const int32_t* sample_slot,
+                                  void* y, void* y2, int cout1, int n, int d, int h, int wdim, int cin, int cout,
+                                  int dtype, int out_f32, int flags, void* stream) {
   RM_REQUIRE(x && w && sample_slot && y, "conv5: null pointer");
   RM_REQUIRE(n > 0 && d > 0 && h > 0 && wdim > 0 && cin > 0 && cout > 0, "conv5: bad shape");
   RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "conv5: bad dtype %d", dtype);
-  RM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0,
-             "conv5: pointers must be 16-byte aligned");
+  RM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+             ((uintptr_t)x2 & 15) == 0 && ((uintptr_t)y2 & 15) == 0, "conv5: pointers must be 16-byte aligned");
+  const int kv = dtype == REPMODE_F32 ? 4 : 8;
+  RM_REQUIRE(cin1 == 0 || (x2 && cin1 > 0 && cin1 < cin && cin1 % (2 * kv) == 0 && (cin - cin1) % kv == 0),
+             "conv5_pair: bad input split %d of %d", cin1, cin);
+  RM_REQUIRE(cout1 == 0 || (y2 && cout1 > 0 && cout1 < cout && cout1 % 32 == 0 && (cout - cout1) % 4 == 0),
+             "conv5_pair: bad output split %d of %d", cout1, cout);
+  RM_REQUIRE((size_t)d * h * wdim * cin * (dtype == REPMODE_F32 ? 4 : 2) < ((size_t)1 << 31),
+             "conv5: one sample of the input must be smaller than 2 GiB (32-bit buffer offsets)");
   ConvArgs a{};
   a.x = x; a.w = w; a.sample_slot = sample_slot; a.y = y;
+  a.x2 = x2; a.y2 = y2; a.Cin1 = cin1; a.Cout1 = cout1;
   a.N = n; a.D = d; a.H = h; a.W = wdim; a.Cin = cin; a.Cout = cout;
   a.CinP = repmode_padded_channels(cin, dtype, 1);
   a.CoutP = repmode_padded_channels(cout, dtype, 0);
   a.out_f32 = (out_f32 != 0) || dtype == REPMODE_F32;
-  // `centre3` is a flag word: bit 0 = 3x3x3 support, bit 1 = accumulate into a float y
-  a.tap_lo = (centre3 & 1) ? 1 : 0;
-  a.tap_hi = (centre3 & 1) ? 3 : 4;
-  a.accum = (centre3 & 2) ? 1 : 0;
-  a.dxc = (centre3 & 4) ? 1 : 0;
+  // `flags`: bit 0 = 3x3x3 support, bit 1 = accumulate into a float y, bit 2 = centre x tap only
+  a.tap_lo = (flags & 1) ? 1 : 0;
+  a.tap_hi = (flags & 1) ? 3 : 4;
+  a.accum = (flags & 2) ? 1 : 0;
+  a.dxc = (flags & 4) ? 1 : 0;
   RM_REQUIRE(!a.accum || a.out_f32, "conv5: accumulation needs a float output");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == REPMODE_F32) return dispatch<float, true>(a, s);

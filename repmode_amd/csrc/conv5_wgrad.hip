@@ -35,6 +35,8 @@ struct WgradArgs {
                         // 2: dw[co][ci][27] (expert layout of a centred 3x3x3 filter, nslots == 1)
   int nslots, direct;   // direct: every workgroup owns its output completely -> plain stores, no memset
   int prezeroed;   // dw is known to be all zero already: no memset before the atomics
+  int CinTot, ci_off;   // layout 0: dw rows have CinTot input channels and this call fills [ci_off, ci_off + Cin)
+                        // (the two halves of a skip connection's filter gradient); CinTot == Cin, ci_off == 0 otherwise
 };
 
 template <typename T>
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void conv5_wgrad_f32c_kernel(WgradArgs a) {
         if (co < Cout) {
           float* p;
           if (a.layout == 0) {
-            p = a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * Cin + ci;
+            p = a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * a.CinTot + a.ci_off + ci;
           } else if (a.layout == 1) {
             p = a.dw + ((size_t)co * Cin + ci) * REPMODE_TAPS + tap;
           } else {
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
         if (co < Cout) {
           float* p;
           if (a.layout == 0) {
-            p = a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * Cin + ci;
+            p = a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * a.CinTot + a.ci_off + ci;
           } else if (a.layout == 1) {
             p = a.dw + ((size_t)co * Cin + ci) * REPMODE_TAPS + tap;
           } else {
@@ -560,7 +562,7 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   a.direct = a.nchunks == 1;
   const long grid = fixed * a.nchunks;
   RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
-  if (!a.direct && !a.prezeroed) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * a.Cout * a.Cin * sizeof(float), s));
+  if (!a.direct && !a.prezeroed) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * a.Cout * a.CinTot * sizeof(float), s));
   repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, s);
   const size_t sample_bytes = (size_t)a.D * a.H * a.W * (a.Cin > a.Cout ? a.Cin : a.Cout) * 2;
   // (levels with W < 16 hand a workgroup only a tile or two per sample: nothing to overlap, and the old loop is ~15 % faster there)
@@ -583,16 +585,34 @@ extern "C" int repmode_conv5_wgrad(const void* x, const void* dy, const int32_t*
   return repmode_conv5_wgrad_ex(x, dy, sample_slot, nslots, dw, n, d, h, wdim, cin, cout, dtype, 0, stream);
 }
 
+extern "C" int repmode_conv5_wgrad_part(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
+                                        float* dw, int n, int d, int h, int wdim, int cin, int cin_total, int ci_off,
+                                        int cout, int dtype, int centre3, void* stream);
+
 extern "C" int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
                                       float* dw, int n, int d, int h, int wdim, int cin, int cout, int dtype,
                                       int centre3, void* stream) {
+  return repmode_conv5_wgrad_part(x, dy, sample_slot, nslots, dw, n, d, h, wdim, cin, cin, 0, cout, dtype, centre3, stream);
+}
+
+// Filter gradient of the input channels [ci_off, ci_off + cin) of a layer with cin_total input channels: x holds
+// only those cin channels ([N][D][H][W][cin]) and dw is the whole layer's [nslots][125][cout][cin_total] (slot
+// layout only).  The two tensors of a skip connection (repmode_conv5_pair) are handled by two such calls on one dw,
+// which the caller must have cleared (mode bit 3).
+extern "C" int repmode_conv5_wgrad_part(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
+                                        float* dw, int n, int d, int h, int wdim, int cin, int cin_total, int ci_off,
+                                        int cout, int dtype, int centre3, void* stream) {
   RM_REQUIRE(x && dy && sample_slot && dw, "conv5_wgrad: null pointer");
+  RM_REQUIRE(cin_total >= cin && ci_off >= 0 && ci_off + cin <= cin_total, "conv5_wgrad: bad channel range");
+  RM_REQUIRE(cin_total == cin || ((centre3 & 8) && (centre3 & 7) < 2),
+             "conv5_wgrad: a partial channel range needs the slot layout and a cleared dw (mode bit 3)");
   RM_REQUIRE(n > 0 && nslots > 0 && d > 0 && h > 0 && wdim > 0 && cin > 0 && cout > 0, "conv5_wgrad: bad shape");
   RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "conv5_wgrad: bad dtype %d", dtype);
   hipStream_t s = static_cast<hipStream_t>(stream);
   WgradArgs a{};
   a.x = x; a.dy = dy; a.sample_slot = sample_slot; a.dw = dw;
   a.N = n; a.D = d; a.H = h; a.W = wdim; a.Cin = cin; a.Cout = cout;
+  a.CinTot = cin_total; a.ci_off = ci_off;
   a.ncot = ceil_div(cout, 32);
   a.ncit = ceil_div(cin, 32);
   a.nslots = nslots;
@@ -627,7 +647,7 @@ extern "C" int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32
     a.direct = a.nchunks == 1;
     const long grid = fixed * a.nchunks;
     RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
-    if (!a.direct && !a.prezeroed) RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * cout * cin * sizeof(float), s));
+    if (!a.direct && !a.prezeroed) RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * cout * a.CinTot * sizeof(float), s));
     repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * d * h * wdim * (double)cin * cout * REPMODE_TAPS, s);
     hipLaunchKernelGGL(conv5_wgrad_f32c_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, a);
   }

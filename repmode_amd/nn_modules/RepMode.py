@@ -81,16 +81,20 @@ class MoDEConv(torch.nn.Module):
             self.subsequent_layer = torch.nn.Identity()
         self.gate = torch.nn.Linear(num_tasks, num_experts * out_chan, bias=True)
 
-    def forward(self, x, t):
+    def forward(self, x, t, x2=None):
+        """``x2``: more input channels, to follow x's (a skip connection's ``torch.cat((x, x2), 1)`` that is never built)."""
         plan = t if isinstance(t, ops.TaskPlan) else ops.TaskPlan(t, self.num_tasks, x.device, self.training)
         dtype = _resolve_dtype(x, self.compute_dtype)
         x_cl = _to_cl(x.to(dtype))
         # float output where a later stage reduces it in f32 anyway: the final layer, and the deep
         # levels whose reduction is split over workgroups (f32 atomics)
         out_f32 = self.conv_type == 'final' or x.shape[-1] < 32
-        y_cl = ops.mode_conv3d(x_cl, self.expert_conv5x5_conv, self.expert_conv3x3_conv, self.expert_conv1x1_conv,
-                               self.expert_avg3x3_conv, self.expert_avg5x5_conv, self.gate.weight, self.gate.bias,
-                               plan, out_f32=out_f32)
+        params = (self.expert_conv5x5_conv, self.expert_conv3x3_conv, self.expert_conv1x1_conv,
+                  self.expert_avg3x3_conv, self.expert_avg5x5_conv, self.gate.weight, self.gate.bias)
+        if x2 is not None:
+            y_cl = ops.mode_conv3d_pair(x_cl, _to_cl(x2.to(dtype)), *params, plan, out_f32=out_f32)
+        else:
+            y_cl = ops.mode_conv3d(x_cl, *params, plan, out_f32=out_f32)
         if self.conv_type == 'normal':                          # RepMode.py:212: BatchNorm3d + ReLU, fused HIP
             y_cl = ops.bn_relu(y_cl, self.subsequent_layer[0], self.training, dtype, count=not getattr(t, 'bn_counted', False))
         return _from_cl(y_cl)
@@ -102,8 +106,8 @@ class MoDESubNet2Conv(torch.nn.Module):                        # RepMode.py:111-
         self.conv1 = MoDEConv(num_experts, num_tasks, n_in, n_out, kernel_size=5, padding='same', dtype=dtype)
         self.conv2 = MoDEConv(num_experts, num_tasks, n_out, n_out, kernel_size=5, padding='same', dtype=dtype)
 
-    def forward(self, x, t):
-        return self.conv2(self.conv1(x, t), t)
+    def forward(self, x, t, x2=None):
+        return self.conv2(self.conv1(x, t, x2), t)
 
 
 class Down2(torch.nn.Module):
@@ -158,7 +162,7 @@ class MoDEDecoderBlock(torch.nn.Module):                       # RepMode.py:92-1
         up = self.convt[0](x)
         up = _from_cl(ops.bn_relu(_to_cl(up), self.convt[1], self.training, x_skip.dtype,
                                    count=not getattr(t, 'bn_counted', False)))   # RepMode.py:99-100
-        return self.conv_less(torch.cat((x_skip, up), 1), t)   # skip first, RepMode.py:106
+        return self.conv_less(x_skip, t, up)                   # = cat((x_skip, up), 1): skip first, RepMode.py:106
 
 
 class Net(torch.nn.Module):

@@ -317,6 +317,102 @@ class _ModeConv3d(torch.autograd.Function):
         return dx, dk5, dk3, dk1, da3, da5, dgw, dgb, None, None
 
 
+class _ModeConv3dPair(torch.autograd.Function):
+    """``_ModeConv3d`` for a skip connection: the block's input is the channel concatenation of two tensors
+    (RepMode.py:106 ``torch.cat((x_skip, up), 1)``), which is never materialised -- the conv kernel reads its channel
+    chunks from either tensor, the data gradient is written to two tensors, and the filter gradient is computed in
+    two channel ranges of one buffer (csrc: repmode_conv5_pair, repmode_conv5_wgrad_part)."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, k5, k3, k1, a3, a5, gate_w, gate_b, plan, out_f32):
+        _require_hip(xa, 'input')
+        co, ci = k5.shape[0], k5.shape[1]
+        ca = xa.shape[-1]
+        n, d, h, w_ = xa.shape[:4]
+        g = gate_softmax(gate_w, gate_b, plan, co)
+        want_wd = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        wf, wd = gatrep_merge(k5, k3, k1, a3, a5, g, xa.dtype, want_wf=True, want_wd=want_wd)
+        code = dtype_code(xa.dtype)
+        out_dtype = torch.float32 if (out_f32 or xa.dtype == torch.float32) else xa.dtype
+        flags = 0
+        if out_dtype == torch.float32 and xa.dtype == torch.bfloat16:
+            y, pre = ZERO_POOL.take((n, d, h, w_, co), xa.device)
+            flags = 2 if pre else 0
+        else:
+            y = torch.empty((n, d, h, w_, co), dtype=out_dtype, device=xa.device)
+        _lib.call('repmode_conv5_pair', _ptr(xa), _ptr(xb), ca, _ptr(wf), _ptr(plan.sample_slot), _ptr(y), None, 0,
+                  n, d, h, w_, ci, co, code, 1 if out_dtype == torch.float32 else 0, flags, _stream())
+        ctx.save_for_backward(xa, xb, k5, k3, k1, a3, a5, g, wd)
+        ctx.plan = plan
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, xb, k5, k3, k1, a3, a5, g, wd = ctx.saved_tensors
+        plan = ctx.plan
+        co, ci = k5.shape[0], k5.shape[1]
+        ca, cb = xa.shape[-1], xb.shape[-1]
+        n, d, h, w_ = xa.shape[:4]
+        dt = xa.dtype
+        code = dtype_code(dt)
+        dy = dy.to(dt).contiguous()
+        dxa = dxb = None
+        if wd is not None:
+            f32 = w_ < 32 or dt == torch.float32        # deep levels: split reduction -> float output (as _ModeConv3d)
+            flags = 0
+            if f32 and dt == torch.bfloat16:
+                (dxa, pa), (dxb, pb) = ZERO_POOL.take((n, d, h, w_, ca), xa.device), ZERO_POOL.take((n, d, h, w_, cb), xa.device)
+                if pa and pb:
+                    flags = 2
+                elif pa or pb:                           # (cannot happen with a consistent pool; stay correct anyway)
+                    dxa.zero_(); dxb.zero_(); flags = 2
+            else:
+                odt = torch.float32 if f32 else dt
+                dxa = torch.empty((n, d, h, w_, ca), dtype=odt, device=xa.device)
+                dxb = torch.empty((n, d, h, w_, cb), dtype=odt, device=xa.device)
+            _lib.call('repmode_conv5_pair', _ptr(dy), None, 0, _ptr(wd), _ptr(plan.sample_slot), _ptr(dxa), _ptr(dxb), ca,
+                      n, d, h, w_, co, ci, code, 1 if f32 else 0, flags, _stream())
+            if dxa.dtype != dt:
+                dxa, dxb = dxa.to(dt), dxb.to(dt)
+        # filter gradient: the two channel ranges of one (cleared) buffer
+        dw, pre = ZERO_POOL.take((plan.nslots, TAPS, co, ci), xa.device)
+        if not pre:
+            dw.zero_()
+        for part, off in ((xa, 0), (xb, ca)):
+            _lib.call('repmode_conv5_wgrad_part', _ptr(part), _ptr(dy), _ptr(plan.sample_slot), plan.nslots, _ptr(dw),
+                      n, d, h, w_, part.shape[-1], ci, off, co, code, 8, _stream())
+        dk5, dk3, dk1 = torch.empty_like(k5), torch.empty_like(k3), torch.empty_like(k1)
+        da3, da5 = torch.empty_like(a3), torch.empty_like(a5)
+        dgw = torch.empty((NUM_EXPERTS * co, plan.num_tasks), dtype=torch.float32, device=k5.device)
+        dgb = torch.empty((NUM_EXPERTS * co,), dtype=torch.float32, device=k5.device)
+        dg_ws = torch.empty_like(g)
+        _lib.call('repmode_gatrep_bwd', _ptr(dw), _ptr(k5), _ptr(k3), _ptr(k1), _ptr(a3), _ptr(a5), _ptr(g),
+                  _ptr(plan.slot_task), plan.nslots, plan.num_tasks, co, ci, _ptr(dk5), _ptr(dk3), _ptr(dk1),
+                  _ptr(da3), _ptr(da5), _ptr(dgw), _ptr(dgb), _ptr(dg_ws), _stream())
+        return dxa, dxb, dk5, dk3, dk1, da3, da5, dgw, dgb, None, None
+
+
+def pair_supported(xa_cl, xb_cl, plan):
+    """The two-tensor path covers the merged formulation with channel counts on tile boundaries."""
+    kc = 16 if xa_cl.dtype == torch.bfloat16 else 8
+    return (xa_cl.shape[-1] % 32 == 0 and xb_cl.shape[-1] % kc == 0 and xa_cl.shape[:4] == xb_cl.shape[:4]
+            and xa_cl.dtype == xb_cl.dtype and not use_unmerged(xa_cl, plan))
+
+
+def mode_conv3d_pair(xa_cl, xb_cl, k5, k3, k1, a3, a5, gate_w, gate_b, plan, out_f32=False):
+    """``mode_conv3d`` of the channel concatenation (xa, xb) without building it; falls back to cat + mode_conv3d
+    where the two-tensor kernels do not apply (per-expert formulation, odd channel counts)."""
+    if not pair_supported(xa_cl, xb_cl, plan):
+        return mode_conv3d(torch.cat((xa_cl, xb_cl), dim=-1), k5, k3, k1, a3, a5, gate_w, gate_b, plan, out_f32)
+    ps = [p.contiguous() for p in (k5, k3, k1, a3, a5, gate_w, gate_b)]
+    for p in ps:
+        if p.dtype != torch.float32:
+            raise TypeError('MoDE parameters must be float32')
+    if plan.n != xa_cl.shape[0]:
+        raise ValueError('task plan is for %d samples, input has %d' % (plan.n, xa_cl.shape[0]))
+    return _ModeConv3dPair.apply(xa_cl.contiguous(), xb_cl.contiguous(), *ps, plan, out_f32)
+
+
 class _BnRelu(torch.autograd.Function):
     """BatchNorm3d + ReLU on a channels-last tensor [..., C] (RepMode.py:146-149, 212; :80-84; :97-101)."""
 

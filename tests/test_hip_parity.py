@@ -237,6 +237,43 @@ def test_zero_pool_steps_agree(mode):
         assert rel_err(b, a) < 1e-5
 
 
+@pytest.mark.parametrize('pooled', [False, True])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('ca,cb,co,shape,tasks', [(32, 32, 32, (4, 8, 32), [3, 3]), (64, 64, 64, (2, 4, 16), [4, 9, 1]),
+                                                  (32, 16, 48, (2, 4, 16), [0, 7]), (128, 128, 128, (2, 4, 8), [5, 5, 2])])
+def test_mode_conv3d_pair_equals_concatenation(ca, cb, co, shape, tasks, dtype, pooled):
+    """The skip-connection form (two input tensors, never concatenated: repmode_conv5_pair / _wgrad_part) against the
+    one-tensor op on torch.cat((xa, xb), -1) -- the same kernels on the same values, so results agree to the order of
+    the float atomics."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(11)
+    n = len(tasks)
+    ps = _rand_experts(co, ca + cb, gen)
+    xa = torch.randn(n, *shape, ca, generator=gen).to(dtype)
+    xb = torch.randn(n, *shape, cb, generator=gen).to(dtype)
+    r = torch.randn(n, *shape, co, generator=gen)
+    out = {}
+    for form in ('cat', 'pair'):
+        for step in range(3 if pooled else 1):
+            if pooled:
+                ops.ZERO_POOL.begin(('test_pair', form, ca, cb, co, str(dtype)), torch.device(DEV))
+            dev = [p.to(DEV).requires_grad_(True) for p in ps]
+            a, b = xa.to(DEV).requires_grad_(True), xb.to(DEV).requires_grad_(True)
+            plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+            if form == 'cat':
+                y = ops.mode_conv3d(torch.cat((a, b), -1), *dev, plan, mode='merged')
+            else:
+                assert ops.pair_supported(a, b, plan) or len(set(tasks)) > 2
+                y = ops._ModeConv3dPair.apply(a, b, *dev, plan, False)
+            (y.float() * r.to(DEV)).sum().backward()
+        ops.ZERO_POOL.end()
+        out[form] = [y.detach().float().cpu(), a.grad.float().cpu(), b.grad.float().cpu()] + [p.grad.cpu() for p in dev]
+    tol = 1e-5 if dtype == torch.float32 else 1e-2        # bf16: an atomics-order difference can flip a bf16 rounding (1 ulp)
+    names = ['y', 'dxa', 'dxb', 'k5', 'k3', 'k1', 'a3', 'a5', 'gate_w', 'gate_b']
+    for name, u, v in zip(names, out['pair'], out['cat']):
+        assert rel_err(u, v) < tol, name
+
+
 def _load_block(g, dtype):
     from repmode_amd.nn_modules.RepMode import MoDEConv
     co, ci = g['p.expert_conv5x5_conv'].shape[:2]
