@@ -182,6 +182,21 @@ def gatrep_merge(k5, k3, k1, a3, a5, g, dtype, want_wf=True, want_wd=False):
     return wf, wd
 
 
+GRAD_SINK = None    # a distributed.GradReducer: parameter gradients are then written straight into its buckets
+
+
+def _grad_out(param):
+    """Output buffer for the gradient of ``param``: its slice of the data-parallel reducer's communication bucket when
+    there is one (no per-gradient bucket copy -- 193 small kernels per step under DistributedDataParallel), else a
+    fresh tensor."""
+    sink = GRAD_SINK
+    if sink is not None:
+        v = sink.grad_buffer(param)
+        if v is not None:
+            return v
+    return torch.empty_like(param)
+
+
 def conv5(x_cl, w, sample_slot, cout, out_f32=False, out=None, centre3=False, accumulate=False, dxc=False):
     """y[n] = x[n] (*) w[sample_slot[n]], 5^3 'same' cross-correlation, NDHWC -- RepMode.py:204-210.
     ``accumulate`` (float ``out`` given): add to ``out`` instead of overwriting it.  ``dxc``: only the centre x tap
@@ -238,13 +253,14 @@ def thin_conv_out1(x_cl, w, sample_slot):
     return y
 
 
-def conv5_wgrad(x_cl, dy_cl, plan, cout, centre3=False, expert_layout=None):
+def conv5_wgrad(x_cl, dy_cl, plan, cout, centre3=False, expert_layout=None, out=None):
     """dw[s, tap, o, i] (float32) summed over the samples of each slot."""
     n, d, h, wd_, cin = x_cl.shape
     if expert_layout is not None:
         # single slot, gradient written directly in the experts' parameter layout: [Co, Ci, 5,5,5] or [Co, Ci, 3,3,3]
         k = expert_layout
-        dw = torch.empty((cout, cin, k, k, k), dtype=torch.float32, device=x_cl.device)
+        dw = out if out is not None else torch.empty((cout, cin, k, k, k), dtype=torch.float32, device=x_cl.device)
+        assert dw.shape == (cout, cin, k, k, k) and dw.dtype == torch.float32 and dw.is_contiguous()
         _lib.call('repmode_conv5_wgrad_ex', _ptr(x_cl), _ptr(dy_cl), _ptr(plan.sample_slot), 1, _ptr(dw),
                   n, d, h, wd_, cin, cout, dtype_code(x_cl.dtype), 2 if k == 5 else 3, _stream())
         return dw
@@ -305,8 +321,7 @@ class _ModeConv3d(torch.autograd.Function):
                 dx = dx.to(x_cl.dtype)
             del wd
         dw = conv5_wgrad(x_cl, dy, plan, co)
-        dk5, dk3, dk1 = torch.empty_like(k5), torch.empty_like(k3), torch.empty_like(k1)
-        da3, da5 = torch.empty_like(a3), torch.empty_like(a5)
+        dk5, dk3, dk1, da3, da5 = _grad_out(k5), _grad_out(k3), _grad_out(k1), _grad_out(a3), _grad_out(a5)
         # gate.weight is [5*Co, T], gate.bias [5*Co]; shapes are recovered from g / plan
         dgw = torch.empty((NUM_EXPERTS * co, plan.num_tasks), dtype=torch.float32, device=k5.device)
         dgb = torch.empty((NUM_EXPERTS * co,), dtype=torch.float32, device=k5.device)
@@ -381,8 +396,7 @@ class _ModeConv3dPair(torch.autograd.Function):
         for part, off in ((xa, 0), (xb, ca)):
             _lib.call('repmode_conv5_wgrad_part', _ptr(part), _ptr(dy), _ptr(plan.sample_slot), plan.nslots, _ptr(dw),
                       n, d, h, w_, part.shape[-1], ci, off, co, code, 8, _stream())
-        dk5, dk3, dk1 = torch.empty_like(k5), torch.empty_like(k3), torch.empty_like(k1)
-        da3, da5 = torch.empty_like(a3), torch.empty_like(a5)
+        dk5, dk3, dk1, da3, da5 = _grad_out(k5), _grad_out(k3), _grad_out(k1), _grad_out(a3), _grad_out(a5)
         dgw = torch.empty((NUM_EXPERTS * co, plan.num_tasks), dtype=torch.float32, device=k5.device)
         dgb = torch.empty((NUM_EXPERTS * co,), dtype=torch.float32, device=k5.device)
         dg_ws = torch.empty_like(g)
@@ -627,11 +641,13 @@ def box_sum(in3=None, in5=None, out=None, add=(), out_dtype=torch.float32):
     return out
 
 
-def tap_transpose(dw_taps, shape):
+def tap_transpose(dw_taps, shape, out=None):
     """Tap-major filter gradient [125, Co, Ci] -> the expert parameter's [Co, Ci, k, k, k] (k = 5: all taps; k = 3:
     the centred 27)."""
     co, ci, k = shape[0], shape[1], shape[2]
-    out = torch.empty(shape, dtype=torch.float32, device=dw_taps.device)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=dw_taps.device)
+    assert tuple(out.shape) == tuple(shape) and out.dtype == torch.float32 and out.is_contiguous()
     _lib.call('repmode_tap_transpose', _ptr(dw_taps), _ptr(out), co * ci, k ** 3, _stream())
     return out
 
@@ -747,13 +763,13 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         one = _SingleSlot(n, dev, 0)
         tiles = ((co + 31) // 32) * ((ci + 31) // 32)
         if dt == torch.bfloat16 and tiles * 5 >= 512:
-            dk5 = conv5_wgrad(x_cl, d01[0], one, co, expert_layout=5)
+            dk5 = conv5_wgrad(x_cl, d01[0], one, co, expert_layout=5, out=_grad_out(k5))
         else:
-            dk5 = tap_transpose(conv5_wgrad(x_cl, d01[0], one, co)[0], k5.shape)
+            dk5 = tap_transpose(conv5_wgrad(x_cl, d01[0], one, co)[0], k5.shape, out=_grad_out(k5))
         if dt == torch.bfloat16 and tiles * 3 >= 512:
-            dk3 = conv5_wgrad(x_cl, d01[1], one, co, expert_layout=3)
+            dk3 = conv5_wgrad(x_cl, d01[1], one, co, expert_layout=3, out=_grad_out(k3))
         else:
-            dk3 = tap_transpose(conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0], k3.shape)
+            dk3 = tap_transpose(conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0], k3.shape, out=_grad_out(k3))
         d1 = torch.bmm(dhi[:, :xb[0].numel() // ci].transpose(1, 2), xb.view(3, -1, ci))   # [3, Co, Ci]
         dk1, da3, da5 = d1[0].reshape(k1.shape), d1[1].reshape(a3.shape), d1[2].reshape(a5.shape)
         return dx, dk5, dk3, dk1, da3, da5, dgw, dgb, None

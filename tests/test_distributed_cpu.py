@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, how='ddp'):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
     torch.set_num_threads(2)
@@ -32,7 +32,15 @@ def _worker(rank, world, port, out_dir):
     assert (r, w) == (rank, world)
     torch.manual_seed(0)
     net = orc.Net(Opts(), mult_chan=2)
-    ddp = dist_.wrap_ddp(net, None)
+    if how == 'ddp':
+        ddp = dist_.wrap_ddp(net, None)
+    else:
+        if rank == 1:                       # the reducer must bring rank 1 onto rank 0's parameters itself
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.add_(0.25)
+        ddp, red = net, dist_.GradReducer(net, bucket_mb=0.01)
+        assert len(red.buckets) > 3
     g = torch.Generator().manual_seed(5)
     x = torch.randn(4, 1, 16, 16, 16, generator=g)
     t = torch.randn(4, 1, 16, 16, 16, generator=g)
@@ -41,6 +49,11 @@ def _worker(rank, world, port, out_dir):
     ddp.train()
     loss = torch.nn.functional.mse_loss(ddp(x[lo:hi], tasks[lo:hi]), t[lo:hi])
     loss.backward()
+    if how != 'ddp':
+        red.finish()
+        assert red.last_copied == len(list(net.parameters()))        # (the CPU oracle does not write into the buckets)
+        lo_, hi_ = red.buckets[0].flat.data_ptr(), red.buckets[0].flat.data_ptr() + red.buckets[0].flat.numel() * 4
+        assert lo_ <= red.buckets[0].entries[0].param.grad.data_ptr() < hi_
     mx = dist_.max_over_ranks(float(rank), torch.device('cpu'))
     assert mx == world - 1
     torch.save({k: p.grad.clone() for k, p in net.named_parameters()}, os.path.join(out_dir, 'g%d.pt' % rank))
@@ -48,9 +61,11 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_ddp_equals_single_process(tmp_path):
+@pytest.mark.parametrize('how', ['reducer', 'ddp'])
+def test_two_rank_ddp_equals_single_process(tmp_path, how):
     world = 2
-    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), how), nprocs=world, join=True,
+                       start_method='spawn')
     g0 = torch.load(tmp_path / 'g0.pt')
     g1 = torch.load(tmp_path / 'g1.pt')
     # single process: mean over shards of per-shard losses (per-shard BN statistics)
@@ -74,3 +89,72 @@ def test_two_rank_ddp_equals_single_process(tmp_path):
 def test_shard_batch():
     from repmode_amd.distributed import shard_batch
     assert [shard_batch(192, r, 8) for r in (0, 7)] == [(0, 24), (168, 192)]
+
+
+class _ToyScale(torch.autograd.Function):
+    """y = x * w (elementwise, w a parameter): writes w's gradient into ops._grad_out like the MoDE kernels' host code."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x * w
+
+    @staticmethod
+    def backward(ctx, dy):
+        from repmode_amd import ops
+        x, w = ctx.saved_tensors
+        gw = ops._grad_out(w)
+        torch.mul(dy, x, out=gw)
+        return dy * w, gw
+
+
+def test_grad_reducer_adopts_bucket_slices_single_process():
+    """Without a process group: gradients written into ``grad_buffer`` slices become ``param.grad`` with no copy, the
+    others are gathered; an existing .grad is never aliased; a parameter without gradient is reported."""
+    from repmode_amd import ops
+    from repmode_amd.distributed import GradReducer
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.randn(5, 7))
+            self.lin = torch.nn.Linear(7, 3)
+            self.b = torch.nn.Parameter(torch.randn(5, 3))
+
+        def forward(self, x):
+            return _ToyScale.apply(self.lin(_ToyScale.apply(x, self.a)), self.b)
+
+    torch.manual_seed(1)
+    net, ref = Toy(), Toy()
+    ref.load_state_dict(net.state_dict())
+    x = torch.randn(5, 7)
+    red = GradReducer(net, bucket_mb=1e-4)
+    assert len(red.buckets) >= 2
+    ops.GRAD_SINK = red
+    try:
+        for step in range(2):
+            net.zero_grad(set_to_none=True)
+            net(x).square().sum().backward()
+            red.finish()
+            assert red.last_copied == 2                          # lin.weight, lin.bias
+            for e in (red.by_param[net.a], red.by_param[net.b]):
+                assert e.param.grad.data_ptr() == e.ptr
+        ref(x).square().sum().backward()
+        for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-6), k
+        # accumulation into an existing gradient: the kernel must get a private buffer, the sum lands in the bucket
+        net(x).square().sum().backward()
+        red.finish()
+        for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, 2 * q.grad, rtol=1e-5, atol=1e-6), k
+        # a parameter left out of the graph
+        net.zero_grad(set_to_none=True)
+        net.lin(x).sum().backward()
+        with pytest.raises(RuntimeError, match='received no gradient'):
+            red.finish()
+        net.zero_grad(set_to_none=True)
+        net(x).square().sum().backward()
+        red.finish()                                             # and the reducer is usable again
+    finally:
+        ops.GRAD_SINK = None
+        red.remove()

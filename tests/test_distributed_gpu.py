@@ -1,7 +1,8 @@
 """Two data-parallel ranks driving the REAL HIP path (both on cuda:0, gloo transport -- RCCL refuses two
-ranks on one device): checks that DistributedDataParallel composes with the custom autograd Functions
-(every parameter gets a gradient every step, gradients are identical on both ranks after the all-reduce,
-and equal the single-process average over shards with per-shard BatchNorm statistics)."""
+ranks on one device): checks that the gradient reducer (repmode_amd.distributed.GradReducer: the MoDE gradient
+kernels write into the communication buckets) and, for comparison, DistributedDataParallel compose with the custom
+autograd Functions (every parameter gets a gradient every step, gradients are identical on both ranks after the
+all-reduce, and equal the single-process average over shards with per-shard BatchNorm statistics)."""
 import os
 import socket
 
@@ -30,19 +31,26 @@ def _data():
     return x, t, [1, 4, 4, 9]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, how):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
     from repmode_amd import distributed as dist_
     from repmode_amd.model import Model
     dist_.init_from_env(backend='gloo')
     torch.manual_seed(0)
-    m = Model(Opts(), lr=1e-4, gpu_ids=0, mult_chan=2, dtype=torch.float32, distributed=True)
+    m = Model(Opts(), lr=1e-4, gpu_ids=0, mult_chan=2, dtype=torch.float32, distributed=how)
     x, t, tasks = _data()
     lo, hi = dist_.shard_batch(4, rank, world)
-    m.ddp.train()
-    out = m.ddp(x[lo:hi].cuda(), tasks[lo:hi])
+    module = m.ddp if how == 'ddp' else m.net
+    module.train()
+    out = module(x[lo:hi].cuda(), tasks[lo:hi])
     torch.nn.functional.mse_loss(out, t[lo:hi].cuda()).backward()
+    if how != 'ddp':
+        m.reducer.finish()
+        # the 19 MoDE blocks' five expert gradients each were written into the buckets by the kernels
+        assert m.reducer.last_copied == len(list(m.net.parameters())) - 19 * 5, m.reducer.last_copied
+        for k, p in m.net.named_parameters():
+            assert p.grad.data_ptr() == m.reducer.by_param[p].ptr, k
     grads = {k: p.grad.detach().cpu().clone() for k, p in m.net.named_parameters()}
     assert all(p.grad is not None for p in m.net.parameters())
     # one full optimiser step through the harness as well
@@ -52,8 +60,9 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(900)
-def test_ddp_two_ranks_on_one_gpu(tmp_path):
-    mp.start_processes(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True, start_method='spawn')
+@pytest.mark.parametrize('how', ['reducer', 'ddp'])
+def test_ddp_two_ranks_on_one_gpu(tmp_path, how):
+    mp.start_processes(_worker, args=(2, _free_port(), str(tmp_path), how), nprocs=2, join=True, start_method='spawn')
     g0, g1 = torch.load(tmp_path / 'g0.pt'), torch.load(tmp_path / 'g1.pt')
     from repmode_amd.model import Model
     torch.manual_seed(0)
@@ -71,3 +80,39 @@ def test_ddp_two_ranks_on_one_gpu(tmp_path):
         # batch-norm chain amplifies it -> 2e-2 like the whole-net golden test.  Parameters whose gradient is tiny
         # next to the network's largest are judged on that scale (their own maximum is mostly that noise).
         assert (g0[k] - ref).abs().max() <= 2e-2 * max(float(ref.abs().max()), 1e-2 * gmax), k
+
+
+def test_reducer_buckets_hold_the_kernels_gradients_single_process():
+    """No process group: the reducer only provides the gradient buffers.  Three distinct tasks -> the deep levels
+    run the per-expert formulation (its 5^3 / 3^3 expert gradients go to the buckets, the 1x1 experts' come out of a
+    batched GEMM and are gathered), the others the merged one; results equal the plain model's."""
+    from repmode_amd.model import Model
+    from repmode_amd import ops
+    x, t, _ = _data()
+    tasks = torch.tensor([1, 4, 9, 4])
+    res = []
+    for distributed in ('reducer', False, False):
+        torch.manual_seed(0)
+        m = Model(Opts(), lr=1e-4, gpu_ids=0, mult_chan=4, dtype=torch.float32, distributed=distributed)
+        m.do_train_iter(x, t, tasks)
+        if distributed:
+            r = m.reducer
+            assert ops.GRAD_SINK is r
+            n_par = len(list(m.net.parameters()))
+            unmerged = 6                                   # enc4, bottleneck, dec4: two MoDE blocks each (W <= 8)
+            assert r.last_copied == n_par - (19 - unmerged) * 5 - unmerged * 2, r.last_copied
+            for p in m.net.parameters():
+                assert p.grad.data_ptr() == r.by_param[p].ptr
+        else:
+            assert ops.GRAD_SINK is None
+        res.append({k: p.grad.detach().cpu() for k, p in m.net.named_parameters()})
+        m.do_train_iter(x, t, tasks)                       # (a second step re-uses the buckets)
+    gmax = max(float(v.abs().max()) for v in res[1].values())
+
+    def worst(a, b):
+        return max(float((a[k] - b[k]).abs().max()) / max(float(b[k].abs().max()), 1e-2 * gmax) for k in b)
+
+    # The order of the f32 atomics differs from run to run and the batch-norm chain (64 values per channel on the
+    # deepest level here) amplifies it: the reducer run may differ from a plain run by what two plain runs differ by.
+    noise = worst(res[2], res[1])
+    assert worst(res[0], res[1]) <= max(5 * noise, 2e-2), (worst(res[0], res[1]), noise)

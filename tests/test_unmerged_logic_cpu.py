@@ -26,12 +26,12 @@ def fake_kernels(monkeypatch):
         dgw.index_add_(1, slot_task.long(), dl.t().contiguous())
         return dgw, dl.sum(dim=0)
 
-    def tap_t(dw_taps, shape):
+    def tap_t(dw_taps, shape, out=None):
         co, ci, k = shape[0], shape[1], shape[2]
         w = dw_taps.view(5, 5, 5, co, ci)
         if k == 3:
             w = w[1:4, 1:4, 1:4]
-        return w.permute(3, 4, 0, 1, 2).contiguous()
+        return out.copy_(w.permute(3, 4, 0, 1, 2))
 
     def merge(k5, k3, k1, a3, a5, g, dtype, want_wf=True, want_wd=False):
         w = orc.merge_filters(orc.expert_bank(k5, k3, k1, a3, a5), g)          # [S,Co,Ci,5,5,5]
@@ -57,16 +57,16 @@ def fake_kernels(monkeypatch):
             return out
         return y
 
-    def wgrad(x_cl, dy_cl, plan, cout, centre3=False, expert_layout=None):
+    def wgrad(x_cl, dy_cl, plan, cout, centre3=False, expert_layout=None, out=None):
         with torch.enable_grad():
             n, ci = x_cl.shape[0], x_cl.shape[-1]
             wt = torch.zeros(1, cout, ci, 5, 5, 5, requires_grad=True)
             y = orc.conv_per_sample(x_cl.detach().float().permute(0, 4, 1, 2, 3), wt.expand(n, -1, -1, -1, -1, -1))
             (y * dy_cl.detach().float().permute(0, 4, 1, 2, 3)).sum().backward()
         if expert_layout == 5:
-            return wt.grad[0].contiguous()
+            return out.copy_(wt.grad[0])
         if expert_layout == 3:
-            return wt.grad[0][:, :, 1:4, 1:4, 1:4].contiguous()
+            return out.copy_(wt.grad[0][:, :, 1:4, 1:4, 1:4])
         return wt.grad.reshape(1, cout, ci, 125).permute(0, 3, 1, 2).contiguous()
 
     def box(in3=None, in5=None, out=None, add=(), out_dtype=torch.float32):

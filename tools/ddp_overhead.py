@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Cost of the DistributedDataParallel wrapper itself on ONE GPU (a single-rank RCCL group: bucket copies, autograd
-hooks and a trivial all-reduce per bucket, no peer traffic) -- the part of multi-GPU scaling loss that is not
-communication.    python tools/ddp_overhead.py"""
+"""Cost of the data-parallel machinery itself on ONE GPU (a single-rank RCCL group: bucket copies, autograd hooks and a
+trivial all-reduce per bucket, no peer traffic) -- the part of multi-GPU scaling loss that is not communication:
+the stock DistributedDataParallel wrapper against repmode_amd.distributed.GradReducer.
+    python tools/ddp_overhead.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,6 +24,7 @@ def run(distributed):
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
 torch.cuda.set_device(0)
 torch.distributed.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
-a = run(False); b = run(True); c = run(False); d = run(True)
-print('plain %.2f / %.2f ms per step, DDP(1 rank) %.2f / %.2f ms per step' % (a, c, b, d))
+a = run(False); b = run('ddp'); e = run('reducer-always'); g = run('reducer'); c = run(False); d = run('ddp'); f = run('reducer-always'); h = run('reducer')
+print('plain %.2f / %.2f ms per step, DDP(1 rank) %.2f / %.2f, GradReducer(1 rank) %.2f / %.2f, GradReducer without the '
+      'collectives %.2f / %.2f' % (a, c, b, d, e, f, g, h))
 torch.distributed.destroy_process_group()
