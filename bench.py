@@ -31,7 +31,7 @@ import torch  # noqa: E402
 
 PATCH = (32, 64, 64)
 PER_GPU_BATCH = 8
-PROF_EVERY = 5           # the per-launch HIP events of the roofline are taken on every 5th timed step
+PROF_EVERY = 10          # the per-launch HIP events of the roofline are taken on every 10th timed step (launched kernel by kernel)
 MULT_CHAN = 32
 NUM_TASKS = 12
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
@@ -79,12 +79,13 @@ def cpu_baseline(seconds_budget=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--batch', type=int, default=PER_GPU_BATCH, help='patches per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events')
+    ap.add_argument('--graph', action='store_true', help='replay the train step as one HIP graph (N = 1; see DESIGN.md 3.5; REPMODE_FORK_MAX_W=16 adds the two-stream layers)')
     ap.add_argument('--prof-all', action='store_true', help='record HIP events for every library kernel, not only conv5_igemm')
     ap.add_argument('--dump-launches', default=None, help='write per-launch (kind, ms, TFLOP/s or TB/s) of the last timed step as JSON')
     args = ap.parse_args()
@@ -105,7 +106,7 @@ def main():
     opts.gpu_ids = local
     torch.manual_seed(0)                       # reference default seed (config.py:47); same init on every rank
     model = Model(opts, nn_module='RepMode', lr=1e-4, gpu_ids=local, mult_chan=MULT_CHAN, dtype=dtype,
-                  distributed=world > 1)
+                  distributed=world > 1, hip_graph=world == 1 and args.graph)
     b = args.batch
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     signal = torch.randn(b, 1, *PATCH, device=device, generator=gen)
@@ -132,7 +133,8 @@ def main():
             on = step % sample == 0
             _lib.prof_pause(not on)
             profiled_steps += on
-        model.do_train_iter(signal, target, task)
+        # (a profiled step is launched kernel by kernel: the library's event pairs are not part of the captured graph)
+        model.do_train_iter(signal, target, task, eager=not args.no_prof and on)
     t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (== dt when the host is the limiter)
     barrier()
     dt = time.perf_counter() - t0
@@ -157,7 +159,8 @@ def main():
         'config': {'workload': 'RepMode U-Net (mult_chan 32, 12 tasks, 123.9M params) full train step '
                                '(fwd + bwd + Adam), batch %d x 1x32x64x64 per GPU' % b,
                    'global_batch': world * b, 'patch': list(PATCH), 'parallelism': 'dp%d' % world,
-                   'final_loss': loss, 'host_issue_ms_per_step': 1e3 * t_issue / args.steps},
+                   'final_loss': loss, 'host_issue_ms_per_step': 1e3 * t_issue / args.steps,
+                   'hip_graph': bool(model.hip_graph), 'steps_launched_kernel_by_kernel': profiled_steps},
     }
     if rank == 0:
         if not args.no_prof:

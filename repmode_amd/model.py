@@ -56,7 +56,7 @@ def patch_grid(img_size, patch_size, overlap=0.5):
 
 class Model(object):
     def __init__(self, opts, nn_module='RepMode', init_weights=True, lr=0.001, criterion_fn=torch.nn.MSELoss,
-                 gpu_ids=0, mult_chan=32, dtype=torch.bfloat16, distributed=False):
+                 gpu_ids=0, mult_chan=32, dtype=torch.bfloat16, distributed=False, hip_graph=False):
         self.opts = opts
         self.nn_module = nn_module
         self.lr = lr
@@ -70,6 +70,13 @@ class Model(object):
         self.mult_chan = mult_chan
         self.dtype = dtype
         self.distributed = distributed
+        # hip_graph: replay the whole train step (forward, backward, Adam: ~490 launches, 13 ms of host time) as ONE
+        # HIP graph per (input shape, number of distinct tasks) -- see _graph_train_iter.  Single-GPU training only.
+        self.hip_graph = bool(hip_graph)
+        if self.hip_graph and distributed:
+            raise ValueError('hip_graph covers single-GPU training (the collectives are not captured)')
+        self._graphs = {}
+        self._capture_stream = None
         self.criterion = criterion_fn(reduction='none')        # fnet_model.py:36
         self._init_model()
 
@@ -89,8 +96,11 @@ class Model(object):
         # process-wide (one training process per GPU): where the MoDE gradient kernels put the parameter gradients
         ops_.GRAD_SINK = self.reducer
         try:
-            self.optimizer = torch.optim.Adam(self.net.parameters(), lr=self.lr, fused=True)
+            # (capturable: the step counters live on the device, so optimizer.step() can be part of a HIP graph)
+            self.optimizer = torch.optim.Adam(self.net.parameters(), lr=self.lr, fused=True, capturable=self.hip_graph)
         except (RuntimeError, TypeError):
+            if self.hip_graph:
+                raise
             self.optimizer = torch.optim.Adam(self.net.parameters(), lr=self.lr)
 
     # ---- checkpoint: fnet_model.py:57-94 (same keys)
@@ -116,19 +126,12 @@ class Model(object):
         self.count_epoch = state.get('count_epoch', 0)
 
     # ---- training step: fnet_model.py:96-132
-    def do_train_iter(self, signal, target, task, sync=False):
-        """One optimisation step.  ``task`` should be a CPU int tensor (as the DataLoader yields it):
-        the slot plan is then built without touching the device.  Returns (output, per-sample loss);
-        both stay on the device unless ``sync`` (then they are copied to the host like the reference
-        does)."""
-        signal = signal.to(self.device, non_blocking=True)
-        target = target.to(self.device, non_blocking=True)
+    def _train_step(self, signal, target, task):
+        """zero_grad, forward, MSELoss('none') -> mean, backward, (all-reduce), Adam.  ``task``: ints or a TaskPlan."""
         module = self.ddp if self.ddp is not None else self.net
         if not module.training:
             module.train()               # (walks the whole module tree: ~0.6 ms, not needed every step)
         self.optimizer.zero_grad(set_to_none=True)
-        if torch.is_tensor(task) and not task.is_cuda:
-            task = [int(t) for t in task.tolist()]   # plain ints: DDP's input scatter would move a tensor to the GPU
         output = module(signal, task)
         loss_nomean = self.criterion(output, target)
         loss = torch.mean(loss_nomean)
@@ -136,12 +139,79 @@ class Model(object):
         if self.reducer is not None:
             self.reducer.finish()
         self.optimizer.step()
-        self.count_iter += 1
         loss_sample = torch.mean(loss_nomean.detach(), dim=(1, 2, 3, 4))
         self.last_loss = loss.detach()
-        if sync:
-            return output.detach().cpu(), loss_sample.cpu()
         return output.detach(), loss_sample
+
+    def do_train_iter(self, signal, target, task, sync=False, eager=False):
+        """One optimisation step.  ``task`` should be a CPU int tensor (as the DataLoader yields it):
+        the slot plan is then built without touching the device.  Returns (output, per-sample loss);
+        both stay on the device unless ``sync`` (then they are copied to the host like the reference
+        does).  With ``hip_graph`` the step is a graph replay (``eager=True``: this step launch by launch) and the
+        returned tensors are overwritten by the next replay of the same shape."""
+        signal = signal.to(self.device, non_blocking=True)
+        target = target.to(self.device, non_blocking=True)
+        if torch.is_tensor(task) and not task.is_cuda:
+            task = [int(t) for t in task.tolist()]   # plain ints: DDP's input scatter would move a tensor to the GPU
+        if self.hip_graph and not eager:
+            output, loss_sample = self._graph_train_iter(signal, target, task)
+        else:
+            output, loss_sample = self._train_step(signal, target, task)
+        self.count_iter += 1
+        if sync:
+            return output.cpu(), loss_sample.cpu()
+        return output, loss_sample
+
+    GRAPH_WARMUP = 2     # launch-by-launch steps on the capture stream before a shape is captured
+
+    def _graph_train_iter(self, signal, target, task):
+        """The train step as a HIP graph.  One graph per (input shape, number of distinct tasks): that pair fixes every
+        launch's grid, every buffer size and which levels take the per-expert formulation; WHICH tasks they are is
+        data (three small index vectors, updated in place before the replay).  The first GRAPH_WARMUP steps of a
+        signature run launch by launch on the capture stream (they create the optimizer state, the library's
+        per-stream scratch and the zero pool's plan), the next one is captured -- into a private memory pool, so the
+        step's activations keep their addresses -- and replayed; from then on a step costs the host three small
+        copies and one graph launch."""
+        from . import ops as ops_
+        plan = task if isinstance(task, ops_.TaskPlan) else None
+        host = list(plan.tasks_host) if plan is not None else [int(t) for t in (task.tolist() if torch.is_tensor(task) else task)]
+        key = (tuple(signal.shape), signal.dtype, len(set(host)))
+        st = self._graphs.get(key)
+        if st is None:
+            st = self._graphs[key] = {'calls': 0, 'graph': None}
+        cur = torch.cuda.current_stream(self.device)
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream(self.device)
+        cs = self._capture_stream
+        if st['graph'] is None:
+            st['calls'] += 1
+            if st['calls'] <= self.GRAPH_WARMUP:
+                cs.wait_stream(cur)
+                with torch.cuda.stream(cs):
+                    out = self._train_step(signal, target, ops_.TaskPlan(host, self.net.num_tasks, self.device, True))
+                cur.wait_stream(cs)
+                return out
+            st['signal'], st['target'] = signal.clone(), target.clone()
+            st['plan'] = ops_.TaskPlan(host, self.net.num_tasks, self.device, True)
+            graph = torch.cuda.CUDAGraph()
+            cs.wait_stream(cur)
+            with torch.cuda.graph(graph, stream=cs):
+                st['out'] = self._train_step(st['signal'], st['target'], st['plan'])
+            st['graph'], st['last_loss'] = graph, self.last_loss
+            st['plan'].bn_counted = False
+        else:
+            st['signal'].copy_(signal, non_blocking=True)
+            st['target'].copy_(target, non_blocking=True)
+        sp = st['plan']
+        if host != sp.tasks_host:
+            new = ops_.TaskPlan(host, self.net.num_tasks, self.device, True)
+            sp.slot_task.copy_(new.slot_task, non_blocking=True)
+            sp.sample_slot.copy_(new.sample_slot, non_blocking=True)
+            sp.sample_task.copy_(new.sample_task, non_blocking=True)
+            sp.tasks_host, sp.slot_task_host = new.tasks_host, new.slot_task_host
+        st['graph'].replay()
+        self.last_loss = st['last_loss']
+        return st['out']
 
     # ---- sliding-window inference: fnet_model.py:149-223
     def predict(self, signal, task, patch_size=None):

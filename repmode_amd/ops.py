@@ -5,6 +5,8 @@ MoDE block runs in the hand-written HIP kernels of librepmode_hip.so.  Tensors h
 library are channels-last (NDHWC) and contiguous.  There is no CPU / eager fallback: calling an
 operator on a non-HIP tensor raises.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -35,6 +37,37 @@ def _require_hip(t, what):
     if not t.is_cuda:
         raise _lib.RepModeHipError(
             '%s is on %s: repmode_amd runs on MI355X (HIP) tensors only and has no CPU fallback' % (what, t.device))
+
+
+# ---- a second HIP stream for independent launches of one layer.  On the deep levels a conv / filter-gradient launch
+# has 128-256 workgroups for 512 slots, and a layer's data gradient, filter gradient and 1x1-expert GEMMs do not depend
+# on each other: issued on two streams they share the chip instead of queueing behind each other's tails.  Opt-in
+# (REPMODE_FORK_MAX_W=16): launched kernel by kernel the host cannot feed two streams fast enough (no gain); inside a
+# HIP graph (Model(hip_graph=True)) it is worth 2.5 % of the step (same box: 14.28 -> 13.93 ms), at the price of
+# per-launch durations that no longer describe one kernel.
+FORK_MAX_W = int(os.environ.get('REPMODE_FORK_MAX_W', '0'))      # layers with W <= this fork (0: never)
+_SIDE_STREAMS = {}
+
+
+def _fork(t):
+    """(main, side) streams for the device of tensor ``t``; the side stream is ordered after everything issued on the
+    current stream so far.  Rules for the caller: every launch that touches a tensor on the side stream lies between
+    ``_fork`` and ``_join``, and ``_join`` comes before the function returns (so no tensor is freed, and no result
+    consumed, while the side stream still works on it)."""
+    main = torch.cuda.current_stream(t.device)
+    side = _SIDE_STREAMS.get(t.device.index)
+    if side is None:
+        side = _SIDE_STREAMS[t.device.index] = torch.cuda.Stream(t.device)
+    side.wait_stream(main)
+    return main, side
+
+
+def _join(main, side):
+    main.wait_stream(side)
+
+
+def _forks(x_cl):
+    return 0 < x_cl.shape[3] <= FORK_MAX_W and x_cl.is_cuda
 
 
 class ZeroPool:
@@ -276,6 +309,20 @@ def conv5_wgrad(x_cl, dy_cl, plan, cout, centre3=False, expert_layout=None, out=
     return dw
 
 
+def _filter_and_expert_grads(dw, k5, k3, k1, a3, a5, g, plan):
+    """GatRep backward: per-slot filter gradient dw [S, 125, Co, Ci] -> (dk5, dk3, dk1, da3, da5, dgate_w, dgate_b)."""
+    co, ci = k5.shape[0], k5.shape[1]
+    dk5, dk3, dk1, da3, da5 = _grad_out(k5), _grad_out(k3), _grad_out(k1), _grad_out(a3), _grad_out(a5)
+    # gate.weight is [5*Co, T], gate.bias [5*Co]; shapes are recovered from g / plan
+    dgw = torch.empty((NUM_EXPERTS * co, plan.num_tasks), dtype=torch.float32, device=k5.device)
+    dgb = torch.empty((NUM_EXPERTS * co,), dtype=torch.float32, device=k5.device)
+    dg_ws = torch.empty_like(g)
+    _lib.call('repmode_gatrep_bwd', _ptr(dw), _ptr(k5), _ptr(k3), _ptr(k1), _ptr(a3), _ptr(a5), _ptr(g),
+              _ptr(plan.slot_task), plan.nslots, plan.num_tasks, co, ci, _ptr(dk5), _ptr(dk3), _ptr(dk1),
+              _ptr(da3), _ptr(da5), _ptr(dgw), _ptr(dgb), _ptr(dg_ws), _stream())
+    return dk5, dk3, dk1, da3, da5, dgw, dgb
+
+
 class _ModeConv3d(torch.autograd.Function):
     """Fused gate-softmax + GatRep + per-slot 5^3 convolution, forward and backward."""
 
@@ -309,6 +356,14 @@ class _ModeConv3d(torch.autograd.Function):
         co, ci = k5.shape[0], k5.shape[1]
         dy = dy.to(x_cl.dtype).contiguous()
         dx = None
+        # the filter gradient and the GatRep backward do not depend on the data gradient: second stream on the deep levels
+        fork = ctx.needs_input_grad[0] and _forks(x_cl)
+        if fork:
+            main, side = _fork(x_cl)
+            with torch.cuda.stream(side):
+                grads = _filter_and_expert_grads(conv5_wgrad(x_cl, dy, plan, co), k5, k3, k1, a3, a5, g, plan)
+        else:
+            grads = _filter_and_expert_grads(conv5_wgrad(x_cl, dy, plan, co), k5, k3, k1, a3, a5, g, plan)
         if ctx.needs_input_grad[0]:
             # deep levels (small volumes) split the channel reduction over workgroups -> float output
             if x_cl.dtype == torch.bfloat16 and co == 1 and ci != 1:     # the last layer: dy has one channel
@@ -320,16 +375,9 @@ class _ModeConv3d(torch.autograd.Function):
             if dx.dtype != x_cl.dtype:
                 dx = dx.to(x_cl.dtype)
             del wd
-        dw = conv5_wgrad(x_cl, dy, plan, co)
-        dk5, dk3, dk1, da3, da5 = _grad_out(k5), _grad_out(k3), _grad_out(k1), _grad_out(a3), _grad_out(a5)
-        # gate.weight is [5*Co, T], gate.bias [5*Co]; shapes are recovered from g / plan
-        dgw = torch.empty((NUM_EXPERTS * co, plan.num_tasks), dtype=torch.float32, device=k5.device)
-        dgb = torch.empty((NUM_EXPERTS * co,), dtype=torch.float32, device=k5.device)
-        dg_ws = torch.empty_like(g)
-        _lib.call('repmode_gatrep_bwd', _ptr(dw), _ptr(k5), _ptr(k3), _ptr(k1), _ptr(a3), _ptr(a5), _ptr(g),
-                  _ptr(plan.slot_task), plan.nslots, plan.num_tasks, co, ci, _ptr(dk5), _ptr(dk3), _ptr(dk1),
-                  _ptr(da3), _ptr(da5), _ptr(dgw), _ptr(dgb), _ptr(dg_ws), _stream())
-        return dx, dk5, dk3, dk1, da3, da5, dgw, dgb, None, None
+        if fork:
+            _join(main, side)
+        return (dx,) + grads + (None, None)
 
 
 class _ModeConv3dPair(torch.autograd.Function):
@@ -371,6 +419,24 @@ class _ModeConv3dPair(torch.autograd.Function):
         dt = xa.dtype
         code = dtype_code(dt)
         dy = dy.to(dt).contiguous()
+
+        def filter_grads():
+            # the two channel ranges of one (cleared) buffer
+            dw, pre = ZERO_POOL.take((plan.nslots, TAPS, co, ci), xa.device)
+            if not pre:
+                dw.zero_()
+            for part, off in ((xa, 0), (xb, ca)):
+                _lib.call('repmode_conv5_wgrad_part', _ptr(part), _ptr(dy), _ptr(plan.sample_slot), plan.nslots, _ptr(dw),
+                          n, d, h, w_, part.shape[-1], ci, off, co, code, 8, _stream())
+            return _filter_and_expert_grads(dw, k5, k3, k1, a3, a5, g, plan)
+
+        fork = wd is not None and _forks(xa)
+        if fork:
+            main, side = _fork(xa)
+            with torch.cuda.stream(side):
+                grads = filter_grads()
+        else:
+            grads = filter_grads()
         dxa = dxb = None
         if wd is not None:
             f32 = w_ < 32 or dt == torch.float32        # deep levels: split reduction -> float output (as _ModeConv3d)
@@ -389,21 +455,9 @@ class _ModeConv3dPair(torch.autograd.Function):
                       n, d, h, w_, co, ci, code, 1 if f32 else 0, flags, _stream())
             if dxa.dtype != dt:
                 dxa, dxb = dxa.to(dt), dxb.to(dt)
-        # filter gradient: the two channel ranges of one (cleared) buffer
-        dw, pre = ZERO_POOL.take((plan.nslots, TAPS, co, ci), xa.device)
-        if not pre:
-            dw.zero_()
-        for part, off in ((xa, 0), (xb, ca)):
-            _lib.call('repmode_conv5_wgrad_part', _ptr(part), _ptr(dy), _ptr(plan.sample_slot), plan.nslots, _ptr(dw),
-                      n, d, h, w_, part.shape[-1], ci, off, co, code, 8, _stream())
-        dk5, dk3, dk1, da3, da5 = _grad_out(k5), _grad_out(k3), _grad_out(k1), _grad_out(a3), _grad_out(a5)
-        dgw = torch.empty((NUM_EXPERTS * co, plan.num_tasks), dtype=torch.float32, device=k5.device)
-        dgb = torch.empty((NUM_EXPERTS * co,), dtype=torch.float32, device=k5.device)
-        dg_ws = torch.empty_like(g)
-        _lib.call('repmode_gatrep_bwd', _ptr(dw), _ptr(k5), _ptr(k3), _ptr(k1), _ptr(a3), _ptr(a5), _ptr(g),
-                  _ptr(plan.slot_task), plan.nslots, plan.num_tasks, co, ci, _ptr(dk5), _ptr(dk3), _ptr(dk1),
-                  _ptr(da3), _ptr(da5), _ptr(dgw), _ptr(dgb), _ptr(dg_ws), _stream())
-        return dxa, dxb, dk5, dk3, dk1, da3, da5, dgw, dgb, None, None
+        if fork:
+            _join(main, side)
+        return (dxa, dxb) + grads + (None, None)
 
 
 def pair_supported(xa_cl, xb_cl, plan):
@@ -717,15 +771,30 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         s0, s1 = _SingleSlot(n, dev, 0), _SingleSlot(n, dev, 1)
         d, h, w = x_cl.shape[1:4]
         p, pre = ZERO_POOL.take((NUM_EXPERTS, n, d, h, w, co), dev)                       # expert outputs P_e
-        conv5(x_cl, wf2, s0.sample_slot, co, out_f32=True, out=p[0], accumulate=pre)
-        conv5(x_cl, wf2, s1.sample_slot, co, out_f32=True, out=p[1], centre3=True, accumulate=pre)   # 3x3x3 support
-        # the three 1x1 experts as ONE batched GEMM: [x | box3(x) | box5(x)] @ [K1 | A3 | A5]^T  -> P_2..P_4
         xb = torch.empty((3, n, d, h, w, ci), dtype=torch.float32, device=dev)
-        xb[0].copy_(x_cl)
-        box_sum(in3=xb[0], out=xb[1])
-        box_sum(in5=xb[0], out=xb[2])
-        w1 = torch.stack((k1.view(co, ci), a3.view(co, ci), a5.view(co, ci)))             # [3, Co, Ci]
-        torch.bmm(xb.view(3, -1, ci), w1.transpose(1, 2), out=p[2:].view(3, -1, co))
+
+        def small_experts():
+            # the 3^3 expert, and the three 1x1 experts as ONE batched GEMM:
+            # [x | box3(x) | box5(x)] @ [K1 | A3 | A5]^T  -> P_2..P_4
+            conv5(x_cl, wf2, s1.sample_slot, co, out_f32=True, out=p[1], centre3=True, accumulate=pre)   # 3x3x3 support
+            xb[0].copy_(x_cl)
+            box_sum(in3=xb[0], out=xb[1])
+            box_sum(in5=xb[0], out=xb[2])
+            w1 = torch.stack((k1.view(co, ci), a3.view(co, ci), a5.view(co, ci)))         # [3, Co, Ci]
+            torch.bmm(xb.view(3, -1, ci), w1.transpose(1, 2), out=p[2:].view(3, -1, co))
+            return w1
+
+        # the 5^3 expert's conv on this stream, the four small experts beside it on the second one
+        fork = _forks(x_cl)
+        if fork:
+            main, side = _fork(x_cl)
+            with torch.cuda.stream(side):
+                w1 = small_experts()
+        else:
+            w1 = small_experts()
+        conv5(x_cl, wf2, s0.sample_slot, co, out_f32=True, out=p[0], accumulate=pre)
+        if fork:
+            _join(main, side)
         y = expert_mix_fwd(p, gn)
         ctx.save_for_backward(x_cl, k5, k3, k1, a3, a5, gn, xb, w1, p, wd2)
         ctx.plan = plan
@@ -744,6 +813,32 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
         dg, d01, dhi = expert_mix_bwd(dy, p, gn, dt)            # <dy, P_e>, and the gate-scaled dy per expert
         dgw, dgb = gate_bwd(gn, dg, plan.sample_task, plan.num_tasks)       # one "slot" per sample
         s0, s1 = _SingleSlot(n, dev, 0), _SingleSlot(n, dev, 1)
+
+        def expert_grads():
+            # filter gradients of the gate-scaled dy, all samples in one slot.  Large layers (every workgroup owns its
+            # outputs: no atomics) write the parameters' [Co][Ci][taps] layout directly, each wave transposing its tile
+            # through LDS; the others accumulate tap-major and are transposed by a second launch.
+            one = _SingleSlot(n, dev, 0)
+            tiles = ((co + 31) // 32) * ((ci + 31) // 32)
+            if dt == torch.bfloat16 and tiles * 5 >= 512:
+                dk5 = conv5_wgrad(x_cl, d01[0], one, co, expert_layout=5, out=_grad_out(k5))
+            else:
+                dk5 = tap_transpose(conv5_wgrad(x_cl, d01[0], one, co)[0], k5.shape, out=_grad_out(k5))
+            if dt == torch.bfloat16 and tiles * 3 >= 512:
+                dk3 = conv5_wgrad(x_cl, d01[1], one, co, expert_layout=3, out=_grad_out(k3))
+            else:
+                dk3 = tap_transpose(conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0], k3.shape, out=_grad_out(k3))
+            d1 = torch.bmm(dhi[:, :xb[0].numel() // ci].transpose(1, 2), xb.view(3, -1, ci))   # [3, Co, Ci]
+            return dk5, dk3, d1[0].reshape(k1.shape), d1[1].reshape(a3.shape), d1[2].reshape(a5.shape)
+
+        # the expert gradients do not depend on the data gradient: second stream
+        fork = ctx.needs_input_grad[0] and _forks(x_cl)
+        if fork:
+            main, side = _fork(x_cl)
+            with torch.cuda.stream(side):
+                dk5, dk3, dk1, da3, da5 = expert_grads()
+        else:
+            dk5, dk3, dk1, da3, da5 = expert_grads()
         dx = None
         if ctx.needs_input_grad[0]:
             dxf = conv5(d01[0], wd2, s0.sample_slot, ci, out_f32=True)
@@ -757,21 +852,8 @@ class _ModeConv3dUnmerged(torch.autograd.Function):
             tv = [t[e, :m].view(shp) for e in range(3)]
             dx = box_sum(in3=tv[1], in5=tv[2], add=(dxf, tv[0]), out_dtype=dt)
             del wd2
-        # ---- expert gradients: filter gradients of the gate-scaled dy, all samples in one slot.  Large layers (every
-        # workgroup owns its outputs: no atomics) write the parameters' [Co][Ci][taps] layout directly, each wave
-        # transposing its tile through LDS; the others accumulate tap-major and are transposed by a second launch.
-        one = _SingleSlot(n, dev, 0)
-        tiles = ((co + 31) // 32) * ((ci + 31) // 32)
-        if dt == torch.bfloat16 and tiles * 5 >= 512:
-            dk5 = conv5_wgrad(x_cl, d01[0], one, co, expert_layout=5, out=_grad_out(k5))
-        else:
-            dk5 = tap_transpose(conv5_wgrad(x_cl, d01[0], one, co)[0], k5.shape, out=_grad_out(k5))
-        if dt == torch.bfloat16 and tiles * 3 >= 512:
-            dk3 = conv5_wgrad(x_cl, d01[1], one, co, expert_layout=3, out=_grad_out(k3))
-        else:
-            dk3 = tap_transpose(conv5_wgrad(x_cl, d01[1], one, co, centre3=True)[0], k3.shape, out=_grad_out(k3))
-        d1 = torch.bmm(dhi[:, :xb[0].numel() // ci].transpose(1, 2), xb.view(3, -1, ci))   # [3, Co, Ci]
-        dk1, da3, da5 = d1[0].reshape(k1.shape), d1[1].reshape(a3.shape), d1[2].reshape(a5.shape)
+        if fork:
+            _join(main, side)
         return dx, dk5, dk3, dk1, da3, da5, dgw, dgb, None
 
 

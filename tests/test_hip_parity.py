@@ -274,6 +274,36 @@ def test_mode_conv3d_pair_equals_concatenation(ca, cb, co, shape, tasks, dtype, 
         assert rel_err(u, v) < tol, name
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('form', ['merged', 'unmerged', 'pair'])
+def test_two_stream_layers_agree(form, dtype, monkeypatch):
+    """ops.FORK_MAX_W: a layer's independent launches (data gradient | filter gradient + GatRep backward; 5^3 expert |
+    the small experts) on two HIP streams give the one-stream results."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(23)
+    ci, co, shape, tasks = 64, 64, (2, 4, 8), [4, 9, 1]
+    ps = _rand_experts(co, ci, gen)
+    x = torch.randn(3, *shape, ci, generator=gen).to(dtype)
+    r = torch.randn(3, *shape, co, generator=gen)
+    res = []
+    for max_w in (0, 16, 16):
+        monkeypatch.setattr(ops, 'FORK_MAX_W', max_w)
+        dev = [p.to(DEV).requires_grad_(True) for p in ps]
+        xd = x.to(DEV).requires_grad_(True)
+        plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+        if form == 'pair':
+            xa, xb = xd[..., :32].contiguous(), xd[..., 32:].contiguous()
+            y = ops._ModeConv3dPair.apply(xa, xb, *dev, plan, False)
+        else:
+            y = ops.mode_conv3d(xd, *dev, plan, mode=form)
+        (y.float() * r.to(DEV)).sum().backward()
+        res.append([y.detach().float().cpu(), xd.grad.float().cpu()] + [p.grad.cpu() for p in dev])
+    tol = 1e-5 if dtype == torch.float32 else 1e-2         # (bf16: an atomics-order difference can flip a rounding)
+    for other in res[1:]:
+        for a, b in zip(other, res[0]):
+            assert rel_err(a, b) < tol
+
+
 def _load_block(g, dtype):
     from repmode_amd.nn_modules.RepMode import MoDEConv
     co, ci = g['p.expert_conv5x5_conv'].shape[:2]
@@ -637,9 +667,9 @@ def test_full_size_linearity_and_oracle_sample():
     assert rel_err(got, yc) < TOL_BF16_ACC
 
 
-def _mc2_model(g, dtype, lr):
+def _mc2_model(g, dtype, lr, **kw):
     from repmode_amd.model import Model
-    m = Model(Opts(), nn_module='RepMode', lr=lr, gpu_ids=0, mult_chan=int(g['mult_chan']), dtype=dtype)
+    m = Model(Opts(), nn_module='RepMode', lr=lr, gpu_ids=0, mult_chan=int(g['mult_chan']), dtype=dtype, **kw)
     m.net.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('p.')})
     return m
 
@@ -655,6 +685,38 @@ def test_train_iter_matches_reference_loss_sequence():
         assert abs(float(m.last_loss) - g['losses'][s]) < 2e-4, s
         assert np.allclose(per.numpy(), g['loss_per_sample'][s], atol=2e-4)
     assert m.count_iter == 5
+
+
+def test_train_iter_as_hip_graph_matches_reference_loss_sequence(monkeypatch):
+    """The same golden sequence with the train step replayed as a HIP graph (Model(hip_graph=True): two steps launch
+    by launch on the capture stream, the third is captured, then replays), followed by steps with other tasks (same
+    number of distinct ones: the same graph, new index vectors; another number: a second graph) against a model
+    that launches kernel by kernel."""
+    g = load_golden('g4_train_mc2.npz')
+    monkeypatch.setattr(_ops(), 'FORK_MAX_W', 16)            # with the two-stream layers: fork / join inside the capture
+    m = _mc2_model(g, torch.float32, float(g['lr']), hip_graph=True)
+    e = _mc2_model(g, torch.float32, float(g['lr']))
+    tasks = torch.from_numpy(g['tasks'])
+    nsteps = len(g['losses'])
+    for s in range(nsteps):
+        x, t = torch.from_numpy(g['xs'][s]), torch.from_numpy(g['targets'][s])
+        out, per = m.do_train_iter(x, t, tasks, sync=True)
+        e.do_train_iter(x, t, tasks)
+        assert abs(float(m.last_loss) - g['losses'][s]) < 2e-4, s
+        assert np.allclose(per.numpy(), g['loss_per_sample'][s], atol=2e-4)
+    assert len(m._graphs) == 1 and next(iter(m._graphs.values()))['graph'] is not None
+    host = [int(v) for v in tasks]
+    distinct = sorted(set(host))
+    other = [(v + 5) % 12 for v in host]                          # same grouping, other tasks
+    fewer = [distinct[0]] * len(host)                             # one distinct task: another graph signature
+    seq = [other, host, other] + [fewer] * 4 + [host]
+    for i, tk in enumerate(seq):
+        x, t = torch.from_numpy(g['xs'][i % nsteps]), torch.from_numpy(g['targets'][i % nsteps])
+        m.do_train_iter(x, t, torch.tensor(tk), eager=(i == 1))   # (a kernel-by-kernel step between replays)
+        e.do_train_iter(x, t, torch.tensor(tk))
+        assert abs(float(m.last_loss) - float(e.last_loss)) < 1e-3 * max(1.0, abs(float(e.last_loss))), (i, tk)
+    assert len(m._graphs) == 2 and all(v['graph'] is not None for v in m._graphs.values())
+    assert m.count_iter == nsteps + len(seq)
 
 
 def test_predict_matches_reference_blend():
