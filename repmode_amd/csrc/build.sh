@@ -3,18 +3,19 @@
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
-OUT="$HERE/../librepmode_hip.so"
+OUT="${REPMODE_OUT:-$HERE/../librepmode_hip.so}"      # (REPMODE_OUT / REPMODE_BUILD_DIR: a variant build next to the product one)
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I$ROOT/include -I$HERE ${REPMODE_EXTRA_FLAGS:-}"
-mkdir -p "$HERE/build"
+BUILD="${REPMODE_BUILD_DIR:-$HERE/build}"
+mkdir -p "$BUILD"
 pids=()
 for f in "$HERE"/*.hip; do
-  o="$HERE/build/$(basename "${f%.hip}").o"
+  o="$BUILD/$(basename "${f%.hip}").o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$ROOT/include/repmode_hip.h" -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/build/*.o -o "$OUT"
+$HIPCC --offload-arch=gfx950 -shared -fPIC "$BUILD"/*.o -o "$OUT"
 echo "built $OUT"

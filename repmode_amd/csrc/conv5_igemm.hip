@@ -62,6 +62,16 @@ __device__ unsigned long long g_conv_timing[64 * 64];
 #define RM_STAMP(slot) do {} while (0)
 #endif
 
+// Experiment (REPMODE_EXTRA_FLAGS=-DRM_CONV_SCHED, tools/ab_variant.sh): without the fence the machine scheduler
+// sinks half of the "one tap ahead" LDS reads to just before the MFMA that consumes them (taps 1 and 3 of every row:
+// ds_read; s_waitcnt lgkmcnt(1); v_mfma), so those MFMAs wait out the LDS latency unless the SIMD's other wave covers.
+// Measured on level 0 (same box, sustained): 226.6 vs 227.1 us per launch -- the other wave does cover; off by default.
+#ifdef RM_CONV_SCHED
+#define RM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define RM_SCHED_FENCE() do {} while (0)
+#endif
+
 #ifndef CONV_SPLIT_TARGET
 #define CONV_SPLIT_TARGET 512
 #endif
@@ -302,11 +312,13 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
           const int offn = (dx < 4) ? rowoff + dx + 1 : rowoff_n;
 #pragma unroll
           for (int vs = 0; vs < VW; ++vs) b_nxt[vs] = lds[vbase[vs] + offn];
+          RM_SCHED_FENCE();   // (RM_CONV_SCHED builds: keep the next tap's LDS reads ahead of this tap's MFMAs)
 #pragma unroll
           for (int vs = 0; vs < VW; ++vs) {
             if constexpr (SWAP) Elem<T>::mma(b_cur[vs], a_cur[dx], acc[0][vs]);
             else Elem<T>::mma(a_cur[dx], b_cur[vs], acc[0][vs]);
           }
+          RM_SCHED_FENCE();
 #pragma unroll
           for (int vs = 0; vs < VW; ++vs) b_cur[vs] = b_nxt[vs];
         }
