@@ -225,12 +225,14 @@ class Model(object):
         patches = patch_grid(img_size, patch_size)
         task_id = int(task.reshape(-1)[0]) if torch.is_tensor(task) else int(task)
         bs = int(self.opts.batch_size_eval)
-        while patches:                                          # LIFO batches, fnet_model.py:196-200
-            batch = [patches.pop() for _ in range(min(bs, len(patches)))]
-            crops = torch.cat([signal[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] for s, e in batch], dim=0)
-            with torch.no_grad():
+        from . import ops as ops_
+        # eval mode: one task, one merged filter per block -- computed for the first batch of patches, re-used for the rest
+        with torch.no_grad(), ops_.eval_filter_cache():
+            while patches:                                      # LIFO batches, fnet_model.py:196-200
+                batch = [patches.pop() for _ in range(min(bs, len(patches)))]
+                crops = torch.cat([signal[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] for s, e in batch], dim=0)
                 out = self.net(crops, [task_id] * len(batch))
-            for i, (s, e) in enumerate(batch):
-                pred_sum[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] += out[i:i + 1] * gauss
-                weight_sum[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] += gauss
+                for i, (s, e) in enumerate(batch):
+                    pred_sum[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] += out[i:i + 1] * gauss
+                    weight_sum[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] += gauss
         return (pred_sum / weight_sum).cpu()

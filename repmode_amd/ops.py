@@ -5,6 +5,7 @@ MoDE block runs in the hand-written HIP kernels of librepmode_hip.so.  Tensors h
 library are channels-last (NDHWC) and contiguous.  There is no CPU / eager fallback: calling an
 operator on a non-HIP tensor raises.
 """
+import contextlib
 import os
 
 import torch
@@ -309,6 +310,37 @@ def conv5_wgrad(x_cl, dy_cl, plan, cout, centre3=False, expert_layout=None, out=
     return dw
 
 
+_EVAL_FILTERS = None     # dict inside ``eval_filter_cache()``: (expert storage, tasks, dtype) -> merged forward filter
+
+
+@contextlib.contextmanager
+def eval_filter_cache():
+    """Inside this context the merged filter of an eval-mode MoDE block (one slot: RepMode.py:209-210) is computed once
+    per (block, task, dtype) instead of once per forward: sliding-window inference re-uses it for every batch of
+    patches of a volume.  The parameters must not change inside the context."""
+    global _EVAL_FILTERS
+    prev, _EVAL_FILTERS = _EVAL_FILTERS, {}
+    try:
+        yield
+    finally:
+        _EVAL_FILTERS = prev
+
+
+def _merged_filters(k5, k3, k1, a3, a5, gate_w, gate_b, plan, dtype, want_wd):
+    """(g, forward filter, data-gradient filter or None) of a MoDE block: gate softmax + GatRep, or the filter kept by
+    ``eval_filter_cache`` for this block and task."""
+    cache = _EVAL_FILTERS if not (plan.training or want_wd or torch.is_grad_enabled()) else None
+    key = (k5.data_ptr(), tuple(plan.slot_task_host), dtype) if cache is not None else None
+    if cache is not None and key in cache:
+        g, wf = cache[key]
+        return g, wf, None
+    g = gate_softmax(gate_w, gate_b, plan, k5.shape[0])
+    wf, wd = gatrep_merge(k5, k3, k1, a3, a5, g, dtype, want_wf=True, want_wd=want_wd)
+    if cache is not None:
+        cache[key] = (g, wf)
+    return g, wf, wd
+
+
 def _filter_and_expert_grads(dw, k5, k3, k1, a3, a5, g, plan):
     """GatRep backward: per-slot filter gradient dw [S, 125, Co, Ci] -> (dk5, dk3, dk1, da3, da5, dgate_w, dgate_b)."""
     co, ci = k5.shape[0], k5.shape[1]
@@ -330,11 +362,9 @@ class _ModeConv3d(torch.autograd.Function):
     def forward(ctx, x_cl, k5, k3, k1, a3, a5, gate_w, gate_b, plan, out_f32):
         _require_hip(x_cl, 'input')
         co = k5.shape[0]
-        g = gate_softmax(gate_w, gate_b, plan, co)
         # the data-gradient filter comes out of the same pass over the experts (one launch, one read of the
         # weights); these are the shallow levels, whose merged filters are small next to the activations
-        want_wd = ctx.needs_input_grad[0]
-        wf, wd = gatrep_merge(k5, k3, k1, a3, a5, g, x_cl.dtype, want_wf=True, want_wd=want_wd)
+        g, wf, wd = _merged_filters(k5, k3, k1, a3, a5, gate_w, gate_b, plan, x_cl.dtype, ctx.needs_input_grad[0])
         ci = k5.shape[1]
         thin = x_cl.dtype == torch.bfloat16 and (ci == 1) != (co == 1)
         if thin and ci == 1:                                  # first layer: x taps folded into input channels
@@ -392,9 +422,8 @@ class _ModeConv3dPair(torch.autograd.Function):
         co, ci = k5.shape[0], k5.shape[1]
         ca = xa.shape[-1]
         n, d, h, w_ = xa.shape[:4]
-        g = gate_softmax(gate_w, gate_b, plan, co)
-        want_wd = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        wf, wd = gatrep_merge(k5, k3, k1, a3, a5, g, xa.dtype, want_wf=True, want_wd=want_wd)
+        g, wf, wd = _merged_filters(k5, k3, k1, a3, a5, gate_w, gate_b, plan, xa.dtype,
+                                    ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         code = dtype_code(xa.dtype)
         out_dtype = torch.float32 if (out_f32 or xa.dtype == torch.float32) else xa.dtype
         flags = 0

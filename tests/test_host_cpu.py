@@ -156,3 +156,36 @@ def test_zero_pool_semantics():
     assert pre0 and not pre1 and not pre2
     pool.end()
     assert pool.take((3,), dev)[1] is False                      # inactive pool
+
+
+def test_eval_filter_cache_scope(monkeypatch):
+    """ops.eval_filter_cache: one GatRep per (block, task, dtype) for eval-mode forwards without autograd inside the
+    context; never for training plans, with autograd, or outside the context."""
+    from repmode_amd import ops
+    calls = []
+    monkeypatch.setattr(ops, 'gate_softmax', lambda gw, gb, plan, co: torch.zeros(plan.nslots, 5, co))
+    monkeypatch.setattr(ops, 'gatrep_merge', lambda k5, *a, **kw: (calls.append(k5.data_ptr()) or torch.zeros(1), None))
+    k5a, k5b = torch.zeros(4, 2, 5, 5, 5), torch.zeros(4, 2, 5, 5, 5)
+    z = torch.zeros(1)
+    ev = lambda task: ops.TaskPlan([task, task], 12, 'cpu', training=False)
+    tr = ops.TaskPlan([3, 5], 12, 'cpu', training=True)
+
+    def run(k5, plan, dtype=torch.float32):
+        return ops._merged_filters(k5, z, z, z, z, z, z, plan, dtype, False)
+
+    with torch.no_grad():
+        run(k5a, ev(3)); run(k5a, ev(3))
+        assert len(calls) == 2                                   # no context: every call merges
+        with ops.eval_filter_cache():
+            g1, w1, _ = run(k5a, ev(3))
+            g2, w2, _ = run(k5a, ev(3))
+            assert w1 is w2 and len(calls) == 3                  # second forward re-uses the filter
+            run(k5a, ev(4)); run(k5b, ev(3)); run(k5a, ev(3), torch.bfloat16)
+            assert len(calls) == 6                               # other task / block / dtype: own entries
+            run(k5a, tr); run(k5a, tr)
+            assert len(calls) == 8                               # training plans are never cached
+        run(k5a, ev(3))
+        assert len(calls) == 9                                   # the cache ends with the context
+    with ops.eval_filter_cache():
+        run(k5a, ev(3)); run(k5a, ev(3))
+        assert len(calls) == 11                                  # autograd enabled: not cached
