@@ -36,6 +36,51 @@ def main():
             continue
         t = sum((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in ks) / steps
         print('%-12s %6.1f launches/step  %8.0f us/step' % (key, len(ks) / steps, t))
+    families(tr)
+
+
+FAMILIES = [('conv5_igemm level 0-1', 'conv5_igemm_kernel<unsigned short, Cfg<4, 4, 32'),
+            ('conv5_igemm level 2', 'conv5_igemm_kernel<unsigned short, Cfg<4, 4, 16'),
+            ('conv5_igemm level 3', 'conv5_igemm_kernel<unsigned short, Cfg<4, 8, 8'),
+            ('conv5_igemm level 4', 'conv5_igemm_kernel<unsigned short, Cfg<2, 4, 4'),
+            ('conv5_wgrad level 0-1', 'conv5_wgrad_bf16_kernel<1, 8, 32'), ('conv5_wgrad level 2', 'conv5_wgrad_bf16_kernel<1, 8, 16'),
+            ('conv5_wgrad level 3', 'conv5_wgrad_bf16_kernel<2, 8, 8'), ('conv5_wgrad level 4', 'conv5_wgrad_bf16_kernel<2, 4, 8'),
+            ('conv5_wgrad_thin', 'wgrad_thin'), ('gatrep_fwd', 'gatrep_fwd'), ('gatrep_bwd', 'gatrep_bwd'),
+            ('expert_frags', 'expert_frags'), ('gate softmax / backward', 'gate_'), ('BatchNorm+ReLU', 'bn_'),
+            ('k2s2 (stride-2 stages)', 'k2'), ('Adam (fused)', 'FusedAdam'), ('box_sum', 'box_sum'),
+            ('expert_mix', 'expert_mix'), ('tap_transpose', 'tap_transpose'), ('thin-layer helpers', 'shift5'),
+            ('thin-layer helpers', 'thin_pack'), ('rocBLAS (1x1 experts)', 'Cijk'), ('cat', 'CatArray'),
+            ('pooled memset / fills', 'FillFunctor'), ('other PyTorch elementwise', 'at::native')]
+
+
+def families(tr):
+    """GPU time per train step by kernel family and U-Net level, over the steady steps of the trace (a step ends with
+    its last fused-Adam launch; the first three steps are skipped), plus the idle time between launches."""
+    tr = sorted(tr, key=lambda r: int(r['Start_Timestamp']))
+    adam = [i for i, r in enumerate(tr) if 'FusedAdam' in r['Kernel_Name']]
+    if len(adam) < 2:
+        return
+    per = 1
+    while per < len(adam) and adam[per] == adam[per - 1] + 1:
+        per += 1                                   # Adam launches per step (consecutive dispatches)
+    ends = [adam[i] for i in range(per - 1, len(adam), per)]
+    if len(ends) < 6:
+        return
+    t, c, n, idle = {}, {}, 0, 0.0
+    for k in range(3, len(ends) - 1):
+        step = tr[ends[k] + 1:ends[k + 1] + 1]
+        n += 1
+        for a, b in zip(step[:-1], step[1:]):
+            idle += max(0, int(b['Start_Timestamp']) - int(a['End_Timestamp'])) / 1e3
+        for r in step:
+            name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
+            fam = next((f for f, pat in FAMILIES if pat in name), 'other')
+            t[fam] = t.get(fam, 0.0) + (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+            c[fam] = c.get(fam, 0) + 1
+    tot = sum(t.values()) / n
+    print('== GPU time per step by family, %d steady steps: %.2f ms busy + %.2f ms idle between launches ==' % (n, tot / 1e3, idle / n / 1e3))
+    for fam in sorted(t, key=lambda f: -t[f]):
+        print('%-28s %8.1f us/step  %6.1f launches  %5.1f%%' % (fam, t[fam] / n, c[fam] / n, 100 * t[fam] / n / tot))
 
 
 if __name__ == '__main__':

@@ -70,7 +70,7 @@ class Model(object):
         self.mult_chan = mult_chan
         self.dtype = dtype
         self.distributed = distributed
-        # hip_graph: replay the whole train step (forward, backward, Adam: ~490 launches, 13 ms of host time) as ONE
+        # hip_graph: replay the whole train step (forward, backward, Adam: ~415 launches, 13 ms of host time) as ONE
         # HIP graph per (input shape, number of distinct tasks) -- see _graph_train_iter.  Single-GPU training only.
         self.hip_graph = bool(hip_graph)
         if self.hip_graph and distributed:
