@@ -84,6 +84,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--batch', type=int, default=PER_GPU_BATCH, help='patches per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--host-inputs', action='store_true', help='inputs start in pinned host memory every step (PCIe-inclusive rate)')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events')
     ap.add_argument('--graph', action='store_true', help='replay the train step as one HIP graph (N = 1; see DESIGN.md 3.5; REPMODE_FORK_MAX_W=16 adds the two-stream layers)')
     ap.add_argument('--prof-all', action='store_true', help='record HIP events for every library kernel, not only conv5_igemm')
@@ -111,6 +112,10 @@ def main():
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     signal = torch.randn(b, 1, *PATCH, device=device, generator=gen)
     target = torch.randn(b, 1, *PATCH, device=device, generator=gen)
+    if args.host_inputs:
+        # the PCIe-inclusive variant: the batch is handed over in (pinned) host memory every step, as a DataLoader
+        # would; never the headline `value` (inputs resident in HBM), reported in DESIGN.md section 5
+        signal, target = signal.cpu().pin_memory(), target.cpu().pin_memory()
     task = (torch.arange(b) + rank * b) % NUM_TASKS            # CPU int tensor, like the DataLoader's
 
     def barrier():
@@ -155,7 +160,7 @@ def main():
         'scaling': 'weak',
         'vs_baseline': None,
         'dtype': args.dtype,
-        'data': 'synthetic',
+        'data': 'synthetic' + (' (inputs in pinned host memory every step: PCIe-inclusive)' if args.host_inputs else ''),
         'config': {'workload': 'RepMode U-Net (mult_chan 32, 12 tasks, 123.9M params) full train step '
                                '(fwd + bwd + Adam), batch %d x 1x32x64x64 per GPU' % b,
                    'global_batch': world * b, 'patch': list(PATCH), 'parallelism': 'dp%d' % world,
