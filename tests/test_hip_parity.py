@@ -268,7 +268,7 @@ def test_mode_conv3d_pair_equals_concatenation(ca, cb, co, shape, tasks, dtype, 
             (y.float() * r.to(DEV)).sum().backward()
         ops.ZERO_POOL.end()
         out[form] = [y.detach().float().cpu(), a.grad.float().cpu(), b.grad.float().cpu()] + [p.grad.cpu() for p in dev]
-    tol = 1e-5 if dtype == torch.float32 else 1e-2        # bf16: an atomics-order difference can flip a bf16 rounding (1 ulp)
+    tol = 5e-5 if dtype == torch.float32 else 1e-2        # bf16: an atomics-order difference can flip a bf16 rounding (1 ulp)
     names = ['y', 'dxa', 'dxb', 'k5', 'k3', 'k1', 'a3', 'a5', 'gate_w', 'gate_b']
     for name, u, v in zip(names, out['pair'], out['cat']):
         assert rel_err(u, v) < tol, name
@@ -298,7 +298,7 @@ def test_two_stream_layers_agree(form, dtype, monkeypatch):
             y = ops.mode_conv3d(xd, *dev, plan, mode=form)
         (y.float() * r.to(DEV)).sum().backward()
         res.append([y.detach().float().cpu(), xd.grad.float().cpu()] + [p.grad.cpu() for p in dev])
-    tol = 1e-5 if dtype == torch.float32 else 1e-2         # (bf16: an atomics-order difference can flip a rounding)
+    tol = 5e-5 if dtype == torch.float32 else 1e-2         # (bf16: an atomics-order difference can flip a rounding)
     for other in res[1:]:
         for a, b in zip(other, res[0]):
             assert rel_err(a, b) < tol
