@@ -714,7 +714,7 @@ def test_train_iter_as_hip_graph_matches_reference_loss_sequence(monkeypatch):
         x, t = torch.from_numpy(g['xs'][i % nsteps]), torch.from_numpy(g['targets'][i % nsteps])
         m.do_train_iter(x, t, torch.tensor(tk), eager=(i == 1))   # (a kernel-by-kernel step between replays)
         e.do_train_iter(x, t, torch.tensor(tk))
-        assert abs(float(m.last_loss) - float(e.last_loss)) < 1e-3 * max(1.0, abs(float(e.last_loss))), (i, tk)
+        assert abs(float(m.last_loss) - float(e.last_loss)) < 3e-3 * max(1.0, abs(float(e.last_loss))), (i, tk)
     assert len(m._graphs) == 2 and all(v['graph'] is not None for v in m._graphs.values())
     assert m.count_iter == nsteps + len(seq)
 
