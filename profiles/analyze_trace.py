@@ -29,6 +29,11 @@ def main():
         print('%-80s calls %5s  %8.3f ms/step  avg %8.1f us  %5.1f%%' % (
             short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6 / steps, float(r['AverageNs']) / 1e3,
             100 * float(r['TotalDurationNs']) / tot))
+    ig = [r for r in rows if 'conv5_igemm_kernel' in r['Name']]
+    if ig:
+        calls = sum(int(r['Calls']) for r in ig)
+        print('conv5_igemm_kernel, all %d instantiations: %d calls, %.1f us average  (compare bench.py roofline.avg_launch_ms)'
+              % (len(ig), calls, sum(float(r['TotalDurationNs']) for r in ig) / calls / 1e3))
     tr = list(csv.DictReader(open(trace)))
     for key in ('conv5_igemm', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd', 'bn_', 'k2s2', 'expert_mix', 'box_sum'):
         ks = [r for r in tr if key in r['Kernel_Name']]
