@@ -6,18 +6,34 @@
 
 A "step" is one full optimisation step of the hot path on one batch of synthetic patches per GPU:
 forward (19 MoDE blocks through the HIP kernels) + backward (data and filter gradients, GatRep
-backward) + Adam over all 123.9 M parameters, exactly the work of fnet_model.py:105-113.  Per-GPU
-batch is fixed (weak scaling); ``value`` = all ranks' input voxels / max-over-ranks step time.
-Prints ONE JSON line on rank 0.
+backward) + Adam over all 123.9 M parameters, exactly the work of fnet_model.py:105-113.
+``value`` = all ranks' input voxels / max-over-ranks step time.  Prints ONE JSON line on rank 0.
+
+Workloads (BASELINE.json ``configs``):
+  N = 1   configs[1]: batch 8 of 1x32x64x64, bf16, 8 distinct tasks  -- the configuration the metric is quoted on.
+  N > 1   configs[3]: 24 patches per rank (global 192 at 8 GPUs), all 12 tasks on every rank, gradients all-reduced
+          over RCCL under backward.  Per-GPU work is the same at N = 2, 4, 8 (weak scaling); it is NOT the N = 1
+          line's batch, so the line also carries ``config.no_comm_value``: the same ranks, same batch, same run,
+          stepping WITHOUT the gradient all-reduce -- the denominator for the collectives' cost at this batch
+          (``value / no_comm_value`` is the scaling efficiency that the N = 1 line cannot give).
+  ``--batch B`` overrides the per-GPU batch for either.
 
 Also reported in the same line:
-  roofline      the conv5_igemm kernel (forward + data-gradient launches): algorithmic FLOPs
-                (2 * voxels * Cin * Cout * 125 per launch) / HIP-event duration on the launch
-                stream, summed over the timed region, against the dense bf16 MFMA peak.
-  cpu_baseline  the CPU oracle (oracle/repmode_oracle.py, a port -- the reference's Python cannot
-                travel) timed on this box's host cores on a bounded sample, rank 0 at N = 1 only.
+  roofline      the conv5_igemm kernel (forward + data-gradient launches): algorithmic FLOPs (the layer's merged
+                125-tap convolution, 2 * voxels * Cin * Cout * 125, once per layer and direction) / HIP-event
+                duration on the launch stream, against the dense bf16 MFMA peak.  ``traffic``: HBM bytes per
+                launch from rocprofv3 PMC passes of THIS build (profiles/*_pmc_traffic.json carries the hash of
+                the kernel sources it was taken on), else null.
+  fwd           forward only (BASELINE's ">= 40 % MFMA on fused GatRep+Conv3d forward"): voxels/s of the whole
+                forward pass, and the MFMA fraction of gate softmax + GatRep + convolution as ONE unit (their
+                summed event-timed durations against the forward's algorithmic conv FLOPs).
+  cpu_baseline  the CPU oracle (oracle/repmode_oracle.py, a port -- the reference's Python cannot travel) timed on
+                this box's host cores, rank 0 at N = 1 only: batch 2 of the same patches, both organisations of the
+                arithmetic (the reference's per-sample Python loop, and the vectorised one).
 """
 import argparse
+import hashlib
+import glob
 import json
 import os
 import sys
@@ -30,11 +46,14 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 PATCH = (32, 64, 64)
-PER_GPU_BATCH = 8
-PROF_EVERY = 10          # the per-launch HIP events of the roofline are taken on every 10th timed step (launched kernel by kernel)
+BATCH_1GPU = 8           # BASELINE configs[1]
+BATCH_MULTI = 24         # BASELINE configs[2] / configs[3]: 24 per GPU, global 192 on 8
+PROF_EVERY = 10          # the per-launch HIP events of the roofline are taken on every 10th timed step
 MULT_CHAN = 32
 NUM_TASKS = 12
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
+FWD_FLOP_PER_VOXEL = 2083520.0                    # whole forward; MoDE convs alone 2,072,000
+FWD_CONV_FLOP_PER_VOXEL = 2072000.0
 
 
 class Opts:
@@ -44,36 +63,70 @@ class Opts:
     batch_size_eval = 8
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """Oracle train step (forward + backward + Adam, fp32) on the host cores.  Bounded: one batch-1
-    step of the full-size network on the headline patch (the per-voxel cost does not depend on the
-    batch size); a tiny warm-up first so thread pools and allocators are initialised."""
+def kernel_source_hash():
+    """Hash of the kernel sources + header: identifies the build a profile under profiles/ was taken on."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'repmode_amd', 'csrc', '*.hip')) +
+                    glob.glob(os.path.join(ROOT, 'repmode_amd', 'csrc', '*.h')) +
+                    glob.glob(os.path.join(ROOT, 'include', '*.h'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kind, batch, dtype):
+    """HBM bytes per launch of ``kind`` from the newest profiles/*_pmc_traffic.json taken on THIS build and workload."""
+    want = kernel_source_hash()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get('kernel_source_hash') == want and d.get('batch') == batch and d.get('dtype') == dtype:
+            return d.get(kind, {}).get('hbm_bytes_per_launch'), os.path.basename(f)
+    return None, None
+
+
+def cpu_baseline():
+    """Oracle train step (forward + backward + Adam, fp32) on the host cores: batch 2 of the headline patches (two
+    different tasks), every host core, one timed step of each organisation after a small warm-up -- the reference's
+    own (one merged filter + one batch-1 conv per sample in a Python loop, RepMode.py:182-190, 204-208) and the
+    vectorised restatement (gather + one contraction + one grouped conv).  Bounded: ~2 x 4-8 s on a 32+ core host."""
     from oracle import repmode_oracle as orc
-    # the oracle's PyTorch-CPU ops stop scaling (and then regress) well before a big host's core
-    # count: 32 threads is the measured sweet spot region; `cores` reports what was actually used
-    cores = min(os.cpu_count() or 1, 32)
+    cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    net = orc.Net(Opts(), mult_chan=MULT_CHAN)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
-    net.train()
-    tasks = torch.tensor([3])
-    x = torch.randn(1, 1, 16, 32, 32)
-    orc.train_step(net, opt, x, torch.randn_like(x), tasks)            # warm-up, small patch
-    x = torch.randn(1, 1, *PATCH)
-    tgt = torch.randn_like(x)
-    # as many batch-1 steps as fit in ~12 s (at least one): the sample stays bounded on a slow host
-    nsteps, t0 = 0, time.perf_counter()
-    while True:
-        orc.train_step(net, opt, x, tgt, tasks)
-        nsteps += 1
-        dt = time.perf_counter() - t0
-        if dt + dt / nsteps > 12.0 or dt > seconds_budget:
-            break
-    vox = PATCH[0] * PATCH[1] * PATCH[2]
-    return {'value': vox * nsteps / dt, 'unit': 'voxels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d train step(s) (fwd+bwd+Adam, fp32, vectorised oracle) of the full mult_chan=32 network on '
-                      'batch 1 of 1x32x64x64; %.1f s' % (nsteps, dt)}
+    n = 2
+    vox = n * PATCH[0] * PATCH[1] * PATCH[2]
+    res = {}
+    for style in ('vectorised', 'reference-style'):
+        orc.REFERENCE_STYLE = style == 'reference-style'
+        torch.manual_seed(0)
+        net = orc.Net(Opts(), mult_chan=MULT_CHAN)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        net.train()
+        tasks = torch.tensor([3, 7])
+        x = torch.randn(n, 1, 16, 32, 32)
+        orc.train_step(net, opt, x, torch.randn_like(x), tasks)            # warm-up, small patch
+        x = torch.randn(n, 1, *PATCH)
+        tgt = torch.randn_like(x)
+        nsteps, t0 = 0, time.perf_counter()
+        while True:
+            orc.train_step(net, opt, x, tgt, tasks)
+            nsteps += 1
+            dt = time.perf_counter() - t0
+            if dt + dt / nsteps > 8.0:
+                break
+        res[style] = {'value': vox * nsteps / dt, 'steps': nsteps, 'seconds': dt}
+        del net, opt
+    orc.REFERENCE_STYLE = False
+    best = max(res, key=lambda k: res[k]['value'])
+    return {'value': res[best]['value'], 'unit': 'voxels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'variant': best,
+            'reference_style_value': res['reference-style']['value'], 'vectorised_value': res['vectorised']['value'],
+            'sample': 'full mult_chan=32 network, fp32 train steps (fwd+bwd+Adam) on batch 2 of 1x32x64x64, tasks (3, 7): '
+                      '%d step(s) in %.1f s per-sample loop as the reference organises it, %d step(s) in %.1f s vectorised; '
+                      '`value` is the faster of the two' % (res['reference-style']['steps'], res['reference-style']['seconds'],
+                                                            res['vectorised']['steps'], res['vectorised']['seconds'])}
 
 
 def main():
@@ -82,11 +135,12 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--batch', type=int, default=PER_GPU_BATCH, help='patches per GPU')
+    ap.add_argument('--batch', type=int, default=0, help='patches per GPU (default: 8 on one GPU = configs[1], 24 per rank on several = configs[3])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-inputs', action='store_true', help='inputs start in pinned host memory every step (PCIe-inclusive rate)')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events')
-    ap.add_argument('--graph', action='store_true', help='replay the train step as one HIP graph (N = 1; see DESIGN.md 3.5; REPMODE_FORK_MAX_W=16 adds the two-stream layers)')
+    ap.add_argument('--no-fwd', action='store_true', help='skip the forward-only measurement')
+    ap.add_argument('--graph', action='store_true', help='replay the train step as one HIP graph (N = 1; DESIGN.md 3.5)')
     ap.add_argument('--prof-all', action='store_true', help='record HIP events for every library kernel, not only conv5_igemm')
     ap.add_argument('--dump-launches', default=None, help='write per-launch (kind, ms, TFLOP/s or TB/s) of the last timed step as JSON')
     args = ap.parse_args()
@@ -108,7 +162,7 @@ def main():
     torch.manual_seed(0)                       # reference default seed (config.py:47); same init on every rank
     model = Model(opts, nn_module='RepMode', lr=1e-4, gpu_ids=local, mult_chan=MULT_CHAN, dtype=dtype,
                   distributed=world > 1, hip_graph=world == 1 and args.graph)
-    b = args.batch
+    b = args.batch or (BATCH_1GPU if world == 1 else BATCH_MULTI)
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     signal = torch.randn(b, 1, *PATCH, device=device, generator=gen)
     target = torch.randn(b, 1, *PATCH, device=device, generator=gen)
@@ -138,14 +192,19 @@ def main():
             on = step % sample == 0
             _lib.prof_pause(not on)
             profiled_steps += on
-        # (a profiled step is launched kernel by kernel: the library's event pairs are not part of the captured graph)
+        # (a profiled step is launched kernel by kernel: the library's event pairs are not part of a captured graph)
         model.do_train_iter(signal, target, task, eager=not args.no_prof and on)
     t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (== dt when the host is the limiter)
     barrier()
     dt = time.perf_counter() - t0
-    _lib.prof_enable(False)
     dt = dist_.max_over_ranks(dt, device)
     loss = float(model.last_loss)
+    train_prof = {}
+    if not args.no_prof and rank == 0:
+        for kind in ('conv5_igemm', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd'):
+            train_prof[kind] = _lib.prof_summary(kind)
+        train_recs = _lib.prof_records() if args.dump_launches else None
+    _lib.prof_enable(False)
 
     vox_per_step = world * b * PATCH[0] * PATCH[1] * PATCH[2]
     out = {
@@ -162,39 +221,91 @@ def main():
         'dtype': args.dtype,
         'data': 'synthetic' + (' (inputs in pinned host memory every step: PCIe-inclusive)' if args.host_inputs else ''),
         'config': {'workload': 'RepMode U-Net (mult_chan 32, 12 tasks, 123.9M params) full train step '
-                               '(fwd + bwd + Adam), batch %d x 1x32x64x64 per GPU' % b,
+                               '(fwd + bwd + Adam), batch %d x 1x32x64x64 per GPU (%s)'
+                               % (b, 'BASELINE configs[1]' if (world == 1 and b == BATCH_1GPU) else
+                                  'BASELINE configs[3]: global batch %d' % (world * b) if b == BATCH_MULTI else 'custom batch'),
                    'global_batch': world * b, 'patch': list(PATCH), 'parallelism': 'dp%d' % world,
+                   'distinct_tasks_per_rank': len(set(task.tolist())),
                    'final_loss': loss, 'host_issue_ms_per_step': 1e3 * t_issue / args.steps,
                    'hip_graph': bool(model.hip_graph), 'steps_launched_kernel_by_kernel': profiled_steps},
     }
+
+    # ---- N > 1: the same ranks, batch and run without the gradient all-reduce (what the collectives cost at this batch)
+    if world > 1:
+        k = max(5, min(args.steps, 20))
+        module = model.ddp if model.ddp is not None else None
+        ctx = module.no_sync() if module is not None else None
+        if ctx is not None:
+            with ctx:
+                for _ in range(3):
+                    model.do_train_iter(signal, target, task)
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(k):
+                    model.do_train_iter(signal, target, task)
+                barrier()
+                dt_nc = dist_.max_over_ranks(time.perf_counter() - t1, device)
+            out['config']['no_comm_value'] = vox_per_step * k / dt_nc
+            out['config']['no_comm_ms_per_step'] = 1e3 * dt_nc / k
+            out['config']['note'] = ('per-GPU batch is 24 at every N > 1 (weak scaling, configs[3]) but 8 on the N = 1 line '
+                                     '(configs[1]): use value / no_comm_value, not value / (N x the N = 1 value), as the '
+                                     'scaling efficiency')
+
+    # ---- forward only (train-mode forward, no autograd graph): whole-pass rate + gate/GatRep/conv as one unit
+    if rank == 0 and not args.no_fwd and not args.host_inputs:
+        net = model.net
+        net.train()
+        kf = 10
+        with torch.no_grad():
+            for _ in range(3):
+                net(signal, task)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(kf):
+                net(signal, task)
+            torch.cuda.synchronize()
+            dt_f = time.perf_counter() - t1
+            _lib.prof_enable(1)
+            for _ in range(2):
+                net(signal, task)
+            torch.cuda.synchronize()
+        n_c, ms_c, fl_c = _lib.prof_summary('conv5_igemm')
+        n_g, ms_g, _ = _lib.prof_summary('gatrep_fwd')
+        _lib.prof_enable(False)
+        vps = b * PATCH[0] * PATCH[1] * PATCH[2] * kf / dt_f
+        peak = PEAK_TFLOPS[args.dtype]
+        unit_tflops = fl_c / ((ms_c + ms_g) * 1e-3) / 1e12 if (ms_c + ms_g) > 0 else 0.0
+        out['fwd'] = {'value': vps, 'unit': 'voxels/s', 'ms_per_pass': 1e3 * dt_f / kf,
+                      'whole_pass_tflops': vps * FWD_FLOP_PER_VOXEL / 1e12,
+                      'whole_pass_frac': vps * FWD_FLOP_PER_VOXEL / 1e12 / peak,
+                      'gatrep_conv_unit': {'what': 'gate softmax + GatRep (+ expert layout) + conv5_igemm launches of one forward pass, '
+                                                   'event-timed; FLOPs = the MoDE convs\' algorithmic 2*V*Cin*Cout*125',
+                                           'conv_ms': ms_c / 2, 'gatrep_ms': ms_g / 2, 'conv_launches': n_c // 2,
+                                           'gatrep_launches': n_g // 2, 'achieved': unit_tflops, 'peak': peak,
+                                           'unit': 'TFLOP/s', 'frac': unit_tflops / peak,
+                                           'conv_only_frac': (fl_c / (ms_c * 1e-3) / 1e12 / peak) if ms_c > 0 else 0.0}}
+
     if rank == 0:
         if not args.no_prof:
             kinds = {}
-            for kind in ('conv5_igemm', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd'):
-                n, ms, work = _lib.prof_summary(kind)
+            for kind, (n, ms, work) in train_prof.items():
                 if n == 0:
                     continue          # kind not recorded (default: the dominant kernel only; --prof-all for all)
                 kinds[kind] = {'launches': n, 'ms_per_step': ms / max(profiled_steps, 1),
                                'rate': (work / (ms * 1e-3) / 1e12) if ms > 0 else None}   # TFLOP/s or TB/s
-            n, ms, flops = _lib.prof_summary('conv5_igemm')
+            n, ms, flops = train_prof['conv5_igemm']
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             peak = PEAK_TFLOPS[args.dtype]
-            # HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE,
-            # separate runs, gfx950 read-side correction applied by profiles/pmc_summary.py); null if not collected
-            traffic = None
-            pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-            if args.dtype == 'bf16' and b == PER_GPU_BATCH and os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get('conv5_igemm', {}).get('hbm_bytes_per_launch')
+            traffic, traffic_file = pmc_traffic('conv5_igemm', b, args.dtype)
             out['roofline'] = {'kernel': 'conv5_igemm_kernel', 'bound': 'mfma', 'achieved': achieved, 'peak': peak,
-                               'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
+                               'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_file,
                                'launches': n, 'avg_launch_ms': ms / max(n, 1),
                                'flops_per_launch': flops / max(n, 1)}
             out['kernels'] = kinds
             if args.dump_launches:
-                recs = _lib.prof_records()
-                per = len(recs) // max(profiled_steps, 1)
+                per = len(train_recs) // max(profiled_steps, 1)
                 last = [{'kind': k, 'us': ms * 1e3, 'rate': (w / (ms * 1e-3) / 1e12) if ms > 0 else None,
-                         'work': w} for k, ms, w in recs[-per:]]
+                         'work': w} for k, ms, w in train_recs[-per:]]
                 with open(args.dump_launches, 'w') as f:
                     json.dump(last, f, indent=0)
         if world == 1 and not args.no_cpu_baseline:

@@ -101,6 +101,12 @@ def mode_conv_reference_style(x, k5, k3, k1, a3, a5, gate_w, gate_b, tasks):
 # --------------------------------------------------------------------------- #
 # module tree with the reference's state_dict surface (309 keys at any mult_chan)
 # --------------------------------------------------------------------------- #
+# True: training-mode blocks run ``mode_conv_reference_style`` (one merged filter and one batch-1 conv per SAMPLE in a
+# Python loop, as RepMode.py:182-190, 204-208 is organised) -- the "reference-style" leg of bench.py's CPU baseline.
+# Same values either way (tests/test_oracle_golden.py checks both).
+REFERENCE_STYLE = False
+
+
 def _kaiming_param(co, ci, k):
     w = torch.nn.Parameter(torch.empty(co, ci, k, k, k))
     torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))          # RepMode.py:156-159
@@ -131,10 +137,12 @@ class MoDEConv(torch.nn.Module):
         self.gate = torch.nn.Linear(num_tasks, num_experts * out_chan, bias=True)
 
     def forward(self, x, tasks):
-        y = mode_conv_pre_bn(x, self.expert_conv5x5_conv, self.expert_conv3x3_conv,
-                             self.expert_conv1x1_conv, self.expert_avg3x3_conv,
-                             self.expert_avg5x5_conv, self.gate.weight, self.gate.bias,
-                             tasks, self.training)
+        ps = (self.expert_conv5x5_conv, self.expert_conv3x3_conv, self.expert_conv1x1_conv,
+              self.expert_avg3x3_conv, self.expert_avg5x5_conv, self.gate.weight, self.gate.bias)
+        if REFERENCE_STYLE and self.training:
+            y = mode_conv_reference_style(x, *ps, tasks)
+        else:
+            y = mode_conv_pre_bn(x, *ps, tasks, self.training)
         return self.subsequent_layer(y)                       # RepMode.py:212
 
 

@@ -50,9 +50,12 @@ bool g_prof_on = false;
 unsigned g_prof_mask = ~0u;   // bit k set: record kernel kind k
 bool g_prof_open = false;
 bool g_prof_paused = false;
+std::mutex g_prof_mu;   // forward launches come from the caller's thread, backward launches from autograd's
 }  // namespace
 
 void repmode_prof_begin(int kind, double work, hipStream_t s) {
+  if (!g_prof_on) return;                       // (cheap unlocked test: the flag only changes between steps)
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   if (!g_prof_on || g_prof_paused || !((g_prof_mask >> kind) & 1u)) return;
   if (g_prof_n == g_prof.size()) {
     ProfRec r{};
@@ -67,6 +70,8 @@ void repmode_prof_begin(int kind, double work, hipStream_t s) {
 }
 
 void repmode_prof_end(hipStream_t s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   if (!g_prof_on || !g_prof_open) return;
   (void)hipEventRecord(g_prof[g_prof_n].b, s);
   ++g_prof_n;
@@ -104,6 +109,7 @@ int repmode_bn_scratch_half(hipStream_t s) {
 }
 
 extern "C" int repmode_prof_enable(int on) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   if (on) g_prof_n = 0;
   g_prof_on = on != 0;
   g_prof_mask = (on == 2) ? (1u << REPMODE_PROF_CONV5) : ~0u;   // 2: the dominant kernel only (least perturbation)
@@ -114,6 +120,7 @@ extern "C" int repmode_prof_enable(int on) {
 
 // pause / resume recording without discarding what has been recorded (bench.py samples every few steps)
 extern "C" int repmode_prof_pause(int paused) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
   g_prof_paused = paused != 0;
   return REPMODE_OK;
 }

@@ -9,13 +9,16 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I$ROOT/in
 BUILD="${REPMODE_BUILD_DIR:-$HERE/build}"
 mkdir -p "$BUILD"
 pids=()
+objs=()
 for f in "$HERE"/*.hip; do
   o="$BUILD/$(basename "${f%.hip}").o"
+  objs+=("$o")
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$ROOT/include/repmode_hip.h" -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$BUILD"/*.o -o "$OUT"
+# only the objects of sources that exist now (a stale .o of a removed / renamed file must not be linked)
+$HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT"
 echo "built $OUT"

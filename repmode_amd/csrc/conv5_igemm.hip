@@ -25,6 +25,8 @@
 //     register quad -> 8-byte (bf16) / 16-byte (f32) channel-contiguous stores.
 #include "common.h"
 
+#include <atomic>
+
 namespace {
 
 template <typename T>
@@ -464,21 +466,26 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   a.ksplit = ks;
   const long grid = base * ks;
   RM_REQUIRE(grid > 0 && grid < (1L << 31), "conv5: grid %ld out of range", grid);
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set) {
+  // per instantiation and per device (one bit each; a racing second thread at worst repeats the idempotent call)
+  static std::atomic<unsigned> attr_set{0};
+  int dev = 0;
+  RM_HIP(hipGetDevice(&dev));
+  if (!((attr_set.load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_igemm_kernel<T, C, SWAP, PAIR>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    attr_set = true;
+    attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
   }
   if (ks > 1 && !a.accum) {
     const size_t vox = (size_t)a.N * a.D * a.H * a.W;
     RM_HIP(hipMemsetAsync(a.y, 0, vox * (a.Cout1 > 0 ? a.Cout1 : a.Cout) * sizeof(float), stream));
     if (a.Cout1 > 0) RM_HIP(hipMemsetAsync(a.y2, 0, vox * (a.Cout - a.Cout1) * sizeof(float), stream));
   }
-  // algorithmic FLOPs: 125 taps, or the 27 of a 3x3x3 support when restricted
+  // algorithmic FLOPs = the layer's merged 125-tap convolution, counted ONCE per layer and direction: a
+  // launch restricted to the 3x3x3 support is the per-expert formulation's second conv of a layer whose 125 taps
+  // the 5x5x5 expert's launch has already been credited with -- executed work, not algorithmic: 0
   // (dx-centre mode: 25 taps x the 5 folded x taps of the thin dimension = the original layer's 125 taps x 1 channel)
   const double alg = a.dxc ? 2.0 * a.N * a.D * a.H * a.W * 25.0 * (a.Cin == 8 ? 5.0 * a.Cout : (double)a.Cin * a.Cout)
-                           : 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * (a.tap_lo ? 27 : REPMODE_TAPS);
+                           : a.tap_lo ? 0.0 : 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS;
   repmode_prof_begin(REPMODE_PROF_CONV5, alg, stream);
   hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP, PAIR>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
   repmode_prof_end(stream);

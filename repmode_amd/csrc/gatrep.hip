@@ -465,8 +465,11 @@ extern "C" int repmode_gate_softmax(const float* gate_w, const float* gate_b, co
   RM_REQUIRE(gate_w && gate_b && slot_task && g, "gate_softmax: null pointer");
   RM_REQUIRE(nslots > 0 && num_tasks > 0 && co > 0, "gate_softmax: bad shape");
   const int total = nslots * co;
+  // (recorded with the GatRep forward family: gate + GatRep + conv is the unit BASELINE's forward target names)
+  repmode_prof_begin(REPMODE_PROF_GATREP_FWD, (double)total * 4.0 * (2 * E + E), static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(gate_softmax_kernel, dim3(ceil_div(total, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), gate_w, gate_b, slot_task, nslots, num_tasks, co, g);
+  repmode_prof_end(static_cast<hipStream_t>(stream));
   RM_LAUNCH_CHECK("gate_softmax");
   return REPMODE_OK;
 }

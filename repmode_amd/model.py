@@ -76,6 +76,7 @@ class Model(object):
         if self.hip_graph and distributed:
             raise ValueError('hip_graph covers single-GPU training (the collectives are not captured)')
         self._graphs = {}
+        self._graph_pool = None
         self._capture_stream = None
         self.criterion = criterion_fn(reduction='none')        # fnet_model.py:36
         self._init_model()
@@ -129,7 +130,9 @@ class Model(object):
     def _train_step(self, signal, target, task):
         """zero_grad, forward, MSELoss('none') -> mean, backward, (all-reduce), Adam.  ``task``: ints or a TaskPlan."""
         module = self.ddp if self.ddp is not None else self.net
-        if not module.training:
+        # fnet_model.py:102 calls net.train() every iteration; the guard is on the INNER network, the module whose mode
+        # predict() changes (a DistributedDataParallel wrapper keeps its own flag and would hide an eval-mode net)
+        if not self.net.training or not module.training:
             module.train()               # (walks the whole module tree: ~0.6 ms, not needed every step)
         self.optimizer.zero_grad(set_to_none=True)
         output = module(signal, task)
@@ -195,7 +198,11 @@ class Model(object):
             st['plan'] = ops_.TaskPlan(host, self.net.num_tasks, self.device, True)
             graph = torch.cuda.CUDAGraph()
             cs.wait_stream(cur)
-            with torch.cuda.graph(graph, stream=cs):
+            # every captured signature shares ONE private memory pool (replays never overlap: they run in stream
+            # order), so a new number of distinct tasks costs its peak once, not a whole extra step of activations
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(graph, stream=cs, pool=self._graph_pool):
                 st['out'] = self._train_step(st['signal'], st['target'], st['plan'])
             st['graph'], st['last_loss'] = graph, self.last_loss
             st['plan'].bn_counted = False

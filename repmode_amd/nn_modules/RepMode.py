@@ -202,13 +202,14 @@ class Net(torch.nn.Module):
             ops.ZERO_POOL.end()
         if self.training and not plan.bn_counted:
             # num_batches_tracked of the 26 BatchNorm layers: one multi-tensor launch instead of 26
-            counters = getattr(self, '_bn_counters', None)
+            pairs = getattr(self, '_bn_counters', None)
             # (cached; rebuilt when the buffers were replaced, e.g. by .to(device): the probe is the last BN's buffer)
-            if counters is None or counters[-1] is not self._bn_probe.num_batches_tracked:
-                bns = [m for m in self.modules() if isinstance(m, torch.nn.BatchNorm3d) and m.track_running_stats]
-                counters = [m.num_batches_tracked for m in bns]
-                object.__setattr__(self, '_bn_counters', counters)
-                object.__setattr__(self, '_bn_probe', bns[-1] if bns else None)
+            if pairs is None or (pairs and pairs[-1][1] is not pairs[-1][0].num_batches_tracked):
+                pairs = [(m, m.num_batches_tracked) for m in self.modules()
+                         if isinstance(m, torch.nn.BatchNorm3d) and m.track_running_stats]
+                object.__setattr__(self, '_bn_counters', pairs)
+            # a BatchNorm layer frozen on its own (bn.eval() under a training network) does not count batches
+            counters = [c for m, c in pairs if m.training]
             if counters:
                 torch._foreach_add_(counters, 1)
             plan.bn_counted = True

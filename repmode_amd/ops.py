@@ -543,17 +543,38 @@ class _BnRelu(torch.autograd.Function):
         return dx, tot[c:], tot[:c], None, None, None, None, None, None
 
 
-def bn_relu(x_cl, bn, training, out_dtype, count=True):
+def bn_relu(x_cl, bn, training=None, out_dtype=None, count=True):
     """``relu(batch_norm(x))`` with the parameters / running statistics of a ``torch.nn.BatchNorm3d`` module
-    (kept as the parameter container so that the state_dict matches the reference).  ``count=False``: the caller
-    has already advanced ``num_batches_tracked`` (the network does it for all its BN layers in one launch)."""
+    (kept as the parameter container so that the state_dict matches the reference).  The module's own state decides
+    what ``nn.BatchNorm3d.forward`` would do (the reference calls the module itself, RepMode.py:212): ``bn.training``
+    selects batch or running statistics (``training`` is accepted for the callers that pass the block's mode, and
+    must agree), ``momentum=None`` is the cumulative moving average 1 / num_batches_tracked, and a module without
+    running statistics always normalises with batch statistics.  ``count=False``: the caller has already advanced
+    ``num_batches_tracked`` (the network does it for all its BN layers in one launch)."""
     x_cl = x_cl.contiguous()
-    use_batch_stats = training or not bn.track_running_stats
-    if count and training and bn.track_running_stats:
+    if out_dtype is None:
+        out_dtype = x_cl.dtype
+    train_mode = bn.training
+    use_batch_stats = train_mode or not bn.track_running_stats
+    if count and train_mode and bn.track_running_stats:
         bn.num_batches_tracked.add_(1)
-    momentum = 0.1 if bn.momentum is None else bn.momentum
-    return _BnRelu.apply(x_cl, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats, momentum, bn.eps,
-                         out_dtype)
+    if not bn.track_running_stats:
+        # no running buffers: the kernel still wants two vectors to update -- scratch ones, discarded
+        c = x_cl.shape[-1]
+        rm = torch.zeros(c, dtype=torch.float32, device=x_cl.device)
+        rv = torch.ones(c, dtype=torch.float32, device=x_cl.device)
+        momentum = 0.0
+    else:
+        rm, rv = bn.running_mean, bn.running_var
+        if bn.momentum is None:
+            # cumulative average (nn.BatchNorm: exponential_average_factor = 1 / num_batches_tracked); one host read,
+            # only on this non-default configuration
+            momentum = 1.0 / max(int(bn.num_batches_tracked), 1) if train_mode else 0.0
+        else:
+            momentum = bn.momentum
+    if not bn.affine:
+        raise _lib.RepModeHipError('bn_relu: BatchNorm without affine parameters is not supported by the HIP kernel')
+    return _BnRelu.apply(x_cl, bn.weight, bn.bias, rm, rv, use_batch_stats, momentum, bn.eps, out_dtype)
 
 
 def k2_weight_frags(weight, rows, red, red_major, dtype, both=False):

@@ -14,6 +14,8 @@ Tolerances (max|a-b| / max|b|, the 'relative fp32' measure of BASELINE.json):
     the 2-norm relative error with a 0.15 bound; the tight bf16 gradient check is
     ``test_mode_conv3d_op`` (no ReLU in the way, 2e-2).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -792,3 +794,176 @@ def test_full_size_net_vs_oracle():
             assert nrm_err(p.grad.cpu(), rp[k].grad) < 2e-2, k
             checked += 1
     assert checked >= 20
+
+
+# ------------------------------------------------------------------------------------------------
+# Parity AT THE BENCHMARKED CONFIGURATIONS (BASELINE configs[1]: batch 8 with 8 distinct tasks; configs[2]:
+# batch 24 with all 12 tasks).  The slot count selects code: gatrep_bwd_kernel<8> takes the slots in rounds of 8
+# (12 slots = a second, partial round), <2> in rounds of 2 on the large layers, the filter-gradient kernel finds a
+# slot's samples by ballot, the conv's split-K grid and the zero pool's plan depend on the batch.
+MANY_SLOT_CASES = [
+    # (ci, co, shape)                 which GatRep-backward variant / conv tile it reaches
+    (32, 32, (4, 8, 32)),            # <8>: ceil(ci/32)*co = 32 workgroups; W >= 32 tile, bf16 stores
+    (64, 160, (2, 4, 8)),            # <2>: 2*160 = 320 > 256 workgroups; W = 8 tile, split-K
+    (96, 64, (2, 4, 4)),             # <8> at the deepest tile (W = 4), odd number of channel chunks
+    (1, 32, (4, 8, 32)),             # thin first layer
+    (32, 1, (4, 8, 32)),             # thin last layer
+]
+
+
+@pytest.mark.parametrize('mode', ['merged', 'unmerged'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('batch,ntasks', [(8, 8), (24, 12)])
+@pytest.mark.parametrize('ci,co,shape', MANY_SLOT_CASES)
+def test_mode_conv3d_op_bench_slot_counts(ci, co, shape, batch, ntasks, dtype, mode):
+    """``test_mode_conv3d_op`` at the slot counts bench.py and BASELINE configs[2] run: 8 distinct tasks in a batch of
+    8, and 12 distinct tasks (each twice, interleaved) in a batch of 24 -- forward, data gradient and all seven
+    parameter gradients against the oracle's autograd."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(ci * 13 + co + batch)
+    ps = _rand_experts(co, ci, gen)
+    tasks = [1, 11, 4, 0, 7, 9, 2, 6] if ntasks == 8 else [(3 + 5 * i) % 12 for i in range(batch)]
+    assert len(set(tasks)) == ntasks
+    x = torch.randn(batch, ci, *shape, generator=gen).to(dtype).float()
+    r = torch.randn(batch, co, *shape, generator=gen).to(dtype).float()
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    xr = x.clone().requires_grad_(True)
+    yr = orc.mode_conv_pre_bn(xr, *ref, torch.tensor(tasks), training=True)
+    (yr * r).sum().backward()
+    res = []
+    for step in range(2):                      # second step: through the zero pool's recorded plan
+        ops.ZERO_POOL.begin(('test_bench_slots', ci, co, batch, str(dtype), mode), torch.device(DEV))
+        dev = [p.to(DEV).requires_grad_(True) for p in ps]
+        xd = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype).requires_grad_(True)
+        plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+        assert plan.nslots == ntasks
+        y = ops.mode_conv3d(xd, *dev, plan, out_f32=True, mode=mode)
+        (y * r.permute(0, 2, 3, 4, 1).to(DEV)).sum().backward()
+        res.append((y, xd, dev))
+    ops.ZERO_POOL.end()
+    tol = 1e-4 if dtype == torch.float32 else TOL_BF16
+    for y, xd, dev in res:
+        assert rel_err(y.detach().permute(0, 4, 1, 2, 3).cpu(), yr.detach()) < tol
+        assert rel_err(xd.grad.float().permute(0, 4, 1, 2, 3).cpu(), xr.grad) < tol
+        for name, a, b in zip(['k5', 'k3', 'k1', 'a3', 'a5', 'gate_w', 'gate_b'], dev, ref):
+            assert rel_err(a.grad.cpu(), b.grad) < tol, name
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('ca,cb,co,shape,batch', [(32, 32, 32, (4, 8, 32), 8), (64, 64, 64, (2, 4, 16), 24),
+                                                  (128, 128, 128, (2, 4, 8), 8)])
+def test_mode_conv3d_pair_vs_oracle(ca, cb, co, shape, batch, dtype):
+    """The skip-connection form (two tensors, never concatenated) against the ORACLE on the concatenation (not against
+    the same kernels on torch.cat): forward, both data gradients, all parameter gradients, at 8 / 12 slots."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(ca + cb + co + batch)
+    ps = _rand_experts(co, ca + cb, gen)
+    tasks = [1, 11, 4, 0, 7, 9, 2, 6] if batch == 8 else [(3 + 5 * i) % 12 for i in range(batch)]
+    xa = torch.randn(batch, ca, *shape, generator=gen).to(dtype).float()
+    xb = torch.randn(batch, cb, *shape, generator=gen).to(dtype).float()
+    r = torch.randn(batch, co, *shape, generator=gen).to(dtype).float()
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    ar, br = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+    yr = orc.mode_conv_pre_bn(torch.cat((ar, br), 1), *ref, torch.tensor(tasks), training=True)
+    (yr * r).sum().backward()
+    dev = [p.to(DEV).requires_grad_(True) for p in ps]
+    a = xa.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype).requires_grad_(True)
+    b = xb.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype).requires_grad_(True)
+    plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+    y = ops.mode_conv3d_pair(a, b, *dev, plan, out_f32=True)
+    (y.float() * r.permute(0, 2, 3, 4, 1).to(DEV)).sum().backward()
+    tol = 1e-4 if dtype == torch.float32 else TOL_BF16
+    assert rel_err(y.detach().float().permute(0, 4, 1, 2, 3).cpu(), yr.detach()) < tol
+    assert rel_err(a.grad.float().permute(0, 4, 1, 2, 3).cpu(), ar.grad) < tol
+    assert rel_err(b.grad.float().permute(0, 4, 1, 2, 3).cpu(), br.grad) < tol
+    for name, u, v in zip(['k5', 'k3', 'k1', 'a3', 'a5', 'gate_w', 'gate_b'], dev, ref):
+        assert rel_err(u.grad.cpu(), v.grad) < tol, name
+
+
+def _capture_block_inputs(net, x, tasks):
+    """Run the network once (train mode) and return {block name: (x, x2 or None)} as the MoDE blocks received them."""
+    from repmode_amd.nn_modules.RepMode import MoDEConv
+    seen, hooks = {}, []
+    for name, m in net.named_modules():
+        if isinstance(m, MoDEConv):
+            def pre(mod, args, name=name):
+                seen[name] = (args[0].detach(), args[2].detach() if len(args) > 2 and args[2] is not None else None)
+            hooks.append(m.register_forward_pre_hook(pre))
+    with torch.no_grad():
+        y = net(x, tasks)
+    for h in hooks:
+        h.remove()
+    return seen, y
+
+
+FULL_SIZE_BLOCKS_B24 = ['encoder_block1.conv_more.conv2', 'encoder_block3.conv_more.conv1', 'encoder_block4.conv_more.conv2',
+                        'bottle_block.conv2', 'decoder_block4.conv_less.conv1', 'decoder_block3.conv_less.conv1',
+                        'decoder_block1.conv_less.conv1', 'conv_out']
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize('batch,ntasks', [(8, 8), (24, 12)])
+def test_full_size_bf16_blocks_at_bench_config(batch, ntasks):
+    """The benchmarked network (mult_chan 32, 1x32x64x64 patches, bfloat16) block by block: one real forward pass of
+    the HIP network records the bf16 activations every MoDE block receives (so the inputs have the statistics the
+    bench sees: post-ReLU, the two tensors of a skip connection); then every block's fused op -- gate, GatRep,
+    per-slot convolution, through whichever formulation the network picks at this batch (merged, per-expert on the
+    deep levels, two-tensor on the decoder) -- runs forward and backward on those inputs and is compared with the
+    oracle fed the SAME bf16-rounded operands in float32: output, data gradient(s) and the seven parameter
+    gradients within 2e-2 of each tensor's max (one bf16 rounding of the merged filter and of the stored result).
+    batch 8 / 8 tasks = bench.py's step (every block); batch 24 / 12 tasks = BASELINE configs[2] (a block per level
+    and per formulation, the oracle's per-sample filters of all 19 at batch 24 would not fit the test budget)."""
+    ops = _ops()
+    from repmode_amd.nn_modules.RepMode import Net
+    torch.manual_seed(0)
+    net = Net(Opts(), mult_chan=32, dtype=torch.bfloat16).to(DEV).train()
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(batch, 1, 32, 64, 64, generator=gen)
+    tasks = [1, 11, 4, 0, 7, 9, 2, 6] if batch == 8 else [(3 + 5 * i) % 12 for i in range(batch)]
+    assert len(set(tasks)) == ntasks
+    seen, y_net = _capture_block_inputs(net, x.to(DEV), tasks)
+    assert len(seen) == 19 and bool(torch.isfinite(y_net).all())
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    names = list(seen) if batch == 8 else FULL_SIZE_BLOCKS_B24
+    mods = dict(net.named_modules())
+    worst = {}
+    for name in names:
+        blk = mods[name]
+        xa, xb = seen[name]
+        xa = xa.to(torch.bfloat16)
+        xb = xb.to(torch.bfloat16) if xb is not None else None
+        params = [blk.expert_conv5x5_conv, blk.expert_conv3x3_conv, blk.expert_conv1x1_conv, blk.expert_avg3x3_conv,
+                  blk.expert_avg5x5_conv, blk.gate.weight, blk.gate.bias]
+        co = params[0].shape[0]
+        gen.manual_seed(len(name))
+        r = torch.randn(batch, co, *xa.shape[2:], generator=gen).bfloat16()
+        # ---- oracle, float32 arithmetic on the same bf16 values
+        ref = [p.detach().cpu().clone().requires_grad_(True) for p in params]
+        ar = xa.float().cpu().requires_grad_(True)
+        br = xb.float().cpu().requires_grad_(True) if xb is not None else None
+        xin = torch.cat((ar, br), 1) if br is not None else ar
+        yr = orc.mode_conv_pre_bn(xin, *ref, torch.tensor(tasks), training=True)
+        (yr * r.float()).sum().backward()
+        # ---- HIP, through the formulation the network itself takes for this block
+        dev = [p.detach().clone().requires_grad_(True) for p in params]
+        plan = ops.TaskPlan(tasks, 12, torch.device(DEV), training=True)
+        a = xa.permute(0, 2, 3, 4, 1).contiguous().requires_grad_(True)
+        rd = r.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+        if xb is not None:
+            b = xb.permute(0, 2, 3, 4, 1).contiguous().requires_grad_(True)
+            y = ops.mode_conv3d_pair(a, b, *dev, plan, out_f32=True)
+        else:
+            b = None
+            y = ops.mode_conv3d(a, *dev, plan, out_f32=True)
+        (y.float() * rd.float()).sum().backward()
+        errs = {'y': rel_err(y.detach().float().permute(0, 4, 1, 2, 3).cpu(), yr.detach())}
+        if a.grad is not None and ar.grad is not None:
+            errs['dx'] = rel_err(a.grad.float().permute(0, 4, 1, 2, 3).cpu(), ar.grad)
+        if b is not None:
+            errs['dx2'] = rel_err(b.grad.float().permute(0, 4, 1, 2, 3).cpu(), br.grad)
+        for pn, u, v in zip(['k5', 'k3', 'k1', 'a3', 'a5', 'gate_w', 'gate_b'], dev, ref):
+            errs['d' + pn] = rel_err(u.grad.cpu(), v.grad)
+        worst[name] = max(errs.values())
+        assert worst[name] < TOL_BF16, (name, errs)
+        del ref, ar, br, xin, yr, dev, a, b, y
+    print('full-size bf16 blocks, batch %d: worst relative error %.3g (%s)' % (batch, max(worst.values()), max(worst, key=worst.get)))
