@@ -89,11 +89,14 @@ def pmc_traffic(kind, batch, dtype):
 
 def cpu_baseline():
     """Oracle train step (forward + backward + Adam, fp32) on the host cores: batch 2 of the headline patches (two
-    different tasks), every host core, one timed step of each organisation after a small warm-up -- the reference's
+    different tasks), up to 32 host threads (see below), ~8 s of steps of each organisation after a small warm-up -- the reference's
     own (one merged filter + one batch-1 conv per sample in a Python loop, RepMode.py:182-190, 204-208) and the
     vectorised restatement (gather + one contraction + one grouped conv).  Bounded: ~2 x 4-8 s on a 32+ core host."""
     from oracle import repmode_oracle as orc
-    cores = os.cpu_count() or 1
+    # the oracle's PyTorch-CPU ops stop scaling well before a big host's hardware-thread count and then regress badly
+    # (all 256+ threads of the GPU box: a batch-2 step did not finish in 5 minutes; 32 threads: ~7 s) -- 32 is the
+    # measured sweet spot; `cores` reports the threads actually used, the sample text the host's count
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     n = 2
     vox = n * PATCH[0] * PATCH[1] * PATCH[2]
@@ -123,6 +126,7 @@ def cpu_baseline():
     return {'value': res[best]['value'], 'unit': 'voxels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'variant': best,
             'reference_style_value': res['reference-style']['value'], 'vectorised_value': res['vectorised']['value'],
+            'host_hw_threads': os.cpu_count(),
             'sample': 'full mult_chan=32 network, fp32 train steps (fwd+bwd+Adam) on batch 2 of 1x32x64x64, tasks (3, 7): '
                       '%d step(s) in %.1f s per-sample loop as the reference organises it, %d step(s) in %.1f s vectorised; '
                       '`value` is the faster of the two' % (res['reference-style']['steps'], res['reference-style']['seconds'],

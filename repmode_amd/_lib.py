@@ -92,6 +92,25 @@ def load():
     return lib
 
 
+TORCH_LIB_PATH = os.path.join(_HERE, 'librepmode_torch.so')
+_torch_ops_loaded = False
+
+
+def load_torch_ops():
+    """Load the operator seam (``torch.ops.repmode.*``: C++ ops + autograd over the C ABI, csrc/torch/repmode_ops.cpp).
+    Raises -- never falls back -- when it has not been built."""
+    global _torch_ops_loaded
+    if _torch_ops_loaded:
+        return
+    load()                      # librepmode_hip.so first (the operator library links against it)
+    if not os.path.exists(TORCH_LIB_PATH):
+        raise RepModeHipError(
+            'librepmode_torch.so not found at %s -- build it with `python -c "import __graft_entry__ as g; g.build()"`. '
+            'repmode_amd has no CPU or eager fallback.' % TORCH_LIB_PATH)
+    torch.ops.load_library(TORCH_LIB_PATH)
+    _torch_ops_loaded = True
+
+
 _FUNCS = {}     # name -> bound foreign function (the hot path makes ~500 calls per train step)
 
 

@@ -22,3 +22,19 @@ for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 # only the objects of sources that exist now (a stale .o of a removed / renamed file must not be linked)
 $HIPCC --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT"
 echo "built $OUT"
+
+# ---- the operator seam: TORCH_LIBRARY ops + C++ autograd over the C ABI (host code only: g++, no device code)
+if [ "${REPMODE_SKIP_TORCH_OPS:-0}" != "1" ]; then
+  TOUT="${REPMODE_TORCH_OUT:-$(dirname "$OUT")/librepmode_torch.so}"
+  TSRC="$HERE/torch/repmode_ops.cpp"
+  if [ ! -f "$TOUT" ] || [ "$TSRC" -nt "$TOUT" ] || [ "$ROOT/include/repmode_hip.h" -nt "$TOUT" ] || [ "$OUT" -nt "$TOUT" ]; then
+    TDIR="$(python3 -c 'import os, torch; print(os.path.dirname(torch.__file__))')"
+    ABI="$(python3 -c 'import torch; print(int(torch._C._GLIBCXX_USE_CXX11_ABI))')"
+    g++ -O2 -std=c++17 -fPIC -shared -D__HIP_PLATFORM_AMD__ -DUSE_ROCM -D_GLIBCXX_USE_CXX11_ABI=$ABI \
+        -I"$TDIR/include" -I"$TDIR/include/torch/csrc/api/include" -I/opt/rocm/include -I"$ROOT/include" \
+        "$TSRC" -o "$TOUT" \
+        -L"$TDIR/lib" -ltorch -ltorch_cpu -lc10 -lc10_hip -ltorch_hip \
+        -L"$(dirname "$OUT")" -l:"$(basename "$OUT")" -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$ORIGIN'
+  fi
+  echo "built $TOUT"
+fi

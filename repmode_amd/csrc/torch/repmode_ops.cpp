@@ -1,0 +1,1047 @@
+// repmode_ops.cpp -- the operator seam of the MI355X MoDE hot path: TORCH_LIBRARY ops in
+// namespace `repmode`, C++ autograd, TORCH_CHECK errors, every launch on c10::hip::getCurrentHIPStream().
+//
+// One op call per MoDE block (gate softmax + GatRep + per-slot 5x5x5 convolution + BatchNorm3d + ReLU, forward; the
+// whole backward chain lives in the C++ autograd nodes it records), one per stride-2 stage: a train step is ~30
+// Python -> C++ transitions instead of ~410 ctypes calls, which is what kept the host as slow as the GPU.
+//
+// This file holds NO arithmetic: every FLOP is a kernel of librepmode_hip.so, reached through the C ABI of
+// include/repmode_hip.h (plain pointers + sizes + stream).  What lives here is the choice of formulation per layer
+// (per-task merged filter / per-expert convs on the deep levels / two-tensor skip connections / the 1-channel ends),
+// output allocation through PyTorch's caching allocator, the pooled memset, the second stream of a layer, and the
+// autograd bookkeeping -- the counterpart of what fnet/nn_modules/RepMode.py:171-214 leaves to stock PyTorch ops.
+//
+// Built by repmode_amd/csrc/build.sh into repmode_amd/librepmode_torch.so (in-tree, next to librepmode_hip.so).
+#include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+#include <torch/autograd.h>
+#include <torch/library.h>
+
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "repmode_hip.h"
+
+namespace rm {
+
+using at::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+using OptTensor = c10::optional<Tensor>;
+
+constexpr int64_t E = REPMODE_NUM_EXPERTS;
+constexpr int64_t TAPS = REPMODE_TAPS;
+
+#define RM_CALL(fn, ...)                                                                          \
+  do {                                                                                            \
+    const int rc__ = fn(__VA_ARGS__);                                                             \
+    TORCH_CHECK(rc__ == 0, #fn " failed (code ", rc__, "): ", repmode_last_error());              \
+  } while (0)
+
+inline void* stream_handle() { return static_cast<void*>(c10::hip::getCurrentHIPStream().stream()); }
+
+inline int dtype_code(at::ScalarType t) {
+  if (t == at::kFloat) return REPMODE_F32;
+  if (t == at::kBFloat16) return REPMODE_BF16;
+  TORCH_CHECK(false, "repmode computes in float32 or bfloat16, got ", t);
+}
+inline at::ScalarType code_dtype(int64_t code) {
+  TORCH_CHECK(code == REPMODE_F32 || code == REPMODE_BF16, "repmode: bad dtype code ", code);
+  return code == REPMODE_F32 ? at::kFloat : at::kBFloat16;
+}
+
+inline void require_hip(const Tensor& t, const char* what) {
+  TORCH_CHECK(t.is_cuda(), what, " is on ", t.device(), ": repmode runs on MI355X (HIP) tensors only and has no CPU fallback");
+}
+
+inline int64_t padded(int64_t c, int code, bool red) { return repmode_padded_channels((int)c, code, red ? 1 : 0); }
+
+inline Tensor empty_like_opts(const Tensor& ref, at::IntArrayRef shape, at::ScalarType dt) {
+  return at::empty(shape, ref.options().dtype(dt));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Which merged filter each sample uses (the Python side builds the three index vectors from the task ids on the
+// host: repmode_amd.ops.TaskPlan; RepMode.py:44-49 one-hot embedding, :209-210 one slot in eval mode).
+struct Plan {
+  Tensor slot_task, sample_slot, sample_task;   // int32, on the device
+  int64_t nslots = 0, n = 0, num_tasks = 0;
+  bool training = true;
+  int64_t task0 = 0;                            // task of slot 0 (key of the eval-mode filter cache)
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// One pre-zeroed buffer per train step for the float accumulation targets of the atomics-based kernels (split-K conv
+// outputs, chunked filter gradients): ~60 memset launches per step become one.  The first step with a given key
+// records the requested sizes in order; later steps allocate the total once, hand out independent tensors over that
+// storage in the same order (not views: views would share ONE version counter) and tell the kernels to skip their own
+// clearing.  Any divergence from the recorded sequence falls back to plain allocations for the rest of the step.
+struct ZeroPool {
+  static constexpr int64_t ALIGN = 64;   // floats (256 bytes)
+  std::mutex mu;
+  std::unordered_map<std::string, std::vector<int64_t>> plans;
+  bool open = false;
+  std::string key;
+  std::vector<int64_t> req, plan;
+  size_t pos = 0;
+  int64_t off = 0;
+  Tensor buf;
+
+  void end_locked() {
+    if (open && !req.empty()) plans[key] = req;
+    open = false;
+    req.clear();
+    plan.clear();
+    buf = Tensor();
+  }
+  void begin(const std::string& k, const Tensor& like) {
+    std::lock_guard<std::mutex> lock(mu);
+    end_locked();
+    open = true;
+    key = k;
+    pos = 0;
+    off = 0;
+    auto it = plans.find(k);
+    if (it != plans.end() && !it->second.empty()) {
+      plan = it->second;
+      int64_t total = 0;
+      for (int64_t v : plan) total += (v + ALIGN - 1) / ALIGN * ALIGN;
+      buf = at::zeros({total}, like.options().dtype(at::kFloat));
+    }
+  }
+  void end() {
+    std::lock_guard<std::mutex> lock(mu);
+    end_locked();
+  }
+  std::pair<Tensor, bool> take(at::IntArrayRef shape, const Tensor& like) {
+    std::lock_guard<std::mutex> lock(mu);
+    int64_t nel = 1;
+    for (int64_t v : shape) nel *= v;
+    if (open) {
+      req.push_back(nel);
+      if (buf.defined() && pos < plan.size() && plan[pos] == nel) {
+        Tensor t = at::empty({0}, buf.options());
+        std::vector<int64_t> strides(shape.size());
+        int64_t s = 1;
+        for (int64_t i = (int64_t)shape.size() - 1; i >= 0; --i) { strides[i] = s; s *= shape[i]; }
+        t.set_(buf.storage(), off, shape, strides);
+        off += (nel + ALIGN - 1) / ALIGN * ALIGN;
+        ++pos;
+        return {t, true};
+      }
+      buf = Tensor();   // sequence differs from the recorded one: plain allocations from here on
+    }
+    return {at::empty(shape, like.options().dtype(at::kFloat)), false};
+  }
+};
+ZeroPool g_pool;
+
+// ------------------------------------------------------------------------------------------------------------
+// Where the MoDE gradient kernels put parameter gradients: a data-parallel reducer's communication buckets
+// (repmode_amd.distributed.GradReducer) when registered, else fresh tensors.
+struct SinkEntry {
+  Tensor param, flat;
+  int64_t offset;
+};
+std::mutex g_sink_mu;
+std::unordered_map<void*, SinkEntry> g_sink;
+
+Tensor grad_out(const Tensor& param) {
+  {
+    std::lock_guard<std::mutex> lock(g_sink_mu);
+    if (!g_sink.empty()) {
+      auto it = g_sink.find(param.data_ptr());
+      if (it != g_sink.end() && !it->second.param.grad().defined() && it->second.param.sizes() == param.sizes())
+        return it->second.flat.as_strided(param.sizes(), param.strides(), it->second.offset);
+    }
+  }
+  return at::empty_like(param);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// A second HIP stream for the independent launches of one layer (deep levels: a launch has 128-256 workgroups for
+// 512 slots; a layer's data gradient does not depend on its filter gradient + GatRep backward).  Everything a
+// side-stream launch touches stays alive until the join, which comes before the op returns.
+int64_t g_fork_max_w = []() {
+  const char* e = std::getenv("REPMODE_FORK_MAX_W");
+  return e ? (int64_t)std::atoi(e) : (int64_t)0;
+}();
+
+#define RM_HIP_CHECK(call)                                                                        \
+  do {                                                                                            \
+    const hipError_t e__ = (call);                                                                \
+    TORCH_CHECK(e__ == hipSuccess, #call ": ", hipGetErrorString(e__));                          \
+  } while (0)
+
+struct Fork {
+  struct PerDevice {
+    c10::hip::HIPStream side;
+    hipEvent_t fork_ev, join_ev;
+  };
+  bool on = false;
+  c10::hip::HIPStream main_s = c10::hip::getDefaultHIPStream();
+  PerDevice* pd = nullptr;
+  explicit Fork(bool enable, const Tensor& t) {
+    if (!enable) return;
+    on = true;
+    const int dev = t.device().index();
+    main_s = c10::hip::getCurrentHIPStream(dev);
+    static std::mutex mu;
+    static std::unordered_map<int, PerDevice> per;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = per.find(dev);
+      if (it == per.end()) {
+        PerDevice d{c10::hip::getStreamFromPool(false, dev), nullptr, nullptr};
+        RM_HIP_CHECK(hipEventCreateWithFlags(&d.fork_ev, hipEventDisableTiming));
+        RM_HIP_CHECK(hipEventCreateWithFlags(&d.join_ev, hipEventDisableTiming));
+        it = per.emplace(dev, d).first;
+      }
+      pd = &it->second;
+    }
+    // the side stream is ordered after everything issued on the current stream so far
+    RM_HIP_CHECK(hipEventRecord(pd->fork_ev, main_s.stream()));
+    RM_HIP_CHECK(hipStreamWaitEvent(pd->side.stream(), pd->fork_ev, 0));
+  }
+  void to_side() const { if (on) c10::hip::setCurrentHIPStream(pd->side); }
+  void to_main() const { if (on) c10::hip::setCurrentHIPStream(main_s); }
+  void join() {
+    if (!on) return;
+    c10::hip::setCurrentHIPStream(main_s);
+    RM_HIP_CHECK(hipEventRecord(pd->join_ev, pd->side.stream()));
+    RM_HIP_CHECK(hipStreamWaitEvent(main_s.stream(), pd->join_ev, 0));
+    on = false;
+  }
+  ~Fork() { if (on) c10::hip::setCurrentHIPStream(main_s); }   // (an exception between fork and join: restore the stream)
+};
+inline bool forks(const Tensor& x_cl) { return x_cl.size(3) > 0 && x_cl.size(3) <= g_fork_max_w; }
+
+// ------------------------------------------------------------------------------------------------------------
+// thin wrappers of the C ABI (allocation + argument marshalling)
+
+Tensor gate_softmax(const Tensor& gw, const Tensor& gb, const Tensor& ids, int64_t rows, int64_t num_tasks, int64_t co) {
+  Tensor g = at::empty({rows, E, co}, gw.options());
+  RM_CALL(repmode_gate_softmax, gw.data_ptr<float>(), gb.data_ptr<float>(), ids.data_ptr<int32_t>(), (int)rows, (int)num_tasks,
+          (int)co, g.data_ptr<float>(), stream_handle());
+  return g;
+}
+
+std::pair<Tensor, Tensor> gatrep_merge(const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3, const Tensor& a5,
+                                       const Tensor& g, at::ScalarType dt, bool want_wf, bool want_wd) {
+  const int64_t co = k5.size(0), ci = k5.size(1), s = g.size(0);
+  const int code = dtype_code(dt);
+  Tensor wf, wd;
+  if (want_wf) wf = at::empty({s, TAPS, padded(co, code, false), padded(ci, code, true)}, k5.options().dtype(dt));
+  if (want_wd) wd = at::empty({s, TAPS, padded(ci, code, false), padded(co, code, true)}, k5.options().dtype(dt));
+  RM_CALL(repmode_gatrep_fwd, k5.data_ptr<float>(), k3.data_ptr<float>(), k1.data_ptr<float>(), a3.data_ptr<float>(),
+          a5.data_ptr<float>(), g.data_ptr<float>(), (int)s, (int)co, (int)ci, code, want_wf ? wf.data_ptr() : nullptr,
+          want_wd ? wd.data_ptr() : nullptr, stream_handle());
+  return {wf, wd};
+}
+
+Tensor expert_selector(int64_t co, const Tensor& like) {
+  // g for two pseudo-slots that select the raw experts: slot 0 = conv5x5, slot 1 = zero-padded conv3x3
+  Tensor g = at::zeros({2, E, co}, like.options().dtype(at::kFloat));
+  g[0][0].fill_(1.0);
+  g[1][1].fill_(1.0);
+  return g;
+}
+
+// The raw 5^3 / 3^3 experts as two un-merged slots of the conv kernels' layouts (slot 1 = K3, valid for centre3
+// convolutions only).  bf16: one layout kernel per role; float32 (parity mode): GatRep with one-hot gates.
+std::pair<Tensor, Tensor> expert_frags(const Tensor& k5, const Tensor& k3, at::ScalarType dt, bool want_wd) {
+  const int64_t co = k5.size(0), ci = k5.size(1);
+  if (dt != at::kBFloat16) {
+    Tensor z = at::zeros({co, ci}, k5.options());
+    return gatrep_merge(k5, k3, z, z, z, expert_selector(co, k5), dt, true, want_wd);
+  }
+  const int code = REPMODE_BF16;
+  Tensor wf = at::empty({2, TAPS, padded(co, code, false), padded(ci, code, true)}, k5.options().dtype(dt));
+  Tensor wd;
+  if (want_wd) wd = at::empty({2, TAPS, padded(ci, code, false), padded(co, code, true)}, k5.options().dtype(dt));
+  RM_CALL(repmode_expert_frags, k5.data_ptr<float>(), k3.data_ptr<float>(), (int)co, (int)ci, wf.data_ptr(),
+          want_wd ? wd.data_ptr() : nullptr, stream_handle());
+  return {wf, wd};
+}
+
+// y[n] = x[n] (*) w[sample_slot[n]], 5^3 'same' cross-correlation, NDHWC -- RepMode.py:204-210
+Tensor conv5(const Tensor& x_cl, const Tensor& w, const Tensor& sample_slot, int64_t cout, bool out_f32, OptTensor out = c10::nullopt,
+             bool centre3 = false, bool accumulate = false, bool dxc = false) {
+  const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), wd_ = x_cl.size(3), cin = x_cl.size(4);
+  const int code = dtype_code(x_cl.scalar_type());
+  const at::ScalarType odt = (out_f32 || x_cl.scalar_type() == at::kFloat) ? at::kFloat : x_cl.scalar_type();
+  Tensor y;
+  if (out.has_value()) {
+    y = *out;
+  } else if (odt == at::kFloat && x_cl.scalar_type() == at::kBFloat16) {
+    // float output = the kernel may split the reduction and add with atomics: a pre-zeroed pool tensor saves its memset
+    auto tk = g_pool.take({n, d, h, wd_, cout}, x_cl);
+    y = tk.first;
+    accumulate = accumulate || tk.second;
+  } else {
+    y = at::empty({n, d, h, wd_, cout}, x_cl.options().dtype(odt));
+  }
+  TORCH_CHECK(y.scalar_type() == odt && y.is_contiguous(), "conv5: bad output tensor");
+  TORCH_CHECK(!accumulate || odt == at::kFloat, "conv5: accumulation needs a float output");
+  RM_CALL(repmode_conv5_ex, x_cl.data_ptr(), w.data_ptr(), sample_slot.data_ptr<int32_t>(), y.data_ptr(), (int)n, (int)d, (int)h,
+          (int)wd_, (int)cin, (int)cout, code, odt == at::kFloat ? 1 : 0, (centre3 ? 1 : 0) | (accumulate ? 2 : 0) | (dxc ? 4 : 0),
+          stream_handle());
+  return y;
+}
+
+Tensor thin_pack(const Tensor& w, bool to_rows) {
+  const int64_t s_ = w.size(0), rp = w.size(2), kp = w.size(3);
+  TORCH_CHECK((kp == 16 && !to_rows) || (rp == 32 && to_rows), "thin_pack: not a thin layer's filter");
+  Tensor out = at::empty_like(w);     // only the 25 (dz, dy, dx=2) taps are written -- and read
+  RM_CALL(repmode_thin_pack, w.data_ptr(), out.data_ptr(), (int)s_, (int)((rp / 32) * (kp / 16)), to_rows ? 1 : 0, stream_handle());
+  return out;
+}
+
+Tensor shift5(const Tensor& t_cl) {
+  const int64_t n = t_cl.size(0), d = t_cl.size(1), h = t_cl.size(2), w_ = t_cl.size(3);
+  Tensor out = at::empty({n, d, h, w_, 8}, t_cl.options().dtype(at::kBFloat16));
+  RM_CALL(repmode_shift5, t_cl.data_ptr(), dtype_code(t_cl.scalar_type()), out.data_ptr(), (long)(n * d * h), (int)w_, stream_handle());
+  return out;
+}
+
+// conv5 for a ONE-channel input: the five x taps become channels, 25 instead of 125 taps (csrc/thin.hip)
+Tensor thin_conv_in1(const Tensor& x_cl, const Tensor& w, const Tensor& sample_slot, int64_t cout, bool out_f32) {
+  return conv5(shift5(x_cl.contiguous()), thin_pack(w, false), sample_slot, cout, out_f32, c10::nullopt, false, false, true);
+}
+
+// conv5 for ONE output channel: the five x taps become output rows, then a 5-tap diagonal sum.  float [N,D,H,W,1]
+Tensor thin_conv_out1(const Tensor& x_cl, const Tensor& w, const Tensor& sample_slot) {
+  const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), w_ = x_cl.size(3);
+  Tensor y5 = conv5(x_cl, thin_pack(w, true), sample_slot, 5, true, c10::nullopt, false, false, true);
+  Tensor y = at::empty({n, d, h, w_, 1}, x_cl.options().dtype(at::kFloat));
+  RM_CALL(repmode_unshift5, y5.data_ptr<float>(), y.data_ptr<float>(), (long)(n * d * h), (int)w_, stream_handle());
+  return y;
+}
+
+// dw[s, tap, o, i] (float32) summed over the samples of each slot
+Tensor conv5_wgrad(const Tensor& x_cl, const Tensor& dy_cl, const Tensor& sample_slot, int64_t nslots, int64_t cout, bool centre3 = false) {
+  const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), wd_ = x_cl.size(3), cin = x_cl.size(4);
+  auto tk = g_pool.take({nslots, TAPS, cout, cin}, x_cl);
+  Tensor dw = tk.first;
+  const bool pre = tk.second;
+  if (x_cl.scalar_type() == at::kBFloat16 && ((cin == 1) != (cout == 1)) && !centre3) {
+    // thin layer: taps stand in for the missing channel dimension (conv5_wgrad_thin)
+    const bool first = cin == 1;
+    const Tensor& a_t = first ? dy_cl : x_cl;
+    const Tensor& b_t = first ? x_cl : dy_cl;
+    RM_CALL(repmode_conv5_wgrad_thin, a_t.data_ptr(), b_t.data_ptr(), sample_slot.data_ptr<int32_t>(), (int)nslots,
+            dw.data_ptr<float>(), (int)n, (int)d, (int)h, (int)wd_, (int)(first ? cout : cin), (first ? 0 : 1) | (pre ? 2 : 0),
+            stream_handle());
+    return dw;
+  }
+  RM_CALL(repmode_conv5_wgrad_ex, x_cl.data_ptr(), dy_cl.data_ptr(), sample_slot.data_ptr<int32_t>(), (int)nslots, dw.data_ptr<float>(),
+          (int)n, (int)d, (int)h, (int)wd_, (int)cin, (int)cout, dtype_code(x_cl.scalar_type()), (centre3 ? 1 : 0) | (pre ? 8 : 0),
+          stream_handle());
+  return dw;
+}
+
+// single slot, gradient written directly in the experts' parameter layout: [Co, Ci, 5,5,5] or [Co, Ci, 3,3,3]
+Tensor conv5_wgrad_expert_layout(const Tensor& x_cl, const Tensor& dy_cl, const Tensor& sample_slot, int64_t cout, int64_t k, Tensor out) {
+  const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), wd_ = x_cl.size(3), cin = x_cl.size(4);
+  TORCH_CHECK(out.scalar_type() == at::kFloat && out.is_contiguous() && out.numel() == cout * cin * k * k * k, "wgrad: bad output");
+  RM_CALL(repmode_conv5_wgrad_ex, x_cl.data_ptr(), dy_cl.data_ptr(), sample_slot.data_ptr<int32_t>(), 1, out.data_ptr<float>(), (int)n,
+          (int)d, (int)h, (int)wd_, (int)cin, (int)cout, dtype_code(x_cl.scalar_type()), k == 5 ? 2 : 3, stream_handle());
+  return out;
+}
+
+Tensor tap_transpose(const Tensor& dw_taps, at::IntArrayRef shape, Tensor out) {
+  const int64_t co = shape[0], ci = shape[1], k = shape[2];
+  TORCH_CHECK(out.sizes() == shape && out.scalar_type() == at::kFloat && out.is_contiguous(), "tap_transpose: bad output");
+  RM_CALL(repmode_tap_transpose, dw_taps.data_ptr<float>(), out.data_ptr<float>(), (long)(co * ci), (int)(k * k * k), stream_handle());
+  return out;
+}
+
+Tensor box_sum(const Tensor* in3, const Tensor* in5, const Tensor* add0, const Tensor* add1, OptTensor out, at::ScalarType out_dtype) {
+  const Tensor& ref = in3 ? *in3 : *in5;
+  Tensor o = out.has_value() ? *out : at::empty(ref.sizes(), ref.options().dtype(out_dtype));
+  RM_CALL(repmode_box_sum_ex, in3 ? in3->data_ptr<float>() : nullptr, in5 ? in5->data_ptr<float>() : nullptr,
+          add0 ? add0->data_ptr<float>() : nullptr, add1 ? add1->data_ptr<float>() : nullptr, o.data_ptr(), dtype_code(o.scalar_type()),
+          (int)ref.size(0), (int)ref.size(1), (int)ref.size(2), (int)ref.size(3), (int)ref.size(4), stream_handle());
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// eval-mode filter cache: inside [begin, end) the merged filter of an eval-mode block (one slot, RepMode.py:209-210)
+// is computed once per (block, task, dtype): sliding-window inference re-uses it for every batch of patches.
+struct EvalKey {
+  void* k5;
+  int64_t task;
+  int dt;
+  bool operator==(const EvalKey& o) const { return k5 == o.k5 && task == o.task && dt == o.dt; }
+};
+struct EvalKeyHash {
+  size_t operator()(const EvalKey& k) const { return std::hash<void*>()(k.k5) ^ (size_t)(k.task * 1315423911u) ^ (size_t)k.dt; }
+};
+std::mutex g_eval_mu;
+int g_eval_depth = 0;
+std::unordered_map<EvalKey, std::pair<Tensor, Tensor>, EvalKeyHash> g_eval;
+
+struct Merged {
+  Tensor g, wf, wd;
+};
+Merged merged_filters(const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3, const Tensor& a5, const Tensor& gw,
+                      const Tensor& gb, const Plan& plan, at::ScalarType dt, bool want_wd, bool grad_enabled) {
+  const bool cacheable = !(plan.training || want_wd || grad_enabled);
+  EvalKey key{k5.data_ptr(), plan.task0, (int)dt};
+  if (cacheable) {
+    std::lock_guard<std::mutex> lock(g_eval_mu);
+    if (g_eval_depth > 0) {
+      auto it = g_eval.find(key);
+      if (it != g_eval.end()) return {it->second.first, it->second.second, Tensor()};
+    }
+  }
+  Merged m;
+  m.g = gate_softmax(gw, gb, plan.slot_task, plan.nslots, plan.num_tasks, k5.size(0));
+  auto w = gatrep_merge(k5, k3, k1, a3, a5, m.g, dt, true, want_wd);
+  m.wf = w.first;
+  m.wd = w.second;
+  if (cacheable) {
+    std::lock_guard<std::mutex> lock(g_eval_mu);
+    if (g_eval_depth > 0) g_eval[key] = {m.g, m.wf};
+  }
+  return m;
+}
+
+// GatRep backward: per-slot filter gradient dw [S, 125, Co, Ci] -> (dk5, dk3, dk1, da3, da5, dgate_w, dgate_b)
+std::vector<Tensor> filter_and_expert_grads(const Tensor& dw, const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3,
+                                            const Tensor& a5, const Tensor& g, const Plan& plan) {
+  const int64_t co = k5.size(0), ci = k5.size(1);
+  Tensor dk5 = grad_out(k5), dk3 = grad_out(k3), dk1 = grad_out(k1), da3 = grad_out(a3), da5 = grad_out(a5);
+  Tensor dgw = at::empty({E * co, plan.num_tasks}, k5.options());
+  Tensor dgb = at::empty({E * co}, k5.options());
+  Tensor dg_ws = at::empty_like(g);
+  RM_CALL(repmode_gatrep_bwd, dw.data_ptr<float>(), k5.data_ptr<float>(), k3.data_ptr<float>(), k1.data_ptr<float>(),
+          a3.data_ptr<float>(), a5.data_ptr<float>(), g.data_ptr<float>(), plan.slot_task.data_ptr<int32_t>(), (int)plan.nslots,
+          (int)plan.num_tasks, (int)co, (int)ci, dk5.data_ptr<float>(), dk3.data_ptr<float>(), dk1.data_ptr<float>(),
+          da3.data_ptr<float>(), da5.data_ptr<float>(), dgw.data_ptr<float>(), dgb.data_ptr<float>(), dg_ws.data_ptr<float>(),
+          stream_handle());
+  return {dk5, dk3, dk1, da3, da5, dgw, dgb};
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// autograd nodes.  Input order of every MoDE function: activations first, then k5 k3 k1 a3 a5 gate_w gate_b.
+
+// Fused gate-softmax + GatRep + per-slot 5^3 convolution (the "merged" formulation), forward and backward.
+struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
+  static Tensor forward(AutogradContext* ctx, Tensor x_cl, Tensor k5, Tensor k3, Tensor k1, Tensor a3, Tensor a5, Tensor gw, Tensor gb,
+                        Plan plan, bool out_f32, bool grad_enabled) {
+    const int64_t co = k5.size(0), ci = k5.size(1);
+    const bool need_dx = grad_enabled && x_cl.requires_grad();
+    // the data-gradient filter comes out of the same pass over the experts (one launch, one read of the weights)
+    Merged m = merged_filters(k5, k3, k1, a3, a5, gw, gb, plan, x_cl.scalar_type(), need_dx, grad_enabled);
+    const bool thin = x_cl.scalar_type() == at::kBFloat16 && ((ci == 1) != (co == 1));
+    Tensor y;
+    if (thin && ci == 1) {                                 // first layer: x taps folded into input channels
+      y = thin_conv_in1(x_cl, m.wf, plan.sample_slot, co, out_f32);
+    } else if (thin) {                                     // last layer: x taps folded into output rows
+      y = thin_conv_out1(x_cl, m.wf, plan.sample_slot);
+      if (!out_f32) y = y.to(x_cl.scalar_type());
+    } else {
+      y = conv5(x_cl, m.wf, plan.sample_slot, co, out_f32);
+    }
+    ctx->save_for_backward({x_cl, k5, k3, k1, a3, a5, m.g, m.wd.defined() ? m.wd : Tensor()});
+    ctx->saved_data["slot_task"] = plan.slot_task;
+    ctx->saved_data["sample_slot"] = plan.sample_slot;
+    ctx->saved_data["nslots"] = plan.nslots;
+    ctx->saved_data["num_tasks"] = plan.num_tasks;
+    return y;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto sv = ctx->get_saved_variables();
+    const Tensor &x_cl = sv[0], &k5 = sv[1], &k3 = sv[2], &k1 = sv[3], &a3 = sv[4], &a5 = sv[5], &g = sv[6];
+    Tensor wd = sv[7];
+    Plan plan;
+    plan.slot_task = ctx->saved_data["slot_task"].toTensor();
+    plan.sample_slot = ctx->saved_data["sample_slot"].toTensor();
+    plan.nslots = ctx->saved_data["nslots"].toInt();
+    plan.num_tasks = ctx->saved_data["num_tasks"].toInt();
+    const int64_t co = k5.size(0), ci = k5.size(1);
+    const at::ScalarType dt = x_cl.scalar_type();
+    Tensor dy = grads[0].to(dt).contiguous();
+    const bool need_dx = ctx->needs_input_grad(0) && wd.defined();
+    // the filter gradient and the GatRep backward do not depend on the data gradient: second stream on the deep levels
+    Fork fork(need_dx && forks(x_cl), x_cl);
+    fork.to_side();
+    std::vector<Tensor> pg = filter_and_expert_grads(conv5_wgrad(x_cl, dy, plan.sample_slot, plan.nslots, co), k5, k3, k1, a3, a5, g, plan);
+    fork.to_main();
+    Tensor dx;
+    if (need_dx) {
+      // deep levels (small volumes) split the channel reduction over workgroups -> float output
+      const bool f32 = x_cl.size(3) < 32;
+      if (dt == at::kBFloat16 && co == 1 && ci != 1) dx = thin_conv_in1(dy, wd, plan.sample_slot, ci, f32);   // last layer: dy has one channel
+      else if (dt == at::kBFloat16 && ci == 1 && co != 1) dx = thin_conv_out1(dy, wd, plan.sample_slot);
+      else dx = conv5(dy, wd, plan.sample_slot, ci, f32);
+      if (dx.scalar_type() != dt) dx = dx.to(dt);
+    }
+    fork.join();
+    return {dx, pg[0], pg[1], pg[2], pg[3], pg[4], pg[5], pg[6], Tensor(), Tensor(), Tensor()};
+  }
+};
+
+// The same for a skip connection: the block's input is the channel concatenation of two tensors (RepMode.py:106
+// torch.cat((x_skip, up), 1)), which is never materialised (repmode_conv5_pair, repmode_conv5_wgrad_part).
+struct ModeConvPair : public torch::autograd::Function<ModeConvPair> {
+  static Tensor forward(AutogradContext* ctx, Tensor xa, Tensor xb, Tensor k5, Tensor k3, Tensor k1, Tensor a3, Tensor a5, Tensor gw,
+                        Tensor gb, Plan plan, bool out_f32, bool grad_enabled) {
+    const int64_t co = k5.size(0), ci = k5.size(1), ca = xa.size(4);
+    const int64_t n = xa.size(0), d = xa.size(1), h = xa.size(2), w_ = xa.size(3);
+    const bool need_dx = grad_enabled && (xa.requires_grad() || xb.requires_grad());
+    Merged m = merged_filters(k5, k3, k1, a3, a5, gw, gb, plan, xa.scalar_type(), need_dx, grad_enabled);
+    const int code = dtype_code(xa.scalar_type());
+    const at::ScalarType odt = (out_f32 || xa.scalar_type() == at::kFloat) ? at::kFloat : xa.scalar_type();
+    int flags = 0;
+    Tensor y;
+    if (odt == at::kFloat && xa.scalar_type() == at::kBFloat16) {
+      auto tk = g_pool.take({n, d, h, w_, co}, xa);
+      y = tk.first;
+      flags = tk.second ? 2 : 0;
+    } else {
+      y = at::empty({n, d, h, w_, co}, xa.options().dtype(odt));
+    }
+    RM_CALL(repmode_conv5_pair, xa.data_ptr(), xb.data_ptr(), (int)ca, m.wf.data_ptr(), plan.sample_slot.data_ptr<int32_t>(), y.data_ptr(),
+            nullptr, 0, (int)n, (int)d, (int)h, (int)w_, (int)ci, (int)co, code, odt == at::kFloat ? 1 : 0, flags, stream_handle());
+    ctx->save_for_backward({xa, xb, k5, k3, k1, a3, a5, m.g, m.wd.defined() ? m.wd : Tensor()});
+    ctx->saved_data["slot_task"] = plan.slot_task;
+    ctx->saved_data["sample_slot"] = plan.sample_slot;
+    ctx->saved_data["nslots"] = plan.nslots;
+    ctx->saved_data["num_tasks"] = plan.num_tasks;
+    return y;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto sv = ctx->get_saved_variables();
+    const Tensor &xa = sv[0], &xb = sv[1], &k5 = sv[2], &k3 = sv[3], &k1 = sv[4], &a3 = sv[5], &a5 = sv[6], &g = sv[7];
+    Tensor wd = sv[8];
+    Plan plan;
+    plan.slot_task = ctx->saved_data["slot_task"].toTensor();
+    plan.sample_slot = ctx->saved_data["sample_slot"].toTensor();
+    plan.nslots = ctx->saved_data["nslots"].toInt();
+    plan.num_tasks = ctx->saved_data["num_tasks"].toInt();
+    const int64_t co = k5.size(0), ci = k5.size(1), ca = xa.size(4), cb = xb.size(4);
+    const int64_t n = xa.size(0), d = xa.size(1), h = xa.size(2), w_ = xa.size(3);
+    const at::ScalarType dt = xa.scalar_type();
+    const int code = dtype_code(dt);
+    Tensor dy = grads[0].to(dt).contiguous();
+    Fork fork(wd.defined() && forks(xa), xa);
+    fork.to_side();
+    std::vector<Tensor> pg;
+    {
+      // the two channel ranges of one (cleared) buffer
+      auto tk = g_pool.take({plan.nslots, TAPS, co, ci}, xa);
+      Tensor dw = tk.first;
+      if (!tk.second) dw.zero_();
+      const Tensor* parts[2] = {&xa, &xb};
+      const int64_t offs[2] = {0, ca};
+      for (int i = 0; i < 2; ++i)
+        RM_CALL(repmode_conv5_wgrad_part, parts[i]->data_ptr(), dy.data_ptr(), plan.sample_slot.data_ptr<int32_t>(), (int)plan.nslots,
+                dw.data_ptr<float>(), (int)n, (int)d, (int)h, (int)w_, (int)parts[i]->size(4), (int)ci, (int)offs[i], (int)co, code, 8,
+                stream_handle());
+      pg = filter_and_expert_grads(dw, k5, k3, k1, a3, a5, g, plan);
+    }
+    fork.to_main();
+    Tensor dxa, dxb;
+    if (wd.defined()) {
+      const bool f32 = w_ < 32 || dt == at::kFloat;   // deep levels: split reduction -> float output
+      int flags = 0;
+      if (f32 && dt == at::kBFloat16) {
+        auto ta = g_pool.take({n, d, h, w_, ca}, xa);
+        auto tb = g_pool.take({n, d, h, w_, cb}, xa);
+        dxa = ta.first;
+        dxb = tb.first;
+        if (ta.second && tb.second) {
+          flags = 2;
+        } else if (ta.second || tb.second) {      // (cannot happen with a consistent pool; stay correct anyway)
+          dxa.zero_();
+          dxb.zero_();
+          flags = 2;
+        }
+      } else {
+        const at::ScalarType odt = f32 ? at::kFloat : dt;
+        dxa = at::empty({n, d, h, w_, ca}, xa.options().dtype(odt));
+        dxb = at::empty({n, d, h, w_, cb}, xa.options().dtype(odt));
+      }
+      RM_CALL(repmode_conv5_pair, dy.data_ptr(), nullptr, 0, wd.data_ptr(), plan.sample_slot.data_ptr<int32_t>(), dxa.data_ptr(),
+              dxb.data_ptr(), (int)ca, (int)n, (int)d, (int)h, (int)w_, (int)co, (int)ci, code, f32 ? 1 : 0, flags, stream_handle());
+      if (dxa.scalar_type() != dt) {
+        dxa = dxa.to(dt);
+        dxb = dxb.to(dt);
+      }
+    }
+    fork.join();
+    return {dxa, dxb, pg[0], pg[1], pg[2], pg[3], pg[4], pg[5], pg[6], Tensor(), Tensor(), Tensor()};
+  }
+};
+
+// constant index vectors of the slot-less per-expert convolutions (slot 0 = K5, slot 1 = K3), cached per (n, device)
+Tensor single_slot(int64_t n, int64_t slot, const Tensor& like) {
+  static std::mutex mu;
+  static std::unordered_map<int64_t, Tensor> cache;
+  const int64_t key = (n * 4 + slot) * 64 + like.device().index();
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(key);
+  if (it == cache.end()) it = cache.emplace(key, at::full({n}, slot, like.options().dtype(at::kInt))).first;
+  return it->second;
+}
+
+// The same MoDE block by linearity of the convolution (property 3):
+//     y[n] = sum_e g[n, e, :] * conv(x[n], K_e)
+// The experts are shared by all samples, so nothing is merged per task: the 5^3 and 3^3 experts are laid out once as
+// two pseudo-slots and the HIP conv kernels run them for the whole batch; the three 1x1 experts (conv1x1, avg3, avg5)
+// are GEMMs on x and its box means.  Used on the deep levels, where the weights (84 % of the parameters) dwarf the
+// activations and per-task merged filters / filter gradients are pure HBM traffic.
+struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
+  static Tensor forward(AutogradContext* ctx, Tensor x_cl, Tensor k5, Tensor k3, Tensor k1, Tensor a3, Tensor a5, Tensor gw, Tensor gb,
+                        Plan plan, bool grad_enabled) {
+    const int64_t co = k5.size(0), ci = k5.size(1);
+    const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), w = x_cl.size(3);
+    const bool need_dx = grad_enabled && x_cl.requires_grad();
+    Tensor gn = gate_softmax(gw, gb, plan.sample_task, plan.n, plan.num_tasks, co);       // g per SAMPLE [N, 5, Co]
+    auto fr = expert_frags(k5, k3, x_cl.scalar_type(), need_dx);
+    Tensor s0 = single_slot(n, 0, x_cl), s1 = single_slot(n, 1, x_cl);
+    auto tk = g_pool.take({E, n, d, h, w, co}, x_cl);                                     // expert outputs P_e
+    Tensor p = tk.first;
+    const bool pre = tk.second;
+    Tensor xb = at::empty({3, n, d, h, w, ci}, x_cl.options().dtype(at::kFloat));
+    Tensor w1;
+    // the 5^3 expert's conv on this stream, the four small experts beside it on the second one
+    Fork fork(forks(x_cl), x_cl);
+    fork.to_side();
+    {
+      // the 3^3 expert, and the three 1x1 experts as ONE batched GEMM: [x | box3(x) | box5(x)] @ [K1 | A3 | A5]^T -> P_2..P_4
+      conv5(x_cl, fr.first, s1, co, true, p[1], true, pre);
+      Tensor xb0 = xb[0], xb1 = xb[1], xb2 = xb[2];
+      xb0.copy_(x_cl);
+      box_sum(&xb0, nullptr, nullptr, nullptr, xb1, at::kFloat);
+      box_sum(nullptr, &xb0, nullptr, nullptr, xb2, at::kFloat);
+      w1 = at::stack({k1.view({co, ci}), a3.view({co, ci}), a5.view({co, ci})});          // [3, Co, Ci]
+      Tensor pv = p.narrow(0, 2, 3).view({3, -1, co});
+      at::bmm_out(pv, xb.view({3, -1, ci}), w1.transpose(1, 2));
+    }
+    fork.to_main();
+    conv5(x_cl, fr.first, s0, co, true, p[0], false, pre);
+    fork.join();
+    Tensor y = at::empty({n, d, h, w, co}, x_cl.options().dtype(at::kFloat));
+    RM_CALL(repmode_expert_mix_fwd, p.data_ptr<float>(), gn.data_ptr<float>(), y.data_ptr<float>(), (int)n, (long)(d * h * w), (int)co,
+            stream_handle());
+    ctx->save_for_backward({x_cl, k5, k3, k1, a3, a5, gn, xb, w1, p, fr.second.defined() ? fr.second : Tensor()});
+    ctx->saved_data["sample_task"] = plan.sample_task;
+    ctx->saved_data["num_tasks"] = plan.num_tasks;
+    return y;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto sv = ctx->get_saved_variables();
+    const Tensor &x_cl = sv[0], &k5 = sv[1], &k3 = sv[2], &k1 = sv[3], &a3 = sv[4], &a5 = sv[5], &gn = sv[6], &xb = sv[7], &w1 = sv[8],
+                 &p = sv[9];
+    Tensor wd2 = sv[10];
+    const Tensor sample_task = ctx->saved_data["sample_task"].toTensor();
+    const int64_t num_tasks = ctx->saved_data["num_tasks"].toInt();
+    const int64_t co = k5.size(0), ci = k5.size(1);
+    const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), w = x_cl.size(3);
+    const at::ScalarType dt = x_cl.scalar_type();
+    Tensor dy = grads[0].to(at::kFloat).contiguous();
+    // ---- gate: dg[n,e,o] = <dy, P_e>, softmax Jacobian, Linear grads (RepMode.py:198-200); and the gate-scaled dy per expert.
+    // The three float matrices feed batched GEMMs; rocBLAS picks a pathological kernel when such a GEMM has exactly
+    // 256 x 256 (or 128 x 256) outputs, so for small M each matrix gets 8 rows of zero padding.
+    const int64_t m = n * d * h * w;
+    const int64_t pad = m <= 512 ? 8 : 0;
+    auto tdg = g_pool.take({n, E, co}, x_cl);
+    Tensor dg = tdg.first;
+    Tensor lo = at::empty({2, n, d, h, w, co}, x_cl.options().dtype(dt));
+    Tensor hi;
+    if (pad) {
+      auto th = g_pool.take({3, m + pad, co}, x_cl);
+      hi = th.first;
+      if (!th.second) hi.narrow(1, m, pad).zero_();
+    } else {
+      hi = at::empty({3, m, co}, x_cl.options().dtype(at::kFloat));
+    }
+    RM_CALL(repmode_expert_mix_bwd_ex, dy.data_ptr<float>(), p.data_ptr<float>(), gn.data_ptr<float>(), dg.data_ptr<float>(), lo.data_ptr(),
+            hi.data_ptr<float>(), (long)((m + pad) * co), (int)n, (long)(d * h * w), (int)co, dtype_code(dt) | (tdg.second ? 16 : 0),
+            stream_handle());
+    Tensor dgw = at::empty({E * co, num_tasks}, k5.options());
+    Tensor dgb = at::empty({E * co}, k5.options());
+    RM_CALL(repmode_gate_bwd, gn.data_ptr<float>(), dg.data_ptr<float>(), sample_task.data_ptr<int32_t>(), (int)n, (int)num_tasks, (int)co,
+            dgw.data_ptr<float>(), dgb.data_ptr<float>(), stream_handle());
+    Tensor s0 = single_slot(n, 0, x_cl), s1 = single_slot(n, 1, x_cl);
+    const bool need_dx = ctx->needs_input_grad(0) && wd2.defined();
+    // the expert gradients do not depend on the data gradient: second stream
+    Fork fork(need_dx && forks(x_cl), x_cl);
+    fork.to_side();
+    Tensor dk5, dk3, d1;
+    {
+      // filter gradients of the gate-scaled dy, all samples in one slot.  Large layers (every workgroup owns its outputs: no
+      // atomics) write the parameters' [Co][Ci][taps] layout directly; the others accumulate tap-major + one transpose launch.
+      const int64_t tiles = ((co + 31) / 32) * ((ci + 31) / 32);
+      Tensor lo0 = lo[0], lo1 = lo[1];
+      if (dt == at::kBFloat16 && tiles * 5 >= 512) dk5 = conv5_wgrad_expert_layout(x_cl, lo0, s0, co, 5, grad_out(k5));
+      else dk5 = tap_transpose(conv5_wgrad(x_cl, lo0, s0, 1, co)[0], k5.sizes(), grad_out(k5));
+      if (dt == at::kBFloat16 && tiles * 3 >= 512) dk3 = conv5_wgrad_expert_layout(x_cl, lo1, s0, co, 3, grad_out(k3));
+      else dk3 = tap_transpose(conv5_wgrad(x_cl, lo1, s0, 1, co, true)[0], k3.sizes(), grad_out(k3));
+      d1 = at::bmm(hi.narrow(1, 0, m).transpose(1, 2), xb.view({3, -1, ci}));              // [3, Co, Ci]
+    }
+    fork.to_main();
+    Tensor dx;
+    if (need_dx) {
+      Tensor lo0 = lo[0], lo1 = lo[1];
+      Tensor dxf = conv5(lo0, wd2, s0, ci, true);
+      conv5(lo1, wd2, s1, ci, true, dxf, true, true);
+      // 1x1 experts: one batched GEMM gives the three partial data gradients; the zero-padded box mean is self-adjoint, so the
+      // avg experts' parts go back through box3 / box5 -- summed with the two conv parts and cast in the same kernel
+      Tensor t = at::bmm(hi, w1);                                                          // [3, M(+pad), Ci]
+      Tensor t0 = t[0].narrow(0, 0, m).view(dxf.sizes()), t1 = t[1].narrow(0, 0, m).view(dxf.sizes()),
+             t2 = t[2].narrow(0, 0, m).view(dxf.sizes());
+      dx = box_sum(&t1, &t2, &dxf, &t0, c10::nullopt, dt);
+    }
+    fork.join();
+    return {dx, dk5, dk3, d1[0].reshape(k1.sizes()), d1[1].reshape(a3.sizes()), d1[2].reshape(a5.sizes()), dgw, dgb, Tensor(), Tensor()};
+  }
+};
+
+// BatchNorm3d + ReLU on a channels-last tensor [..., C] (RepMode.py:146-149, 212; :80-84; :97-101)
+struct BnRelu : public torch::autograd::Function<BnRelu> {
+  static Tensor forward(AutogradContext* ctx, Tensor x_cl, Tensor weight, Tensor bias, Tensor rm_, Tensor rv_, bool batch_stats,
+                        double momentum, double eps, at::ScalarType out_dtype) {
+    const int64_t c = x_cl.size(-1), m = x_cl.numel() / c;
+    Tensor out = at::empty(x_cl.sizes(), x_cl.options().dtype(out_dtype));
+    Tensor save = at::empty({2, c}, x_cl.options().dtype(at::kFloat));
+    RM_CALL(repmode_bn_relu_fwd, x_cl.data_ptr(), out.data_ptr(), weight.data_ptr<float>(), bias.data_ptr<float>(), rm_.data_ptr<float>(),
+            rv_.data_ptr<float>(), save[0].data_ptr<float>(), save[1].data_ptr<float>(), (long)m, (int)c, (float)eps, (float)momentum,
+            batch_stats ? 1 : 0, dtype_code(x_cl.scalar_type()), dtype_code(out_dtype), stream_handle());
+    ctx->save_for_backward({x_cl, weight, bias, save});
+    ctx->saved_data["batch_stats"] = batch_stats;
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto sv = ctx->get_saved_variables();
+    const Tensor &x_cl = sv[0], &weight = sv[1], &bias = sv[2], &save = sv[3];
+    const int64_t c = x_cl.size(-1), m = x_cl.numel() / c;
+    Tensor dy = grads[0].contiguous();
+    Tensor dx = at::empty_like(x_cl);
+    Tensor tot = at::empty({2 * c}, x_cl.options().dtype(at::kFloat));    // [0:c) = dbeta, [c:2c) = dgamma
+    RM_CALL(repmode_bn_relu_bwd, x_cl.data_ptr(), dy.data_ptr(), weight.data_ptr<float>(), bias.data_ptr<float>(), save[0].data_ptr<float>(),
+            save[1].data_ptr<float>(), dx.data_ptr(), tot.data_ptr<float>(), (long)m, (int)c, ctx->saved_data["batch_stats"].toBool() ? 1 : 0,
+            dtype_code(x_cl.scalar_type()), dtype_code(dy.scalar_type()), stream_handle());
+    return {dx, tot.narrow(0, c, c), tot.narrow(0, 0, c), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+// ---- the stride-2 2x2x2 stages
+std::pair<Tensor, Tensor> k2_weight_frags(const Tensor& weight, int64_t rows, int64_t red, bool red_major, at::ScalarType dt, bool both) {
+  const int code = dtype_code(dt);
+  Tensor out = at::empty({8, padded(rows, code, false), padded(red, code, true)}, weight.options().dtype(dt));
+  if (!both) {
+    RM_CALL(repmode_k2_frags, weight.data_ptr<float>(), (int)rows, (int)red, red_major ? 1 : 0, code, out.data_ptr(), stream_handle());
+    return {out, Tensor()};
+  }
+  Tensor out_t = at::empty({8, padded(red, code, false), padded(rows, code, true)}, weight.options().dtype(dt));
+  RM_CALL(repmode_k2_frags2, weight.data_ptr<float>(), (int)rows, (int)red, red_major ? 1 : 0, code, out.data_ptr(), out_t.data_ptr(),
+          stream_handle());
+  return {out, out_t};
+}
+
+Tensor k2s2(const Tensor& in_cl, const Tensor& w_frag, int64_t cout, bool scatter) {
+  const int64_t n = in_cl.size(0), a = in_cl.size(1), b = in_cl.size(2), c = in_cl.size(3), cin = in_cl.size(4);
+  const int64_t d = scatter ? a : a / 2, h = scatter ? b : b / 2, w = scatter ? c : c / 2;
+  Tensor out = scatter ? at::empty({n, 2 * d, 2 * h, 2 * w, cout}, in_cl.options()) : at::empty({n, d, h, w, cout}, in_cl.options());
+  RM_CALL(repmode_k2s2, in_cl.data_ptr(), w_frag.data_ptr(), out.data_ptr(), (int)n, (int)d, (int)h, (int)w, (int)cin, (int)cout,
+          dtype_code(in_cl.scalar_type()), scatter ? 1 : 0, stream_handle());
+  return out;
+}
+
+// dw in a parameter's layout [A, B, 2, 2, 2] (A = coarse channels, B = fine channels)
+Tensor k2s2_wgrad_param(const Tensor& coarse_cl, const Tensor& fine_cl) {
+  const int64_t n = coarse_cl.size(0), d = coarse_cl.size(1), h = coarse_cl.size(2), w = coarse_cl.size(3), ca = coarse_cl.size(4);
+  const int64_t cb = fine_cl.size(4);
+  if (coarse_cl.scalar_type() == at::kBFloat16) {
+    // the kernel accumulates tap-major (atomics into the parameter layout, 32-byte stride, measured 5x slower); one small
+    // transpose launch behind it
+    auto tk = g_pool.take({8, ca, cb}, coarse_cl);
+    RM_CALL(repmode_k2s2_wgrad_ex, coarse_cl.data_ptr(), fine_cl.data_ptr(), tk.first.data_ptr<float>(), (int)n, (int)d, (int)h, (int)w,
+            (int)ca, (int)cb, tk.second ? 4 : 0, stream_handle());
+    Tensor dw = at::empty({ca, cb, 2, 2, 2}, coarse_cl.options().dtype(at::kFloat));
+    RM_CALL(repmode_tap_transpose, tk.first.data_ptr<float>(), dw.data_ptr<float>(), (long)(ca * cb), 8, stream_handle());
+    return dw;
+  }
+  // float32 (parity mode only): a library GEMM on gathered patches
+  Tensor g = fine_cl.view({n, d, 2, h, 2, w, 2, cb}).permute({0, 1, 3, 5, 2, 4, 6, 7}).reshape({-1, 8 * cb});   // [M, 8*B]
+  Tensor dw8 = at::matmul(coarse_cl.view({-1, ca}).t(), g).view({ca, 8, cb}).permute({1, 0, 2});             // [8, A, B]
+  return dw8.view({2, 2, 2, ca, cb}).permute({3, 4, 0, 1, 2}).contiguous();
+}
+
+// Conv3d(C, C, kernel_size=2, stride=2, bias=False) on channels-last data (RepMode.py:81)
+struct Down2 : public torch::autograd::Function<Down2> {
+  static Tensor forward(AutogradContext* ctx, Tensor x_cl, Tensor weight, bool grad_enabled) {
+    const int64_t co = weight.size(0), ci = weight.size(1);
+    auto fr = k2_weight_frags(weight, co, ci, false, x_cl.scalar_type(), grad_enabled && x_cl.requires_grad());
+    ctx->save_for_backward({x_cl, weight, fr.second.defined() ? fr.second : Tensor()});
+    return k2s2(x_cl, fr.first, co, false);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto sv = ctx->get_saved_variables();
+    const Tensor &x_cl = sv[0], &weight = sv[1];
+    Tensor wb = sv[2];
+    Tensor dy = grads[0].to(x_cl.scalar_type()).contiguous();
+    Tensor dx;
+    if (ctx->needs_input_grad(0) && wb.defined()) dx = k2s2(dy, wb, weight.size(1), true);
+    Tensor dw = k2s2_wgrad_param(dy, x_cl);                              // [Co, Ci, 2, 2, 2]
+    return {dx, dw, Tensor()};
+  }
+};
+
+// ConvTranspose3d(Ci, Co, kernel_size=2, stride=2, bias=False) on channels-last data (RepMode.py:98)
+struct Up2 : public torch::autograd::Function<Up2> {
+  static Tensor forward(AutogradContext* ctx, Tensor x_cl, Tensor weight, bool grad_enabled) {
+    const int64_t ci = weight.size(0), co = weight.size(1);
+    auto fr = k2_weight_frags(weight, co, ci, true, x_cl.scalar_type(), grad_enabled && x_cl.requires_grad());
+    ctx->save_for_backward({x_cl, weight, fr.second.defined() ? fr.second : Tensor()});
+    return k2s2(x_cl, fr.first, co, true);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto sv = ctx->get_saved_variables();
+    const Tensor &x_cl = sv[0], &weight = sv[1];
+    Tensor wb = sv[2];
+    Tensor dy = grads[0].to(x_cl.scalar_type()).contiguous();
+    Tensor dx;
+    if (ctx->needs_input_grad(0) && wb.defined()) dx = k2s2(dy, wb, weight.size(0), false);
+    Tensor dw = k2s2_wgrad_param(x_cl, dy);                              // [Ci, Co, 2, 2, 2]
+    return {dx, dw, Tensor()};
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// op entry points
+
+inline Tensor to_cl(const Tensor& x, at::ScalarType dt) {       // logical NCDHW (any strides) -> contiguous NDHWC in dt
+  return x.to(dt).permute({0, 2, 3, 4, 1}).contiguous();
+}
+inline Tensor from_cl(const Tensor& x_cl) { return x_cl.permute({0, 4, 1, 2, 3}); }
+
+void check_params(const Tensor& x_cl, const Tensor* x2_cl, const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3,
+                  const Tensor& a5, const Tensor& gw, const Tensor& gb, const Plan& plan) {
+  require_hip(x_cl, "input");
+  TORCH_CHECK(x_cl.dim() == 5, "mode_conv3d: input must be [N, D, H, W, C], got ", x_cl.sizes());
+  TORCH_CHECK(x_cl.scalar_type() == at::kFloat || x_cl.scalar_type() == at::kBFloat16, "mode_conv3d: float32 or bfloat16 input, got ",
+              x_cl.scalar_type());
+  const int64_t cin = x_cl.size(4) + (x2_cl ? x2_cl->size(4) : 0);
+  TORCH_CHECK(k5.dim() == 5 && k5.size(2) == 5 && k5.size(3) == 5 && k5.size(4) == 5, "mode_conv3d: expert_conv5x5 must be [Co, Ci, 5, 5, 5]");
+  const int64_t co = k5.size(0), ci = k5.size(1);
+  TORCH_CHECK(ci == cin, "mode_conv3d: input has ", cin, " channels, the experts take ", ci);
+  TORCH_CHECK(k3.sizes() == at::IntArrayRef({co, ci, 3, 3, 3}), "mode_conv3d: expert_conv3x3 must be [Co, Ci, 3, 3, 3]");
+  for (const Tensor* t : {&k1, &a3, &a5}) TORCH_CHECK(t->numel() == co * ci, "mode_conv3d: 1x1 experts must be [Co, Ci, 1, 1, 1]");
+  TORCH_CHECK(gw.dim() == 2 && gw.size(0) == E * co && gw.size(1) == plan.num_tasks, "mode_conv3d: gate.weight must be [5*Co, T], got ", gw.sizes());
+  TORCH_CHECK(gb.numel() == E * co, "mode_conv3d: gate.bias must be [5*Co]");
+  for (const Tensor* t : {&k5, &k3, &k1, &a3, &a5, &gw, &gb}) {
+    TORCH_CHECK(t->scalar_type() == at::kFloat, "MoDE parameters must be float32");
+    TORCH_CHECK(t->device() == x_cl.device(), "mode_conv3d: parameter on ", t->device(), ", input on ", x_cl.device());
+  }
+  TORCH_CHECK(plan.n == x_cl.size(0), "task plan is for ", plan.n, " samples, input has ", x_cl.size(0));
+  TORCH_CHECK(plan.nslots >= 1 && plan.nslots <= plan.n && plan.sample_slot.numel() == plan.n && plan.slot_task.numel() == plan.nslots &&
+                  plan.sample_task.numel() == plan.n, "mode_conv3d: inconsistent task plan");
+  for (const Tensor* t : {&plan.slot_task, &plan.sample_slot, &plan.sample_task})
+    TORCH_CHECK(t->scalar_type() == at::kInt && t->device() == x_cl.device(), "mode_conv3d: plan vectors must be int32 on the input's device");
+  if (x2_cl) {
+    TORCH_CHECK(x2_cl->dim() == 5 && x2_cl->sizes().slice(0, 4) == x_cl.sizes().slice(0, 4) && x2_cl->scalar_type() == x_cl.scalar_type() &&
+                    x2_cl->device() == x_cl.device(), "mode_conv3d: the two inputs of a skip connection must agree in shape, dtype and device");
+  }
+}
+
+// Heuristic: small volumes (levels 3-4) with several distinct tasks in the batch take the per-expert formulation.
+inline bool use_unmerged(const Tensor& x_cl, const Plan& plan) { return plan.training && plan.nslots > 2 && x_cl.size(3) <= 8; }
+
+inline bool pair_shapes_ok(const Tensor& xa, const Tensor& xb) {
+  const int64_t kc = xa.scalar_type() == at::kBFloat16 ? 16 : 8;
+  return xa.size(4) % 32 == 0 && xb.size(4) % kc == 0;
+}
+
+// The MoDE block up to (not including) BN/ReLU on channels-last tensors.  mode: 0 auto, 1 merged, 2 unmerged (per-expert), 3 merged two-tensor form (needs x2).
+Tensor mode_conv3d_cl(const Tensor& x_cl_in, const OptTensor& x2_cl_in, const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3,
+                      const Tensor& a5, const Tensor& gw, const Tensor& gb, const Plan& plan, bool out_f32, int64_t mode) {
+  require_hip(x_cl_in, "input");
+  c10::hip::HIPGuard guard(x_cl_in.device());
+  Tensor x_cl = x_cl_in.contiguous();
+  Tensor x2_cl = x2_cl_in.has_value() ? x2_cl_in->contiguous() : Tensor();
+  Tensor ps[7] = {k5.contiguous(), k3.contiguous(), k1.contiguous(), a3.contiguous(), a5.contiguous(), gw.contiguous(), gb.contiguous()};
+  check_params(x_cl, x2_cl.defined() ? &x2_cl : nullptr, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan);
+  const bool grad_enabled = at::GradMode::is_enabled();
+  if (x2_cl.defined()) {
+    // two-tensor kernels: the merged formulation with channel counts on tile boundaries (mode 3 insists on them)
+    const bool shapes_ok = pair_shapes_ok(x_cl, x2_cl);
+    TORCH_CHECK(mode != 3 || shapes_ok, "mode_conv3d: the two-tensor form needs ", x_cl.size(4), " % 32 == 0 and ", x2_cl.size(4), " % 16 (8) == 0");
+    if (mode == 3 || (mode == 1 && shapes_ok) || (mode == 0 && shapes_ok && !use_unmerged(x_cl, plan)))
+      return ModeConvPair::apply(x_cl, x2_cl, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan, out_f32, grad_enabled);
+    x_cl = at::cat({x_cl, x2_cl}, -1);      // per-expert formulation / odd channel counts: the concatenated tensor
+  }
+  if (mode == 0) mode = use_unmerged(x_cl, plan) ? 2 : 1;
+  if (mode == 2) return ModeConvUnmerged::apply(x_cl, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan, grad_enabled);
+  return ModeConvMerged::apply(x_cl, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan, out_f32, grad_enabled);
+}
+
+Tensor bn_relu_cl(const Tensor& x_cl_in, const Tensor& weight, const Tensor& bias, const Tensor& rm_, const Tensor& rv_, bool batch_stats,
+                  double momentum, double eps, at::ScalarType out_dtype) {
+  require_hip(x_cl_in, "input");
+  c10::hip::HIPGuard guard(x_cl_in.device());
+  Tensor x_cl = x_cl_in.contiguous();
+  const int64_t c = x_cl.size(-1);
+  TORCH_CHECK(c <= 512, "bn_relu: at most 512 channels, got ", c);
+  for (const Tensor* t : {&weight, &bias, &rm_, &rv_})
+    TORCH_CHECK(t->scalar_type() == at::kFloat && t->numel() == c && t->is_contiguous() && t->device() == x_cl.device(),
+                "bn_relu: BatchNorm parameters / running statistics must be contiguous float32 [C] on the input's device");
+  return BnRelu::apply(x_cl, weight, bias, rm_, rv_, batch_stats, momentum, eps, out_dtype);
+}
+
+Plan make_plan(const Tensor& slot_task, const Tensor& sample_slot, const Tensor& sample_task, int64_t nslots, int64_t num_tasks, bool training,
+               int64_t task0) {
+  Plan p;
+  p.slot_task = slot_task;
+  p.sample_slot = sample_slot;
+  p.sample_task = sample_task;
+  p.nslots = nslots;
+  p.n = sample_slot.numel();
+  p.num_tasks = num_tasks;
+  p.training = training;
+  p.task0 = task0;
+  return p;
+}
+
+// ---- exported ops (schemas at the bottom)
+
+Tensor op_mode_conv3d(const Tensor& x_cl, const OptTensor& x2_cl, const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3,
+                      const Tensor& a5, const Tensor& gw, const Tensor& gb, const Tensor& slot_task, const Tensor& sample_slot,
+                      const Tensor& sample_task, int64_t nslots, int64_t num_tasks, bool training, int64_t task0, bool out_f32, int64_t mode) {
+  return mode_conv3d_cl(x_cl, x2_cl, k5, k3, k1, a3, a5, gw, gb, make_plan(slot_task, sample_slot, sample_task, nslots, num_tasks, training, task0),
+                        out_f32, mode);
+}
+
+// One MoDE block (RepMode.py:194-214) on logical NCDHW tensors: cast + channels-last, fused op, BatchNorm3d + ReLU when the
+// block has them ('normal'), NCDHW view of the channels-last result.
+Tensor op_mode_block(const Tensor& x, const OptTensor& x2, const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3,
+                     const Tensor& a5, const Tensor& gw, const Tensor& gb, const OptTensor& bn_w, const OptTensor& bn_b, const OptTensor& bn_rm,
+                     const OptTensor& bn_rv, bool bn_batch_stats, double bn_momentum, double bn_eps, const Tensor& slot_task,
+                     const Tensor& sample_slot, const Tensor& sample_task, int64_t nslots, int64_t num_tasks, bool training, int64_t task0,
+                     int64_t dtype, bool out_f32) {
+  require_hip(x, "input");
+  TORCH_CHECK(x.dim() == 5, "MoDE block: input must be [N, C, D, H, W], got ", x.sizes());
+  const at::ScalarType dt = code_dtype(dtype);
+  Plan plan = make_plan(slot_task, sample_slot, sample_task, nslots, num_tasks, training, task0);
+  OptTensor x2_cl;
+  if (x2.has_value()) x2_cl = to_cl(*x2, dt);
+  Tensor y = mode_conv3d_cl(to_cl(x, dt), x2_cl, k5, k3, k1, a3, a5, gw, gb, plan, out_f32, 0);
+  if (bn_w.has_value()) {
+    TORCH_CHECK(bn_b.has_value() && bn_rm.has_value() && bn_rv.has_value(), "MoDE block: incomplete BatchNorm state");
+    y = bn_relu_cl(y, *bn_w, *bn_b, *bn_rm, *bn_rv, bn_batch_stats, bn_momentum, bn_eps, dt);
+  }
+  return from_cl(y);
+}
+
+Tensor op_bn_relu(const Tensor& x_cl, const Tensor& weight, const Tensor& bias, const Tensor& rm_, const Tensor& rv_, bool batch_stats,
+                  double momentum, double eps, int64_t out_dtype) {
+  return bn_relu_cl(x_cl, weight, bias, rm_, rv_, batch_stats, momentum, eps, code_dtype(out_dtype));
+}
+
+void check_k2(const Tensor& x_cl, const Tensor& weight, const char* what) {
+  require_hip(x_cl, "input");
+  TORCH_CHECK(x_cl.dim() == 5 && weight.dim() == 5 && weight.size(2) == 2 && weight.size(3) == 2 && weight.size(4) == 2 &&
+                  weight.scalar_type() == at::kFloat && weight.device() == x_cl.device(), what, ": bad input / weight");
+}
+
+Tensor op_down2(const Tensor& x_cl, const Tensor& weight) {
+  check_k2(x_cl, weight, "down2");
+  TORCH_CHECK(x_cl.size(1) % 2 == 0 && x_cl.size(2) % 2 == 0 && x_cl.size(3) % 2 == 0 && x_cl.size(4) == weight.size(1), "down2: bad shape ", x_cl.sizes());
+  c10::hip::HIPGuard guard(x_cl.device());
+  return Down2::apply(x_cl.contiguous(), weight.contiguous(), at::GradMode::is_enabled());
+}
+
+Tensor op_up2(const Tensor& x_cl, const Tensor& weight) {
+  check_k2(x_cl, weight, "up2");
+  TORCH_CHECK(x_cl.size(4) == weight.size(0), "up2: bad shape ", x_cl.sizes());
+  c10::hip::HIPGuard guard(x_cl.device());
+  return Up2::apply(x_cl.contiguous(), weight.contiguous(), at::GradMode::is_enabled());
+}
+
+// Conv3d(k2, s2) / ConvTranspose3d(k2, s2) + BatchNorm3d + ReLU of the encoder / decoder (RepMode.py:80-84, 97-101), NCDHW in and out
+Tensor op_stage2_bn_relu(const Tensor& x, const Tensor& weight, const Tensor& bn_w, const Tensor& bn_b, const Tensor& bn_rm, const Tensor& bn_rv,
+                         bool bn_batch_stats, double bn_momentum, double bn_eps, bool up, int64_t out_dtype) {
+  TORCH_CHECK(x.dim() == 5, "stride-2 stage: input must be [N, C, D, H, W]");
+  Tensor x_cl = x.permute({0, 2, 3, 4, 1});
+  Tensor y = up ? op_up2(x_cl, weight) : op_down2(x_cl, weight);
+  return from_cl(bn_relu_cl(y, bn_w, bn_b, bn_rm, bn_rv, bn_batch_stats, bn_momentum, bn_eps, code_dtype(out_dtype)));
+}
+
+void op_zero_pool_begin(const std::string& key, const Tensor& like) { g_pool.begin(key, like); }
+void op_zero_pool_end() { g_pool.end(); }
+bool op_zero_pool_has_plan(const std::string& key) {
+  std::lock_guard<std::mutex> lock(g_pool.mu);
+  auto it = g_pool.plans.find(key);
+  return it != g_pool.plans.end() && !it->second.empty();
+}
+std::tuple<Tensor, bool> op_zero_pool_take(std::vector<int64_t> shape, const Tensor& like) {
+  auto tk = g_pool.take(shape, like);
+  return std::make_tuple(tk.first, tk.second);
+}
+Tensor op_grad_out(const Tensor& param) { return grad_out(param); }
+int64_t op_eval_cache_size() {
+  std::lock_guard<std::mutex> lock(g_eval_mu);
+  return (int64_t)g_eval.size();
+}
+void op_set_fork_max_w(int64_t w) { g_fork_max_w = w; }
+int64_t op_get_fork_max_w() { return g_fork_max_w; }
+void op_eval_cache_begin() {
+  std::lock_guard<std::mutex> lock(g_eval_mu);
+  ++g_eval_depth;
+}
+void op_eval_cache_end() {
+  std::lock_guard<std::mutex> lock(g_eval_mu);
+  if (g_eval_depth > 0 && --g_eval_depth == 0) g_eval.clear();
+}
+void op_grad_sink_set(const std::vector<Tensor>& params, const std::vector<Tensor>& flats, const std::vector<int64_t>& offsets) {
+  TORCH_CHECK(params.size() == flats.size() && params.size() == offsets.size(), "grad_sink_set: list lengths differ");
+  std::lock_guard<std::mutex> lock(g_sink_mu);
+  g_sink.clear();
+  for (size_t i = 0; i < params.size(); ++i) g_sink[params[i].data_ptr()] = SinkEntry{params[i], flats[i], offsets[i]};
+}
+void op_grad_sink_clear() {
+  std::lock_guard<std::mutex> lock(g_sink_mu);
+  g_sink.clear();
+}
+
+}  // namespace rm
+
+TORCH_LIBRARY(repmode, m) {
+  m.def("mode_conv3d(Tensor x_cl, Tensor? x2_cl, Tensor k5, Tensor k3, Tensor k1, Tensor a3, Tensor a5, Tensor gate_w, Tensor gate_b, "
+        "Tensor slot_task, Tensor sample_slot, Tensor sample_task, int nslots, int num_tasks, bool training, int task0, bool out_f32, "
+        "int mode) -> Tensor", &rm::op_mode_conv3d);
+  m.def("mode_block(Tensor x, Tensor? x2, Tensor k5, Tensor k3, Tensor k1, Tensor a3, Tensor a5, Tensor gate_w, Tensor gate_b, "
+        "Tensor? bn_w, Tensor? bn_b, Tensor? bn_rm, Tensor? bn_rv, bool bn_batch_stats, float bn_momentum, float bn_eps, "
+        "Tensor slot_task, Tensor sample_slot, Tensor sample_task, int nslots, int num_tasks, bool training, int task0, int dtype, "
+        "bool out_f32) -> Tensor", &rm::op_mode_block);
+  m.def("bn_relu(Tensor x_cl, Tensor weight, Tensor bias, Tensor running_mean, Tensor running_var, bool batch_stats, float momentum, "
+        "float eps, int out_dtype) -> Tensor", &rm::op_bn_relu);
+  m.def("down2(Tensor x_cl, Tensor weight) -> Tensor", &rm::op_down2);
+  m.def("up2(Tensor x_cl, Tensor weight) -> Tensor", &rm::op_up2);
+  m.def("stage2_bn_relu(Tensor x, Tensor weight, Tensor bn_w, Tensor bn_b, Tensor bn_rm, Tensor bn_rv, bool bn_batch_stats, "
+        "float bn_momentum, float bn_eps, bool up, int out_dtype) -> Tensor", &rm::op_stage2_bn_relu);
+  m.def("zero_pool_begin(str key, Tensor like) -> ()", &rm::op_zero_pool_begin);
+  m.def("zero_pool_end() -> ()", &rm::op_zero_pool_end);
+  m.def("zero_pool_has_plan(str key) -> bool", &rm::op_zero_pool_has_plan);
+  m.def("zero_pool_take(int[] shape, Tensor like) -> (Tensor, bool)", &rm::op_zero_pool_take);
+  m.def("grad_out(Tensor param) -> Tensor", &rm::op_grad_out);
+  m.def("eval_cache_size() -> int", &rm::op_eval_cache_size);
+  m.def("set_fork_max_w(int w) -> ()", &rm::op_set_fork_max_w);
+  m.def("get_fork_max_w() -> int", &rm::op_get_fork_max_w);
+  m.def("eval_cache_begin() -> ()", &rm::op_eval_cache_begin);
+  m.def("eval_cache_end() -> ()", &rm::op_eval_cache_end);
+  m.def("grad_sink_set(Tensor[] params, Tensor[] flats, int[] offsets) -> ()", &rm::op_grad_sink_set);
+  m.def("grad_sink_clear() -> ()", &rm::op_grad_sink_clear);
+}

@@ -95,7 +95,7 @@ class Model(object):
         elif self.distributed:
             self.ddp = dist_.wrap_ddp(self.net, self.device)
         # process-wide (one training process per GPU): where the MoDE gradient kernels put the parameter gradients
-        ops_.GRAD_SINK = self.reducer
+        ops_.set_grad_sink(self.reducer)
         try:
             # (capturable: the step counters live on the device, so optimizer.step() can be part of a HIP graph)
             self.optimizer = torch.optim.Adam(self.net.parameters(), lr=self.lr, fused=True, capturable=self.hip_graph)

@@ -82,22 +82,22 @@ class MoDEConv(torch.nn.Module):
         self.gate = torch.nn.Linear(num_tasks, num_experts * out_chan, bias=True)
 
     def forward(self, x, t, x2=None):
-        """``x2``: more input channels, to follow x's (a skip connection's ``torch.cat((x, x2), 1)`` that is never built)."""
+        """``x2``: more input channels, to follow x's (a skip connection's ``torch.cat((x, x2), 1)`` that is never built).
+        One call into the operator library: cast + channels-last, gate softmax, GatRep, per-slot convolution and -- for a
+        'normal' block -- BatchNorm3d + ReLU (RepMode.py:194-214)."""
         plan = t if isinstance(t, ops.TaskPlan) else ops.TaskPlan(t, self.num_tasks, x.device, self.training)
         dtype = _resolve_dtype(x, self.compute_dtype)
-        x_cl = _to_cl(x.to(dtype))
         # float output where a later stage reduces it in f32 anyway: the final layer, and the deep
         # levels whose reduction is split over workgroups (f32 atomics)
         out_f32 = self.conv_type == 'final' or x.shape[-1] < 32
-        params = (self.expert_conv5x5_conv, self.expert_conv3x3_conv, self.expert_conv1x1_conv,
-                  self.expert_avg3x3_conv, self.expert_avg5x5_conv, self.gate.weight, self.gate.bias)
-        if x2 is not None:
-            y_cl = ops.mode_conv3d_pair(x_cl, _to_cl(x2.to(dtype)), *params, plan, out_f32=out_f32)
+        if self.conv_type == 'normal':
+            bn = ops.bn_args(self.subsequent_layer[0], x.device, count=not getattr(t, 'bn_counted', False))
         else:
-            y_cl = ops.mode_conv3d(x_cl, *params, plan, out_f32=out_f32)
-        if self.conv_type == 'normal':                          # RepMode.py:212: BatchNorm3d + ReLU, fused HIP
-            y_cl = ops.bn_relu(y_cl, self.subsequent_layer[0], self.training, dtype, count=not getattr(t, 'bn_counted', False))
-        return _from_cl(y_cl)
+            bn = (None, None, None, None, False, 0.0, 0.0)
+        return ops.torch_ops().mode_block(
+            x, x2, self.expert_conv5x5_conv, self.expert_conv3x3_conv, self.expert_conv1x1_conv, self.expert_avg3x3_conv,
+            self.expert_avg5x5_conv, self.gate.weight, self.gate.bias, *bn, plan.slot_task, plan.sample_slot, plan.sample_task,
+            plan.nslots, plan.num_tasks, plan.training, plan.task0, ops.dtype_code(dtype), out_f32)
 
 
 class MoDESubNet2Conv(torch.nn.Module):                        # RepMode.py:111-120
@@ -121,6 +121,10 @@ class Down2(torch.nn.Module):
     def forward(self, x):
         return _from_cl(ops.down2(_to_cl(x), self.weight))
 
+    def forward_bn_relu(self, x, bn, count):
+        """The stage with its BatchNorm3d + ReLU (RepMode.py:80-84) in one operator call."""
+        return ops.torch_ops().stage2_bn_relu(x, self.weight, *ops.bn_args(bn, x.device, count), False, ops.dtype_code(x.dtype))
+
 
 class Up2(torch.nn.Module):
     """``ConvTranspose3d(Ci, Co, kernel_size=2, stride=2, bias=False)`` (RepMode.py:98): every input
@@ -133,6 +137,10 @@ class Up2(torch.nn.Module):
     def forward(self, x):
         return _from_cl(ops.up2(_to_cl(x), self.weight))
 
+    def forward_bn_relu(self, x, bn, count):
+        """The stage with its BatchNorm3d + ReLU (RepMode.py:97-101) in one operator call."""
+        return ops.torch_ops().stage2_bn_relu(x, self.weight, *ops.bn_args(bn, x.device, count), True, ops.dtype_code(x.dtype))
+
 
 class MoDEEncoderBlock(torch.nn.Module):                       # RepMode.py:74-89
     def __init__(self, num_experts, num_tasks, in_chan, out_chan, dtype=None):
@@ -144,10 +152,8 @@ class MoDEEncoderBlock(torch.nn.Module):                       # RepMode.py:74-8
 
     def forward(self, x, t):
         x_skip = self.conv_more(x, t)
-        y = self.conv_down[0](x_skip)                                           # stride-2 conv as a GEMM
-        y_cl = ops.bn_relu(_to_cl(y), self.conv_down[1], self.training, x_skip.dtype,          # BN + ReLU, RepMode.py:82-83
-                           count=not getattr(t, 'bn_counted', False))
-        return _from_cl(y_cl), x_skip
+        # stride-2 conv as a GEMM + BN + ReLU (RepMode.py:81-83)
+        return self.conv_down[0].forward_bn_relu(x_skip, self.conv_down[1], not getattr(t, 'bn_counted', False)), x_skip
 
 
 class MoDEDecoderBlock(torch.nn.Module):                       # RepMode.py:92-108
@@ -159,9 +165,7 @@ class MoDEDecoderBlock(torch.nn.Module):                       # RepMode.py:92-1
         self.conv_less = MoDESubNet2Conv(num_experts, num_tasks, in_chan, out_chan, dtype=dtype)
 
     def forward(self, x, x_skip, t):
-        up = self.convt[0](x)
-        up = _from_cl(ops.bn_relu(_to_cl(up), self.convt[1], self.training, x_skip.dtype,
-                                   count=not getattr(t, 'bn_counted', False)))   # RepMode.py:99-100
+        up = self.convt[0].forward_bn_relu(x, self.convt[1], not getattr(t, 'bn_counted', False))   # RepMode.py:98-100
         return self.conv_less(x_skip, t, up)                   # = cat((x_skip, up), 1): skip first, RepMode.py:106
 
 

@@ -130,7 +130,7 @@ def test_grad_reducer_adopts_bucket_slices_single_process():
     x = torch.randn(5, 7)
     red = GradReducer(net, bucket_mb=1e-4)
     assert len(red.buckets) >= 2
-    ops.GRAD_SINK = red
+    ops.set_grad_sink(red)
     try:
         for step in range(2):
             net.zero_grad(set_to_none=True)
@@ -156,5 +156,5 @@ def test_grad_reducer_adopts_bucket_slices_single_process():
         net(x).square().sum().backward()
         red.finish()                                             # and the reducer is usable again
     finally:
-        ops.GRAD_SINK = None
+        ops.set_grad_sink(None)
         red.remove()

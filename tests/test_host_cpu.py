@@ -102,7 +102,7 @@ def test_no_cpu_fallback():
     from repmode_amd import _lib
     from repmode_amd.nn_modules.RepMode import Net
     net = Net(Opts(), mult_chan=2)
-    with pytest.raises(_lib.RepModeHipError, match='no CPU fallback'):
+    with pytest.raises(RuntimeError, match='no CPU fallback'):       # TORCH_CHECK of the operator library
         net(torch.randn(1, 1, 16, 16, 16), torch.tensor([0]))
     with pytest.raises(ValueError, match='multiples of 16'):
         net(torch.randn(1, 1, 16, 16, 20), torch.tensor([0]))
@@ -128,28 +128,33 @@ def test_predict_helpers_match_golden():
 
 
 def test_zero_pool_semantics():
-    """ops.ZeroPool on CPU tensors: the first step of a key records, later steps hand out zeroed, non-overlapping,
-    independently versioned tensors in the recorded order, and any divergence falls back to plain allocations."""
+    """The operator library's ZeroPool (csrc/torch/repmode_ops.cpp) on CPU tensors: the first step of a key records,
+    later steps hand out zeroed, non-overlapping, independently versioned tensors in the recorded order, and any
+    divergence falls back to plain allocations."""
     import torch
-    from repmode_amd.ops import ZeroPool
-    pool, dev = ZeroPool(), torch.device('cpu')
+    from repmode_amd.ops import ZERO_POOL as pool
+    dev = torch.device('cpu')
+    key = ('test_zero_pool_semantics', 1)
     shapes = [(3, 5), (7,), (2, 2, 4)]
-    pool.begin('k', dev)
+    assert not pool.has_plan(key)
+    pool.begin(key, dev)
     first = [pool.take(s, dev) for s in shapes]
     assert all(not pre for _, pre in first)                      # recording step: nothing pooled
-    pool.begin('k', dev)                                         # (begin() closes the previous step)
+    pool.begin(key, dev)                                         # (begin() closes the previous step)
+    assert pool.has_plan(key)
     got = [pool.take(s, dev) for s in shapes]
     assert all(pre for _, pre in got)
     ts = [t for t, _ in got]
-    assert all(float(t.abs().sum()) == 0.0 and tuple(t.shape) == s for t, s in zip(ts, shapes))
+    assert all(float(t.abs().sum()) == 0.0 and tuple(t.shape) == s and t.dtype == torch.float32 for t, s in zip(ts, shapes))
     v1 = ts[1]._version
     ts[0].fill_(1.0)                                             # in-place op on one tensor ...
     assert ts[1]._version == v1 and float(ts[1].sum()) == 0.0    # ... neither touches nor re-versions another
     ptrs = sorted((t.data_ptr(), t.numel() * 4) for t in ts)
     assert all(a + n <= b for (a, n), (b, _) in zip(ptrs, ptrs[1:]))
+    assert all(p % 256 == ptrs[0][0] % 256 for p, _ in ptrs)     # 64-float granules
     extra, pre = pool.take((4,), dev)                            # more requests than recorded: plain allocation
     assert not pre
-    pool.begin('k', dev)
+    pool.begin(key, dev)
     _, pre0 = pool.take(shapes[0], dev)
     _, pre1 = pool.take((9, 9), dev)                             # diverges from the recorded sequence
     _, pre2 = pool.take(shapes[2], dev)
@@ -158,34 +163,28 @@ def test_zero_pool_semantics():
     assert pool.take((3,), dev)[1] is False                      # inactive pool
 
 
-def test_eval_filter_cache_scope(monkeypatch):
-    """ops.eval_filter_cache: one GatRep per (block, task, dtype) for eval-mode forwards without autograd inside the
-    context; never for training plans, with autograd, or outside the context."""
+def test_operator_library_schemas():
+    """librepmode_torch.so loads without a GPU and registers the ops of the seam with the
+    argument lists the Python side passes; a CPU tensor is refused with a RuntimeError that says why (TORCH_CHECK)."""
+    import pytest
+    import torch
     from repmode_amd import ops
-    calls = []
-    monkeypatch.setattr(ops, 'gate_softmax', lambda gw, gb, plan, co: torch.zeros(plan.nslots, 5, co))
-    monkeypatch.setattr(ops, 'gatrep_merge', lambda k5, *a, **kw: (calls.append(k5.data_ptr()) or torch.zeros(1), None))
-    k5a, k5b = torch.zeros(4, 2, 5, 5, 5), torch.zeros(4, 2, 5, 5, 5)
-    z = torch.zeros(1)
-    ev = lambda task: ops.TaskPlan([task, task], 12, 'cpu', training=False)
-    tr = ops.TaskPlan([3, 5], 12, 'cpu', training=True)
-
-    def run(k5, plan, dtype=torch.float32):
-        return ops._merged_filters(k5, z, z, z, z, z, z, plan, dtype, False)
-
-    with torch.no_grad():
-        run(k5a, ev(3)); run(k5a, ev(3))
-        assert len(calls) == 2                                   # no context: every call merges
-        with ops.eval_filter_cache():
-            g1, w1, _ = run(k5a, ev(3))
-            g2, w2, _ = run(k5a, ev(3))
-            assert w1 is w2 and len(calls) == 3                  # second forward re-uses the filter
-            run(k5a, ev(4)); run(k5b, ev(3)); run(k5a, ev(3), torch.bfloat16)
-            assert len(calls) == 6                               # other task / block / dtype: own entries
-            run(k5a, tr); run(k5a, tr)
-            assert len(calls) == 8                               # training plans are never cached
-        run(k5a, ev(3))
-        assert len(calls) == 9                                   # the cache ends with the context
+    t = ops.torch_ops()
+    for name in ('mode_block', 'mode_conv3d', 'bn_relu', 'down2', 'up2', 'stage2_bn_relu', 'zero_pool_begin', 'zero_pool_end',
+                 'grad_sink_set', 'grad_sink_clear', 'eval_cache_begin', 'eval_cache_end', 'set_fork_max_w'):
+        assert hasattr(t, name), name
+    schema = str(torch.ops.repmode.mode_block.default._schema)
+    assert 'Tensor? x2' in schema and 'Tensor slot_task' in schema and 'bool out_f32' in schema
+    plan = ops.TaskPlan([3, 5], 12, 'cpu', training=True)
+    co, ci = 4, 2
+    ps = [torch.zeros(co, ci, 5, 5, 5), torch.zeros(co, ci, 3, 3, 3)] + [torch.zeros(co, ci, 1, 1, 1)] * 3 + \
+         [torch.zeros(5 * co, 12), torch.zeros(5 * co)]
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.mode_conv3d(torch.zeros(2, 4, 4, 4, ci), *ps, plan)
+    ops.set_fork_max_w(16)
+    assert ops.get_fork_max_w() == 16
+    ops.set_fork_max_w(0)
     with ops.eval_filter_cache():
-        run(k5a, ev(3)); run(k5a, ev(3))
-        assert len(calls) == 11                                  # autograd enabled: not cached
+        assert int(t.eval_cache_size()) == 0
+
+
