@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define REPMODE_ABI_VERSION 2
+#define REPMODE_ABI_VERSION 3
 
 /* element types of activations / merged filters */
 #define REPMODE_F32 0  /* float in, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)          */
@@ -233,6 +233,26 @@ int repmode_gate_bwd(const float* g, const float* dg, const int32_t* slot_task, 
  * wf: [2][125][padded Co][padded Ci] (rows = co), wd: [2][125][padded Ci][padded Co] (rows = ci, taps
  * flipped); either may be NULL. */
 int repmode_expert_frags(const float* k5, const float* k3, int co, int ci, void* wf, void* wd, void* stream);
+
+/* ---- the two ends of the train step that the reference runs on the host ----
+ * crop_flip: fnet/data/SSPdataset.py:137-155 (data_aug) for a whole batch from DEVICE-RESIDENT volumes: sample i is the
+ *   [pd][ph][pw] crop of its (signal, target) volume pair -- float [D_i][H_i][W_i], dims[3i..3i+2] -- at starts[3i..3i+2],
+ *   then flipped along z / y / x where bit 0 / 1 / 2 of flips[i] is set (torch.flip after the crop, :151-153).
+ *   signal_vols / target_vols / dims / starts / flips are HOST arrays of n entries (device pointers inside the first two);
+ *   they are copied into the launch's arguments.  n <= REPMODE_CROP_MAX_SAMPLES per call.
+ *   signal_out, target_out: float [n][pd][ph][pw] on the device. */
+#define REPMODE_CROP_MAX_SAMPLES 32
+int repmode_crop_flip(const float* const* signal_vols, const float* const* target_vols, const int* dims, const int* starts,
+                      const int* flips, int n, int pd, int ph, int pw, float* signal_out, float* target_out, void* stream);
+/* mse_loss: fnet/fnet_model.py:108-109 (MSELoss(reduction='none') -> torch.mean) and :115-122 (per-sample means
+ *   `loss_diff`, per-task means of the logged dict) in one pass over out / target (float [n][v]) + a one-workgroup finish:
+ *   loss[0] = mean((out-target)^2);  loss_sample[i] = per-sample mean;  dout (may be NULL) = d loss / d out =
+ *   2 (out-target) / (n v);  task_mean / task_count [num_tasks] (may both be NULL; then sample_task may be NULL too):
+ *   mean of loss_sample over the samples of each task, and how many there were (0 -> mean 0).
+ *   sums_ws: float [n] workspace that must be ALL ZERO on entry and is left all zero (allocate and clear it once). */
+int repmode_mse_loss(const float* out, const float* target, const int32_t* sample_task, int n, long v, int num_tasks,
+                     float* dout, float* sums_ws, float* loss, float* loss_sample, float* task_mean, float* task_count,
+                     void* stream);
 
 /* ---- measurement: per-launch HIP-event timing of the library's kernels on their own stream.
  * repmode_prof_enable(1) clears the records and starts recording every kind, (2) records conv5_igemm only

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librepmode_hip.so')
 
 F32, BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c = ctypes
 _P = _c.c_void_p
@@ -52,6 +52,8 @@ _SIGNATURES = {
     'repmode_tap_transpose': [_P, _P, _c.c_long, _I, _P],
     'repmode_gate_bwd': [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     'repmode_expert_frags': [_P, _P, _I, _I, _P, _P, _P],
+    'repmode_crop_flip': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    'repmode_mse_loss': [_P, _P, _P, _I, _c.c_long, _I, _P, _P, _P, _P, _P, _P, _P],
     'repmode_prof_enable': [_I],
     'repmode_prof_pause': [_I],
     'repmode_prof_summary': [_I, _P, _P, _P],

@@ -1,0 +1,162 @@
+// pipeline.hip -- the two ends of the train step that the reference runs on the host.
+//
+//   crop_flip   fnet/data/SSPdataset.py:137-155 (data_aug): random crop of a (signal, target) volume pair to the patch
+//               size + flips along z / y / x, for a whole batch in one launch from DEVICE-RESIDENT volumes.  The random
+//               draws stay on the host (same numpy call order as the reference, repmode_amd/data.py); the kernel does the
+//               indexing: out[n][z][y][x] = vol_n[s0 + (fz ? pd-1-z : z)][s1 + (fy ? ..)][s2 + (fx ? ..)].
+//   mse_loss    fnet/fnet_model.py:108-109, 115-122: MSELoss(reduction='none') -> mean, its gradient, the per-sample
+//               means (`loss_diff`) and the per-task means of the logged dict, without a host synchronisation:
+//               one pass over (output, target) writes d(loss)/d(output) and per-sample sums; a one-workgroup kernel
+//               finishes loss, per-sample and per-task means.  Replaces ~10 stock elementwise / reduction launches.
+//
+// Both are HBM-bound single passes: crop_flip moves 2 * N * patch floats in and out, mse_loss reads 2 and writes 1
+// float per voxel.
+#include "common.h"
+
+namespace {
+
+constexpr int CF_MAX = REPMODE_CROP_MAX_SAMPLES;
+
+struct CropArgs {
+  const float* sig[CF_MAX];
+  const float* tgt[CF_MAX];
+  int dims[CF_MAX][3];     // source volume D, H, W
+  int start[CF_MAX][3];
+  int flip[CF_MAX];        // bit 0: z, bit 1: y, bit 2: x
+  int pd, ph, pw;
+};
+
+// grid (ceil(pw/256 per row..), rows = pd*ph, 2n): one thread per output voxel; rows of the patch are contiguous in
+// the source too (reversed when x is flipped), so reads and writes coalesce along x
+__global__ __launch_bounds__(256) void crop_flip_kernel(CropArgs a, float* __restrict__ sig_out, float* __restrict__ tgt_out) {
+  const int which = blockIdx.z & 1, n = blockIdx.z >> 1;
+  const int row = blockIdx.y;                       // z * ph + y of the patch
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= a.pw) return;
+  const int z = row / a.ph, y = row % a.ph;
+  const int f = a.flip[n];
+  const int sz = a.start[n][0] + ((f & 1) ? a.pd - 1 - z : z);
+  const int sy = a.start[n][1] + ((f & 2) ? a.ph - 1 - y : y);
+  const int sx = a.start[n][2] + ((f & 4) ? a.pw - 1 - x : x);
+  const float* src = which ? a.tgt[n] : a.sig[n];
+  float* dst = which ? tgt_out : sig_out;
+  const size_t H = a.dims[n][1], W = a.dims[n][2];
+  dst[((size_t)n * a.pd * a.ph + row) * a.pw + x] = src[((size_t)sz * H + sy) * W + sx];
+}
+
+constexpr int MSE_THREADS = 256;
+
+// grid (blocks per sample, n): grid-stride over the sample's v voxels, 4 floats per thread per iteration
+__global__ __launch_bounds__(MSE_THREADS) void mse_fwd_bwd_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                                 float* __restrict__ dout, float* __restrict__ sums, long v,
+                                                                 float gscale) {
+  const int n = blockIdx.y;
+  const float* o = out + (size_t)n * v;
+  const float* t = tgt + (size_t)n * v;
+  float* d = dout ? dout + (size_t)n * v : nullptr;
+  float acc = 0.f;
+  const long v4 = v >> 2;
+  for (long i = (long)blockIdx.x * MSE_THREADS + threadIdx.x; i < v4; i += (long)gridDim.x * MSE_THREADS) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(o)[i], b = reinterpret_cast<const f32x4*>(t)[i];
+    const f32x4 e = a - b;
+    acc += e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
+    if (d) reinterpret_cast<f32x4*>(d)[i] = e * gscale;
+  }
+  if (blockIdx.x == 0) {
+    for (long i = (v4 << 2) + threadIdx.x; i < v; i += MSE_THREADS) {
+      const float e = o[i] - t[i];
+      acc += e * e;
+      if (d) d[i] = e * gscale;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ float part[MSE_THREADS / 64];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < MSE_THREADS / 64; ++w) s += part[w];
+    atomicAdd(&sums[n], s);
+  }
+}
+
+// one workgroup: per-sample means, the batch mean, per-task means (NaN-free: tasks absent from the batch report 0 with count 0)
+__global__ void mse_finish_kernel(float* __restrict__ sums, const int32_t* __restrict__ sample_task, int n, long v, int num_tasks,
+                                  float* __restrict__ loss, float* __restrict__ loss_sample, float* __restrict__ task_mean,
+                                  float* __restrict__ task_count) {
+  __shared__ float tsum[64], tcnt[64];
+  const int tid = threadIdx.x;
+  if (tid < 64) { tsum[tid] = 0.f; tcnt[tid] = 0.f; }
+  __syncthreads();
+  float total = 0.f;
+  if (tid == 0) {
+    for (int i = 0; i < n; ++i) {
+      const float m = sums[i] / (float)v;
+      loss_sample[i] = m;
+      total += m;
+      if (sample_task) {
+        const int t = sample_task[i];
+        if (t >= 0 && t < num_tasks && t < 64) { tsum[t] += m; tcnt[t] += 1.f; }
+      }
+      sums[i] = 0.f;                       // leave the accumulator clear for the next call
+    }
+    *loss = total / (float)n;
+  }
+  __syncthreads();
+  if (task_mean && tid < num_tasks && tid < 64) {
+    task_mean[tid] = tcnt[tid] > 0.f ? tsum[tid] / tcnt[tid] : 0.f;
+    task_count[tid] = tcnt[tid];
+  }
+}
+
+}  // namespace
+
+extern "C" int repmode_crop_flip(const float* const* signal_vols, const float* const* target_vols, const int* dims,
+                                 const int* starts, const int* flips, int n, int pd, int ph, int pw, float* signal_out,
+                                 float* target_out, void* stream) {
+  RM_REQUIRE(signal_vols && target_vols && dims && starts && flips && signal_out && target_out, "crop_flip: null pointer");
+  RM_REQUIRE(n > 0 && n <= CF_MAX, "crop_flip: 1..%d samples per call, got %d", CF_MAX, n);
+  RM_REQUIRE(pd > 0 && ph > 0 && pw > 0, "crop_flip: bad patch size");
+  CropArgs a{};
+  a.pd = pd; a.ph = ph; a.pw = pw;
+  for (int i = 0; i < n; ++i) {
+    RM_REQUIRE(signal_vols[i] && target_vols[i], "crop_flip: null volume %d", i);
+    a.sig[i] = signal_vols[i];
+    a.tgt[i] = target_vols[i];
+    const int p[3] = {pd, ph, pw};
+    for (int k = 0; k < 3; ++k) {
+      a.dims[i][k] = dims[3 * i + k];
+      a.start[i][k] = starts[3 * i + k];
+      RM_REQUIRE(a.start[i][k] >= 0 && a.start[i][k] + p[k] <= a.dims[i][k], "crop_flip: crop of sample %d leaves its volume (axis %d)", i, k);
+    }
+    RM_REQUIRE(flips[i] >= 0 && flips[i] < 8, "crop_flip: bad flip mask %d", flips[i]);
+    a.flip[i] = flips[i];
+  }
+  hipLaunchKernelGGL(crop_flip_kernel, dim3((pw + 255) / 256, pd * ph, 2 * n), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                     signal_out, target_out);
+  RM_LAUNCH_CHECK("crop_flip");
+  return REPMODE_OK;
+}
+
+extern "C" int repmode_mse_loss(const float* out, const float* target, const int32_t* sample_task, int n, long v, int num_tasks,
+                                float* dout, float* sums_ws, float* loss, float* loss_sample, float* task_mean, float* task_count,
+                                void* stream) {
+  RM_REQUIRE(out && target && sums_ws && loss && loss_sample, "mse_loss: null pointer");
+  RM_REQUIRE(n > 0 && v > 0, "mse_loss: bad shape");
+  RM_REQUIRE(((uintptr_t)out & 15) == 0 && ((uintptr_t)target & 15) == 0 && ((uintptr_t)dout & 15) == 0 && (v % 4 == 0 || n == 1),
+             "mse_loss: 16-byte aligned tensors with a multiple of 4 voxels per sample");
+  RM_REQUIRE(!task_mean || (sample_task && task_count && num_tasks > 0 && num_tasks <= 64), "mse_loss: per-task means need sample_task, task_count and at most 64 tasks");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  long blocks = (v / 4 + MSE_THREADS * 4 - 1) / (MSE_THREADS * 4);
+  if (blocks < 1) blocks = 1;
+  if (blocks * n > 2048) blocks = (2048 + n - 1) / n;
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3((unsigned)blocks, n), dim3(MSE_THREADS), 0, s, out, target, dout, sums_ws, v,
+                     2.0f / ((float)n * (float)v));
+  RM_LAUNCH_CHECK("mse_fwd_bwd");
+  hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(64), 0, s, sums_ws, sample_task, n, v, num_tasks, loss, loss_sample, task_mean,
+                     task_count);
+  RM_LAUNCH_CHECK("mse_finish");
+  return REPMODE_OK;
+}

@@ -13,12 +13,12 @@
 //
 // Built by repmode_amd/csrc/build.sh into repmode_amd/librepmode_torch.so (in-tree, next to librepmode_hip.so).
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 #include <torch/autograd.h>
 #include <torch/library.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -42,6 +42,19 @@ constexpr int64_t TAPS = REPMODE_TAPS;
     const int rc__ = fn(__VA_ARGS__);                                                             \
     TORCH_CHECK(rc__ == 0, #fn " failed (code ", rc__, "): ", repmode_last_error());              \
   } while (0)
+
+// Current-device guard on the HIP runtime itself (PyTorch-ROCm labels its device type "cuda"; the c10::hip guards want
+// their own label -- the runtime call needs neither).  One process per GPU: normally a no-op.
+struct DeviceGuard {
+  int prev = -1, want = -1;
+  explicit DeviceGuard(const at::Device& d) : want(d.index()) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (want >= 0 && prev != want) TORCH_CHECK(hipSetDevice(want) == hipSuccess, "repmode: cannot select HIP device ", want);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0 && want >= 0 && prev != want) (void)hipSetDevice(prev);
+  }
+};
 
 inline void* stream_handle() { return static_cast<void*>(c10::hip::getCurrentHIPStream().stream()); }
 
@@ -869,7 +882,7 @@ inline bool pair_shapes_ok(const Tensor& xa, const Tensor& xb) {
 Tensor mode_conv3d_cl(const Tensor& x_cl_in, const OptTensor& x2_cl_in, const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3,
                       const Tensor& a5, const Tensor& gw, const Tensor& gb, const Plan& plan, bool out_f32, int64_t mode) {
   require_hip(x_cl_in, "input");
-  c10::hip::HIPGuard guard(x_cl_in.device());
+  DeviceGuard guard(x_cl_in.device());
   Tensor x_cl = x_cl_in.contiguous();
   Tensor x2_cl = x2_cl_in.has_value() ? x2_cl_in->contiguous() : Tensor();
   Tensor ps[7] = {k5.contiguous(), k3.contiguous(), k1.contiguous(), a3.contiguous(), a5.contiguous(), gw.contiguous(), gb.contiguous()};
@@ -891,7 +904,7 @@ Tensor mode_conv3d_cl(const Tensor& x_cl_in, const OptTensor& x2_cl_in, const Te
 Tensor bn_relu_cl(const Tensor& x_cl_in, const Tensor& weight, const Tensor& bias, const Tensor& rm_, const Tensor& rv_, bool batch_stats,
                   double momentum, double eps, at::ScalarType out_dtype) {
   require_hip(x_cl_in, "input");
-  c10::hip::HIPGuard guard(x_cl_in.device());
+  DeviceGuard guard(x_cl_in.device());
   Tensor x_cl = x_cl_in.contiguous();
   const int64_t c = x_cl.size(-1);
   TORCH_CHECK(c <= 512, "bn_relu: at most 512 channels, got ", c);
@@ -959,14 +972,14 @@ void check_k2(const Tensor& x_cl, const Tensor& weight, const char* what) {
 Tensor op_down2(const Tensor& x_cl, const Tensor& weight) {
   check_k2(x_cl, weight, "down2");
   TORCH_CHECK(x_cl.size(1) % 2 == 0 && x_cl.size(2) % 2 == 0 && x_cl.size(3) % 2 == 0 && x_cl.size(4) == weight.size(1), "down2: bad shape ", x_cl.sizes());
-  c10::hip::HIPGuard guard(x_cl.device());
+  DeviceGuard guard(x_cl.device());
   return Down2::apply(x_cl.contiguous(), weight.contiguous(), at::GradMode::is_enabled());
 }
 
 Tensor op_up2(const Tensor& x_cl, const Tensor& weight) {
   check_k2(x_cl, weight, "up2");
   TORCH_CHECK(x_cl.size(4) == weight.size(0), "up2: bad shape ", x_cl.sizes());
-  c10::hip::HIPGuard guard(x_cl.device());
+  DeviceGuard guard(x_cl.device());
   return Up2::apply(x_cl.contiguous(), weight.contiguous(), at::GradMode::is_enabled());
 }
 
@@ -994,6 +1007,23 @@ Tensor op_grad_out(const Tensor& param) { return grad_out(param); }
 int64_t op_eval_cache_size() {
   std::lock_guard<std::mutex> lock(g_eval_mu);
   return (int64_t)g_eval.size();
+}
+// diagnostics: host microseconds per launch of a tiny library kernel (n back-to-back launches on the current stream), and
+// per allocation of a small tensor -- what a launch / an output buffer costs the host on this box
+double op_debug_launch_cost(const Tensor& t, int64_t n) {
+  require_hip(t, "input");
+  Tensor y5 = at::zeros({4, 8, 5}, t.options().dtype(at::kFloat)), y = at::empty({4, 8}, t.options().dtype(at::kFloat));
+  void* s = stream_handle();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int64_t i = 0; i < n; ++i) RM_CALL(repmode_unshift5, y5.data_ptr<float>(), y.data_ptr<float>(), 4L, 8, s);
+  const auto t1 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double, std::micro>(t1 - t0).count() / (double)n;
+}
+double op_debug_alloc_cost(const Tensor& t, int64_t n) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int64_t i = 0; i < n; ++i) { Tensor a = at::empty({1024}, t.options()); (void)a; }
+  const auto t1 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double, std::micro>(t1 - t0).count() / (double)n;
 }
 void op_set_fork_max_w(int64_t w) { g_fork_max_w = w; }
 int64_t op_get_fork_max_w() { return g_fork_max_w; }
@@ -1038,6 +1068,8 @@ TORCH_LIBRARY(repmode, m) {
   m.def("zero_pool_take(int[] shape, Tensor like) -> (Tensor, bool)", &rm::op_zero_pool_take);
   m.def("grad_out(Tensor param) -> Tensor", &rm::op_grad_out);
   m.def("eval_cache_size() -> int", &rm::op_eval_cache_size);
+  m.def("debug_launch_cost(Tensor t, int n) -> float", &rm::op_debug_launch_cost);
+  m.def("debug_alloc_cost(Tensor t, int n) -> float", &rm::op_debug_alloc_cost);
   m.def("set_fork_max_w(int w) -> ()", &rm::op_set_fork_max_w);
   m.def("get_fork_max_w() -> int", &rm::op_get_fork_max_w);
   m.def("eval_cache_begin() -> ()", &rm::op_eval_cache_begin);

@@ -17,6 +17,9 @@ Fixture index:
   g3_net_mc2.npz                  Net(mult_chan=2) fwd+bwd, full state_dict + grads
   g4_train_mc2.npz                5 Adam steps in fnet_model.do_train_iter order
   g5_predict.npz                  get_gaussian maps, predict() patch lists, blend
+  g4b_model_train_iter.npz        the REAL fnet_model.Model.do_train_iter (mult_chan 32, seed 0): scalars only --
+                                  losses, the per-sample DataFrame, the dict handed to wandb.log
+  g6_data_aug.npz                 SSPDataset.data_aug (SSPdataset.py:137-155): crops + flips under fixed numpy seeds
 """
 import importlib
 import os
@@ -242,10 +245,101 @@ def capture_predict(ref, name):
     print('wrote', name)
 
 
+def capture_model_train_iter(name, steps=2):
+    """The real ``Model.do_train_iter`` (fnet_model.py:96-132) with its hard-wired mult_chan=32 network on CPU (autocast
+    and GradScaler disable themselves without CUDA: pure fp32).  Only scalars are kept: the initial state is
+    ``torch.manual_seed(0)`` + the reference's construction order, which repmode_amd's Net and the oracle's reproduce
+    bit for bit (tests/test_host_cpu.py::test_seeded_init_matches_reference_fixture), so the 0.5 GB state is not stored."""
+    logged = []
+    sys.modules['wandb'] = types.SimpleNamespace(log=lambda d, *a, **k: logged.append(dict(d)))
+    import warnings
+    warnings.filterwarnings('ignore')
+    fm = importlib.import_module('fnet.fnet_model')
+    fm.wandb = sys.modules['wandb']
+    torch.manual_seed(0)
+    model = fm.Model(Opts(), nn_module='RepMode', lr=0.001, gpu_ids=-1)
+    # a fingerprint of the seeded initial state (checked against the build's own seeded construction)
+    sd = model.net.state_dict()
+    finger = np.asarray([float(sd[k].double().sum()) for k in sorted(sd) if sd[k].dtype.is_floating_point], np.float64)
+    gen = torch.Generator().manual_seed(123)
+    tasks = torch.tensor([3, 7, 3])
+    out = {'tasks': npy(tasks), 'lr': np.float64(0.001), 'state_fingerprint': finger,
+           'state_fingerprint_keys': np.asarray([k for k in sorted(sd) if sd[k].dtype.is_floating_point])}
+    xs, ts, losses, per_sample, out_sums = [], [], [], [], []
+    for s in range(steps):
+        x = torch.randn(3, 1, 16, 64, 64, generator=gen)
+        t = torch.randn(3, 1, 16, 64, 64, generator=gen)
+        output, df = model.do_train_iter(x, t, tasks)
+        xs.append(npy(x)); ts.append(npy(t))
+        losses.append(logged[-1]['loss/iter'])
+        per_sample.append(np.asarray(df['loss'], np.float64))
+        out_sums.append(float(output.double().abs().sum()))
+        assert list(df['dataset']) == [Opts.adopted_datasets[i] for i in tasks.tolist()]
+        print('step', s, logged[-1]['loss/iter'])
+    out['xs'], out['targets'] = np.stack(xs), np.stack(ts)
+    out['losses'] = np.asarray(losses, np.float64)
+    out['loss_per_sample'] = np.stack(per_sample)
+    out['output_abs_sum'] = np.asarray(out_sums, np.float64)
+    out['df_dataset'] = np.asarray([Opts.adopted_datasets[i] for i in tasks.tolist()])
+    keys = sorted(logged[-1])
+    out['log_keys'] = np.asarray(keys)
+    out['log_values'] = np.asarray([[float(d[k]) for k in keys] for d in logged], np.float64)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print('wrote', name)
+
+
+def capture_data_aug(name):
+    """``SSPDataset.data_aug`` (SSPdataset.py:137-155) called unbound on a plain namespace carrying the two attributes it
+    reads (patch_size, random_flip_prob).  The module imports tifffile / pandas helpers that this image lacks, so it is
+    loaded with ``tifffile`` absent-safe: only the function object is used."""
+    for mod in ('tifffile', 'wandb'):
+        sys.modules.setdefault(mod, types.SimpleNamespace(log=lambda *a, **k: None, imread=None, imsave=None))
+    try:
+        ds = importlib.import_module('fnet.data.SSPdataset')
+        fn = ds.SSPDataset.data_aug
+    except Exception as e:                      # pragma: no cover - depends on the image
+        raise SystemExit('cannot import fnet.data.SSPdataset here: %r' % (e,))
+    out = {}
+    cases = [((40, 100, 120), (32, 64, 64), 0.5, 11), ((32, 64, 64), (32, 64, 64), 0.5, 12), ((20, 33, 47), (16, 32, 32), 1.0, 13),
+             ((50, 70, 90), (16, 32, 32), 0.0, 14)]
+    for ci, (vol, patch, prob, seed) in enumerate(cases):
+        selfish = types.SimpleNamespace(patch_size=np.asarray(patch), random_flip_prob=prob)
+        sig = torch.arange(int(np.prod(vol)), dtype=torch.float32).view(1, *vol)       # voxel = its linear index
+        tgt = -sig
+        np.random.seed(seed)
+        crops = []
+        for rep in range(6):
+            a, b = fn(selfish, sig, tgt)
+            assert torch.equal(a, -b)
+            crops.append(npy(a)[0].astype(np.int64))
+        out['case%d_vol' % ci] = np.asarray(vol)
+        out['case%d_patch' % ci] = np.asarray(patch)
+        out['case%d_prob' % ci] = np.float64(prob)
+        out['case%d_seed' % ci] = np.int64(seed)
+        # a crop of the index volume is fully described by 3 corner probes; keep first / last voxel and the three
+        # axis neighbours of the first voxel (enough to recover starts and flips), plus a checksum
+        cs = np.stack(crops)
+        out['case%d_first' % ci] = cs[:, 0, 0, 0]
+        out['case%d_last' % ci] = cs[:, -1, -1, -1]
+        out['case%d_nz' % ci] = cs[:, 1, 0, 0]
+        out['case%d_ny' % ci] = cs[:, 0, 1, 0]
+        out['case%d_nx' % ci] = cs[:, 0, 0, 1]
+        out['case%d_sum' % ci] = cs.reshape(len(crops), -1).sum(1)
+    out['ncases'] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print('wrote', name)
+
+
 def main():
     assert os.path.isdir(REF), 'reference checkout not present; fixtures are committed, nothing to do'
     sys.path.insert(0, REF)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:                       # only the named fixtures: `make_golden.py g6 g4b`
+        if 'g6' in sys.argv:
+            capture_data_aug('g6_data_aug.npz')
+        if 'g4b' in sys.argv:
+            capture_model_train_iter('g4b_model_train_iter.npz')
+        return
     ref = importlib.import_module('fnet.nn_modules.RepMode')
     capture_block(ref, 1, 32, 'normal', (16, 32, 32), [4], 0, 'g1_config1.npz')
     capture_block(ref, 1, 32, 'normal', (8, 16, 16), [3, 7, 3], 1, 'g1_block_1_32.npz')
@@ -258,6 +352,8 @@ def main():
     capture_net(ref, 2, (16, 64, 64), [3, 7], 0, 'g3_net_mc2.npz')
     capture_train(ref, 2, (16, 32, 32), [3, 7], 0, 5, 'g4_train_mc2.npz')
     capture_predict(ref, 'g5_predict.npz')
+    capture_data_aug('g6_data_aug.npz')
+    capture_model_train_iter('g4b_model_train_iter.npz')
 
 
 if __name__ == '__main__':
