@@ -149,7 +149,7 @@ def main():
     ap.add_argument('--dump-launches', default=None, help='write per-launch (kind, ms, TFLOP/s or TB/s) of the last timed step as JSON')
     args = ap.parse_args()
 
-    from repmode_amd import _lib, distributed as dist_
+    from repmode_amd import _lib, ops as ops_, distributed as dist_
     from repmode_amd.model import Model
 
     rank, world, local = dist_.init_from_env()
@@ -190,19 +190,35 @@ def main():
     if not args.no_prof:
         _lib.prof_enable(1 if (args.prof_all or args.dump_launches) else 2)
     profiled_steps = 0
+    overlap = ops_.get_overlap()
     t0 = time.perf_counter()
     for step in range(args.steps):
         if not args.no_prof:
             on = step % sample == 0
             _lib.prof_pause(not on)
             profiled_steps += on
+            # a step whose launches are timed one by one runs them one after the other: with the GatRep kernels beside
+            # the convolutions on a second stream, an event pair would time the pair of kernels, not the kernel
+            ops_.set_overlap(overlap and not on)
         # (a profiled step is launched kernel by kernel: the library's event pairs are not part of a captured graph)
         model.do_train_iter(signal, target, task, eager=not args.no_prof and on)
-    t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (== dt when the host is the limiter)
+    t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (includes waiting on a full queue)
     barrier()
     dt = time.perf_counter() - t0
     dt = dist_.max_over_ranks(dt, device)
+    ops_.set_overlap(overlap)
     loss = float(model.last_loss)
+    # what ENQUEUEING one step costs the host: timed with the GPU idle at the start of the step, so that nothing waits
+    # on a full queue (over many back-to-back steps the host runs ahead until the runtime blocks it, and
+    # `host_issue_ms_per_step` then reads as the GPU's own step time)
+    _lib.prof_pause(True)
+    enq = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        model.do_train_iter(signal, target, task)
+        enq.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
     train_prof = {}
     if not args.no_prof and rank == 0:
         for kind in ('conv5_igemm', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd'):
@@ -230,7 +246,8 @@ def main():
                                   'BASELINE configs[3]: global batch %d' % (world * b) if b == BATCH_MULTI else 'custom batch'),
                    'global_batch': world * b, 'patch': list(PATCH), 'parallelism': 'dp%d' % world,
                    'distinct_tasks_per_rank': len(set(task.tolist())),
-                   'final_loss': loss, 'host_issue_ms_per_step': 1e3 * t_issue / args.steps,
+                   'final_loss': loss, 'host_enqueue_ms_per_step': 1e3 * sorted(enq)[len(enq) // 2],
+                   'host_issue_ms_per_step': 1e3 * t_issue / args.steps, 'kernel_overlap': overlap,
                    'hip_graph': bool(model.hip_graph), 'steps_launched_kernel_by_kernel': profiled_steps},
     }
 

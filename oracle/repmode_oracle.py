@@ -281,3 +281,31 @@ def predict(net, signal, task, patch_size, batch_size_eval):
             pred_sum[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] += out[i:i + 1] * gm
             weight_sum[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] += gm
     return pred_sum / weight_sum
+
+
+def data_aug(signal, target, patch_size, random_flip_prob, rng):
+    """fnet/data/SSPdataset.py:137-155 restated with numpy: random crop (one ``randint`` per axis, z y x), then flips along
+    the axes whose ``uniform(0, 1)`` draw is <= ``random_flip_prob`` (three draws in one call).  ``signal`` / ``target``:
+    [1, D, H, W] arrays; ``rng``: ``numpy.random`` or a ``RandomState`` (the reference uses the global one)."""
+    import numpy as np
+    img = signal.shape[-3:]
+    starts = np.array([rng.randint(0, i - c + 1) for i, c in zip(img, patch_size)])
+    ends = starts + np.asarray(patch_size)
+    sl = (slice(None), slice(starts[0], ends[0]), slice(starts[1], ends[1]), slice(starts[2], ends[2]))
+    s, t = signal[sl], target[sl]
+    p = rng.uniform(0, 1, size=3)
+    dims = [int(d) + 1 for d in np.where(p <= random_flip_prob)[0]]
+    for d in dims:
+        s, t = np.flip(s, d), np.flip(t, d)
+    return np.ascontiguousarray(s), np.ascontiguousarray(t)
+
+
+def loss_log(loss_per_sample, tasks, dataset_names, count_iter):
+    """fnet_model.py:115-122: the dict handed to ``wandb.log`` -- iteration, batch loss (the mean of all voxels == the
+    mean of the equally sized samples' means) and the per-task means of the per-sample losses."""
+    import numpy as np
+    per = np.asarray(loss_per_sample, np.float64)
+    log = {'X-axis/iter': count_iter, 'loss/iter': float(per.mean())}
+    for i in sorted(set(int(t) for t in tasks)):
+        log['loss_iter/%s' % dataset_names[i]] = float(per[[j for j, t in enumerate(tasks) if int(t) == i]].mean())
+    return log

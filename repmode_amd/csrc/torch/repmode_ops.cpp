@@ -191,11 +191,29 @@ int64_t g_fork_max_w = []() {
     TORCH_CHECK(e__ == hipSuccess, #call ": ", hipGetErrorString(e__));                          \
   } while (0)
 
+// the library's own streams of a device: `side` for the second chain of one layer, `prep` for the step's filter
+// preparation (separate, so that a layer's fork does not queue behind the remaining preparations)
+struct SideStreams {
+  c10::hip::HIPStream side, prep;
+  hipEvent_t fork_ev, join_ev, prep_fork_ev;
+};
+SideStreams& side_streams(int dev) {
+  static std::mutex mu;
+  static std::unordered_map<int, SideStreams> per;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = per.find(dev);
+  if (it == per.end()) {
+    SideStreams d{c10::hip::getStreamFromPool(false, dev), c10::hip::getStreamFromPool(false, dev), nullptr, nullptr, nullptr};
+    RM_HIP_CHECK(hipEventCreateWithFlags(&d.fork_ev, hipEventDisableTiming));
+    RM_HIP_CHECK(hipEventCreateWithFlags(&d.join_ev, hipEventDisableTiming));
+    RM_HIP_CHECK(hipEventCreateWithFlags(&d.prep_fork_ev, hipEventDisableTiming));
+    it = per.emplace(dev, d).first;
+  }
+  return it->second;
+}
+
 struct Fork {
-  struct PerDevice {
-    c10::hip::HIPStream side;
-    hipEvent_t fork_ev, join_ev;
-  };
+  using PerDevice = SideStreams;
   bool on = false;
   c10::hip::HIPStream main_s = c10::hip::getDefaultHIPStream();
   PerDevice* pd = nullptr;
@@ -204,19 +222,7 @@ struct Fork {
     on = true;
     const int dev = t.device().index();
     main_s = c10::hip::getCurrentHIPStream(dev);
-    static std::mutex mu;
-    static std::unordered_map<int, PerDevice> per;
-    {
-      std::lock_guard<std::mutex> lock(mu);
-      auto it = per.find(dev);
-      if (it == per.end()) {
-        PerDevice d{c10::hip::getStreamFromPool(false, dev), nullptr, nullptr};
-        RM_HIP_CHECK(hipEventCreateWithFlags(&d.fork_ev, hipEventDisableTiming));
-        RM_HIP_CHECK(hipEventCreateWithFlags(&d.join_ev, hipEventDisableTiming));
-        it = per.emplace(dev, d).first;
-      }
-      pd = &it->second;
-    }
+    pd = &side_streams(dev);
     // the side stream is ordered after everything issued on the current stream so far
     RM_HIP_CHECK(hipEventRecord(pd->fork_ev, main_s.stream()));
     RM_HIP_CHECK(hipStreamWaitEvent(pd->side.stream(), pd->fork_ev, 0));
@@ -233,6 +239,13 @@ struct Fork {
   ~Fork() { if (on) c10::hip::setCurrentHIPStream(main_s); }   // (an exception between fork and join: restore the stream)
 };
 inline bool forks(const Tensor& x_cl) { return x_cl.size(3) > 0 && x_cl.size(3) <= g_fork_max_w; }
+// Overlap of the HBM-bound GatRep kernels with the MFMA-bound convolutions (second stream): the forward's filter
+// preparation of all blocks at the start of the step (op prepare_filters), and a layer's GatRep backward beside its
+// data-gradient conv.  On by default; bench.py switches it off on the steps whose launches it times one by one.
+bool g_overlap = []() {
+  const char* e = std::getenv("REPMODE_OVERLAP");
+  return e ? std::atoi(e) != 0 : true;
+}();
 
 // ------------------------------------------------------------------------------------------------------------
 // thin wrappers of the C ABI (allocation + argument marshalling)
@@ -402,6 +415,39 @@ std::unordered_map<EvalKey, std::pair<Tensor, Tensor>, EvalKeyHash> g_eval;
 struct Merged {
   Tensor g, wf, wd;
 };
+
+// Filters prepared ahead of the forward pass on the `prep` stream (op prepare_filters): they depend on the parameters and
+// the batch's tasks only, not on activations, so all 19 blocks' gate softmax + GatRep (or expert layout) launches are
+// issued when the step starts and run beside the first convolutions.  A block takes its entry (ordering its own stream
+// behind the entry's event) or, when there is none that fits, computes the filters itself.
+struct PrepEntry {
+  Tensor g, wf, wd;
+  hipEvent_t ev = nullptr;
+  int64_t rows = 0;          // slots (merged) or samples (per-expert)
+  at::ScalarType dt = at::kFloat;
+  bool unmerged = false;
+};
+std::mutex g_prep_mu;
+std::unordered_map<void*, PrepEntry> g_prep;
+std::vector<hipEvent_t> g_prep_events;
+
+bool take_prepared(const Tensor& k5, int64_t rows, at::ScalarType dt, bool unmerged, bool want_wd, Merged* out) {
+  PrepEntry e;
+  {
+    std::lock_guard<std::mutex> lock(g_prep_mu);
+    if (g_prep.empty()) return false;
+    auto it = g_prep.find(k5.data_ptr());
+    if (it == g_prep.end()) return false;
+    e = it->second;
+    g_prep.erase(it);
+  }
+  if (e.rows != rows || e.dt != dt || e.unmerged != unmerged || (want_wd && !e.wd.defined())) return false;
+  RM_HIP_CHECK(hipStreamWaitEvent(c10::hip::getCurrentHIPStream(k5.device().index()).stream(), e.ev, 0));
+  out->g = e.g;
+  out->wf = e.wf;
+  out->wd = want_wd ? e.wd : Tensor();
+  return true;
+}
 Merged merged_filters(const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3, const Tensor& a5, const Tensor& gw,
                       const Tensor& gb, const Plan& plan, at::ScalarType dt, bool want_wd, bool grad_enabled) {
   const bool cacheable = !(plan.training || want_wd || grad_enabled);
@@ -414,6 +460,7 @@ Merged merged_filters(const Tensor& k5, const Tensor& k3, const Tensor& k1, cons
     }
   }
   Merged m;
+  if (take_prepared(k5, plan.nslots, dt, false, want_wd, &m)) return m;
   m.g = gate_softmax(gw, gb, plan.slot_task, plan.nslots, plan.num_tasks, k5.size(0));
   auto w = gatrep_merge(k5, k3, k1, a3, a5, m.g, dt, true, want_wd);
   m.wf = w.first;
@@ -483,10 +530,16 @@ struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
     const at::ScalarType dt = x_cl.scalar_type();
     Tensor dy = grads[0].to(dt).contiguous();
     const bool need_dx = ctx->needs_input_grad(0) && wd.defined();
-    // the filter gradient and the GatRep backward do not depend on the data gradient: second stream on the deep levels
-    Fork fork(need_dx && forks(x_cl), x_cl);
+    // Neither the filter gradient nor the GatRep backward depends on the data gradient.  Deep levels (a launch does not
+    // fill the chip): both on the second stream.  Elsewhere: the filter gradient stays in line with the data gradient
+    // (both MFMA-bound), only the HBM-bound GatRep backward goes beside the data-gradient conv.
+    const bool whole = need_dx && forks(x_cl);
+    Tensor dw;
+    if (!whole) dw = conv5_wgrad(x_cl, dy, plan.sample_slot, plan.nslots, co);
+    Fork fork(need_dx && (whole || g_overlap), x_cl);
     fork.to_side();
-    std::vector<Tensor> pg = filter_and_expert_grads(conv5_wgrad(x_cl, dy, plan.sample_slot, plan.nslots, co), k5, k3, k1, a3, a5, g, plan);
+    if (whole) dw = conv5_wgrad(x_cl, dy, plan.sample_slot, plan.nslots, co);
+    std::vector<Tensor> pg = filter_and_expert_grads(dw, k5, k3, k1, a3, a5, g, plan);
     fork.to_main();
     Tensor dx;
     if (need_dx) {
@@ -546,13 +599,12 @@ struct ModeConvPair : public torch::autograd::Function<ModeConvPair> {
     const at::ScalarType dt = xa.scalar_type();
     const int code = dtype_code(dt);
     Tensor dy = grads[0].to(dt).contiguous();
-    Fork fork(wd.defined() && forks(xa), xa);
-    fork.to_side();
-    std::vector<Tensor> pg;
-    {
+    const bool whole = wd.defined() && forks(xa);
+    Tensor dw;
+    auto filter_grad = [&]() {
       // the two channel ranges of one (cleared) buffer
       auto tk = g_pool.take({plan.nslots, TAPS, co, ci}, xa);
-      Tensor dw = tk.first;
+      dw = tk.first;
       if (!tk.second) dw.zero_();
       const Tensor* parts[2] = {&xa, &xb};
       const int64_t offs[2] = {0, ca};
@@ -560,8 +612,12 @@ struct ModeConvPair : public torch::autograd::Function<ModeConvPair> {
         RM_CALL(repmode_conv5_wgrad_part, parts[i]->data_ptr(), dy.data_ptr(), plan.sample_slot.data_ptr<int32_t>(), (int)plan.nslots,
                 dw.data_ptr<float>(), (int)n, (int)d, (int)h, (int)w_, (int)parts[i]->size(4), (int)ci, (int)offs[i], (int)co, code, 8,
                 stream_handle());
-      pg = filter_and_expert_grads(dw, k5, k3, k1, a3, a5, g, plan);
-    }
+    };
+    if (!whole) filter_grad();
+    Fork fork(wd.defined() && (whole || g_overlap), xa);      // (as ModeConvMerged::backward)
+    fork.to_side();
+    if (whole) filter_grad();
+    std::vector<Tensor> pg = filter_and_expert_grads(dw, k5, k3, k1, a3, a5, g, plan);
     fork.to_main();
     Tensor dxa, dxb;
     if (wd.defined()) {
@@ -619,8 +675,16 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     const int64_t co = k5.size(0), ci = k5.size(1);
     const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), w = x_cl.size(3);
     const bool need_dx = grad_enabled && x_cl.requires_grad();
-    Tensor gn = gate_softmax(gw, gb, plan.sample_task, plan.n, plan.num_tasks, co);       // g per SAMPLE [N, 5, Co]
-    auto fr = expert_frags(k5, k3, x_cl.scalar_type(), need_dx);
+    Tensor gn;                                                                            // g per SAMPLE [N, 5, Co]
+    std::pair<Tensor, Tensor> fr;
+    Merged pm;
+    if (take_prepared(k5, plan.n, x_cl.scalar_type(), true, need_dx, &pm)) {
+      gn = pm.g;
+      fr = {pm.wf, pm.wd};
+    } else {
+      gn = gate_softmax(gw, gb, plan.sample_task, plan.n, plan.num_tasks, co);
+      fr = expert_frags(k5, k3, x_cl.scalar_type(), need_dx);
+    }
     Tensor s0 = single_slot(n, 0, x_cl), s1 = single_slot(n, 1, x_cl);
     auto tk = g_pool.take({E, n, d, h, w, co}, x_cl);                                     // expert outputs P_e
     Tensor p = tk.first;
@@ -833,6 +897,50 @@ struct Up2 : public torch::autograd::Function<Up2> {
   }
 };
 
+// MSELoss(reduction='none') -> mean with the per-sample and per-task means the reference logs (fnet_model.py:108-109,
+// 115-122), one pass + a one-workgroup finish; d loss / d output comes out of the same pass.
+Tensor mse_sums_ws(const Tensor& like) {
+  static std::mutex mu;
+  static std::unordered_map<int, Tensor> ws;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = ws.find(like.device().index());
+  if (it == ws.end()) it = ws.emplace(like.device().index(), at::zeros({1024}, like.options().dtype(at::kFloat))).first;
+  return it->second;
+}
+
+struct MseLoss : public torch::autograd::Function<MseLoss> {
+  static variable_list forward(AutogradContext* ctx, Tensor out, Tensor target, Tensor sample_task, int64_t num_tasks, bool want_grad) {
+    const int64_t n = out.size(0), v = out.numel() / n;
+    Tensor loss = at::empty({}, out.options()), loss_sample = at::empty({n}, out.options());
+    Tensor task_mean = at::empty({num_tasks}, out.options()), task_count = at::empty({num_tasks}, out.options());
+    Tensor dout = want_grad ? at::empty_like(out) : Tensor();
+    Tensor ws = mse_sums_ws(out);
+    RM_CALL(repmode_mse_loss, out.data_ptr<float>(), target.data_ptr<float>(), sample_task.data_ptr<int32_t>(), (int)n, (long)v,
+            (int)num_tasks, want_grad ? dout.data_ptr<float>() : nullptr, ws.data_ptr<float>(), loss.data_ptr<float>(),
+            loss_sample.data_ptr<float>(), task_mean.data_ptr<float>(), task_count.data_ptr<float>(), stream_handle());
+    ctx->save_for_backward({dout});
+    ctx->mark_non_differentiable({loss_sample, task_mean, task_count});
+    return {loss, loss_sample, task_mean, task_count};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    Tensor dout = ctx->get_saved_variables()[0];
+    TORCH_CHECK(dout.defined(), "mse_loss: the forward pass ran without autograd");
+    return {dout * grads[0], Tensor(), Tensor(), Tensor(), Tensor()};
+  }
+};
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> op_mse_loss(const Tensor& out, const Tensor& target, const Tensor& sample_task, int64_t num_tasks) {
+  require_hip(out, "output");
+  TORCH_CHECK(out.scalar_type() == at::kFloat && target.scalar_type() == at::kFloat && out.sizes() == target.sizes() && out.dim() >= 2 &&
+                  target.device() == out.device(), "mse_loss: float32 output / target of one shape on one device");
+  TORCH_CHECK(sample_task.scalar_type() == at::kInt && sample_task.numel() == out.size(0) && sample_task.device() == out.device(),
+              "mse_loss: sample_task must be int32 [N] on the output's device");
+  TORCH_CHECK(num_tasks >= 1 && num_tasks <= 64 && out.size(0) <= 1024, "mse_loss: at most 64 tasks and 1024 samples");
+  DeviceGuard guard(out.device());
+  auto r = MseLoss::apply(out.contiguous(), target.contiguous(), sample_task, num_tasks, at::GradMode::is_enabled() && out.requires_grad());
+  return std::make_tuple(r[0], r[1], r[2], r[3]);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // op entry points
 
@@ -992,6 +1100,88 @@ Tensor op_stage2_bn_relu(const Tensor& x, const Tensor& weight, const Tensor& bn
   return from_cl(bn_relu_cl(y, bn_w, bn_b, bn_rm, bn_rv, bn_batch_stats, bn_momentum, bn_eps, code_dtype(out_dtype)));
 }
 
+// All blocks' forward filters on the `prep` stream, ahead of the forward pass (see PrepEntry).  w_in[i]: the x extent of
+// block i's input (selects the formulation exactly as mode_conv3d does), need_dx[i]: the block's input needs a gradient.
+void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>& k3, const std::vector<Tensor>& k1,
+                        const std::vector<Tensor>& a3, const std::vector<Tensor>& a5, const std::vector<Tensor>& gw,
+                        const std::vector<Tensor>& gb, const std::vector<int64_t>& w_in, const std::vector<int64_t>& need_dx,
+                        const Tensor& slot_task, const Tensor& sample_slot, const Tensor& sample_task, int64_t nslots, int64_t num_tasks,
+                        bool training, int64_t dtype) {
+  const size_t nb = k5.size();
+  TORCH_CHECK(k3.size() == nb && k1.size() == nb && a3.size() == nb && a5.size() == nb && gw.size() == nb && gb.size() == nb &&
+                  w_in.size() == nb && need_dx.size() == nb, "prepare_filters: list lengths differ");
+  {
+    std::lock_guard<std::mutex> lock(g_prep_mu);
+    g_prep.clear();                        // (entries a failed forward left behind)
+  }
+  if (!g_overlap || nb == 0) return;
+  require_hip(k5[0], "parameters");
+  const at::ScalarType dt = code_dtype(dtype);
+  DeviceGuard guard(k5[0].device());
+  const int dev = k5[0].device().index();
+  SideStreams& ss = side_streams(dev);
+  const c10::hip::HIPStream main_s = c10::hip::getCurrentHIPStream(dev);
+  {
+    std::lock_guard<std::mutex> lock(g_prep_mu);
+    while (g_prep_events.size() < nb) {
+      hipEvent_t ev;
+      RM_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      g_prep_events.push_back(ev);
+    }
+  }
+  Plan plan = make_plan(slot_task, sample_slot, sample_task, nslots, num_tasks, training, 0);
+  RM_HIP_CHECK(hipEventRecord(ss.prep_fork_ev, main_s.stream()));
+  RM_HIP_CHECK(hipStreamWaitEvent(ss.prep.stream(), ss.prep_fork_ev, 0));
+  c10::hip::setCurrentHIPStream(ss.prep);
+  try {
+    for (size_t i = 0; i < nb; ++i) {
+      Tensor K5 = k5[i].contiguous(), K3 = k3[i].contiguous();
+      const int64_t co = K5.size(0);
+      PrepEntry e;
+      e.dt = dt;
+      e.unmerged = plan.training && plan.nslots > 2 && w_in[i] <= 8;
+      if (e.unmerged) {
+        e.rows = plan.n;
+        e.g = gate_softmax(gw[i].contiguous(), gb[i].contiguous(), plan.sample_task, plan.n, plan.num_tasks, co);
+        auto fr = expert_frags(K5, K3, dt, need_dx[i] != 0);
+        e.wf = fr.first;
+        e.wd = fr.second;
+      } else {
+        e.rows = plan.nslots;
+        e.g = gate_softmax(gw[i].contiguous(), gb[i].contiguous(), plan.slot_task, plan.nslots, plan.num_tasks, co);
+        auto w = gatrep_merge(K5, K3, k1[i].contiguous(), a3[i].contiguous(), a5[i].contiguous(), e.g, dt, true, need_dx[i] != 0);
+        e.wf = w.first;
+        e.wd = w.second;
+      }
+      e.ev = g_prep_events[i];
+      RM_HIP_CHECK(hipEventRecord(e.ev, ss.prep.stream()));
+      std::lock_guard<std::mutex> lock(g_prep_mu);
+      g_prep[K5.data_ptr()] = e;
+    }
+  } catch (...) {
+    c10::hip::setCurrentHIPStream(main_s);
+    throw;
+  }
+  c10::hip::setCurrentHIPStream(main_s);
+}
+// Forget prepared filters nobody took (the end of a forward pass).  Orders the current stream behind the preparation
+// stream first, so that no launch of it is left running unobserved (and a capturing stream is re-joined).
+void op_finish_prepared(const Tensor& like) {
+  bool any;
+  {
+    std::lock_guard<std::mutex> lock(g_prep_mu);
+    any = !g_prep.empty();
+    g_prep.clear();
+  }
+  if (!any || !like.is_cuda()) return;
+  const int dev = like.device().index();
+  SideStreams& ss = side_streams(dev);
+  RM_HIP_CHECK(hipEventRecord(ss.prep_fork_ev, ss.prep.stream()));
+  RM_HIP_CHECK(hipStreamWaitEvent(c10::hip::getCurrentHIPStream(dev).stream(), ss.prep_fork_ev, 0));
+}
+void op_set_overlap(bool on) { g_overlap = on; }
+bool op_get_overlap() { return g_overlap; }
+
 void op_zero_pool_begin(const std::string& key, const Tensor& like) { g_pool.begin(key, like); }
 void op_zero_pool_end() { g_pool.end(); }
 bool op_zero_pool_has_plan(const std::string& key) {
@@ -1062,6 +1252,13 @@ TORCH_LIBRARY(repmode, m) {
   m.def("up2(Tensor x_cl, Tensor weight) -> Tensor", &rm::op_up2);
   m.def("stage2_bn_relu(Tensor x, Tensor weight, Tensor bn_w, Tensor bn_b, Tensor bn_rm, Tensor bn_rv, bool bn_batch_stats, "
         "float bn_momentum, float bn_eps, bool up, int out_dtype) -> Tensor", &rm::op_stage2_bn_relu);
+  m.def("mse_loss(Tensor out, Tensor target, Tensor sample_task, int num_tasks) -> (Tensor, Tensor, Tensor, Tensor)", &rm::op_mse_loss);
+  m.def("prepare_filters(Tensor[] k5, Tensor[] k3, Tensor[] k1, Tensor[] a3, Tensor[] a5, Tensor[] gate_w, Tensor[] gate_b, int[] w_in, "
+        "int[] need_dx, Tensor slot_task, Tensor sample_slot, Tensor sample_task, int nslots, int num_tasks, bool training, "
+        "int dtype) -> ()", &rm::op_prepare_filters);
+  m.def("finish_prepared(Tensor like) -> ()", &rm::op_finish_prepared);
+  m.def("set_overlap(bool on) -> ()", &rm::op_set_overlap);
+  m.def("get_overlap() -> bool", &rm::op_get_overlap);
   m.def("zero_pool_begin(str key, Tensor like) -> ()", &rm::op_zero_pool_begin);
   m.def("zero_pool_end() -> ()", &rm::op_zero_pool_end);
   m.def("zero_pool_has_plan(str key) -> bool", &rm::op_zero_pool_has_plan);

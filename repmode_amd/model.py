@@ -79,6 +79,8 @@ class Model(object):
         self._graph_pool = None
         self._capture_stream = None
         self.criterion = criterion_fn(reduction='none')        # fnet_model.py:36
+        self._fused_mse = criterion_fn is torch.nn.MSELoss     # the reference's criterion: fused HIP pass (csrc/pipeline.hip)
+        self._last_log = None
         self._init_model()
 
     def _init_model(self):
@@ -129,22 +131,49 @@ class Model(object):
     # ---- training step: fnet_model.py:96-132
     def _train_step(self, signal, target, task):
         """zero_grad, forward, MSELoss('none') -> mean, backward, (all-reduce), Adam.  ``task``: ints or a TaskPlan."""
+        from . import ops as ops_
         module = self.ddp if self.ddp is not None else self.net
         # fnet_model.py:102 calls net.train() every iteration; the guard is on the INNER network, the module whose mode
         # predict() changes (a DistributedDataParallel wrapper keeps its own flag and would hide an eval-mode net)
         if not self.net.training or not module.training:
             module.train()               # (walks the whole module tree: ~0.6 ms, not needed every step)
+        plan = task if isinstance(task, ops_.TaskPlan) else ops_.TaskPlan(task, self.net.num_tasks, self.device, True)
         self.optimizer.zero_grad(set_to_none=True)
-        output = module(signal, task)
-        loss_nomean = self.criterion(output, target)
-        loss = torch.mean(loss_nomean)
+        output = module(signal, plan)
+        if self._fused_mse:
+            # one pass: loss, d loss / d output, per-sample and per-task means (fnet_model.py:108-109, 115-122), all on the device
+            loss, loss_sample, task_mean, task_count = ops_.torch_ops().mse_loss(output, target, plan.sample_task, self.net.num_tasks)
+        else:
+            loss_nomean = self.criterion(output, target)
+            loss = torch.mean(loss_nomean)
+            loss_sample = torch.mean(loss_nomean.detach(), dim=(1, 2, 3, 4))
+            task_mean = task_count = None
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
         self.optimizer.step()
-        loss_sample = torch.mean(loss_nomean.detach(), dim=(1, 2, 3, 4))
         self.last_loss = loss.detach()
+        self._last_log = (self.last_loss, loss_sample, task_mean, task_count, plan.tasks_host)
         return output.detach(), loss_sample
+
+    def loss_log(self):
+        """The dict the reference hands to ``wandb.log`` and its per-sample DataFrame (fnet_model.py:115-130) for the last
+        ``do_train_iter``.  The values were computed on the device during the step; THIS call copies them to the host
+        (one synchronisation, when and if the caller wants the numbers -- the reference pays ~4 per iteration)."""
+        import pandas as pd
+        loss, loss_sample, task_mean, task_count, tasks = self._last_log
+        names = self.opts.adopted_datasets
+        per = loss_sample.float().cpu().numpy()
+        log = {'X-axis/iter': self.count_iter, 'loss/iter': float(loss)}     # (count_iter is the caller's: main.py:250 sets it before the call)
+        if task_mean is not None:
+            tm = task_mean.cpu().numpy()
+            for i in sorted(set(tasks)):
+                log['loss_iter/%s' % names[i]] = float(tm[i])
+        else:
+            for i in sorted(set(tasks)):
+                log['loss_iter/%s' % names[i]] = float(per[[j for j, t in enumerate(tasks) if t == i]].mean())
+        frame = pd.DataFrame({'dataset': [names[i] for i in tasks], 'loss': list(per)})
+        return log, frame
 
     def do_train_iter(self, signal, target, task, sync=False, eager=False):
         """One optimisation step.  ``task`` should be a CPU int tensor (as the DataLoader yields it):
@@ -160,7 +189,6 @@ class Model(object):
             output, loss_sample = self._graph_train_iter(signal, target, task)
         else:
             output, loss_sample = self._train_step(signal, target, task)
-        self.count_iter += 1
         if sync:
             return output.cpu(), loss_sample.cpu()
         return output, loss_sample
@@ -205,6 +233,7 @@ class Model(object):
             with torch.cuda.graph(graph, stream=cs, pool=self._graph_pool):
                 st['out'] = self._train_step(st['signal'], st['target'], st['plan'])
             st['graph'], st['last_loss'] = graph, self.last_loss
+            st['log'] = self._last_log[:4]
             st['plan'].bn_counted = False
         else:
             st['signal'].copy_(signal, non_blocking=True)
@@ -218,6 +247,7 @@ class Model(object):
             sp.tasks_host, sp.slot_task_host = new.tasks_host, new.slot_task_host
         st['graph'].replay()
         self.last_loss = st['last_loss']
+        self._last_log = st['log'] + (host,)
         return st['out']
 
     # ---- sliding-window inference: fnet_model.py:149-223

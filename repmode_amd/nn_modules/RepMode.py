@@ -217,6 +217,8 @@ class Net(torch.nn.Module):
             if counters:
                 torch._foreach_add_(counters, 1)
             plan.bn_counted = True
+        if self.training:
+            self._prepare_filters(x, plan)
         x, s1 = self.encoder_block1(x, plan)
         x, s2 = self.encoder_block2(x, plan)
         x, s3 = self.encoder_block3(x, plan)
@@ -226,4 +228,28 @@ class Net(torch.nn.Module):
         x = self.decoder_block3(x, s3, plan)
         x = self.decoder_block2(x, s2, plan)
         x = self.decoder_block1(x, s1, plan)
-        return self.conv_out(x, plan).float()
+        y = self.conv_out(x, plan).float()
+        if self.training:
+            ops.torch_ops().finish_prepared(y)
+        return y
+
+    def _prepare_filters(self, x, plan):
+        """The forward filters of all 19 MoDE blocks depend on the parameters and the batch's tasks only: their gate softmax +
+        GatRep (or expert layout) launches are issued now, on the library's preparation stream, and run beside the first
+        convolutions instead of in front of each block (csrc/torch/repmode_ops.cpp: prepare_filters)."""
+        blocks = getattr(self, '_mode_blocks', None)
+        if blocks is None:
+            e, d = 'encoder_block%d', 'decoder_block%d'
+            order = [(getattr(self, e % (l + 1)).conv_more, l) for l in range(4)] + [(self.bottle_block, 4)] + \
+                    [(getattr(self, d % (l + 1)).conv_less, l) for l in (3, 2, 1, 0)]
+            blocks = [(c, l) for sub, l in order for c in (sub.conv1, sub.conv2)] + [(self.conv_out, 0)]
+            object.__setattr__(self, '_mode_blocks', blocks)
+        grad = torch.is_grad_enabled()
+        mods = [b for b, _ in blocks]
+        need_dx = [int(grad and (i > 0 or x.requires_grad)) for i in range(len(mods))]
+        dtype = _resolve_dtype(x, self.compute_dtype)
+        ops.torch_ops().prepare_filters(
+            [m.expert_conv5x5_conv for m in mods], [m.expert_conv3x3_conv for m in mods], [m.expert_conv1x1_conv for m in mods],
+            [m.expert_avg3x3_conv for m in mods], [m.expert_avg5x5_conv for m in mods], [m.gate.weight for m in mods],
+            [m.gate.bias for m in mods], [x.shape[-1] >> l for _, l in blocks], need_dx, plan.slot_task, plan.sample_slot,
+            plan.sample_task, plan.nslots, plan.num_tasks, plan.training, ops.dtype_code(dtype))

@@ -73,6 +73,17 @@ def get_fork_max_w():
     return int(torch_ops().get_fork_max_w())
 
 
+def set_overlap(on):
+    """Overlap of the HBM-bound GatRep kernels with the convolutions on the library's own streams (the step's filter
+    preparation beside the first convolutions, a layer's GatRep backward beside its data-gradient conv).  On by default
+    (REPMODE_OVERLAP=0 turns it off); switched off to time launches one by one."""
+    torch_ops().set_overlap(bool(on))
+
+
+def get_overlap():
+    return bool(torch_ops().get_overlap())
+
+
 class ZeroPool:
     """One pre-zeroed buffer per train step for the float accumulation targets of the atomics-based kernels (split-K
     conv outputs, chunked filter gradients): ~60 memset launches per step become one.  The state lives in the operator

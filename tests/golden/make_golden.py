@@ -292,8 +292,21 @@ def capture_data_aug(name):
     """``SSPDataset.data_aug`` (SSPdataset.py:137-155) called unbound on a plain namespace carrying the two attributes it
     reads (patch_size, random_flip_prob).  The module imports tifffile / pandas helpers that this image lacks, so it is
     loaded with ``tifffile`` absent-safe: only the function object is used."""
-    for mod in ('tifffile', 'wandb'):
-        sys.modules.setdefault(mod, types.SimpleNamespace(log=lambda *a, **k: None, imread=None, imsave=None))
+    # the data package's import chain reaches the vendored CZI / TIFF readers, whose third-party modules this image lacks;
+    # they are never CALLED on this path, so permissive empty modules stand in for them (capture script only)
+    class _Anything(types.ModuleType):
+        __path__ = []
+
+        def __getattr__(self, name):
+            if name.startswith('__'):
+                raise AttributeError(name)
+            return _Anything(self.__name__ + '.' + name)
+
+        def __call__(self, *a, **k):
+            return self
+
+    for mod in ('tifffile', 'tifffile.tifffile', 'wandb', 'czifile', 'aicsimage', 'aicsimage.io', 'lxml', 'lxml.etree'):
+        sys.modules.setdefault(mod, _Anything(mod))
     try:
         ds = importlib.import_module('fnet.data.SSPdataset')
         fn = ds.SSPDataset.data_aug

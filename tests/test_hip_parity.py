@@ -687,7 +687,7 @@ def test_train_iter_matches_reference_loss_sequence():
         out, per = m.do_train_iter(torch.from_numpy(g['xs'][s]), torch.from_numpy(g['targets'][s]), tasks, sync=True)
         assert abs(float(m.last_loss) - g['losses'][s]) < 2e-4, s
         assert np.allclose(per.numpy(), g['loss_per_sample'][s], atol=2e-4)
-    assert m.count_iter == 5
+    assert m.count_iter == 0          # the caller owns the iteration counter (main.py:250), as in the reference
 
 
 def test_train_iter_as_hip_graph_matches_reference_loss_sequence():
@@ -720,7 +720,6 @@ def test_train_iter_as_hip_graph_matches_reference_loss_sequence():
         assert abs(float(m.last_loss) - float(e.last_loss)) < 3e-3 * max(1.0, abs(float(e.last_loss))), (i, tk)
     _ops().set_fork_max_w(0)
     assert len(m._graphs) == 2 and all(v['graph'] is not None for v in m._graphs.values())
-    assert m.count_iter == nsteps + len(seq)
 
 
 def test_predict_matches_reference_blend():
@@ -969,3 +968,106 @@ def test_full_size_bf16_blocks_at_bench_config(batch, ntasks):
         assert worst[name] < TOL_BF16, (name, errs)
         del ref, ar, br, xin, yr, dev, a, b, y
     print('full-size bf16 blocks, batch %d: worst relative error %.3g (%s)' % (batch, max(worst.values()), max(worst, key=worst.get)))
+
+
+# ------------------------------------------------------------------------------------------------
+# the two ends of the train step: device-side crop + flip, fused MSE / per-task loss
+
+def test_crop_flip_matches_reference_fixture():
+    """repmode_amd.data.DeviceVolumes (one repmode_crop_flip launch per batch) against the crops the REFERENCE's own
+    SSPDataset.data_aug produced under the same numpy seeds (g6; the volume holds its own linear indices, the target its
+    negation), bit exact: a gather copies floats."""
+    from repmode_amd.data import DeviceVolumes
+    g = load_golden('g6_data_aug.npz')
+    for ci in range(int(g['ncases'])):
+        vol, patch = tuple(int(v) for v in g['case%d_vol' % ci]), tuple(int(v) for v in g['case%d_patch' % ci])
+        dv = DeviceVolumes(DEV, patch, float(g['case%d_prob' % ci]))
+        sig = np.arange(int(np.prod(vol)), dtype=np.float32).reshape(1, *vol)
+        dv.add(sig, -sig, task=ci)
+        reps = len(g['case%d_first' % ci])
+        np.random.seed(int(g['case%d_seed' % ci]))
+        s, t, task = dv.sample_batch([0] * reps, np.random)        # one launch for the whole batch, draws in sample order
+        assert tuple(s.shape) == (reps, 1) + patch and task.tolist() == [ci] * reps
+        a = s.cpu().numpy()[:, 0].astype(np.int64)
+        assert np.array_equal(a, -t.cpu().numpy()[:, 0].astype(np.int64))
+        assert np.array_equal(a[:, 0, 0, 0], g['case%d_first' % ci]) and np.array_equal(a[:, -1, -1, -1], g['case%d_last' % ci])
+        assert np.array_equal(a[:, 1, 0, 0], g['case%d_nz' % ci]) and np.array_equal(a[:, 0, 1, 0], g['case%d_ny' % ci])
+        assert np.array_equal(a[:, 0, 0, 1], g['case%d_nx' % ci]) and np.array_equal(a.reshape(reps, -1).sum(1), g['case%d_sum' % ci])
+
+
+def test_crop_flip_batch_vs_oracle():
+    """A batch over several volumes of different sizes (more samples than one launch takes), every voxel against the
+    oracle's numpy restatement of data_aug under the same seed; out-of-volume crops are refused."""
+    from repmode_amd.data import DeviceVolumes
+    from repmode_amd import _lib
+    rs = np.random.RandomState(3)
+    patch = (8, 16, 24)
+    vols = [(9, 17, 24), (20, 33, 47), (8, 16, 24), (12, 40, 31)]
+    dv = DeviceVolumes(DEV, patch, 0.5)
+    host = []
+    for i, v in enumerate(vols):
+        s, t = rs.randn(1, *v).astype(np.float32), rs.randn(1, *v).astype(np.float32)
+        host.append((s, t))
+        dv.add(s, t, task=i % 12)
+    idx = [int(i) for i in rs.randint(0, len(vols), size=40)]
+    s, t, task = dv.sample_batch(idx, np.random.RandomState(77))
+    ref_rng = np.random.RandomState(77)
+    for n, i in enumerate(idx):
+        a, b = orc.data_aug(host[i][0], host[i][1], patch, 0.5, ref_rng)
+        assert np.array_equal(s[n].cpu().numpy(), a) and np.array_equal(t[n].cpu().numpy(), b), n
+    assert task.tolist() == [i % 12 for i in idx]
+    with pytest.raises(_lib.RepModeHipError, match='leaves its volume'):
+        dv.crop_flip([0], [[2, 0, 0]], [0])
+
+
+@pytest.mark.parametrize('n,shape,tasks', [(3, (4, 8, 8), [3, 7, 3]), (8, (32, 64, 64), [1, 11, 4, 0, 7, 9, 2, 6]), (1, (3, 5, 7), [5])])
+def test_fused_mse_loss(n, shape, tasks):
+    """torch.ops.repmode.mse_loss (one pass + finish kernel) against MSELoss('none') -> mean, its autograd, the per-sample
+    means and the per-task means of fnet_model.py:108-122 (oracle.loss_log)."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(n + sum(shape))
+    out = torch.randn(n, 1, *shape, generator=gen)
+    tgt = torch.randn(n, 1, *shape, generator=gen)
+    ro = out.clone().requires_grad_(True)
+    ln = torch.nn.functional.mse_loss(ro, tgt, reduction='none')
+    (ln.mean() * 3.0).backward()
+    per = ln.detach().mean(dim=(1, 2, 3, 4))
+    d = out.to(DEV).requires_grad_(True)
+    plan = ops.TaskPlan(tasks, 12, DEV, training=True)
+    loss, loss_sample, task_mean, task_count = ops.torch_ops().mse_loss(d, tgt.to(DEV), plan.sample_task, 12)
+    (loss * 3.0).backward()
+    assert rel_err(loss.cpu(), ln.mean().detach()) < 1e-5
+    assert rel_err(loss_sample.cpu(), per) < 1e-5
+    assert rel_err(d.grad.cpu(), ro.grad) < 1e-5
+    log = orc.loss_log(per.numpy(), tasks, Opts.adopted_datasets, 0)
+    for i in range(12):
+        key = 'loss_iter/%s' % Opts.adopted_datasets[i]
+        assert float(task_count[i]) == tasks.count(i)
+        if key in log:
+            assert abs(float(task_mean[i]) - log[key]) < 1e-5 * max(1.0, abs(log[key]))
+    # a second call (the accumulator must have been left clear), without autograd
+    with torch.no_grad():
+        l2 = ops.torch_ops().mse_loss(d.detach(), tgt.to(DEV), plan.sample_task, 12)[0]
+    assert rel_err(l2.cpu(), ln.mean().detach()) < 1e-5
+
+
+@pytest.mark.timeout(600)
+def test_full_size_train_iter_scalars_match_reference():
+    """G4b: the scalars of the REAL fnet_model.Model.do_train_iter at mult_chan 32 (seed 0, Adam lr 1e-3, two
+    steps on three 16x64x64 patches, tasks 3, 7, 3) against repmode_amd.Model on the float32 HIP path from the same
+    seed: losses within 1e-3 relative, per-sample losses, the per-sample DataFrame and the dict the reference logs."""
+    from repmode_amd.model import Model
+    g = load_golden('g4b_model_train_iter.npz')
+    torch.manual_seed(0)
+    m = Model(Opts(), nn_module='RepMode', lr=float(g['lr']), gpu_ids=0, mult_chan=32, dtype=torch.float32)
+    tasks = torch.from_numpy(g['tasks'])
+    keys = [str(k) for k in g['log_keys']]
+    for s in range(len(g['losses'])):
+        out, per = m.do_train_iter(torch.from_numpy(g['xs'][s]), torch.from_numpy(g['targets'][s]), tasks, sync=True)
+        log, frame = m.loss_log()
+        assert abs(log['loss/iter'] - g['losses'][s]) < 1e-3 * abs(g['losses'][s]), (s, log['loss/iter'], g['losses'][s])
+        assert np.allclose(per.numpy(), g['loss_per_sample'][s], rtol=1e-3)
+        assert sorted(log) == keys and log['X-axis/iter'] == 0      # (the caller owns count_iter; the capture left it at 0)
+        assert np.allclose([log[k] for k in keys], g['log_values'][s], rtol=1e-3)
+        assert list(frame['dataset']) == [str(d) for d in g['df_dataset']] and np.allclose(frame['loss'], g['loss_per_sample'][s], rtol=1e-3)
+        assert abs(float(out.double().abs().sum()) - g['output_abs_sum'][s]) < 1e-3 * g['output_abs_sum'][s]

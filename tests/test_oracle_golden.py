@@ -163,3 +163,57 @@ def test_predict_blend():
     pred = orc.predict(net, torch.from_numpy(g['blend_signal']), torch.tensor([int(g['blend_task'])]),
                        (16, 32, 32), 2)
     assert rel_err(pred, g['blend_pred']) < 1e-4
+
+
+def test_data_aug_matches_reference_fixture():
+    """The oracle's restatement of SSPDataset.data_aug against crops captured by calling the reference's own method under
+    the same numpy seeds (g6): same starts, same flips, same voxels (the volume holds its own linear indices)."""
+    g = load_golden('g6_data_aug.npz')
+    for ci in range(int(g['ncases'])):
+        vol, patch = tuple(int(v) for v in g['case%d_vol' % ci]), tuple(int(v) for v in g['case%d_patch' % ci])
+        sig = np.arange(int(np.prod(vol)), dtype=np.float32).reshape(1, *vol)
+        np.random.seed(int(g['case%d_seed' % ci]))
+        for rep in range(len(g['case%d_first' % ci])):
+            a, b = orc.data_aug(sig, -sig, patch, float(g['case%d_prob' % ci]), np.random)
+            a = a[0].astype(np.int64)
+            assert np.array_equal(a, -b[0].astype(np.int64))
+            assert a[0, 0, 0] == g['case%d_first' % ci][rep] and a[-1, -1, -1] == g['case%d_last' % ci][rep]
+            assert a[1, 0, 0] == g['case%d_nz' % ci][rep] and a[0, 1, 0] == g['case%d_ny' % ci][rep] and a[0, 0, 1] == g['case%d_nx' % ci][rep]
+            assert a.sum() == g['case%d_sum' % ci][rep]
+
+
+def test_host_sampler_draws_like_the_oracle():
+    """repmode_amd.data.draw_augmentation consumes numpy's generator exactly like data_aug: same starts and flips."""
+    from repmode_amd.data import draw_augmentation
+    vol, patch = (40, 100, 120), (32, 64, 64)
+    sig = np.arange(int(np.prod(vol)), dtype=np.float32).reshape(1, *vol)
+    np.random.seed(5)
+    want = [orc.data_aug(sig, -sig, patch, 0.5, np.random)[0][0] for _ in range(8)]
+    np.random.seed(5)
+    for w in want:
+        starts, mask = draw_augmentation(vol, patch, 0.5, np.random)
+        crop = sig[0][starts[0]:starts[0] + patch[0], starts[1]:starts[1] + patch[1], starts[2]:starts[2] + patch[2]]
+        for axis in range(3):
+            if mask >> axis & 1:
+                crop = np.flip(crop, axis)
+        assert np.array_equal(crop, w)
+
+
+def test_full_size_train_iter_scalars_match_reference():
+    """G4b: the REAL fnet_model.Model.do_train_iter (mult_chan 32, seed 0, lr 1e-3) for two steps -- losses, per-sample
+    losses and the logged dict -- reproduced by the oracle's network + train_step from the same seed (the initial state
+    is bit-identical: test_host_cpu.py::test_seeded_init_matches_reference_fixture)."""
+    g = load_golden('g4b_model_train_iter.npz')
+    torch.manual_seed(0)
+    net = orc.Net(Opts(), mult_chan=32)
+    opt = torch.optim.Adam(net.parameters(), lr=float(g['lr']))
+    net.train()
+    tasks = torch.from_numpy(g['tasks'])
+    keys = [str(k) for k in g['log_keys']]
+    for s in range(len(g['losses'])):
+        loss, per = orc.train_step(net, opt, torch.from_numpy(g['xs'][s]), torch.from_numpy(g['targets'][s]), tasks)
+        assert abs(float(loss) - g['losses'][s]) < 1e-4 * abs(g['losses'][s]), s
+        assert np.allclose(per.numpy(), g['loss_per_sample'][s], rtol=1e-4)
+        log = orc.loss_log(per.numpy(), tasks.tolist(), Opts.adopted_datasets, 0)   # (count_iter is the caller's; left at 0)
+        assert sorted(log) == keys
+        assert np.allclose([log[k] for k in keys], g['log_values'][s], rtol=1e-4)

@@ -1,0 +1,14 @@
+set -x
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2d; rm -rf $O; mkdir -p $O
+cd $R
+timeout 1500 python -m pytest tests -m gpu -x -q --durations=5 > $O/pytest.log 2>&1; tail -12 $O/pytest.log
+for rep in 1 2; do
+REPMODE_OVERLAP=0 timeout 300 python bench.py --no-cpu-baseline --no-fwd --steps 60 --warmup 20 > $O/bench_nooverlap_$rep.json 2>> $O/bench.err; cut -c1-330 $O/bench_nooverlap_$rep.json
+timeout 300 python bench.py --no-cpu-baseline --no-fwd --steps 60 --warmup 20 > $O/bench_overlap_$rep.json 2>> $O/bench.err; cut -c1-330 $O/bench_overlap_$rep.json
+done
+timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_driver.json 2>> $O/bench.err; cut -c1-1800 $O/bench_driver.json
+tail -3 $O/bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/bench.py --no-cpu-baseline --no-prof --no-fwd --steps 10 --warmup 3 > $O/trace.log 2>&1
+cd $R; python profiles/analyze_trace.py $O/trace 13 > $O/trace_summary.txt 2>&1; head -70 $O/trace_summary.txt
+rm -rf $O/trace
