@@ -102,6 +102,18 @@ int repmode_conv5_pair(const void* x, const void* x2, int cin1, const void* w, c
                        void* y2, int cout1, int n, int d, int h, int wdim, int cin, int cout, int dtype, int out_f32,
                        int flags, void* stream);
 
+/* The forward conv of a MoDE block with an epilogue that takes over part of the BatchNorm3d + ReLU behind it
+ * (RepMode.py:146-149, 212).  Inputs as repmode_conv5_pair (cin1 == 0: one tensor), one output, flags as repmode_conv5_ex.
+ *   bias != NULL and / or relu: y = max(conv + bias[co], 0) -- an eval-mode BatchNorm whose scale gamma / sqrt(var + eps)
+ *     was folded into the merged filter (through the gate probabilities) and whose shift is `bias`.  The reduction is
+ *     then never split over workgroups.
+ *   want_stats (bf16 input, bf16 output): the per-channel sum and sum of squares of the STORED outputs are accumulated
+ *     into the library's BatchNorm scratch as the launch's epilogue; *stats_half receives the value to pass to
+ *     repmode_bn_relu_fwd_ex, which must be the next BatchNorm call on the same stream and then runs no statistics pass. */
+int repmode_conv5_epi(const void* x, const void* x2, int cin1, const void* w, const int32_t* sample_slot, void* y, int n,
+                      int d, int h, int wdim, int cin, int cout, int dtype, int out_f32, int flags, const float* bias,
+                      int relu, int want_stats, int* stats_half, void* stream);
+
 /* ---- weight gradient of the same conv (aten::convolution_backward weight grad), summed over
  * the samples of each slot:  dw[s][tap][o][i] = sum_{n in s} sum_v dy[n][v][o] * x[n][v+tap][i]
  * dw: float [nslots][125][Cout][Cin], OVERWRITTEN (zeroed inside, then accumulated). */
@@ -165,6 +177,10 @@ int repmode_gatrep_bwd(const float* dw, const float* k5, const float* k3, const 
 int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
                         float* running_var, float* save_mean, float* save_invstd, long m, int c,
                         float eps, float momentum, int training, int in_dtype, int out_dtype, void* stream);
+/* Same; stats_half >= 0 (training): the statistics were produced by repmode_conv5_epi (see there), -1: as above. */
+int repmode_bn_relu_fwd_ex(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float* save_mean, float* save_invstd, long m, int c, float eps,
+                           float momentum, int training, int in_dtype, int out_dtype, int stats_half, void* stream);
 /* Backward of the same: dx (in_dtype) from dy (out_dtype); totals [2c] float output: [0..c) = dbeta,
  * [c..2c) = dgamma. */
 int repmode_bn_relu_bwd(const void* x, const void* dy, const float* gamma, const float* beta,

@@ -29,6 +29,7 @@ _SIGNATURES = {
     'repmode_conv5': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_ex': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_pair': [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_conv5_epi': [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P],
     'repmode_conv5_wgrad': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad_ex': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad_part': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -38,6 +39,7 @@ _SIGNATURES = {
     'repmode_unshift5': [_P, _P, _c.c_long, _I, _P],
     'repmode_gatrep_bwd': [_P] * 8 + [_I] * 4 + [_P] * 9,
     'repmode_bn_relu_fwd': [_P] * 8 + [_c.c_long, _I, _c.c_float, _c.c_float, _I, _I, _I, _P],
+    'repmode_bn_relu_fwd_ex': [_P] * 8 + [_c.c_long, _I, _c.c_float, _c.c_float, _I, _I, _I, _I, _P],
     'repmode_bn_relu_bwd': [_P] * 8 + [_c.c_long, _I, _I, _I, _I, _P],
     'repmode_k2s2': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_k2s2_wgrad': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

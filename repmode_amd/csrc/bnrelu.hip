@@ -370,17 +370,35 @@ int grid_for(long M, int C) {
 }  // namespace
 
 // in_dtype: dtype of x (and dx); out_dtype: dtype of out (and dy).  REPMODE_F32 / REPMODE_BF16.
+extern "C" int repmode_bn_relu_fwd_ex(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
+                                      float* running_var, float* save_mean, float* save_invstd, long m, int c, float eps,
+                                      float momentum, int training, int in_dtype, int out_dtype, int stats_half, void* stream);
+
 extern "C" int repmode_bn_relu_fwd(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
                                    float* running_var, float* save_mean, float* save_invstd, long m,
                                    int c, float eps, float momentum, int training, int in_dtype, int out_dtype,
                                    void* stream) {
+  return repmode_bn_relu_fwd_ex(x, out, gamma, beta, running_mean, running_var, save_mean, save_invstd, m, c, eps, momentum, training,
+                                in_dtype, out_dtype, -1, stream);
+}
+
+// stats_half >= 0 (training only): the batch statistics are already in that half of the library's BatchNorm scratch -- the
+// producing convolution's epilogue put them there (repmode_conv5_epi) -- so only the normalise + ReLU launch runs.
+extern "C" int repmode_bn_relu_fwd_ex(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
+                                      float* running_var, float* save_mean, float* save_invstd, long m, int c, float eps,
+                                      float momentum, int training, int in_dtype, int out_dtype, int stats_half, void* stream) {
   RM_REQUIRE(x && out && gamma && beta && running_mean && running_var && save_mean && save_invstd,
              "bn_relu_fwd: null pointer");
   RM_REQUIRE(m > 0 && c > 0 && c <= BN_MAXC, "bn_relu_fwd: bad shape (C <= %d)", BN_MAXC);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int grid = grid_for(m, c);
   float* own = nullptr;
-  if (training) {
+  RM_REQUIRE(stats_half < 0 || (training && stats_half <= 1), "bn_relu_fwd: bad statistics half %d", stats_half);
+  if (training && stats_half >= 0) {
+    float* scratch = repmode_zero_scratch(s);
+    if (!scratch) return REPMODE_ELAUNCH;
+    own = scratch + (size_t)stats_half * REPMODE_SCRATCH_BN_HALF;
+  } else if (training) {
     // partial sums: this call's half of the library's zero scratch (see slice_total)
     float* scratch = repmode_zero_scratch(s);
     if (!scratch) return REPMODE_ELAUNCH;

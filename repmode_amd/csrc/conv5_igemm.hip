@@ -93,6 +93,15 @@ struct ConvArgs {
   const void* x2;
   void* y2;
   int Cin1, Cout1;
+  // epilogue extras (repmode_conv5_epi).  bias / relu: y = max(acc + bias[co], 0) -- an eval-mode BatchNorm folded into
+  // the merged filter (scale, in the gate probabilities) and this bias (RepMode.py:209-212).  stats: per-channel sum and
+  // sum of squares of the STORED (rounded) outputs, added to slice blockIdx % 16 of a [16][2 Cout] float array -- the
+  // batch statistics of the training-mode BatchNorm that follows (RepMode.py:146-149, 212) without a read pass;
+  // stats_clear: 16 K floats this launch puts back to zero (the BatchNorm scratch half the previous call used).
+  const float* bias;
+  int relu;
+  float* stats;
+  float* stats_clear;
 };
 
 // Tile configuration.  BZ*BY*BX output voxels = 32 * WV * VW; 32 * WC * CW output channels.
@@ -394,19 +403,36 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
           const int cw = Cout1 > 0 ? (out2 ? Cout - Cout1 : Cout1) : Cout;
           float* yp = static_cast<float*>(out2 ? a.y2 : a.y) + (((size_t)(n * D + gz) * H + gy) * W + gx) * cw +
                       (out2 ? co - Cout1 : co);
-          if (a.ksplit > 1 || a.accum) unsafeAtomicAdd(yp, acc[cs][vs][r]);
-          else *yp = acc[cs][vs][r];
+          if (a.ksplit > 1 || a.accum) {
+            unsafeAtomicAdd(yp, acc[cs][vs][r]);
+          } else {
+            float v = acc[cs][vs][r];
+            if (a.bias) v += a.bias[co];
+            if (a.relu) v = fmaxf(v, 0.f);
+            *yp = v;
+          }
         }
       }
     }
   } else {
     // rows = output channels (4 consecutive per register quad), column = this lane's voxel; T output
+    const bool want_stats = a.stats != nullptr;
+    float ssum[CW][16], ssq[CW][16];
+    if (want_stats) {
+#pragma unroll
+      for (int cs = 0; cs < CW; ++cs)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ssum[cs][r] = 0.f; ssq[cs][r] = 0.f; }
+      // put the zeros back into the BatchNorm scratch half the previous call used (what bn_stats_kernel does)
+      for (int i = blockIdx.x * NT + tid; i < (int)REPMODE_SCRATCH_BN_HALF; i += gridDim.x * NT) a.stats_clear[i] = 0.f;
+    }
 #pragma unroll
     for (int vs = 0; vs < VW; ++vs) {
       const int m = (wv * VW + vs) * 32 + l31;
       const int lx = m % BX, ly = (m / BX) % BY, lz = m / (BX * BY);
       const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
-      if (gz >= D || gy >= H || gx >= W) continue;
+      const bool inside = gz < D && gy < H && gx < W;
+      if (!inside && !want_stats) continue;
       const size_t vox = ((size_t)(n * D + gz) * H + gy) * W + gx;
 #pragma unroll
       for (int cs = 0; cs < CW; ++cs) {
@@ -418,9 +444,23 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
           const int Cout_ = Cout1 > 0 ? (out2 ? Cout - Cout1 : Cout1) : Cout;
           const int co = out2 ? co_all - Cout1 : co_all;
           void* ybase = out2 ? a.y2 : a.y;
-          const float v0 = acc[cs][vs][4 * q + 0], v1 = acc[cs][vs][4 * q + 1];
-          const float v2 = acc[cs][vs][4 * q + 2], v3 = acc[cs][vs][4 * q + 3];
+          float v0 = acc[cs][vs][4 * q + 0], v1 = acc[cs][vs][4 * q + 1];
+          float v2 = acc[cs][vs][4 * q + 2], v3 = acc[cs][vs][4 * q + 3];
+          if (a.bias) {
+            v0 += a.bias[co_all];
+            if (co_all + 1 < Cout) v1 += a.bias[co_all + 1];
+            if (co_all + 2 < Cout) v2 += a.bias[co_all + 2];
+            if (co_all + 3 < Cout) v3 += a.bias[co_all + 3];
+          }
+          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
           if constexpr (sizeof(T) == 4) {
+            if (want_stats && inside) {
+              ssum[cs][4 * q + 0] += v0; ssq[cs][4 * q + 0] += v0 * v0;
+              ssum[cs][4 * q + 1] += v1; ssq[cs][4 * q + 1] += v1 * v1;
+              ssum[cs][4 * q + 2] += v2; ssq[cs][4 * q + 2] += v2 * v2;
+              ssum[cs][4 * q + 3] += v3; ssq[cs][4 * q + 3] += v3 * v3;
+            }
+            if (!inside) continue;
             float* yp = static_cast<float*>(ybase) + vox * Cout_ + co;
             if ((Cout_ & 3) == 0) {
               *reinterpret_cast<f32x4*>(yp) = f32x4{v0, v1, v2, v3};
@@ -431,15 +471,45 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
               if (co + 3 < Cout_) yp[3] = v3;
             }
           } else {
+            const uint32_t p01 = pack_bf16x2(v0, v1), p23 = pack_bf16x2(v2, v3);
+            if (want_stats && inside) {
+              // the statistics of what is stored: the bf16-rounded values the normalisation will read back
+              const float r0 = __uint_as_float(p01 << 16), r1 = __uint_as_float(p01 & 0xffff0000u);
+              const float r2 = __uint_as_float(p23 << 16), r3 = __uint_as_float(p23 & 0xffff0000u);
+              ssum[cs][4 * q + 0] += r0; ssq[cs][4 * q + 0] += r0 * r0;
+              ssum[cs][4 * q + 1] += r1; ssq[cs][4 * q + 1] += r1 * r1;
+              ssum[cs][4 * q + 2] += r2; ssq[cs][4 * q + 2] += r2 * r2;
+              ssum[cs][4 * q + 3] += r3; ssq[cs][4 * q + 3] += r3 * r3;
+            }
+            if (!inside) continue;
             bf16_t* yp = static_cast<bf16_t*>(ybase) + vox * Cout_ + co;
             if ((Cout_ & 3) == 0) {
-              *reinterpret_cast<u32x2*>(yp) = u32x2{pack_bf16x2(v0, v1), pack_bf16x2(v2, v3)};
+              *reinterpret_cast<u32x2*>(yp) = u32x2{p01, p23};
             } else {
-              yp[0] = f32_to_bf16(v0);
-              if (co + 1 < Cout_) yp[1] = f32_to_bf16(v1);
-              if (co + 2 < Cout_) yp[2] = f32_to_bf16(v2);
-              if (co + 3 < Cout_) yp[3] = f32_to_bf16(v3);
+              yp[0] = (bf16_t)(p01 & 0xffffu);
+              if (co + 1 < Cout_) yp[1] = (bf16_t)(p01 >> 16);
+              if (co + 2 < Cout_) yp[2] = (bf16_t)(p23 & 0xffffu);
+              if (co + 3 < Cout_) yp[3] = (bf16_t)(p23 >> 16);
             }
+          }
+        }
+      }
+    }
+    if (want_stats) {
+      // lanes with equal khalf hold the same 16 channels of different voxels: butterfly over the 32 lanes, then one lane
+      // per half-wave adds the wave's totals to this workgroup's slice (BatchNorm's slice layout, bnrelu.hip)
+      float* slice = a.stats + (size_t)(blockIdx.x & 15) * 2 * Cout;
+#pragma unroll
+      for (int cs = 0; cs < CW; ++cs) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float sv = ssum[cs][r], qv = ssq[cs][r];
+#pragma unroll
+          for (int off = 1; off < 32; off <<= 1) { sv += __shfl_xor(sv, off, 64); qv += __shfl_xor(qv, off, 64); }
+          const int co_all = cot * C::COT + (wc * CW + cs) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+          if (l31 == 0 && co_all < Cout) {
+            unsafeAtomicAdd(slice + co_all, sv);
+            unsafeAtomicAdd(slice + Cout + co_all, qv);
           }
         }
       }
@@ -460,9 +530,10 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   const int nchunks = a.CinP / (2 * Elem<T>::KV);
   long base = (long)a.N * a.nbz * a.nby * a.nbx * a.ncot;
   int ks = 1;
-  if (SWAP) {
+  if (SWAP && !a.bias && !a.relu) {   // (a bias / ReLU epilogue needs the whole sum in one workgroup)
     while (ks * 4 <= nchunks && base * ks < CONV_SPLIT_TARGET && ks < 64) ks *= 2;
   }
+  RM_REQUIRE(!a.stats || !SWAP, "conv5: output statistics need the element-typed output path (bf16 input, not out_f32)");
   a.ksplit = ks;
   const long grid = base * ks;
   RM_REQUIRE(grid > 0 && grid < (1L << 31), "conv5: grid %ld out of range", grid);
@@ -524,6 +595,9 @@ extern "C" int repmode_padded_channels(int channels, int dtype, int is_reduction
 extern "C" int repmode_conv5_ex(const void* x, const void* w, const int32_t* sample_slot, void* y, int n,
                                 int d, int h, int wdim, int cin, int cout, int dtype, int out_f32,
                                 int centre3, void* stream);
+static int conv5_common(const void* x, const void* x2, int cin1, const void* w, const int32_t* sample_slot, void* y, void* y2,
+                        int cout1, int n, int d, int h, int wdim, int cin, int cout, int dtype, int out_f32, int flags,
+                        const float* bias, int relu, int want_stats, int* stats_half, void* stream);
 
 extern "C" int repmode_conv5(const void* x, const void* w, const int32_t* sample_slot, void* y, int n,
                              int d, int h, int wdim, int cin, int cout, int dtype, int out_f32,
@@ -534,6 +608,9 @@ extern "C" int repmode_conv5(const void* x, const void* w, const int32_t* sample
 extern "C" int repmode_conv5_pair(const void* x, const void* x2, int cin1, const void* w, const int32_t* sample_slot,
                                   void* y, void* y2, int cout1, int n, int d, int h, int wdim, int cin, int cout,
                                   int dtype, int out_f32, int flags, void* stream);
+extern "C" int repmode_conv5_epi(const void* x, const void* x2, int cin1, const void* w, const int32_t* sample_slot, void* y,
+                                 int n, int d, int h, int wdim, int cin, int cout, int dtype, int out_f32, int flags,
+                                 const float* bias, int relu, int want_stats, int* stats_half, void* stream);
 
 extern "C" int repmode_conv5_ex(const void* x, const void* w, const int32_t* sample_slot, void* y, int n,
                                 int d, int h, int wdim, int cin, int cout, int dtype, int out_f32,
@@ -550,6 +627,30 @@ extern "C" int repmode_conv5_ex(const void* x, const void* w, const int32_t* sam
 extern "C" int repmode_conv5_pair(const void* x, const void* x2, int cin1, const void* w, const int32_t* sample_slot,
                                   void* y, void* y2, int cout1, int n, int d, int h, int wdim, int cin, int cout,
                                   int dtype, int out_f32, int flags, void* stream) {
+  return conv5_common(x, x2, cin1, w, sample_slot, y, y2, cout1, n, d, h, wdim, cin, cout, dtype, out_f32, flags, nullptr, 0, 0,
+                      nullptr, stream);
+}
+
+// The forward conv of a MoDE block with an epilogue that takes over part of the BatchNorm3d + ReLU behind it
+// (RepMode.py:146-149, 212).  One or two input tensors (cin1 as repmode_conv5_pair), one output.
+//   bias != NULL / relu: y = max(conv + bias[co], 0): an eval-mode BatchNorm whose scale was folded into the merged filter.
+//   want_stats (bf16 input, element-typed output only): per-channel sum / sum of squares of the stored outputs go to the
+//     library's BatchNorm scratch; *stats_half receives the half to hand to repmode_bn_relu_fwd_ex, which then skips its
+//     own statistics pass.  The two calls must follow each other on the same stream.
+extern "C" int repmode_conv5_epi(const void* x, const void* x2, int cin1, const void* w, const int32_t* sample_slot, void* y,
+                                 int n, int d, int h, int wdim, int cin, int cout, int dtype, int out_f32, int flags,
+                                 const float* bias, int relu, int want_stats, int* stats_half, void* stream) {
+  RM_REQUIRE(!want_stats || stats_half, "conv5_epi: stats_half must be given with want_stats");
+  RM_REQUIRE(!want_stats || (dtype == REPMODE_BF16 && !out_f32), "conv5_epi: statistics need bf16 in and out");
+  RM_REQUIRE(!want_stats || cout <= 512, "conv5_epi: statistics for at most 512 channels");
+  RM_REQUIRE(!(flags & 2) || !(bias || relu), "conv5_epi: bias / ReLU cannot be applied to an accumulating output");
+  return conv5_common(x, x2, cin1, w, sample_slot, y, nullptr, 0, n, d, h, wdim, cin, cout, dtype, out_f32, flags, bias, relu,
+                      want_stats, stats_half, stream);
+}
+
+static int conv5_common(const void* x, const void* x2, int cin1, const void* w, const int32_t* sample_slot, void* y, void* y2,
+                        int cout1, int n, int d, int h, int wdim, int cin, int cout, int dtype, int out_f32, int flags,
+                        const float* bias, int relu, int want_stats, int* stats_half, void* stream) {
   RM_REQUIRE(x && w && sample_slot && y, "conv5: null pointer");
   RM_REQUIRE(n > 0 && d > 0 && h > 0 && wdim > 0 && cin > 0 && cout > 0, "conv5: bad shape");
   RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "conv5: bad dtype %d", dtype);
@@ -576,6 +677,16 @@ extern "C" int repmode_conv5_pair(const void* x, const void* x2, int cin1, const
   a.dxc = (flags & 4) ? 1 : 0;
   RM_REQUIRE(!a.accum || a.out_f32, "conv5: accumulation needs a float output");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  a.bias = bias;
+  a.relu = relu ? 1 : 0;
+  if (want_stats) {
+    float* scratch = repmode_zero_scratch(s);
+    if (!scratch) return REPMODE_ELAUNCH;
+    const int half = repmode_bn_scratch_half(s);
+    a.stats = scratch + (size_t)half * REPMODE_SCRATCH_BN_HALF;
+    a.stats_clear = scratch + (size_t)(1 - half) * REPMODE_SCRATCH_BN_HALF;
+    *stats_half = half;
+  }
   if (dtype == REPMODE_F32) return dispatch<float, true>(a, s);
   if (a.out_f32) return dispatch<bf16_t, true>(a, s);
   return dispatch<bf16_t, false>(a, s);

@@ -241,10 +241,19 @@ struct Fork {
 inline bool forks(const Tensor& x_cl) { return x_cl.size(3) > 0 && x_cl.size(3) <= g_fork_max_w; }
 // Overlap of the HBM-bound GatRep kernels with the MFMA-bound convolutions (second stream): the forward's filter
 // preparation of all blocks at the start of the step (op prepare_filters), and a layer's GatRep backward beside its
-// data-gradient conv.  On by default; bench.py switches it off on the steps whose launches it times one by one.
+// data-gradient conv.  OFF by default (REPMODE_OVERLAP=1 / set_overlap): measured on one box, interleaved, 60 steps each,
+// 13.71 / 13.72 ms per step without and 13.94 / 13.94 ms with -- a conv launch holds every CU's LDS and registers with
+// two resident workgroups, so the GatRep workgroups only get in as the conv drains (gatrep_bwd: 30 -> 179 us per launch
+// under rocprofv3) and the layer's join then waits for them.
+// BatchNorm work taken over by the forward conv's epilogue (Epi); REPMODE_BN_EPILOGUE=0 / set_bn_epilogue(false): the
+// separate kernels only (A/B measurements, and the reference point of the parity tests)
+bool g_bn_epilogue = []() {
+  const char* e = std::getenv("REPMODE_BN_EPILOGUE");
+  return e ? std::atoi(e) != 0 : true;
+}();
 bool g_overlap = []() {
   const char* e = std::getenv("REPMODE_OVERLAP");
-  return e ? std::atoi(e) != 0 : true;
+  return e ? std::atoi(e) != 0 : false;
 }();
 
 // ------------------------------------------------------------------------------------------------------------
@@ -295,9 +304,20 @@ std::pair<Tensor, Tensor> expert_frags(const Tensor& k5, const Tensor& k3, at::S
   return {wf, wd};
 }
 
+// What the forward conv's epilogue takes over from the BatchNorm3d + ReLU behind it (RepMode.py:146-149, 212).
+struct Epi {
+  bool stats = false;   // training: accumulate the BatchNorm batch statistics of the stored outputs (no separate read pass)
+  Tensor scale, bias;   // eval: the BatchNorm folded -- scale into the gate probabilities (hence the merged filter),
+  bool relu = false;    //       bias + ReLU into the epilogue
+  bool any() const { return stats || bias.defined() || relu; }
+};
+// the BatchNorm-scratch half the last statistics-producing conv of this thread used (-1: none pending); consumed by the
+// BatchNorm forward that follows it
+thread_local int tl_stats_half = -1;
+
 // y[n] = x[n] (*) w[sample_slot[n]], 5^3 'same' cross-correlation, NDHWC -- RepMode.py:204-210
 Tensor conv5(const Tensor& x_cl, const Tensor& w, const Tensor& sample_slot, int64_t cout, bool out_f32, OptTensor out = c10::nullopt,
-             bool centre3 = false, bool accumulate = false, bool dxc = false) {
+             bool centre3 = false, bool accumulate = false, bool dxc = false, const Epi* epi = nullptr) {
   const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), wd_ = x_cl.size(3), cin = x_cl.size(4);
   const int code = dtype_code(x_cl.scalar_type());
   const at::ScalarType odt = (out_f32 || x_cl.scalar_type() == at::kFloat) ? at::kFloat : x_cl.scalar_type();
@@ -314,9 +334,19 @@ Tensor conv5(const Tensor& x_cl, const Tensor& w, const Tensor& sample_slot, int
   }
   TORCH_CHECK(y.scalar_type() == odt && y.is_contiguous(), "conv5: bad output tensor");
   TORCH_CHECK(!accumulate || odt == at::kFloat, "conv5: accumulation needs a float output");
+  const int flags = (centre3 ? 1 : 0) | (accumulate ? 2 : 0) | (dxc ? 4 : 0);
+  if (epi && epi->any()) {
+    const bool stats = epi->stats && odt == at::kBFloat16;
+    // (a pool tensor is pre-zeroed for atomics; a bias / ReLU epilogue overwrites instead: drop the accumulate flag)
+    int half = -1;
+    RM_CALL(repmode_conv5_epi, x_cl.data_ptr(), nullptr, 0, w.data_ptr(), sample_slot.data_ptr<int32_t>(), y.data_ptr(), (int)n, (int)d,
+            (int)h, (int)wd_, (int)cin, (int)cout, code, odt == at::kFloat ? 1 : 0, (epi->bias.defined() || epi->relu) ? (flags & ~2) : flags,
+            epi->bias.defined() ? epi->bias.data_ptr<float>() : nullptr, epi->relu ? 1 : 0, stats ? 1 : 0, &half, stream_handle());
+    tl_stats_half = stats ? half : -1;
+    return y;
+  }
   RM_CALL(repmode_conv5_ex, x_cl.data_ptr(), w.data_ptr(), sample_slot.data_ptr<int32_t>(), y.data_ptr(), (int)n, (int)d, (int)h,
-          (int)wd_, (int)cin, (int)cout, code, odt == at::kFloat ? 1 : 0, (centre3 ? 1 : 0) | (accumulate ? 2 : 0) | (dxc ? 4 : 0),
-          stream_handle());
+          (int)wd_, (int)cin, (int)cout, code, odt == at::kFloat ? 1 : 0, flags, stream_handle());
   return y;
 }
 
@@ -336,8 +366,8 @@ Tensor shift5(const Tensor& t_cl) {
 }
 
 // conv5 for a ONE-channel input: the five x taps become channels, 25 instead of 125 taps (csrc/thin.hip)
-Tensor thin_conv_in1(const Tensor& x_cl, const Tensor& w, const Tensor& sample_slot, int64_t cout, bool out_f32) {
-  return conv5(shift5(x_cl.contiguous()), thin_pack(w, false), sample_slot, cout, out_f32, c10::nullopt, false, false, true);
+Tensor thin_conv_in1(const Tensor& x_cl, const Tensor& w, const Tensor& sample_slot, int64_t cout, bool out_f32, const Epi* epi = nullptr) {
+  return conv5(shift5(x_cl.contiguous()), thin_pack(w, false), sample_slot, cout, out_f32, c10::nullopt, false, false, true, epi);
 }
 
 // conv5 for ONE output channel: the five x taps become output rows, then a 5-tap diagonal sum.  float [N,D,H,W,1]
@@ -402,7 +432,7 @@ Tensor box_sum(const Tensor* in3, const Tensor* in5, const Tensor* add0, const T
 struct EvalKey {
   void* k5;
   int64_t task;
-  int dt;
+  int dt;      // element type, + 64 when an eval-mode BatchNorm scale is folded into the filter
   bool operator==(const EvalKey& o) const { return k5 == o.k5 && task == o.task && dt == o.dt; }
 };
 struct EvalKeyHash {
@@ -448,10 +478,14 @@ bool take_prepared(const Tensor& k5, int64_t rows, at::ScalarType dt, bool unmer
   out->wd = want_wd ? e.wd : Tensor();
   return true;
 }
+// fold_scale (eval only): per-output-channel factor gamma / sqrt(running_var + eps) of the BatchNorm behind the block; it
+// multiplies the gate probabilities, which multiply the experts per output channel -- so the merged filter comes out
+// scaled with no change to the GatRep kernel.
 Merged merged_filters(const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3, const Tensor& a5, const Tensor& gw,
-                      const Tensor& gb, const Plan& plan, at::ScalarType dt, bool want_wd, bool grad_enabled) {
+                      const Tensor& gb, const Plan& plan, at::ScalarType dt, bool want_wd, bool grad_enabled,
+                      const Tensor* fold_scale = nullptr) {
   const bool cacheable = !(plan.training || want_wd || grad_enabled);
-  EvalKey key{k5.data_ptr(), plan.task0, (int)dt};
+  EvalKey key{k5.data_ptr(), plan.task0, (int)dt + (fold_scale ? 64 : 0)};
   if (cacheable) {
     std::lock_guard<std::mutex> lock(g_eval_mu);
     if (g_eval_depth > 0) {
@@ -460,8 +494,9 @@ Merged merged_filters(const Tensor& k5, const Tensor& k3, const Tensor& k1, cons
     }
   }
   Merged m;
-  if (take_prepared(k5, plan.nslots, dt, false, want_wd, &m)) return m;
+  if (!fold_scale && take_prepared(k5, plan.nslots, dt, false, want_wd, &m)) return m;
   m.g = gate_softmax(gw, gb, plan.slot_task, plan.nslots, plan.num_tasks, k5.size(0));
+  if (fold_scale) m.g = m.g * fold_scale->view({1, 1, -1});
   auto w = gatrep_merge(k5, k3, k1, a3, a5, m.g, dt, true, want_wd);
   m.wf = w.first;
   m.wd = w.second;
@@ -494,20 +529,23 @@ std::vector<Tensor> filter_and_expert_grads(const Tensor& dw, const Tensor& k5, 
 // Fused gate-softmax + GatRep + per-slot 5^3 convolution (the "merged" formulation), forward and backward.
 struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
   static Tensor forward(AutogradContext* ctx, Tensor x_cl, Tensor k5, Tensor k3, Tensor k1, Tensor a3, Tensor a5, Tensor gw, Tensor gb,
-                        Plan plan, bool out_f32, bool grad_enabled) {
+                        Plan plan, bool out_f32, bool grad_enabled, Epi epi) {
     const int64_t co = k5.size(0), ci = k5.size(1);
     const bool need_dx = grad_enabled && x_cl.requires_grad();
     // the data-gradient filter comes out of the same pass over the experts (one launch, one read of the weights)
-    Merged m = merged_filters(k5, k3, k1, a3, a5, gw, gb, plan, x_cl.scalar_type(), need_dx, grad_enabled);
+    Merged m = merged_filters(k5, k3, k1, a3, a5, gw, gb, plan, x_cl.scalar_type(), need_dx, grad_enabled,
+                              epi.scale.defined() ? &epi.scale : nullptr);
     const bool thin = x_cl.scalar_type() == at::kBFloat16 && ((ci == 1) != (co == 1));
     Tensor y;
+    tl_stats_half = -1;
     if (thin && ci == 1) {                                 // first layer: x taps folded into input channels
-      y = thin_conv_in1(x_cl, m.wf, plan.sample_slot, co, out_f32);
+      y = thin_conv_in1(x_cl, m.wf, plan.sample_slot, co, out_f32, &epi);
     } else if (thin) {                                     // last layer: x taps folded into output rows
+      TORCH_CHECK(!epi.any(), "the one-output-channel layer has no BatchNorm to take over");
       y = thin_conv_out1(x_cl, m.wf, plan.sample_slot);
       if (!out_f32) y = y.to(x_cl.scalar_type());
     } else {
-      y = conv5(x_cl, m.wf, plan.sample_slot, co, out_f32);
+      y = conv5(x_cl, m.wf, plan.sample_slot, co, out_f32, c10::nullopt, false, false, false, &epi);
     }
     ctx->save_for_backward({x_cl, k5, k3, k1, a3, a5, m.g, m.wd.defined() ? m.wd : Tensor()});
     ctx->saved_data["slot_task"] = plan.slot_task;
@@ -551,7 +589,7 @@ struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
       if (dx.scalar_type() != dt) dx = dx.to(dt);
     }
     fork.join();
-    return {dx, pg[0], pg[1], pg[2], pg[3], pg[4], pg[5], pg[6], Tensor(), Tensor(), Tensor()};
+    return {dx, pg[0], pg[1], pg[2], pg[3], pg[4], pg[5], pg[6], Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -559,11 +597,13 @@ struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
 // torch.cat((x_skip, up), 1)), which is never materialised (repmode_conv5_pair, repmode_conv5_wgrad_part).
 struct ModeConvPair : public torch::autograd::Function<ModeConvPair> {
   static Tensor forward(AutogradContext* ctx, Tensor xa, Tensor xb, Tensor k5, Tensor k3, Tensor k1, Tensor a3, Tensor a5, Tensor gw,
-                        Tensor gb, Plan plan, bool out_f32, bool grad_enabled) {
+                        Tensor gb, Plan plan, bool out_f32, bool grad_enabled, Epi epi) {
     const int64_t co = k5.size(0), ci = k5.size(1), ca = xa.size(4);
     const int64_t n = xa.size(0), d = xa.size(1), h = xa.size(2), w_ = xa.size(3);
     const bool need_dx = grad_enabled && (xa.requires_grad() || xb.requires_grad());
-    Merged m = merged_filters(k5, k3, k1, a3, a5, gw, gb, plan, xa.scalar_type(), need_dx, grad_enabled);
+    Merged m = merged_filters(k5, k3, k1, a3, a5, gw, gb, plan, xa.scalar_type(), need_dx, grad_enabled,
+                              epi.scale.defined() ? &epi.scale : nullptr);
+    tl_stats_half = -1;
     const int code = dtype_code(xa.scalar_type());
     const at::ScalarType odt = (out_f32 || xa.scalar_type() == at::kFloat) ? at::kFloat : xa.scalar_type();
     int flags = 0;
@@ -575,8 +615,17 @@ struct ModeConvPair : public torch::autograd::Function<ModeConvPair> {
     } else {
       y = at::empty({n, d, h, w_, co}, xa.options().dtype(odt));
     }
-    RM_CALL(repmode_conv5_pair, xa.data_ptr(), xb.data_ptr(), (int)ca, m.wf.data_ptr(), plan.sample_slot.data_ptr<int32_t>(), y.data_ptr(),
-            nullptr, 0, (int)n, (int)d, (int)h, (int)w_, (int)ci, (int)co, code, odt == at::kFloat ? 1 : 0, flags, stream_handle());
+    if (epi.any()) {
+      const bool stats = epi.stats && odt == at::kBFloat16;
+      int half = -1;
+      RM_CALL(repmode_conv5_epi, xa.data_ptr(), xb.data_ptr(), (int)ca, m.wf.data_ptr(), plan.sample_slot.data_ptr<int32_t>(), y.data_ptr(),
+              (int)n, (int)d, (int)h, (int)w_, (int)ci, (int)co, code, odt == at::kFloat ? 1 : 0, (epi.bias.defined() || epi.relu) ? 0 : flags,
+              epi.bias.defined() ? epi.bias.data_ptr<float>() : nullptr, epi.relu ? 1 : 0, stats ? 1 : 0, &half, stream_handle());
+      tl_stats_half = stats ? half : -1;
+    } else {
+      RM_CALL(repmode_conv5_pair, xa.data_ptr(), xb.data_ptr(), (int)ca, m.wf.data_ptr(), plan.sample_slot.data_ptr<int32_t>(), y.data_ptr(),
+              nullptr, 0, (int)n, (int)d, (int)h, (int)w_, (int)ci, (int)co, code, odt == at::kFloat ? 1 : 0, flags, stream_handle());
+    }
     ctx->save_for_backward({xa, xb, k5, k3, k1, a3, a5, m.g, m.wd.defined() ? m.wd : Tensor()});
     ctx->saved_data["slot_task"] = plan.slot_task;
     ctx->saved_data["sample_slot"] = plan.sample_slot;
@@ -648,7 +697,7 @@ struct ModeConvPair : public torch::autograd::Function<ModeConvPair> {
       }
     }
     fork.join();
-    return {dxa, dxb, pg[0], pg[1], pg[2], pg[3], pg[4], pg[5], pg[6], Tensor(), Tensor(), Tensor()};
+    return {dxa, dxb, pg[0], pg[1], pg[2], pg[3], pg[4], pg[5], pg[6], Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -788,14 +837,15 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
 
 // BatchNorm3d + ReLU on a channels-last tensor [..., C] (RepMode.py:146-149, 212; :80-84; :97-101)
 struct BnRelu : public torch::autograd::Function<BnRelu> {
+  // stats_half >= 0: the producing conv's epilogue left the batch statistics in that half of the library's scratch
   static Tensor forward(AutogradContext* ctx, Tensor x_cl, Tensor weight, Tensor bias, Tensor rm_, Tensor rv_, bool batch_stats,
-                        double momentum, double eps, at::ScalarType out_dtype) {
+                        double momentum, double eps, at::ScalarType out_dtype, int64_t stats_half) {
     const int64_t c = x_cl.size(-1), m = x_cl.numel() / c;
     Tensor out = at::empty(x_cl.sizes(), x_cl.options().dtype(out_dtype));
     Tensor save = at::empty({2, c}, x_cl.options().dtype(at::kFloat));
-    RM_CALL(repmode_bn_relu_fwd, x_cl.data_ptr(), out.data_ptr(), weight.data_ptr<float>(), bias.data_ptr<float>(), rm_.data_ptr<float>(),
+    RM_CALL(repmode_bn_relu_fwd_ex, x_cl.data_ptr(), out.data_ptr(), weight.data_ptr<float>(), bias.data_ptr<float>(), rm_.data_ptr<float>(),
             rv_.data_ptr<float>(), save[0].data_ptr<float>(), save[1].data_ptr<float>(), (long)m, (int)c, (float)eps, (float)momentum,
-            batch_stats ? 1 : 0, dtype_code(x_cl.scalar_type()), dtype_code(out_dtype), stream_handle());
+            batch_stats ? 1 : 0, dtype_code(x_cl.scalar_type()), dtype_code(out_dtype), batch_stats ? (int)stats_half : -1, stream_handle());
     ctx->save_for_backward({x_cl, weight, bias, save});
     ctx->saved_data["batch_stats"] = batch_stats;
     return out;
@@ -810,7 +860,7 @@ struct BnRelu : public torch::autograd::Function<BnRelu> {
     RM_CALL(repmode_bn_relu_bwd, x_cl.data_ptr(), dy.data_ptr(), weight.data_ptr<float>(), bias.data_ptr<float>(), save[0].data_ptr<float>(),
             save[1].data_ptr<float>(), dx.data_ptr(), tot.data_ptr<float>(), (long)m, (int)c, ctx->saved_data["batch_stats"].toBool() ? 1 : 0,
             dtype_code(x_cl.scalar_type()), dtype_code(dy.scalar_type()), stream_handle());
-    return {dx, tot.narrow(0, c, c), tot.narrow(0, 0, c), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
+    return {dx, tot.narrow(0, c, c), tot.narrow(0, 0, c), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -988,7 +1038,8 @@ inline bool pair_shapes_ok(const Tensor& xa, const Tensor& xb) {
 
 // The MoDE block up to (not including) BN/ReLU on channels-last tensors.  mode: 0 auto, 1 merged, 2 unmerged (per-expert), 3 merged two-tensor form (needs x2).
 Tensor mode_conv3d_cl(const Tensor& x_cl_in, const OptTensor& x2_cl_in, const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3,
-                      const Tensor& a5, const Tensor& gw, const Tensor& gb, const Plan& plan, bool out_f32, int64_t mode) {
+                      const Tensor& a5, const Tensor& gw, const Tensor& gb, const Plan& plan, bool out_f32, int64_t mode,
+                      const Epi& epi = Epi()) {
   require_hip(x_cl_in, "input");
   DeviceGuard guard(x_cl_in.device());
   Tensor x_cl = x_cl_in.contiguous();
@@ -1001,16 +1052,20 @@ Tensor mode_conv3d_cl(const Tensor& x_cl_in, const OptTensor& x2_cl_in, const Te
     const bool shapes_ok = pair_shapes_ok(x_cl, x2_cl);
     TORCH_CHECK(mode != 3 || shapes_ok, "mode_conv3d: the two-tensor form needs ", x_cl.size(4), " % 32 == 0 and ", x2_cl.size(4), " % 16 (8) == 0");
     if (mode == 3 || (mode == 1 && shapes_ok) || (mode == 0 && shapes_ok && !use_unmerged(x_cl, plan)))
-      return ModeConvPair::apply(x_cl, x2_cl, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan, out_f32, grad_enabled);
+      return ModeConvPair::apply(x_cl, x2_cl, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan, out_f32, grad_enabled, epi);
     x_cl = at::cat({x_cl, x2_cl}, -1);      // per-expert formulation / odd channel counts: the concatenated tensor
   }
   if (mode == 0) mode = use_unmerged(x_cl, plan) ? 2 : 1;
-  if (mode == 2) return ModeConvUnmerged::apply(x_cl, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan, grad_enabled);
-  return ModeConvMerged::apply(x_cl, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan, out_f32, grad_enabled);
+  if (mode == 2) {
+    TORCH_CHECK(!epi.bias.defined() && !epi.relu, "the per-expert formulation is a training-mode path: no folded BatchNorm");
+    tl_stats_half = -1;
+    return ModeConvUnmerged::apply(x_cl, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan, grad_enabled);
+  }
+  return ModeConvMerged::apply(x_cl, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan, out_f32, grad_enabled, epi);
 }
 
 Tensor bn_relu_cl(const Tensor& x_cl_in, const Tensor& weight, const Tensor& bias, const Tensor& rm_, const Tensor& rv_, bool batch_stats,
-                  double momentum, double eps, at::ScalarType out_dtype) {
+                  double momentum, double eps, at::ScalarType out_dtype, int64_t stats_half = -1) {
   require_hip(x_cl_in, "input");
   DeviceGuard guard(x_cl_in.device());
   Tensor x_cl = x_cl_in.contiguous();
@@ -1019,7 +1074,7 @@ Tensor bn_relu_cl(const Tensor& x_cl_in, const Tensor& weight, const Tensor& bia
   for (const Tensor* t : {&weight, &bias, &rm_, &rv_})
     TORCH_CHECK(t->scalar_type() == at::kFloat && t->numel() == c && t->is_contiguous() && t->device() == x_cl.device(),
                 "bn_relu: BatchNorm parameters / running statistics must be contiguous float32 [C] on the input's device");
-  return BnRelu::apply(x_cl, weight, bias, rm_, rv_, batch_stats, momentum, eps, out_dtype);
+  return BnRelu::apply(x_cl, weight, bias, rm_, rv_, batch_stats, momentum, eps, out_dtype, stats_half);
 }
 
 Plan make_plan(const Tensor& slot_task, const Tensor& sample_slot, const Tensor& sample_task, int64_t nslots, int64_t num_tasks, bool training,
@@ -1058,10 +1113,33 @@ Tensor op_mode_block(const Tensor& x, const OptTensor& x2, const Tensor& k5, con
   Plan plan = make_plan(slot_task, sample_slot, sample_task, nslots, num_tasks, training, task0);
   OptTensor x2_cl;
   if (x2.has_value()) x2_cl = to_cl(*x2, dt);
-  Tensor y = mode_conv3d_cl(to_cl(x, dt), x2_cl, k5, k3, k1, a3, a5, gw, gb, plan, out_f32, 0);
-  if (bn_w.has_value()) {
-    TORCH_CHECK(bn_b.has_value() && bn_rm.has_value() && bn_rv.has_value(), "MoDE block: incomplete BatchNorm state");
-    y = bn_relu_cl(y, *bn_w, *bn_b, *bn_rm, *bn_rv, bn_batch_stats, bn_momentum, bn_eps, dt);
+  Tensor x_cl = to_cl(x, dt);
+  const bool has_bn = bn_w.has_value();
+  if (has_bn) TORCH_CHECK(bn_b.has_value() && bn_rm.has_value() && bn_rv.has_value(), "MoDE block: incomplete BatchNorm state");
+  Epi epi;
+  bool folded = false;
+  if (has_bn && g_bn_epilogue) {
+    if (bn_batch_stats) {
+      // training: the batch statistics come out of the conv's epilogue where the conv writes the element-typed tensor the
+      // BatchNorm normalises (bf16, levels 0-1: 94 % of the normalised bytes); elsewhere the separate statistics pass
+      epi.stats = dt == at::kBFloat16 && !out_f32 && !use_unmerged(x_cl, plan) && k5.size(0) <= 512;
+    } else if (!plan.training && !at::GradMode::is_enabled()) {
+      // eval, no autograd: y = relu(gamma (conv - mean) / sqrt(var + eps) + beta) = relu(conv with scaled filter + bias)
+      epi.scale = *bn_w * at::rsqrt(*bn_rv + bn_eps);
+      epi.bias = (*bn_b - *bn_rm * epi.scale).contiguous();
+      epi.relu = true;
+      folded = true;
+    }
+  }
+  Tensor y = mode_conv3d_cl(x_cl, x2_cl, k5, k3, k1, a3, a5, gw, gb, plan, out_f32, 0, epi);
+  if (has_bn) {
+    if (folded) {
+      if (y.scalar_type() != dt) y = y.to(dt);
+    } else {
+      const int half = epi.stats ? tl_stats_half : -1;
+      tl_stats_half = -1;
+      y = bn_relu_cl(y, *bn_w, *bn_b, *bn_rm, *bn_rv, bn_batch_stats, bn_momentum, bn_eps, dt, half);
+    }
   }
   return from_cl(y);
 }
@@ -1179,6 +1257,7 @@ void op_finish_prepared(const Tensor& like) {
   RM_HIP_CHECK(hipEventRecord(ss.prep_fork_ev, ss.prep.stream()));
   RM_HIP_CHECK(hipStreamWaitEvent(c10::hip::getCurrentHIPStream(dev).stream(), ss.prep_fork_ev, 0));
 }
+void op_set_bn_epilogue(bool on) { g_bn_epilogue = on; }
 void op_set_overlap(bool on) { g_overlap = on; }
 bool op_get_overlap() { return g_overlap; }
 
@@ -1257,6 +1336,7 @@ TORCH_LIBRARY(repmode, m) {
         "int[] need_dx, Tensor slot_task, Tensor sample_slot, Tensor sample_task, int nslots, int num_tasks, bool training, "
         "int dtype) -> ()", &rm::op_prepare_filters);
   m.def("finish_prepared(Tensor like) -> ()", &rm::op_finish_prepared);
+  m.def("set_bn_epilogue(bool on) -> ()", &rm::op_set_bn_epilogue);
   m.def("set_overlap(bool on) -> ()", &rm::op_set_overlap);
   m.def("get_overlap() -> bool", &rm::op_get_overlap);
   m.def("zero_pool_begin(str key, Tensor like) -> ()", &rm::op_zero_pool_begin);

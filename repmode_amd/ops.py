@@ -73,10 +73,17 @@ def get_fork_max_w():
     return int(torch_ops().get_fork_max_w())
 
 
+def set_bn_epilogue(on):
+    """BatchNorm work taken over by the forward conv's epilogue (csrc/conv5_igemm.hip, repmode_conv5_epi): in training the
+    batch statistics of the bf16 layers (no separate read pass), in eval mode without autograd the whole BatchNorm + ReLU
+    (scale folded into the merged filter, bias + ReLU in the epilogue).  On by default (REPMODE_BN_EPILOGUE=0: off)."""
+    torch_ops().set_bn_epilogue(bool(on))
+
+
 def set_overlap(on):
     """Overlap of the HBM-bound GatRep kernels with the convolutions on the library's own streams (the step's filter
-    preparation beside the first convolutions, a layer's GatRep backward beside its data-gradient conv).  On by default
-    (REPMODE_OVERLAP=0 turns it off); switched off to time launches one by one."""
+    preparation beside the first convolutions, a layer's GatRep backward beside its data-gradient conv).  Off by default
+    (REPMODE_OVERLAP=1 turns it on): measured 1.6 % slower than launching in line, see csrc/torch/repmode_ops.cpp."""
     torch_ops().set_overlap(bool(on))
 
 

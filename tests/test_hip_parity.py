@@ -1036,7 +1036,7 @@ def test_fused_mse_loss(n, shape, tasks):
     plan = ops.TaskPlan(tasks, 12, DEV, training=True)
     loss, loss_sample, task_mean, task_count = ops.torch_ops().mse_loss(d, tgt.to(DEV), plan.sample_task, 12)
     (loss * 3.0).backward()
-    assert rel_err(loss.cpu(), ln.mean().detach()) < 1e-5
+    assert rel_err(loss.detach().cpu(), ln.mean().detach()) < 1e-5
     assert rel_err(loss_sample.cpu(), per) < 1e-5
     assert rel_err(d.grad.cpu(), ro.grad) < 1e-5
     log = orc.loss_log(per.numpy(), tasks, Opts.adopted_datasets, 0)
@@ -1071,3 +1071,76 @@ def test_full_size_train_iter_scalars_match_reference():
         assert np.allclose([log[k] for k in keys], g['log_values'][s], rtol=1e-3)
         assert list(frame['dataset']) == [str(d) for d in g['df_dataset']] and np.allclose(frame['loss'], g['loss_per_sample'][s], rtol=1e-3)
         assert abs(float(out.double().abs().sum()) - g['output_abs_sum'][s]) < 1e-3 * g['output_abs_sum'][s]
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm work in the conv epilogue
+
+@pytest.mark.parametrize('ci,co,shape,tasks', [(32, 32, (4, 8, 32), [4, 9, 4]), (16, 48, (5, 7, 33), [1, 1, 6, 2]),
+                                               (1, 32, (4, 8, 32), [3, 7]), (64, 64, (2, 4, 64), [0, 5, 5])])
+def test_bn_statistics_from_the_conv_epilogue(ci, co, shape, tasks):
+    """Training-mode block in bf16 on the layers whose conv writes the bf16 tensor BatchNorm normalises (W >= 32): the batch
+    statistics accumulated in the conv's epilogue (repmode_conv5_epi) against the separate statistics pass over the same
+    stored values -- output, saved running statistics, every gradient -- and the running statistics against the oracle
+    in float32 arithmetic.  Ragged volumes: voxels outside the volume are computed by the tile but must not be counted."""
+    ops = _ops()
+    from repmode_amd.nn_modules.RepMode import MoDEConv
+    gen = torch.Generator().manual_seed(ci + co)
+    n = len(tasks)
+    torch.manual_seed(ci * 5 + co)
+    ref = orc.MoDEConv(5, 12, ci, co)
+    x = torch.randn(n, ci, *shape, generator=gen).bfloat16()
+    r = torch.randn(n, co, *shape, generator=gen)
+    res = []
+    for epilogue in (True, False):
+        ops.set_bn_epilogue(epilogue)
+        blk = MoDEConv(5, 12, ci, co, dtype=torch.bfloat16)
+        blk.load_state_dict(ref.state_dict())
+        blk.to(DEV).train()
+        xd = x.to(DEV).float().requires_grad_(True)
+        y = blk(xd, torch.tensor(tasks))
+        (y.float() * r.to(DEV)).sum().backward()
+        bn = blk.subsequent_layer[0]
+        res.append([y.detach().float().cpu(), bn.running_mean.cpu().clone(), bn.running_var.cpu().clone(), xd.grad.cpu()] +
+                   [p.grad.cpu() for p in blk.parameters()])
+    ops.set_bn_epilogue(True)
+    for a, b in zip(res[0], res[1]):
+        assert rel_err(a, b) < 2e-3          # same stored values, other summation order (+ a rare 1-ulp bf16 flip downstream)
+    ref.train()
+    yr = ref(x.float(), torch.tensor(tasks))
+    rb = ref.subsequent_layer[0]
+    assert rel_err(res[0][1], rb.running_mean) < 2e-2 and rel_err(res[0][2], rb.running_var) < 2e-2
+    assert nrm_err(res[0][0], yr.detach()) < 2e-2
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('ci,co,shape', [(8, 16, (4, 8, 32)), (32, 32, (2, 4, 8)), (1, 32, (4, 8, 32)), (48, 24, (3, 5, 9))])
+def test_eval_batchnorm_folded_into_the_filter(ci, co, shape, dtype):
+    """Eval mode without autograd: BatchNorm folded (scale into the gate probabilities = the merged filter, bias + ReLU in
+    the conv epilogue) against the unfolded kernels and against the oracle block in eval mode."""
+    ops = _ops()
+    from repmode_amd.nn_modules.RepMode import MoDEConv
+    torch.manual_seed(ci + 3 * co)
+    ref = orc.MoDEConv(5, 12, ci, co)
+    bn = ref.subsequent_layer[0]
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5); bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    blk = MoDEConv(5, 12, ci, co, dtype=dtype)
+    blk.load_state_dict(ref.state_dict())
+    blk.to(DEV).eval()
+    ref.eval()
+    x = torch.randn(3, ci, *shape).to(dtype).float()
+    tasks = torch.tensor([7, 7, 7])
+    with torch.no_grad():
+        yr = ref(x, tasks)
+        ops.set_bn_epilogue(True)
+        y_fold = blk(x.to(DEV), tasks).float().cpu()
+        with ops.eval_filter_cache():
+            y_c1 = blk(x.to(DEV), tasks).float().cpu()
+            y_c2 = blk(x.to(DEV), tasks).float().cpu()          # second call: the cached folded filter
+        ops.set_bn_epilogue(False)
+        y_plain = blk(x.to(DEV), tasks).float().cpu()
+        ops.set_bn_epilogue(True)
+    tol = 1e-4 if dtype == torch.float32 else TOL_BF16
+    assert rel_err(y_fold, yr) < tol and rel_err(y_plain, yr) < tol
+    assert torch.equal(y_c1, y_fold) and torch.equal(y_c2, y_fold)
