@@ -88,7 +88,12 @@ int repmode_conv5(const void* x, const void* w, const int32_t* sample_slot, void
  * support is the centred 3x3x3 -- the zero-padded conv3x3 expert of RepMode.py:174 -- skips the 80 all-zero
  * taps); bit 1 (float output only) ADDS the result to y instead of overwriting it; bit 2 uses only the centre
  * x tap (dx = 2) of every (dz, dy) row -- the thin first / last layers with their x taps folded into channels,
- * see repmode_shift5 / repmode_thin_pack. */
+ * see repmode_shift5 / repmode_thin_pack.
+ * Bit 3: dual-expert launch (per-expert formulation, float output only): ONE grid runs two jobs over the n samples --
+ * slot 0 of w with all 125 taps (the 5x5x5 expert) and slot 1 with the centred 3x3x3 support (the padded 3x3x3 expert);
+ * sample_slot is not read.  Bit 4: x holds 2 n samples, the second job reads samples n .. 2n-1 (else both read the same n
+ * samples).  Bit 5: y holds 2 n samples, the second job writes samples n .. 2n-1 (else both jobs ADD into the same n
+ * samples, y cleared by the call unless bit 1 says it is zero already). */
 int repmode_conv5_ex(const void* x, const void* w, const int32_t* sample_slot, void* y, int n, int d,
                      int h, int wdim, int cin, int cout, int dtype, int out_f32, int centre3,
                      void* stream);

@@ -102,6 +102,12 @@ struct ConvArgs {
   int relu;
   float* stats;
   float* stats_clear;
+  // dual-expert launch (per-expert formulation of the deep levels): 2 N "virtual samples" in one grid -- virtual sample
+  // v < N is sample v with slot 0 and all 125 taps (the 5x5x5 expert), v >= N is sample v - N with slot 1 and the
+  // centred 3x3x3 support (the padded 3x3x3 expert); sample_slot is not read.  dual & 1: on; dual & 2: the input holds
+  // 2 N samples (the two gate-scaled output gradients), else both jobs read sample v % N; dual & 4: the output holds
+  // 2 N samples (the two expert outputs), else both jobs ADD into sample v % N.
+  int dual;
 };
 
 // Tile configuration.  BZ*BY*BX output voxels = 32 * WV * VW; 32 * WC * CW output channels.
@@ -151,12 +157,16 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   const int bx = bid % a.nbx;     bid /= a.nbx;
   const int by = bid % a.nby;     bid /= a.nby;
   const int bz = bid % a.nbz;
-  const int n = bid / a.nbz;
+  const int nv = bid / a.nbz;                            // (virtual) sample of this workgroup
+  const bool second = a.dual && nv >= a.N;               // dual launch: the 3x3x3 expert's job
+  const int n = (a.dual && !(a.dual & 2)) ? (second ? nv - a.N : nv) : nv;      // input sample
+  const int n_out = (a.dual && !(a.dual & 4)) ? (second ? nv - a.N : nv) : nv;  // output sample
   const int z0 = bz * BZ, y0 = by * BY, x0 = bx * BX;
   const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, CinP = a.CinP, CoutP = a.CoutP;
 
   const int Cin1 = PAIR ? a.Cin1 : 0, Cout1 = PAIR ? a.Cout1 : 0;
-  const int slot = a.sample_slot[n];
+  const int slot = a.dual ? (second ? 1 : 0) : a.sample_slot[n];
+  const int tap_lo = second ? 1 : a.tap_lo, tap_hi = second ? 3 : a.tap_hi;
   const T* __restrict__ xn = static_cast<const T*>(a.x) + (size_t)n * D * H * W * (Cin1 > 0 ? Cin1 : Cin);
   const T* __restrict__ xn2 = Cin1 > 0 ? static_cast<const T*>(a.x2) + (size_t)n * D * H * W * (Cin - Cin1) : nullptr;
   // filter layout (fragment-major): [slot][tap][co tile (32)][ci chunk (KC)][32][KC]; a lane's 16 bytes
@@ -183,8 +193,8 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   }
 
   // taps whose input plane/row lies outside the volume for every voxel of the brick are skipped
-  const int dz_lo = max(a.tap_lo, 2 - z0 - (BZ - 1)), dz_hi = min(a.tap_hi, D + 1 - z0);
-  const int dy_lo = max(a.tap_lo, 2 - y0 - (BY - 1)), dy_hi = min(a.tap_hi, H + 1 - y0);
+  const int dz_lo = max(tap_lo, 2 - z0 - (BZ - 1)), dz_hi = min(tap_hi, D + 1 - z0);
+  const int dy_lo = max(tap_lo, 2 - y0 - (BY - 1)), dy_hi = min(tap_hi, H + 1 - y0);
   const int ndy = dy_hi - dy_lo + 1;
   const int nrows = (dz_hi - dz_lo + 1) * ndy;
 
@@ -218,10 +228,10 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
     __syncthreads();  // all waves finished reading the previous chunk's halo image
     RM_STAMP((chunk - c_begin) * 4 + 1);
     // ---- stage the halo brick: item = (halo voxel, plane), two 16-byte items per voxel
-    const bool second = Cin1 > 0 && ci0 >= Cin1;
-    const T* __restrict__ xsrc = second ? xn2 : xn;
-    const int csrc = Cin1 > 0 ? (second ? Cin - Cin1 : Cin1) : Cin;     // channel stride of the source tensor
-    const int cbase = second ? Cin1 : 0;                                     // first channel the source holds
+    const bool from2 = Cin1 > 0 && ci0 >= Cin1;
+    const T* __restrict__ xsrc = from2 ? xn2 : xn;
+    const int csrc = Cin1 > 0 ? (from2 ? Cin - Cin1 : Cin1) : Cin;     // channel stride of the source tensor
+    const int cbase = from2 ? Cin1 : 0;                                     // first channel the source holds
     constexpr int NITEMS = 2 * VH;
     constexpr int UNR = (NITEMS + NT - 1) / NT >= 9 ? 9 : 4;   // loads in flight per thread per batch (latency-bound phase)
     for (int it0 = 0; it0 < NITEMS; it0 += NT * UNR) {
@@ -401,9 +411,9 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
           if (gz >= D || gy >= H || gx >= W) continue;
           const bool out2 = Cout1 > 0 && co >= Cout1;                   // (two-output mode: the data gradient of a pair)
           const int cw = Cout1 > 0 ? (out2 ? Cout - Cout1 : Cout1) : Cout;
-          float* yp = static_cast<float*>(out2 ? a.y2 : a.y) + (((size_t)(n * D + gz) * H + gy) * W + gx) * cw +
+          float* yp = static_cast<float*>(out2 ? a.y2 : a.y) + (((size_t)(n_out * D + gz) * H + gy) * W + gx) * cw +
                       (out2 ? co - Cout1 : co);
-          if (a.ksplit > 1 || a.accum) {
+          if (a.ksplit > 1 || a.accum || (a.dual && !(a.dual & 4))) {
             unsafeAtomicAdd(yp, acc[cs][vs][r]);
           } else {
             float v = acc[cs][vs][r];
@@ -433,7 +443,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
       const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
       const bool inside = gz < D && gy < H && gx < W;
       if (!inside && !want_stats) continue;
-      const size_t vox = ((size_t)(n * D + gz) * H + gy) * W + gx;
+      const size_t vox = ((size_t)(n_out * D + gz) * H + gy) * W + gx;
 #pragma unroll
       for (int cs = 0; cs < CW; ++cs) {
 #pragma unroll
@@ -528,7 +538,7 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   // workgroups per CU, and at least two channel chunks per workgroup -- every slice pays one un-overlapped halo
   // staging and a full tile of atomics (same-box sweep: 1024 -> 512 workgroups is +16..24 % on levels 2-3)
   const int nchunks = a.CinP / (2 * Elem<T>::KV);
-  long base = (long)a.N * a.nbz * a.nby * a.nbx * a.ncot;
+  long base = (long)(a.dual ? 2 * a.N : a.N) * a.nbz * a.nby * a.nbx * a.ncot;
   int ks = 1;
   if (SWAP && !a.bias && !a.relu) {   // (a bias / ReLU epilogue needs the whole sum in one workgroup)
     while (ks * 4 <= nchunks && base * ks < CONV_SPLIT_TARGET && ks < 64) ks *= 2;
@@ -546,8 +556,8 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
   }
-  if (ks > 1 && !a.accum) {
-    const size_t vox = (size_t)a.N * a.D * a.H * a.W;
+  if ((ks > 1 || (a.dual && !(a.dual & 4))) && !a.accum) {
+    const size_t vox = (size_t)((a.dual & 4) ? 2 * a.N : a.N) * a.D * a.H * a.W;
     RM_HIP(hipMemsetAsync(a.y, 0, vox * (a.Cout1 > 0 ? a.Cout1 : a.Cout) * sizeof(float), stream));
     if (a.Cout1 > 0) RM_HIP(hipMemsetAsync(a.y2, 0, vox * (a.Cout - a.Cout1) * sizeof(float), stream));
   }
@@ -675,6 +685,10 @@ static int conv5_common(const void* x, const void* x2, int cin1, const void* w, 
   a.tap_hi = (flags & 1) ? 3 : 4;
   a.accum = (flags & 2) ? 1 : 0;
   a.dxc = (flags & 4) ? 1 : 0;
+  // bits 3-5: dual-expert launch (see ConvArgs::dual): 8 = on, 16 = the input holds 2 n samples, 32 = the output does
+  a.dual = (flags & 8) ? (1 | ((flags & 16) ? 2 : 0) | ((flags & 32) ? 4 : 0)) : 0;
+  RM_REQUIRE(!a.dual || (a.out_f32 && !(flags & 1) && !a.dxc && cin1 == 0 && cout1 == 0 && !bias && !relu && !want_stats),
+             "conv5: a dual-expert launch is a float-output, full-support, one-tensor convolution");
   RM_REQUIRE(!a.accum || a.out_f32, "conv5: accumulation needs a float output");
   hipStream_t s = static_cast<hipStream_t>(stream);
   a.bias = bias;

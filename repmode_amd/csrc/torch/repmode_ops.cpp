@@ -245,11 +245,31 @@ inline bool forks(const Tensor& x_cl) { return x_cl.size(3) > 0 && x_cl.size(3) 
 // 13.71 / 13.72 ms per step without and 13.94 / 13.94 ms with -- a conv launch holds every CU's LDS and registers with
 // two resident workgroups, so the GatRep workgroups only get in as the conv drains (gatrep_bwd: 30 -> 179 us per launch
 // under rocprofv3) and the layer's join then waits for them.
-// BatchNorm work taken over by the forward conv's epilogue (Epi); REPMODE_BN_EPILOGUE=0 / set_bn_epilogue(false): the
-// separate kernels only (A/B measurements, and the reference point of the parity tests)
-bool g_bn_epilogue = []() {
-  const char* e = std::getenv("REPMODE_BN_EPILOGUE");
+// Volumes up to this x extent take the per-expert formulation when the batch has more than two distinct tasks
+// (REPMODE_UNMERGED_MAX_W / set_unmerged_max_w; 8 = levels 3-4 of a 64-wide patch).  Measured on one box, interleaved,
+// batch 8 with 8 tasks: 8 -> 13.73 ms per step, 4 (level 4 only) -> 14.37, 0 (merged everywhere) -> 16.55.
+int64_t g_unmerged_max_w = []() {
+  const char* e = std::getenv("REPMODE_UNMERGED_MAX_W");
+  return e ? (int64_t)std::atoi(e) : (int64_t)8;
+}();
+// The 5x5x5 and the 3x3x3 expert's convolutions of the per-expert formulation as one launch (twice the workgroups on
+// levels whose launches do not fill the chip, one launch gap less); REPMODE_DUAL_LAUNCH=0: two launches
+bool g_dual_launch = []() {
+  const char* e = std::getenv("REPMODE_DUAL_LAUNCH");
   return e ? std::atoi(e) != 0 : true;
+}();
+// BatchNorm work taken over by the forward conv's epilogue (Epi), a bit mask (REPMODE_BN_EPILOGUE / set_bn_epilogue):
+//   1  eval mode without autograd: the whole BatchNorm + ReLU folded (scale into the filter, bias + ReLU in the epilogue)
+//      on the layers whose conv writes the element-typed tensor -- default ON (sliding-window inference; time-neutral on
+//      the 64x624x924 stack: 0.49 s with and without, the forward is conv-bound);
+//   2  training: the batch statistics from the conv's epilogue instead of a statistics pass -- default OFF: measured on
+//      one box, interleaved, 60 steps each: 13.90 / 13.89 ms per step with the separate pass, 14.10 / 14.12 ms with the
+//      epilogue.  The pass it removes streams a tensor that is still in the 256 MB Infinity Cache at full rate (11-25 us
+//      per layer); the epilogue's cross-lane reduction and atomics run inside the MFMA-bound, power-capped conv launch
+//      and cost more than that.
+int64_t g_bn_epilogue = []() {
+  const char* e = std::getenv("REPMODE_BN_EPILOGUE");
+  return e ? (int64_t)std::atoi(e) : (int64_t)1;
 }();
 bool g_overlap = []() {
   const char* e = std::getenv("REPMODE_OVERLAP");
@@ -316,9 +336,14 @@ struct Epi {
 thread_local int tl_stats_half = -1;
 
 // y[n] = x[n] (*) w[sample_slot[n]], 5^3 'same' cross-correlation, NDHWC -- RepMode.py:204-210
+// dual (per-expert formulation): 0 = off; else the 5x5x5 and the 3x3x3 expert's convolutions in ONE launch (see
+// repmode_conv5_ex): DUAL_OUT2 = x holds n samples, the output 2 n (the two expert outputs); DUAL_IN2 = x holds 2 n samples
+// (the two gate-scaled output gradients), both jobs add into the n-sample output.
+constexpr int DUAL_OUT2 = 8 | 32, DUAL_IN2 = 8 | 16;
 Tensor conv5(const Tensor& x_cl, const Tensor& w, const Tensor& sample_slot, int64_t cout, bool out_f32, OptTensor out = c10::nullopt,
-             bool centre3 = false, bool accumulate = false, bool dxc = false, const Epi* epi = nullptr) {
-  const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), wd_ = x_cl.size(3), cin = x_cl.size(4);
+             bool centre3 = false, bool accumulate = false, bool dxc = false, const Epi* epi = nullptr, int dual = 0) {
+  const int64_t n = dual == DUAL_IN2 ? x_cl.size(0) / 2 : x_cl.size(0);
+  const int64_t d = x_cl.size(1), h = x_cl.size(2), wd_ = x_cl.size(3), cin = x_cl.size(4);
   const int code = dtype_code(x_cl.scalar_type());
   const at::ScalarType odt = (out_f32 || x_cl.scalar_type() == at::kFloat) ? at::kFloat : x_cl.scalar_type();
   Tensor y;
@@ -326,15 +351,15 @@ Tensor conv5(const Tensor& x_cl, const Tensor& w, const Tensor& sample_slot, int
     y = *out;
   } else if (odt == at::kFloat && x_cl.scalar_type() == at::kBFloat16) {
     // float output = the kernel may split the reduction and add with atomics: a pre-zeroed pool tensor saves its memset
-    auto tk = g_pool.take({n, d, h, wd_, cout}, x_cl);
+    auto tk = g_pool.take({dual == DUAL_OUT2 ? 2 * n : n, d, h, wd_, cout}, x_cl);
     y = tk.first;
     accumulate = accumulate || tk.second;
   } else {
-    y = at::empty({n, d, h, wd_, cout}, x_cl.options().dtype(odt));
+    y = at::empty({dual == DUAL_OUT2 ? 2 * n : n, d, h, wd_, cout}, x_cl.options().dtype(odt));
   }
   TORCH_CHECK(y.scalar_type() == odt && y.is_contiguous(), "conv5: bad output tensor");
   TORCH_CHECK(!accumulate || odt == at::kFloat, "conv5: accumulation needs a float output");
-  const int flags = (centre3 ? 1 : 0) | (accumulate ? 2 : 0) | (dxc ? 4 : 0);
+  const int flags = (centre3 ? 1 : 0) | (accumulate ? 2 : 0) | (dxc ? 4 : 0) | dual;
   if (epi && epi->any()) {
     const bool stats = epi->stats && odt == at::kBFloat16;
     // (a pool tensor is pre-zeroed for atomics; a bias / ReLU epilogue overwrites instead: drop the accumulate flag)
@@ -745,7 +770,7 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     fork.to_side();
     {
       // the 3^3 expert, and the three 1x1 experts as ONE batched GEMM: [x | box3(x) | box5(x)] @ [K1 | A3 | A5]^T -> P_2..P_4
-      conv5(x_cl, fr.first, s1, co, true, p[1], true, pre);
+      if (!g_dual_launch) conv5(x_cl, fr.first, s1, co, true, p[1], true, pre);
       Tensor xb0 = xb[0], xb1 = xb[1], xb2 = xb[2];
       xb0.copy_(x_cl);
       box_sum(&xb0, nullptr, nullptr, nullptr, xb1, at::kFloat);
@@ -755,7 +780,8 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
       at::bmm_out(pv, xb.view({3, -1, ci}), w1.transpose(1, 2));
     }
     fork.to_main();
-    conv5(x_cl, fr.first, s0, co, true, p[0], false, pre);
+    if (g_dual_launch) conv5(x_cl, fr.first, s0, co, true, p.narrow(0, 0, 2).view({2 * n, d, h, w, co}), false, pre, false, nullptr, DUAL_OUT2);
+    else conv5(x_cl, fr.first, s0, co, true, p[0], false, pre);
     fork.join();
     Tensor y = at::empty({n, d, h, w, co}, x_cl.options().dtype(at::kFloat));
     RM_CALL(repmode_expert_mix_fwd, p.data_ptr<float>(), gn.data_ptr<float>(), y.data_ptr<float>(), (int)n, (long)(d * h * w), (int)co,
@@ -821,8 +847,13 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     Tensor dx;
     if (need_dx) {
       Tensor lo0 = lo[0], lo1 = lo[1];
-      Tensor dxf = conv5(lo0, wd2, s0, ci, true);
-      conv5(lo1, wd2, s1, ci, true, dxf, true, true);
+      Tensor dxf;
+      if (g_dual_launch) {
+        dxf = conv5(lo.view({2 * n, d, h, w, co}), wd2, s0, ci, true, c10::nullopt, false, false, false, nullptr, DUAL_IN2);
+      } else {
+        dxf = conv5(lo0, wd2, s0, ci, true);
+        conv5(lo1, wd2, s1, ci, true, dxf, true, true);
+      }
       // 1x1 experts: one batched GEMM gives the three partial data gradients; the zero-padded box mean is self-adjoint, so the
       // avg experts' parts go back through box3 / box5 -- summed with the two conv parts and cast in the same kernel
       Tensor t = at::bmm(hi, w1);                                                          // [3, M(+pad), Ci]
@@ -1029,7 +1060,7 @@ void check_params(const Tensor& x_cl, const Tensor* x2_cl, const Tensor& k5, con
 }
 
 // Heuristic: small volumes (levels 3-4) with several distinct tasks in the batch take the per-expert formulation.
-inline bool use_unmerged(const Tensor& x_cl, const Plan& plan) { return plan.training && plan.nslots > 2 && x_cl.size(3) <= 8; }
+inline bool use_unmerged(const Tensor& x_cl, const Plan& plan) { return plan.training && plan.nslots > 2 && x_cl.size(3) <= g_unmerged_max_w; }
 
 inline bool pair_shapes_ok(const Tensor& xa, const Tensor& xb) {
   const int64_t kc = xa.scalar_type() == at::kBFloat16 ? 16 : 8;
@@ -1119,12 +1150,16 @@ Tensor op_mode_block(const Tensor& x, const OptTensor& x2, const Tensor& k5, con
   Epi epi;
   bool folded = false;
   if (has_bn && g_bn_epilogue) {
-    if (bn_batch_stats) {
+    if (bn_batch_stats && (g_bn_epilogue & 2)) {
       // training: the batch statistics come out of the conv's epilogue where the conv writes the element-typed tensor the
       // BatchNorm normalises (bf16, levels 0-1: 94 % of the normalised bytes); elsewhere the separate statistics pass
       epi.stats = dt == at::kBFloat16 && !out_f32 && !use_unmerged(x_cl, plan) && k5.size(0) <= 512;
-    } else if (!plan.training && !at::GradMode::is_enabled()) {
-      // eval, no autograd: y = relu(gamma (conv - mean) / sqrt(var + eps) + beta) = relu(conv with scaled filter + bias)
+    } else if (!bn_batch_stats && (g_bn_epilogue & 1) && !plan.training && !at::GradMode::is_enabled() &&
+               ((dt == at::kBFloat16 && !out_f32) || dt == at::kFloat)) {
+      // eval, no autograd: y = relu(gamma (conv - mean) / sqrt(var + eps) + beta) = relu(conv with scaled filter + bias).
+      // Not where the bf16 path writes a float tensor (small volumes): a bias / ReLU epilogue cannot split the reduction
+      // over workgroups, which is what fills the chip there (measured on the 64x624x924 stack: 0.49 -> 0.57 s when folded
+      // everywhere); those levels keep the separate normalise + ReLU launch.
       epi.scale = *bn_w * at::rsqrt(*bn_rv + bn_eps);
       epi.bias = (*bn_b - *bn_rm * epi.scale).contiguous();
       epi.relu = true;
@@ -1217,7 +1252,7 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
       const int64_t co = K5.size(0);
       PrepEntry e;
       e.dt = dt;
-      e.unmerged = plan.training && plan.nslots > 2 && w_in[i] <= 8;
+      e.unmerged = plan.training && plan.nslots > 2 && w_in[i] <= g_unmerged_max_w;
       if (e.unmerged) {
         e.rows = plan.n;
         e.g = gate_softmax(gw[i].contiguous(), gb[i].contiguous(), plan.sample_task, plan.n, plan.num_tasks, co);
@@ -1257,7 +1292,10 @@ void op_finish_prepared(const Tensor& like) {
   RM_HIP_CHECK(hipEventRecord(ss.prep_fork_ev, ss.prep.stream()));
   RM_HIP_CHECK(hipStreamWaitEvent(c10::hip::getCurrentHIPStream(dev).stream(), ss.prep_fork_ev, 0));
 }
-void op_set_bn_epilogue(bool on) { g_bn_epilogue = on; }
+void op_set_bn_epilogue(int64_t mask) { g_bn_epilogue = mask; }
+void op_set_unmerged_max_w(int64_t w) { g_unmerged_max_w = w; }
+void op_set_dual_launch(bool on) { g_dual_launch = on; }
+int64_t op_get_unmerged_max_w() { return g_unmerged_max_w; }
 void op_set_overlap(bool on) { g_overlap = on; }
 bool op_get_overlap() { return g_overlap; }
 
@@ -1336,7 +1374,10 @@ TORCH_LIBRARY(repmode, m) {
         "int[] need_dx, Tensor slot_task, Tensor sample_slot, Tensor sample_task, int nslots, int num_tasks, bool training, "
         "int dtype) -> ()", &rm::op_prepare_filters);
   m.def("finish_prepared(Tensor like) -> ()", &rm::op_finish_prepared);
-  m.def("set_bn_epilogue(bool on) -> ()", &rm::op_set_bn_epilogue);
+  m.def("set_bn_epilogue(int mask) -> ()", &rm::op_set_bn_epilogue);
+  m.def("set_unmerged_max_w(int w) -> ()", &rm::op_set_unmerged_max_w);
+  m.def("set_dual_launch(bool on) -> ()", &rm::op_set_dual_launch);
+  m.def("get_unmerged_max_w() -> int", &rm::op_get_unmerged_max_w);
   m.def("set_overlap(bool on) -> ()", &rm::op_set_overlap);
   m.def("get_overlap() -> bool", &rm::op_get_overlap);
   m.def("zero_pool_begin(str key, Tensor like) -> ()", &rm::op_zero_pool_begin);

@@ -73,11 +73,18 @@ def get_fork_max_w():
     return int(torch_ops().get_fork_max_w())
 
 
-def set_bn_epilogue(on):
-    """BatchNorm work taken over by the forward conv's epilogue (csrc/conv5_igemm.hip, repmode_conv5_epi): in training the
-    batch statistics of the bf16 layers (no separate read pass), in eval mode without autograd the whole BatchNorm + ReLU
-    (scale folded into the merged filter, bias + ReLU in the epilogue).  On by default (REPMODE_BN_EPILOGUE=0: off)."""
-    torch_ops().set_bn_epilogue(bool(on))
+def set_bn_epilogue(mask):
+    """BatchNorm work taken over by the forward conv's epilogue (csrc/conv5_igemm.hip, repmode_conv5_epi), a bit mask:
+    1 = eval mode without autograd: the whole BatchNorm + ReLU (scale folded into the merged filter, bias + ReLU in the
+    epilogue) on the layers whose conv writes the element-typed tensor (default ON); 2 = training: the batch statistics of
+    those layers from the conv launch instead of a statistics pass (default OFF: measured 1.5 % slower per step, see
+    csrc/torch/repmode_ops.cpp).  REPMODE_BN_EPILOGUE sets the initial mask."""
+    torch_ops().set_bn_epilogue(int(mask))
+
+
+def set_dual_launch(on):
+    """Per-expert formulation: the 5x5x5 and the 3x3x3 expert's convolutions as one launch (default) or two."""
+    torch_ops().set_dual_launch(bool(on))
 
 
 def set_overlap(on):
@@ -549,7 +556,7 @@ def use_unmerged(x_cl, plan):
     per-expert formulation  y[n] = sum_e g[n, e, :] * conv(x[n], K_e)  (linearity, SURVEY.md section 4 property 3):
     the experts are shared by all samples, so nothing is merged per task -- on the deep levels the weights (84 % of the
     parameters) dwarf the activations and per-task merged filters / filter gradients are pure HBM traffic."""
-    return plan.training and plan.nslots > 2 and x_cl.shape[3] <= 8
+    return plan.training and plan.nslots > 2 and x_cl.shape[3] <= int(torch_ops().get_unmerged_max_w())
 
 
 def mode_conv3d(x_cl, k5, k3, k1, a3, a5, gate_w, gate_b, plan, out_f32=False, mode='auto'):

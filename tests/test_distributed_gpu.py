@@ -31,20 +31,23 @@ def _data():
     return x, t, [1, 4, 4, 9]
 
 
-def _worker(rank, world, port, out_dir, how):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
-                      MASTER_PORT=str(port))
+def _worker(rank, world, port, out_dir, how, backend='gloo'):
+    # gloo: both ranks on device 0; nccl (= RCCL): one device per rank
+    local = rank if backend == 'nccl' else 0
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(local), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     from repmode_amd import distributed as dist_
     from repmode_amd.model import Model
-    dist_.init_from_env(backend='gloo')
+    dist_.init_from_env(backend=backend)
+    torch.cuda.set_device(local)
     torch.manual_seed(0)
-    m = Model(Opts(), lr=1e-4, gpu_ids=0, mult_chan=2, dtype=torch.float32, distributed=how)
+    m = Model(Opts(), lr=1e-4, gpu_ids=local, mult_chan=2, dtype=torch.float32, distributed=how)
     x, t, tasks = _data()
     lo, hi = dist_.shard_batch(4, rank, world)
     module = m.ddp if how == 'ddp' else m.net
     module.train()
-    out = module(x[lo:hi].cuda(), tasks[lo:hi])
-    torch.nn.functional.mse_loss(out, t[lo:hi].cuda()).backward()
+    out = module(x[lo:hi].to(m.device), tasks[lo:hi])
+    torch.nn.functional.mse_loss(out, t[lo:hi].to(m.device)).backward()
     if how != 'ddp':
         m.reducer.finish()
         # the 19 MoDE blocks' five expert gradients each were written into the buckets by the kernels
@@ -80,6 +83,19 @@ def test_ddp_two_ranks_on_one_gpu(tmp_path, how):
         # batch-norm chain amplifies it -> 2e-2 like the whole-net golden test.  Parameters whose gradient is tiny
         # next to the network's largest are judged on that scale (their own maximum is mostly that noise).
         assert (g0[k] - ref).abs().max() <= 2e-2 * max(float(ref.abs().max()), 1e-2 * gmax), k
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('how', ['reducer', 'ddp'])
+def test_two_ranks_over_rccl(tmp_path, how):
+    """The same two-rank check over RCCL (backend "nccl"), one GPU per rank: needs two devices -- skipped on the 1-GPU
+    boxes this round's tests run on, there for the driver's multi-GPU node."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs (RCCL refuses two ranks on one device)')
+    mp.start_processes(_worker, args=(2, _free_port(), str(tmp_path), how, 'nccl'), nprocs=2, join=True, start_method='spawn')
+    g0, g1 = torch.load(tmp_path / 'g0.pt'), torch.load(tmp_path / 'g1.pt')
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k               # identical averages on both ranks
 
 
 def test_reducer_buckets_hold_the_kernels_gradients_single_process():

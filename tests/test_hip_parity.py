@@ -1092,7 +1092,7 @@ def test_bn_statistics_from_the_conv_epilogue(ci, co, shape, tasks):
     x = torch.randn(n, ci, *shape, generator=gen).bfloat16()
     r = torch.randn(n, co, *shape, generator=gen)
     res = []
-    for epilogue in (True, False):
+    for epilogue in (3, 0):
         ops.set_bn_epilogue(epilogue)
         blk = MoDEConv(5, 12, ci, co, dtype=torch.bfloat16)
         blk.load_state_dict(ref.state_dict())
@@ -1103,7 +1103,7 @@ def test_bn_statistics_from_the_conv_epilogue(ci, co, shape, tasks):
         bn = blk.subsequent_layer[0]
         res.append([y.detach().float().cpu(), bn.running_mean.cpu().clone(), bn.running_var.cpu().clone(), xd.grad.cpu()] +
                    [p.grad.cpu() for p in blk.parameters()])
-    ops.set_bn_epilogue(True)
+    ops.set_bn_epilogue(1)
     for a, b in zip(res[0], res[1]):
         assert rel_err(a, b) < 2e-3          # same stored values, other summation order (+ a rare 1-ulp bf16 flip downstream)
     ref.train()
@@ -1133,14 +1133,41 @@ def test_eval_batchnorm_folded_into_the_filter(ci, co, shape, dtype):
     tasks = torch.tensor([7, 7, 7])
     with torch.no_grad():
         yr = ref(x, tasks)
-        ops.set_bn_epilogue(True)
+        ops.set_bn_epilogue(1)
         y_fold = blk(x.to(DEV), tasks).float().cpu()
         with ops.eval_filter_cache():
             y_c1 = blk(x.to(DEV), tasks).float().cpu()
             y_c2 = blk(x.to(DEV), tasks).float().cpu()          # second call: the cached folded filter
-        ops.set_bn_epilogue(False)
+        ops.set_bn_epilogue(0)
         y_plain = blk(x.to(DEV), tasks).float().cpu()
-        ops.set_bn_epilogue(True)
+        ops.set_bn_epilogue(1)
     tol = 1e-4 if dtype == torch.float32 else TOL_BF16
     assert rel_err(y_fold, yr) < tol and rel_err(y_plain, yr) < tol
     assert torch.equal(y_c1, y_fold) and torch.equal(y_c2, y_fold)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('ci,co,shape,n', [(64, 64, (2, 4, 4), 8), (48, 96, (4, 8, 8), 3), (32, 32, (1, 2, 2), 5)])
+def test_dual_expert_launch(ci, co, shape, n, dtype):
+    """Per-expert formulation: the 5x5x5 and the 3x3x3 expert's convolutions (forward: two outputs; data gradient: two
+    inputs summed into one output) as ONE launch against two launches of the same kernel -- and, through
+    test_mode_conv3d_op[unmerged] / the bench-configuration tests, against the oracle (the one-launch form is the default)."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(ci + co + n)
+    ps = _rand_experts(co, ci, gen)
+    tasks = [(3 * i + 1) % 12 for i in range(n)]
+    x = torch.randn(n, *shape, ci, generator=gen).to(dtype)
+    r = torch.randn(n, *shape, co, generator=gen)
+    res = []
+    for dual in (True, False):
+        ops.set_dual_launch(dual)
+        dev = [p.to(DEV).requires_grad_(True) for p in ps]
+        xd = x.to(DEV).requires_grad_(True)
+        plan = ops.TaskPlan(tasks, 12, DEV, training=True)
+        y = ops.mode_conv3d(xd, *dev, plan, mode='unmerged')
+        (y.float() * r.to(DEV)).sum().backward()
+        res.append([y.detach().float().cpu(), xd.grad.float().cpu()] + [p.grad.cpu() for p in dev])
+    ops.set_dual_launch(True)
+    tol = 5e-5 if dtype == torch.float32 else 1e-2          # (bf16: an atomics-order difference can flip a rounding)
+    for a, b in zip(res[0], res[1]):
+        assert rel_err(a, b) < tol
