@@ -75,6 +75,12 @@ int repmode_gatrep_fwd(const float* k5, const float* k3, const float* k1, const 
                        const float* a5, const float* g, int nslots, int co, int ci, int dtype,
                        void* wf, void* wd, void* stream);
 
+/* The two calls above as ONE launch: the merging workgroups compute the gate probabilities of their channels themselves
+ * and write them to g_out [nslots][5][co] (kept for the backward pass).  wf and g_out are required, wd optional. */
+int repmode_gatrep_fwd_gate(const float* k5, const float* k3, const float* k1, const float* a3, const float* a5,
+                            const float* gate_w, const float* gate_b, const int32_t* slot_task, int nslots, int num_tasks,
+                            int co, int ci, int dtype, float* g_out, void* wf, void* wd, void* stream);
+
 /* ---- conv: RepMode.py:204-208 (train, per-sample filter) and :209-210 (eval, one filter) ----
  * y[n] = cross-correlation of x[n] with w[sample_slot[n]], 5^3, stride 1, zero pad 2, no bias.
  * x: [N][D][H][W][Cin] dtype;  w: fragment-major merged filter of nslots slots (rows = Cout, red = Cin);
@@ -231,6 +237,17 @@ int repmode_expert_mix_bwd(const float* dy, const float* p, const float* g, floa
 int repmode_expert_mix_bwd_ex(const float* dy, const float* p, const float* g, float* dg, void* dye_lo,
                               float* dye_hi, long hi_stride, int n, long v, int c, int dtype, void* stream);
 
+/* ---- the three 1x1x1 experts (conv1x1, avg3x3, avg5x5: RepMode.py:135-142, 175-180) of the per-expert formulation as
+ * three small float32 GEMMs in one launch:  C_i[m][n] = sum_k A_i(m, k) * B_i(n, k),  i = 0..2,
+ * A_i(m, k) at a[i] + m * a_ms + k * a_ks, B_i(n, k) at b[i] + n * b_ns + k * b_ks (element strides), C_i row-major with
+ * leading dimension ldc.  a, b, c: HOST arrays of three device pointers.  Covers the forward (X W^T), the filter gradient
+ * (G^T X) and the data gradient (G W) of those experts through the strides.  c_is_zero != 0: the three C matrices are all
+ * zero on entry -- the launch may then split K over workgroups and ADD the parts (these GEMMs are latency-bound: tens of
+ * output tiles for 256 CUs); 0: C is overwritten by one workgroup per tile.  bf16_mfma != 0: the operands are rounded to
+ * bfloat16 on their way into the matrix cores (float32 accumulation; the throughput mode), 0: exact float32 products. */
+int repmode_gemm3(const float* const* a, long a_ms, long a_ks, const float* const* b, long b_ns, long b_ks, float* const* c,
+                  int ldc, int m, int n, int k, int c_is_zero, int bf16_mfma, void* stream);
+
 /* ---- box means of the avg-pool experts (RepMode.py:139-142, 161-163, 176-180): by linearity
  * conv(x, w1x1 (x) 1/k^3) = w1x1 applied to the zero-padded k^3 box mean of x.
  * out = box3(in3) + box5(in5); float NDHWC tensors; either input may be NULL (not both). */
@@ -239,6 +256,9 @@ int repmode_box_sum(const float* in3, const float* in5, float* out, int n, int d
 /* out = box3(in3) + box5(in5) [+ add0] [+ add1], stored in out_dtype (float inputs; add0 / add1 may be NULL). */
 int repmode_box_sum_ex(const float* in3, const float* in5, const float* add0, const float* add1, void* out,
                        int out_dtype, int n, int d, int h, int w, int c, void* stream);
+/* x (dtype) -> out[0] = x widened, out[1] = box3(x), out[2] = box5(x), float [3][n][d][h][w][c]: the three 1x1 experts'
+ * GEMM inputs from one launch.  Only for volumes that fit in LDS with c % 4 == 0 (REPMODE_EINVAL otherwise). */
+int repmode_box_expand(const void* x, int dtype, float* out, int n, int d, int h, int w, int c, void* stream);
 /* Filter gradient from the kernels' tap-major layout to the experts' parameter layout: out[m][t] = in[tap(t)][m]
  * for the m = Co*Ci channel pairs; ntaps_out = 125 (all taps), 27 (the centred 3x3x3 taps of the [125][m] input)
  * or 8 (the 2x2x2 stride-2 filters, input [8][m]). */

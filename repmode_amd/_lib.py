@@ -26,6 +26,7 @@ _SIGNATURES = {
     'repmode_padded_channels': [_I, _I, _I],
     'repmode_gate_softmax': [_P, _P, _P, _I, _I, _I, _P, _P],
     'repmode_gatrep_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    'repmode_gatrep_fwd_gate': [_P] * 8 + [_I] * 5 + [_P] * 4,
     'repmode_conv5': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_ex': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_pair': [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -49,6 +50,8 @@ _SIGNATURES = {
     'repmode_expert_mix_fwd': [_P, _P, _P, _I, _c.c_long, _I, _P],
     'repmode_expert_mix_bwd': [_P, _P, _P, _P, _P, _P, _I, _c.c_long, _I, _I, _P],
     'repmode_expert_mix_bwd_ex': [_P, _P, _P, _P, _P, _P, _c.c_long, _I, _c.c_long, _I, _I, _P],
+    'repmode_gemm3': [_P, _c.c_long, _c.c_long, _P, _c.c_long, _c.c_long, _P, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_box_expand': [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     'repmode_box_sum': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'repmode_box_sum_ex': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'repmode_tap_transpose': [_P, _P, _c.c_long, _I, _P],

@@ -348,6 +348,136 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Small tensors (the deep levels: a few thousand rows): ONE launch per pass.  A workgroup owns 8 channels for ALL rows, so
+// the batch statistics never leave it -- no partial-sum slices, no second launch, no scratch.  The tensor (<= a few MB) is
+// read a second time from L2 for the normalisation.  These layers were 2 launches of ~10 us each per pass, all latency.
+constexpr int BN_SMALL_MAX_ROWS = 16384;
+
+// wave butterfly + cross-wave LDS reduction of NV per-thread values; every thread gets the totals
+template <int NV>
+__device__ __forceinline__ void block_allreduce(float* v, float* lds /* [4][NV] */) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) lds[wave * NV + k] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = lds[k] + lds[NV + k] + lds[2 * NV + k] + lds[3 * NV + k];
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(BN_THREADS) void bn_small_fwd_kernel(
+    const TI* __restrict__ x, TO* __restrict__ out, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ save_mean, float* __restrict__ save_invstd, float eps,
+    float momentum, long M, int C) {
+  __shared__ float red[4 * 2 * CV];
+  const int c0 = blockIdx.x * CV;
+  const bool vec = (C % CV) == 0;
+  float v[2 * CV];
+#pragma unroll
+  for (int k = 0; k < 2 * CV; ++k) v[k] = 0.f;
+  for (long r = threadIdx.x; r < M; r += BN_THREADS) {
+    float t[CV];
+    load_row<TI, CV>(x + r * C, c0, C, vec, t);
+#pragma unroll
+    for (int k = 0; k < CV; ++k) { v[k] += t[k]; v[CV + k] += t[k] * t[k]; }
+  }
+  block_allreduce<2 * CV>(v, red);
+  float scale[CV], shift[CV];
+#pragma unroll
+  for (int k = 0; k < CV; ++k) {
+    const int c = c0 + k;
+    scale[k] = 0.f; shift[k] = 0.f;
+    if (c < C) {
+      const float mean = v[k] / (float)M;
+      const float var = fmaxf(v[CV + k] / (float)M - mean * mean, 0.f);
+      const float invstd = rsqrtf(var + eps);
+      if (threadIdx.x == 0) {
+        const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+      }
+      scale[k] = gamma[c] * invstd;
+      shift[k] = beta[c] - mean * scale[k];
+    }
+  }
+  for (long r = threadIdx.x; r < M; r += BN_THREADS) {
+    float t[CV];
+    load_row<TI, CV>(x + r * C, c0, C, vec, t);
+#pragma unroll
+    for (int k = 0; k < CV; ++k) t[k] = fmaxf(t[k] * scale[k] + shift[k], 0.f);
+    store_row<TO, CV>(out + r * C, c0, C, vec, t);
+  }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(BN_THREADS) void bn_small_bwd_kernel(
+    const TI* __restrict__ x, const TO* __restrict__ dy, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ totals, long M, int C, int training,
+    TI* __restrict__ dx) {
+  __shared__ float red[4 * 2 * CV];
+  const int c0 = blockIdx.x * CV;
+  const bool vec = (C % CV) == 0;
+  float mu[CV], is[CV], ga[CV], be[CV], v[2 * CV];
+#pragma unroll
+  for (int k = 0; k < CV; ++k) {
+    const bool ok = c0 + k < C;
+    mu[k] = ok ? mean[c0 + k] : 0.f; is[k] = ok ? invstd[c0 + k] : 0.f;
+    ga[k] = ok ? gamma[c0 + k] : 0.f; be[k] = ok ? beta[c0 + k] : 0.f;
+    v[k] = 0.f; v[CV + k] = 0.f;
+  }
+  for (long r = threadIdx.x; r < M; r += BN_THREADS) {
+    float t[CV], d[CV];
+    load_row<TI, CV>(x + r * C, c0, C, vec, t);
+    load_row<TO, CV>(dy + r * C, c0, C, vec, d);
+#pragma unroll
+    for (int k = 0; k < CV; ++k) {
+      const float xh = (t[k] - mu[k]) * is[k];
+      const float dz = (xh * ga[k] + be[k] > 0.f) ? d[k] : 0.f;
+      v[k] += dz;
+      v[CV + k] += dz * xh;
+    }
+  }
+  block_allreduce<2 * CV>(v, red);
+  float m1[CV], m2[CV];
+#pragma unroll
+  for (int k = 0; k < CV; ++k) {
+    const int c = c0 + k;
+    if (c < C && threadIdx.x == 0) { totals[c] = v[k]; totals[C + c] = v[CV + k]; }
+    m1[k] = training ? v[k] / (float)M : 0.f;
+    m2[k] = training ? v[CV + k] / (float)M : 0.f;
+  }
+  for (long r = threadIdx.x; r < M; r += BN_THREADS) {
+    float t[CV], d[CV];
+    load_row<TI, CV>(x + r * C, c0, C, vec, t);
+    load_row<TO, CV>(dy + r * C, c0, C, vec, d);
+#pragma unroll
+    for (int k = 0; k < CV; ++k) {
+      const float xh = (t[k] - mu[k]) * is[k];
+      const float dz = (xh * ga[k] + be[k] > 0.f) ? d[k] : 0.f;
+      t[k] = ga[k] * is[k] * (dz - m1[k] - xh * m2[k]);
+    }
+    store_row<TI, CV>(dx + r * C, c0, C, vec, t);
+  }
+}
+
+// OFF: measured slower than the two-launch passes (one MI355X, batch 8: the train step went from 13.6 to 15.1 ms;
+// bn_small_fwd 50 us / bn_small_bwd 83 us per launch against 2 x 10-20 us) -- with one workgroup per 8 channels a lane
+// reads 16 bytes of a row that is 256 B - 1 KB long, and C / 8 workgroups (16-64) cannot stream even these few MB.
+// Kept for the record (-DBN_SMALL=1 builds it in); the cross-workgroup two-launch scheme above is the product path.
+#ifndef BN_SMALL
+#define BN_SMALL 0
+#endif
+inline bool bn_small(long m, int c) { return BN_SMALL && m <= BN_SMALL_MAX_ROWS && (long)m * c <= (4L << 20) && c >= 64; }
+
 // the two reduction kernels end in 2C global atomics per workgroup: cap them at 4 workgroups per CU
 int grid_for_reduce(long M, int C) {
   const int ngroups = (C + CV - 1) / CV;
@@ -394,6 +524,19 @@ extern "C" int repmode_bn_relu_fwd_ex(const void* x, void* out, const float* gam
   const int grid = grid_for(m, c);
   float* own = nullptr;
   RM_REQUIRE(stats_half < 0 || (training && stats_half <= 1), "bn_relu_fwd: bad statistics half %d", stats_half);
+  if (training && stats_half < 0 && bn_small(m, c)) {
+    const dim3 g((unsigned)((c + CV - 1) / CV));
+#define RM_BN_SMALL(TI, TO)                                                                                        \
+    hipLaunchKernelGGL((bn_small_fwd_kernel<TI, TO>), g, dim3(BN_THREADS), 0, s, (const TI*)x, (TO*)out, gamma, beta, \
+                       running_mean, running_var, save_mean, save_invstd, eps, momentum, m, c)
+    if (in_dtype == REPMODE_F32 && out_dtype == REPMODE_F32) RM_BN_SMALL(float, float);
+    else if (in_dtype == REPMODE_F32) RM_BN_SMALL(float, bf16_t);
+    else if (out_dtype == REPMODE_F32) RM_BN_SMALL(bf16_t, float);
+    else RM_BN_SMALL(bf16_t, bf16_t);
+#undef RM_BN_SMALL
+    RM_LAUNCH_CHECK("bn_small_fwd");
+    return REPMODE_OK;
+  }
   if (training && stats_half >= 0) {
     float* scratch = repmode_zero_scratch(s);
     if (!scratch) return REPMODE_ELAUNCH;
@@ -431,6 +574,19 @@ extern "C" int repmode_bn_relu_bwd(const void* x, const void* dy, const float* g
   RM_REQUIRE(m > 0 && c > 0 && c <= BN_MAXC, "bn_relu_bwd: bad shape (C <= %d)", BN_MAXC);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int grid = grid_for(m, c);
+  if (bn_small(m, c)) {
+    const dim3 g((unsigned)((c + CV - 1) / CV));
+#define RM_BN_SMALL(TI, TO)                                                                                              \
+    hipLaunchKernelGGL((bn_small_bwd_kernel<TI, TO>), g, dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy, save_mean,  \
+                       save_invstd, gamma, beta, totals, m, c, training, (TI*)dx)
+    if (in_dtype == REPMODE_F32 && out_dtype == REPMODE_F32) RM_BN_SMALL(float, float);
+    else if (in_dtype == REPMODE_F32) RM_BN_SMALL(float, bf16_t);
+    else if (out_dtype == REPMODE_F32) RM_BN_SMALL(bf16_t, float);
+    else RM_BN_SMALL(bf16_t, bf16_t);
+#undef RM_BN_SMALL
+    RM_LAUNCH_CHECK("bn_small_bwd");
+    return REPMODE_OK;
+  }
   float* scratch = repmode_zero_scratch(s);
   if (!scratch) return REPMODE_ELAUNCH;
   const int half = repmode_bn_scratch_half(s);

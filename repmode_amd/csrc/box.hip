@@ -173,6 +173,99 @@ __global__ __launch_bounds__(256) void box_sum_lds_kernel(const float* __restric
 }
 }  // namespace
 
+// x (bf16 or float) -> out[0] = x, out[1] = box3(x), out[2] = box5(x), all float [n][v][c]: the inputs of the three 1x1
+// experts' GEMM in ONE launch (a widening copy and two box launches before).  Same separable scheme as above.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void box_expand_lds_kernel(const T* __restrict__ x, float* __restrict__ out, size_t estride, int D,
+                                                             int H, int W, int C, int CB) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char box_smem[];
+  const int V = D * H * W, c4n = CB / 4, items = V * c4n;
+  f32x4* A = reinterpret_cast<f32x4*>(box_smem);
+  f32x4* B = A + items;
+  const int n = blockIdx.x, c0 = blockIdx.y * CB;
+  const int tid = threadIdx.x;
+  constexpr int MAXI = 16;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r = pass ? 2 : 1;
+    const float scale = pass ? 1.0f / 125.0f : 1.0f / 27.0f;
+    __syncthreads();
+    for (int i = tid; i < items; i += 256) {
+      const int v = i / c4n, q = i % c4n;
+      const int c = c0 + 4 * q;
+      f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < C) {
+        const T* p = x + ((size_t)n * V + v) * C + c;
+        if constexpr (sizeof(T) == 4) {
+          t = *reinterpret_cast<const f32x4*>(p);
+        } else {
+          const u32x2 w = *reinterpret_cast<const u32x2*>(p);
+          t = f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                    __uint_as_float(w.y & 0xffff0000u)};
+        }
+        if (pass == 0) *reinterpret_cast<f32x4*>(out + ((size_t)n * V + v) * C + c) = t;
+      }
+      A[i] = t;
+    }
+    __syncthreads();
+    for (int i = tid; i < items; i += 256) {       // along x: A -> B
+      const int v = i / c4n, xx = v % W;
+      f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int d = -r; d <= r; ++d)
+        if ((unsigned)(xx + d) < (unsigned)W) t += A[i + d * c4n];
+      B[i] = t;
+    }
+    __syncthreads();
+    for (int i = tid; i < items; i += 256) {       // along y: B -> A
+      const int v = i / c4n, y = (v / W) % H;
+      f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int d = -r; d <= r; ++d)
+        if ((unsigned)(y + d) < (unsigned)H) t += B[i + d * W * c4n];
+      A[i] = t;
+    }
+    __syncthreads();
+    float* dst = out + (size_t)(pass + 1) * estride;
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {               // along z: A -> out
+      const int i = tid + j * 256;
+      if (i < items) {
+        const int v = i / c4n, q = i % c4n, z = v / (W * H);
+        const int c = c0 + 4 * q;
+        f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int d = -r; d <= r; ++d)
+          if ((unsigned)(z + d) < (unsigned)D) t += A[i + d * H * W * c4n];
+        if (c < C) *reinterpret_cast<f32x4*>(dst + ((size_t)n * V + v) * C + c) = t * scale;
+      }
+    }
+  }
+}
+}  // namespace
+
+// out: float [3][n][d][h][w][c].  Volumes that fit in LDS with c % 4 == 0 (the deep levels this runs on); returns
+// REPMODE_EINVAL otherwise (the caller then uses a copy + repmode_box_sum_ex).
+extern "C" int repmode_box_expand(const void* x, int dtype, float* out, int n, int d, int h, int w, int c, void* stream) {
+  RM_REQUIRE(x && out, "box_expand: null pointer");
+  RM_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && c > 0, "box_expand: bad shape");
+  RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "box_expand: bad dtype %d", dtype);
+  const long V = (long)d * h * w;
+  int cb = 0;
+  if ((c & 3) == 0)
+    for (int t = 16; t >= 4; t >>= 1)
+      if (V * t * 4 * 2 <= 60 * 1024 && V * (t / 4) <= 256 * 16) { cb = t; break; }
+  RM_REQUIRE(cb > 0, "box_expand: the volume does not fit in LDS (or c %% 4 != 0)");
+  const size_t lds = (size_t)V * cb * 4 * 2;
+  const dim3 grid((unsigned)n, (unsigned)((c + cb - 1) / cb));
+  const size_t estride = (size_t)n * V * c;
+  if (dtype == REPMODE_BF16)
+    hipLaunchKernelGGL(box_expand_lds_kernel<bf16_t>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), (const bf16_t*)x, out,
+                       estride, d, h, w, c, cb);
+  else
+    hipLaunchKernelGGL(box_expand_lds_kernel<float>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), (const float*)x, out,
+                       estride, d, h, w, c, cb);
+  RM_LAUNCH_CHECK("box_expand");
+  return REPMODE_OK;
+}
+
 extern "C" int repmode_box_sum_ex(const float* in3, const float* in5, const float* add0, const float* add1, void* out,
                                   int out_dtype, int n, int d, int h, int w, int c, void* stream) {
   RM_REQUIRE(out && (in3 || in5), "box_sum: null pointer");

@@ -93,10 +93,61 @@ struct GatrepFwdLds {
 
 // one workgroup: (reduction chunk kc, row tile rt, zidx = group of 4 rows x tap part); 256 threads =
 // (PAIRS / 2 element pairs) x TQ tap phases
+// Gate probabilities of slots [s0, s0 + ns) for the KC columns this workgroup needs, into L.sg.  Either read from g, or
+// (gate_w != nullptr) computed here -- g[s][e][o] = softmax_e(gate_w[e*Co+o][task_s] + gate_b[e*Co+o]), RepMode.py:198-200
+// -- which folds the gate softmax launch into this one; the forward-filter workgroups of reduction chunk 0 / tap part 0
+// then also write their four channels to g_out (every channel exactly once), for the backward pass.
+struct GateSrc {
+  const float* g;          // precomputed probabilities [S][5][Co], or nullptr
+  const float* gate_w;     // [5*Co][T]
+  const float* gate_b;     // [5*Co]
+  const int32_t* slot_task;
+  int num_tasks;
+  float* g_out;            // [S][5][Co] (may be nullptr)
+};
+
+template <typename T, bool WRITE_WD>
+__device__ __forceinline__ void load_gate(GatrepFwdLds<T>& L, const GateSrc& gs, int s0, int ns, int co_n, int kc, int rt, int grp,
+                                          bool writer) {
+  constexpr int KC = FragGeom<T>::KC;
+  const int tid = threadIdx.x;
+  if (gs.gate_w == nullptr) {
+    for (int i = tid; i < ns * E * KC; i += 256) {
+      const int col = i % KC, e = (i / KC) % E, sl = i / (KC * E);
+      // column -> co: wf: rows grp*4 + col (col < 4), wd: reduction channels kc*KC + col
+      const int co = WRITE_WD ? kc * KC + col : rt * 32 + grp * 4 + (col & 3);
+      L.sg[sl][e][col] = gs.g[((size_t)(s0 + sl) * E + e) * co_n + min(co, co_n - 1)];
+    }
+    return;
+  }
+  for (int i = tid; i < ns * KC; i += 256) {
+    const int col = i % KC, sl = i / KC;
+    const int cog = WRITE_WD ? kc * KC + col : rt * 32 + grp * 4 + (col & 3);
+    const int co = min(cog, co_n - 1);
+    const int task = gs.slot_task[s0 + sl];
+    float logit[E], mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      logit[e] = gs.gate_w[(size_t)(e * co_n + co) * gs.num_tasks + task] + gs.gate_b[e * co_n + co];
+      mx = fmaxf(mx, logit[e]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { logit[e] = expf(logit[e] - mx); sum += logit[e]; }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float p = logit[e] * inv;
+      L.sg[sl][e][col] = p;
+      if (writer && !WRITE_WD && col < 4 && cog < co_n && gs.g_out) gs.g_out[((size_t)(s0 + sl) * E + e) * co_n + cog] = p;
+    }
+  }
+}
+
 template <typename T, bool WRITE_WD>
 __device__ __forceinline__ void gatrep_fwd_body(
     GatrepFwdLds<T>& L, const float* __restrict__ k5, const float* __restrict__ k3, const float* __restrict__ k1,
-    const float* __restrict__ a3, const float* __restrict__ a5, const float* __restrict__ g, int nslots,
+    const float* __restrict__ a3, const float* __restrict__ a5, const GateSrc& gs, int nslots,
     int co_n, int ci_n, int nrt, int nkc, int tsplit, T* __restrict__ wout, int kc, int rt, int zidx) {
   using G = FragGeom<T>;
   constexpr int KC = G::KC, PAIRS = G::PAIRS, TQ = G::TQ;
@@ -149,13 +200,10 @@ __device__ __forceinline__ void gatrep_fwd_body(
     sa3[tid] = live ? a3[oi] * (1.0f / 27.0f) : 0.f;
     sa5[tid] = live ? a5[oi] * (1.0f / 125.0f) : 0.f;
   }
-  // gate probabilities of the first 16 slots: loaded here, with everything else the workgroup needs, before the
-  // first barrier (one round trip to memory instead of two when the inputs are cold)
-  for (int i = tid; i < min(16, nslots) * E * KC; i += 256) {
-    const int col = i % KC, e = (i / KC) % E, sl = i / (KC * E);
-    const int cog = WRITE_WD ? kc * KC + col : rt * 32 + grp * 4 + (col & 3);
-    sg[sl][e][col] = g[((size_t)sl * E + e) * co_n + min(cog, co_n - 1)];
-  }
+  // gate probabilities of the first 16 slots: loaded (or computed) here, with everything else the workgroup needs,
+  // before the first barrier (one round trip to memory instead of two when the inputs are cold)
+  const bool gate_writer = !WRITE_WD && kc == 0 && part == 0;
+  load_gate<T, WRITE_WD>(L, gs, 0, min(16, nslots), co_n, kc, rt, grp, gate_writer);
   __syncthreads();
   // ---- merge: this thread owns elements pr and pr + 1 (adjacent reduction channels of one row)
   const int p2 = tid % (PAIRS / 2), tq = tid / (PAIRS / 2);
@@ -193,12 +241,7 @@ __device__ __forceinline__ void gatrep_fwd_body(
     const int ns = min(16, nslots - s0);
     if (s0 > 0) {
       __syncthreads();
-      for (int i = tid; i < ns * E * KC; i += 256) {
-        const int col = i % KC, e = (i / KC) % E, sl = i / (KC * E);
-        // column -> co: wf: rows grp*4 + col (col < 4), wd: reduction channels kc*KC + col
-        const int co = WRITE_WD ? kc * KC + col : rt * 32 + grp * 4 + (col & 3);
-        sg[sl][e][col] = g[((size_t)(s0 + sl) * E + e) * co_n + min(co, co_n - 1)];
-      }
+      load_gate<T, WRITE_WD>(L, gs, s0, ns, co_n, kc, rt, grp, gate_writer);
       __syncthreads();
     }
     for (int sl = 0; sl < ns; ++sl) {
@@ -232,7 +275,7 @@ __device__ __forceinline__ void gatrep_fwd_body(
 template <typename T>
 __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
     const float* __restrict__ k5, const float* __restrict__ k3, const float* __restrict__ k1,
-    const float* __restrict__ a3, const float* __restrict__ a5, const float* __restrict__ g, int nslots,
+    const float* __restrict__ a3, const float* __restrict__ a5, GateSrc gs, int nslots,
     int co_n, int ci_n, int nwf, int nrt_f, int nkc_f, int ts_f, T* __restrict__ wf, int nrt_d, int nkc_d, int ts_d,
     T* __restrict__ wd) {
   __shared__ GatrepFwdLds<T> L;
@@ -240,12 +283,12 @@ __global__ __launch_bounds__(256) void gatrep_fwd_kernel(
   if (b < nwf) {
     const int kc = b % nkc_f; b /= nkc_f;
     const int rt = b % nrt_f;
-    gatrep_fwd_body<T, false>(L, k5, k3, k1, a3, a5, g, nslots, co_n, ci_n, nrt_f, nkc_f, ts_f, wf, kc, rt, b / nrt_f);
+    gatrep_fwd_body<T, false>(L, k5, k3, k1, a3, a5, gs, nslots, co_n, ci_n, nrt_f, nkc_f, ts_f, wf, kc, rt, b / nrt_f);
   } else {
     b -= nwf;
     const int kc = b % nkc_d; b /= nkc_d;
     const int rt = b % nrt_d;
-    gatrep_fwd_body<T, true>(L, k5, k3, k1, a3, a5, g, nslots, co_n, ci_n, nrt_d, nkc_d, ts_d, wd, kc, rt, b / nrt_d);
+    gatrep_fwd_body<T, true>(L, k5, k3, k1, a3, a5, gs, nslots, co_n, ci_n, nrt_d, nkc_d, ts_d, wd, kc, rt, b / nrt_d);
   }
 }
 
@@ -476,7 +519,7 @@ extern "C" int repmode_gate_softmax(const float* gate_w, const float* gate_b, co
 
 template <typename T>
 static int gatrep_fwd_t(const float* k5, const float* k3, const float* k1, const float* a3, const float* a5,
-                        const float* g, int nslots, int co, int ci, int dtype, void* wf, void* wd, hipStream_t s) {
+                        GateSrc gs, int nslots, int co, int ci, int dtype, void* wf, void* wd, hipStream_t s) {
   constexpr int KC = FragGeom<T>::KC;
   // algorithmic bytes: 155 expert floats read once + 125 merged elements written per slot and layout
   const double bytes = (double)co * ci * (155.0 * 4 + 125.0 * nslots * sizeof(T) * ((wf ? 1 : 0) + (wd ? 1 : 0)));
@@ -495,7 +538,7 @@ static int gatrep_fwd_t(const float* k5, const float* k3, const float* k1, const
     nwd = (long)nkc_d * nrt_d * 8 * ts_d;
   }
   RM_REQUIRE(nwf + nwd < (1L << 31), "gatrep_fwd: grid too large");
-  hipLaunchKernelGGL((gatrep_fwd_kernel<T>), dim3((unsigned)(nwf + nwd)), dim3(256), 0, s, k5, k3, k1, a3, a5, g, nslots, co,
+  hipLaunchKernelGGL((gatrep_fwd_kernel<T>), dim3((unsigned)(nwf + nwd)), dim3(256), 0, s, k5, k3, k1, a3, a5, gs, nslots, co,
                      ci, (int)nwf, nrt_f, nkc_f, ts_f, static_cast<T*>(wf), nrt_d, nkc_d, ts_d, static_cast<T*>(wd));
   RM_LAUNCH_CHECK("gatrep_fwd");
   repmode_prof_end(s);
@@ -510,8 +553,25 @@ extern "C" int repmode_gatrep_fwd(const float* k5, const float* k3, const float*
   RM_REQUIRE(nslots > 0 && co > 0 && ci > 0, "gatrep_fwd: bad shape");
   RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "gatrep_fwd: bad dtype %d", dtype);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == REPMODE_F32) return gatrep_fwd_t<float>(k5, k3, k1, a3, a5, g, nslots, co, ci, dtype, wf, wd, s);
-  return gatrep_fwd_t<bf16_t>(k5, k3, k1, a3, a5, g, nslots, co, ci, dtype, wf, wd, s);
+  const GateSrc gs{g, nullptr, nullptr, nullptr, 0, nullptr};
+  if (dtype == REPMODE_F32) return gatrep_fwd_t<float>(k5, k3, k1, a3, a5, gs, nslots, co, ci, dtype, wf, wd, s);
+  return gatrep_fwd_t<bf16_t>(k5, k3, k1, a3, a5, gs, nslots, co, ci, dtype, wf, wd, s);
+}
+
+// Gate softmax + GatRep forward in ONE launch (RepMode.py:198-200 + :165-192): the workgroups compute the probabilities
+// of the channels they merge from gate_w / gate_b / slot_task themselves; g_out [nslots][5][co] receives them for the
+// backward pass (needs wf: the forward-filter workgroups are the ones that write it).
+extern "C" int repmode_gatrep_fwd_gate(const float* k5, const float* k3, const float* k1, const float* a3, const float* a5,
+                                       const float* gate_w, const float* gate_b, const int32_t* slot_task, int nslots,
+                                       int num_tasks, int co, int ci, int dtype, float* g_out, void* wf, void* wd, void* stream) {
+  RM_REQUIRE(k5 && k3 && k1 && a3 && a5 && gate_w && gate_b && slot_task, "gatrep_fwd_gate: null pointer");
+  RM_REQUIRE(wf && g_out, "gatrep_fwd_gate: the forward filter and g_out must be given");
+  RM_REQUIRE(nslots > 0 && num_tasks > 0 && co > 0 && ci > 0, "gatrep_fwd_gate: bad shape");
+  RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "gatrep_fwd_gate: bad dtype %d", dtype);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const GateSrc gs{nullptr, gate_w, gate_b, slot_task, num_tasks, g_out};
+  if (dtype == REPMODE_F32) return gatrep_fwd_t<float>(k5, k3, k1, a3, a5, gs, nslots, co, ci, dtype, wf, wd, s);
+  return gatrep_fwd_t<bf16_t>(k5, k3, k1, a3, a5, gs, nslots, co, ci, dtype, wf, wd, s);
 }
 
 // ------------------------------------------------------------------------------------------------

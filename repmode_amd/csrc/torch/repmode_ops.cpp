@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -164,16 +165,24 @@ struct SinkEntry {
 std::mutex g_sink_mu;
 std::unordered_map<void*, SinkEntry> g_sink;
 
-Tensor grad_out(const Tensor& param) {
+// from_sink (optional out): the buffer is a slice of a reducer's bucket (NOT a fresh tensor)
+Tensor grad_out(const Tensor& param, bool* from_sink = nullptr) {
+  if (from_sink) *from_sink = false;
   {
     std::lock_guard<std::mutex> lock(g_sink_mu);
     if (!g_sink.empty()) {
       auto it = g_sink.find(param.data_ptr());
-      if (it != g_sink.end() && !it->second.param.grad().defined() && it->second.param.sizes() == param.sizes())
+      if (it != g_sink.end() && !it->second.param.grad().defined() && it->second.param.sizes() == param.sizes()) {
+        if (from_sink) *from_sink = true;
         return it->second.flat.as_strided(param.sizes(), param.strides(), it->second.offset);
+      }
     }
   }
   return at::empty_like(param);
+}
+bool grad_sink_active() {
+  std::lock_guard<std::mutex> lock(g_sink_mu);
+  return !g_sink.empty();
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -297,6 +306,22 @@ std::pair<Tensor, Tensor> gatrep_merge(const Tensor& k5, const Tensor& k3, const
           a5.data_ptr<float>(), g.data_ptr<float>(), (int)s, (int)co, (int)ci, code, want_wf ? wf.data_ptr() : nullptr,
           want_wd ? wd.data_ptr() : nullptr, stream_handle());
   return {wf, wd};
+}
+
+// gate softmax + GatRep in one launch (repmode_gatrep_fwd_gate): (g [S,5,Co], wf, wd or undefined)
+std::tuple<Tensor, Tensor, Tensor> gatrep_merge_gate(const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3, const Tensor& a5,
+                                                      const Tensor& gw, const Tensor& gb, const Tensor& slot_task, int64_t nslots,
+                                                      int64_t num_tasks, at::ScalarType dt, bool want_wd) {
+  const int64_t co = k5.size(0), ci = k5.size(1);
+  const int code = dtype_code(dt);
+  Tensor g = at::empty({nslots, E, co}, k5.options());
+  Tensor wf = at::empty({nslots, TAPS, padded(co, code, false), padded(ci, code, true)}, k5.options().dtype(dt));
+  Tensor wd;
+  if (want_wd) wd = at::empty({nslots, TAPS, padded(ci, code, false), padded(co, code, true)}, k5.options().dtype(dt));
+  RM_CALL(repmode_gatrep_fwd_gate, k5.data_ptr<float>(), k3.data_ptr<float>(), k1.data_ptr<float>(), a3.data_ptr<float>(),
+          a5.data_ptr<float>(), gw.data_ptr<float>(), gb.data_ptr<float>(), slot_task.data_ptr<int32_t>(), (int)nslots, (int)num_tasks,
+          (int)co, (int)ci, code, g.data_ptr<float>(), wf.data_ptr(), want_wd ? wd.data_ptr() : nullptr, stream_handle());
+  return std::make_tuple(g, wf, wd);
 }
 
 Tensor expert_selector(int64_t co, const Tensor& like) {
@@ -451,6 +476,37 @@ Tensor box_sum(const Tensor* in3, const Tensor* in5, const Tensor* add0, const T
   return o;
 }
 
+// the three 1x1 experts' GEMMs in one launch (csrc/gemm3.hip): C_i[m][n] = sum_k A_i(m, k) B_i(n, k)
+void gemm3(const Tensor a[3], int64_t a_ms, int64_t a_ks, const Tensor b[3], int64_t b_ns, int64_t b_ks, Tensor c[3], int64_t ldc,
+           int64_t m, int64_t n, int64_t k, bool c_is_zero, bool bf16_mfma) {
+  const float* ap[3] = {a[0].data_ptr<float>(), a[1].data_ptr<float>(), a[2].data_ptr<float>()};
+  const float* bp[3] = {b[0].data_ptr<float>(), b[1].data_ptr<float>(), b[2].data_ptr<float>()};
+  float* cp[3] = {c[0].data_ptr<float>(), c[1].data_ptr<float>(), c[2].data_ptr<float>()};
+  RM_CALL(repmode_gemm3, ap, (long)a_ms, (long)a_ks, bp, (long)b_ns, (long)b_ks, cp, (int)ldc, (int)m, (int)n, (int)k, c_is_zero ? 1 : 0,
+          bf16_mfma ? 1 : 0, stream_handle());
+}
+
+// [x | box3(x) | box5(x)] as float [3][n][d][h][w][c]: one launch when the volume fits in LDS (repmode_box_expand's rule)
+Tensor box_expand(const Tensor& x_cl) {
+  const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), w = x_cl.size(3), c = x_cl.size(4);
+  Tensor xb = at::empty({3, n, d, h, w, c}, x_cl.options().dtype(at::kFloat));
+  const int64_t v = d * h * w;
+  bool fits = false;
+  if ((c & 3) == 0)
+    for (int64_t t = 16; t >= 4; t >>= 1)
+      if (v * t * 8 <= 60 * 1024 && v * (t / 4) <= 256 * 16) { fits = true; break; }
+  if (fits) {
+    RM_CALL(repmode_box_expand, x_cl.data_ptr(), dtype_code(x_cl.scalar_type()), xb.data_ptr<float>(), (int)n, (int)d, (int)h, (int)w, (int)c,
+            stream_handle());
+  } else {
+    Tensor xb0 = xb[0], xb1 = xb[1], xb2 = xb[2];
+    xb0.copy_(x_cl);
+    box_sum(&xb0, nullptr, nullptr, nullptr, xb1, at::kFloat);
+    box_sum(nullptr, &xb0, nullptr, nullptr, xb2, at::kFloat);
+  }
+  return xb;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // eval-mode filter cache: inside [begin, end) the merged filter of an eval-mode block (one slot, RepMode.py:209-210)
 // is computed once per (block, task, dtype): sliding-window inference re-uses it for every batch of patches.
@@ -520,11 +576,15 @@ Merged merged_filters(const Tensor& k5, const Tensor& k3, const Tensor& k1, cons
   }
   Merged m;
   if (!fold_scale && take_prepared(k5, plan.nslots, dt, false, want_wd, &m)) return m;
-  m.g = gate_softmax(gw, gb, plan.slot_task, plan.nslots, plan.num_tasks, k5.size(0));
-  if (fold_scale) m.g = m.g * fold_scale->view({1, 1, -1});
-  auto w = gatrep_merge(k5, k3, k1, a3, a5, m.g, dt, true, want_wd);
-  m.wf = w.first;
-  m.wd = w.second;
+  if (fold_scale) {
+    m.g = gate_softmax(gw, gb, plan.slot_task, plan.nslots, plan.num_tasks, k5.size(0));
+    m.g = m.g * fold_scale->view({1, 1, -1});
+    auto w = gatrep_merge(k5, k3, k1, a3, a5, m.g, dt, true, want_wd);
+    m.wf = w.first;
+    m.wd = w.second;
+  } else {
+    std::tie(m.g, m.wf, m.wd) = gatrep_merge_gate(k5, k3, k1, a3, a5, gw, gb, plan.slot_task, plan.nslots, plan.num_tasks, dt, want_wd);
+  }
   if (cacheable) {
     std::lock_guard<std::mutex> lock(g_eval_mu);
     if (g_eval_depth > 0) g_eval[key] = {m.g, m.wf};
@@ -763,21 +823,18 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     auto tk = g_pool.take({E, n, d, h, w, co}, x_cl);                                     // expert outputs P_e
     Tensor p = tk.first;
     const bool pre = tk.second;
-    Tensor xb = at::empty({3, n, d, h, w, ci}, x_cl.options().dtype(at::kFloat));
-    Tensor w1;
-    // the 5^3 expert's conv on this stream, the four small experts beside it on the second one
+    Tensor xb;
+    // the 5^3 (+ 3^3) expert's conv on this stream, the small experts beside it on the second one
     Fork fork(forks(x_cl), x_cl);
     fork.to_side();
     {
-      // the 3^3 expert, and the three 1x1 experts as ONE batched GEMM: [x | box3(x) | box5(x)] @ [K1 | A3 | A5]^T -> P_2..P_4
+      // the 3^3 expert (unless it shares the 5^3 expert's launch), and the three 1x1 experts as ONE batched GEMM launch:
+      // [x | box3(x) | box5(x)] @ [K1 | A3 | A5]^T  -> P_2..P_4
       if (!g_dual_launch) conv5(x_cl, fr.first, s1, co, true, p[1], true, pre);
-      Tensor xb0 = xb[0], xb1 = xb[1], xb2 = xb[2];
-      xb0.copy_(x_cl);
-      box_sum(&xb0, nullptr, nullptr, nullptr, xb1, at::kFloat);
-      box_sum(nullptr, &xb0, nullptr, nullptr, xb2, at::kFloat);
-      w1 = at::stack({k1.view({co, ci}), a3.view({co, ci}), a5.view({co, ci})});          // [3, Co, Ci]
-      Tensor pv = p.narrow(0, 2, 3).view({3, -1, co});
-      at::bmm_out(pv, xb.view({3, -1, ci}), w1.transpose(1, 2));
+      xb = box_expand(x_cl);
+      const Tensor am[3] = {xb[0], xb[1], xb[2]}, bm[3] = {k1, a3, a5};
+      Tensor cm[3] = {p[2], p[3], p[4]};
+      gemm3(am, ci, 1, bm, ci, 1, cm, co, n * d * h * w, co, ci, pre, x_cl.scalar_type() == at::kBFloat16);      // (P lives in the step's pre-zeroed pool tensor)
     }
     fork.to_main();
     if (g_dual_launch) conv5(x_cl, fr.first, s0, co, true, p.narrow(0, 0, 2).view({2 * n, d, h, w, co}), false, pre, false, nullptr, DUAL_OUT2);
@@ -786,7 +843,7 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     Tensor y = at::empty({n, d, h, w, co}, x_cl.options().dtype(at::kFloat));
     RM_CALL(repmode_expert_mix_fwd, p.data_ptr<float>(), gn.data_ptr<float>(), y.data_ptr<float>(), (int)n, (long)(d * h * w), (int)co,
             stream_handle());
-    ctx->save_for_backward({x_cl, k5, k3, k1, a3, a5, gn, xb, w1, p, fr.second.defined() ? fr.second : Tensor()});
+    ctx->save_for_backward({x_cl, k5, k3, k1, a3, a5, gn, xb, p, fr.second.defined() ? fr.second : Tensor()});
     ctx->saved_data["sample_task"] = plan.sample_task;
     ctx->saved_data["num_tasks"] = plan.num_tasks;
     return y;
@@ -794,31 +851,22 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     auto sv = ctx->get_saved_variables();
-    const Tensor &x_cl = sv[0], &k5 = sv[1], &k3 = sv[2], &k1 = sv[3], &a3 = sv[4], &a5 = sv[5], &gn = sv[6], &xb = sv[7], &w1 = sv[8],
-                 &p = sv[9];
-    Tensor wd2 = sv[10];
+    const Tensor &x_cl = sv[0], &k5 = sv[1], &k3 = sv[2], &k1 = sv[3], &a3 = sv[4], &a5 = sv[5], &gn = sv[6], &xb = sv[7], &p = sv[8];
+    Tensor wd2 = sv[9];
     const Tensor sample_task = ctx->saved_data["sample_task"].toTensor();
     const int64_t num_tasks = ctx->saved_data["num_tasks"].toInt();
     const int64_t co = k5.size(0), ci = k5.size(1);
     const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), w = x_cl.size(3);
     const at::ScalarType dt = x_cl.scalar_type();
     Tensor dy = grads[0].to(at::kFloat).contiguous();
-    // ---- gate: dg[n,e,o] = <dy, P_e>, softmax Jacobian, Linear grads (RepMode.py:198-200); and the gate-scaled dy per expert.
-    // The three float matrices feed batched GEMMs; rocBLAS picks a pathological kernel when such a GEMM has exactly
-    // 256 x 256 (or 128 x 256) outputs, so for small M each matrix gets 8 rows of zero padding.
+    // ---- gate: dg[n,e,o] = <dy, P_e>, softmax Jacobian, Linear grads (RepMode.py:198-200); and the gate-scaled dy per
+    // expert: the two conv experts' in the element type (operands of the conv kernels), the three 1x1 experts' in float
     const int64_t m = n * d * h * w;
-    const int64_t pad = m <= 512 ? 8 : 0;
+    const int64_t pad = 0;
     auto tdg = g_pool.take({n, E, co}, x_cl);
     Tensor dg = tdg.first;
     Tensor lo = at::empty({2, n, d, h, w, co}, x_cl.options().dtype(dt));
-    Tensor hi;
-    if (pad) {
-      auto th = g_pool.take({3, m + pad, co}, x_cl);
-      hi = th.first;
-      if (!th.second) hi.narrow(1, m, pad).zero_();
-    } else {
-      hi = at::empty({3, m, co}, x_cl.options().dtype(at::kFloat));
-    }
+    Tensor hi = at::empty({3, m, co}, x_cl.options().dtype(at::kFloat));
     RM_CALL(repmode_expert_mix_bwd_ex, dy.data_ptr<float>(), p.data_ptr<float>(), gn.data_ptr<float>(), dg.data_ptr<float>(), lo.data_ptr(),
             hi.data_ptr<float>(), (long)((m + pad) * co), (int)n, (long)(d * h * w), (int)co, dtype_code(dt) | (tdg.second ? 16 : 0),
             stream_handle());
@@ -831,7 +879,7 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     // the expert gradients do not depend on the data gradient: second stream
     Fork fork(need_dx && forks(x_cl), x_cl);
     fork.to_side();
-    Tensor dk5, dk3, d1;
+    Tensor dk5, dk3, dk1, da3, da5;
     {
       // filter gradients of the gate-scaled dy, all samples in one slot.  Large layers (every workgroup owns its outputs: no
       // atomics) write the parameters' [Co][Ci][taps] layout directly; the others accumulate tap-major + one transpose launch.
@@ -841,7 +889,26 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
       else dk5 = tap_transpose(conv5_wgrad(x_cl, lo0, s0, 1, co)[0], k5.sizes(), grad_out(k5));
       if (dt == at::kBFloat16 && tiles * 3 >= 512) dk3 = conv5_wgrad_expert_layout(x_cl, lo1, s0, co, 3, grad_out(k3));
       else dk3 = tap_transpose(conv5_wgrad(x_cl, lo1, s0, 1, co, true)[0], k3.sizes(), grad_out(k3));
-      d1 = at::bmm(hi.narrow(1, 0, m).transpose(1, 2), xb.view({3, -1, ci}));              // [3, Co, Ci]
+      // the 1x1 experts' filter gradients dW_e[co][ci] = sum_m G_e[m][co] X_e[m][ci], straight into the parameters' gradients
+      // (K = all voxel rows: split over workgroups when the three outputs can come pre-zeroed out of the step's pool --
+      // not when they are slices of a data-parallel reducer's bucket)
+      bool zeroed = true;
+      Tensor* outs[3] = {&dk1, &da3, &da5};
+      const Tensor* prm[3] = {&k1, &a3, &a5};
+      for (int e = 0; e < 3; ++e) {
+        bool from_sink = false;
+        if (grad_sink_active()) *outs[e] = grad_out(*prm[e], &from_sink);
+        if (from_sink) {
+          zeroed = false;
+        } else {
+          auto tk = g_pool.take(prm[e]->sizes(), x_cl);
+          *outs[e] = tk.first;
+          zeroed = zeroed && tk.second;
+        }
+      }
+      const Tensor am[3] = {hi[0], hi[1], hi[2]}, bm[3] = {xb[0], xb[1], xb[2]};
+      Tensor cm[3] = {dk1, da3, da5};
+      gemm3(am, 1, co, bm, 1, ci, cm, ci, co, ci, m, zeroed, dt == at::kBFloat16);
     }
     fork.to_main();
     Tensor dx;
@@ -854,15 +921,21 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
         dxf = conv5(lo0, wd2, s0, ci, true);
         conv5(lo1, wd2, s1, ci, true, dxf, true, true);
       }
-      // 1x1 experts: one batched GEMM gives the three partial data gradients; the zero-padded box mean is self-adjoint, so the
-      // avg experts' parts go back through box3 / box5 -- summed with the two conv parts and cast in the same kernel
-      Tensor t = at::bmm(hi, w1);                                                          // [3, M(+pad), Ci]
-      Tensor t0 = t[0].narrow(0, 0, m).view(dxf.sizes()), t1 = t[1].narrow(0, 0, m).view(dxf.sizes()),
-             t2 = t[2].narrow(0, 0, m).view(dxf.sizes());
+      // 1x1 experts: one batched GEMM launch gives the three partial data gradients T_e = G_e W_e; the zero-padded box mean is
+      // self-adjoint, so the avg experts' parts go back through box3 / box5 -- summed with the two conv parts and cast in
+      // the same kernel
+      auto tt = g_pool.take({3, m, ci}, x_cl);
+      Tensor t = tt.first;
+      {
+        const Tensor am[3] = {hi[0], hi[1], hi[2]}, bm[3] = {k1, a3, a5};
+        Tensor cm[3] = {t[0], t[1], t[2]};
+        gemm3(am, co, 1, bm, 1, ci, cm, ci, m, ci, co, tt.second, dt == at::kBFloat16);
+      }
+      Tensor t0 = t[0].view(dxf.sizes()), t1 = t[1].view(dxf.sizes()), t2 = t[2].view(dxf.sizes());
       dx = box_sum(&t1, &t2, &dxf, &t0, c10::nullopt, dt);
     }
     fork.join();
-    return {dx, dk5, dk3, d1[0].reshape(k1.sizes()), d1[1].reshape(a3.sizes()), d1[2].reshape(a5.sizes()), dgw, dgb, Tensor(), Tensor()};
+    return {dx, dk5, dk3, dk1, da3, da5, dgw, dgb, Tensor(), Tensor()};
   }
 };
 
@@ -1261,10 +1334,8 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
         e.wd = fr.second;
       } else {
         e.rows = plan.nslots;
-        e.g = gate_softmax(gw[i].contiguous(), gb[i].contiguous(), plan.slot_task, plan.nslots, plan.num_tasks, co);
-        auto w = gatrep_merge(K5, K3, k1[i].contiguous(), a3[i].contiguous(), a5[i].contiguous(), e.g, dt, true, need_dx[i] != 0);
-        e.wf = w.first;
-        e.wd = w.second;
+        std::tie(e.g, e.wf, e.wd) = gatrep_merge_gate(K5, K3, k1[i].contiguous(), a3[i].contiguous(), a5[i].contiguous(), gw[i].contiguous(),
+                                                      gb[i].contiguous(), plan.slot_task, plan.nslots, plan.num_tasks, dt, need_dx[i] != 0);
       }
       e.ev = g_prep_events[i];
       RM_HIP_CHECK(hipEventRecord(e.ev, ss.prep.stream()));
@@ -1310,7 +1381,7 @@ std::tuple<Tensor, bool> op_zero_pool_take(std::vector<int64_t> shape, const Ten
   auto tk = g_pool.take(shape, like);
   return std::make_tuple(tk.first, tk.second);
 }
-Tensor op_grad_out(const Tensor& param) { return grad_out(param); }
+Tensor op_grad_out(const Tensor& param) { return grad_out(param, nullptr); }
 int64_t op_eval_cache_size() {
   std::lock_guard<std::mutex> lock(g_eval_mu);
   return (int64_t)g_eval.size();

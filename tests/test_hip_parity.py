@@ -1171,3 +1171,85 @@ def test_dual_expert_launch(ci, co, shape, n, dtype):
     tol = 5e-5 if dtype == torch.float32 else 1e-2          # (bf16: an atomics-order difference can flip a rounding)
     for a, b in zip(res[0], res[1]):
         assert rel_err(a, b) < tol
+
+
+@pytest.mark.parametrize('m,n,k', [(256, 512, 512), (2048, 256, 128), (70, 40, 24), (33, 65, 17)])
+def test_gemm3_three_layouts(m, n, k):
+    """repmode_gemm3 (the three 1x1 experts' GEMMs, one launch, exact-f32 MFMA) in the three stride patterns the per-expert
+    formulation uses -- X W^T, G^T X, G W -- against float64 matmuls."""
+    import ctypes
+    from repmode_amd import _lib
+    gen = torch.Generator().manual_seed(m + n + k)
+
+    def run(a_list, a_ms, a_ks, b_list, b_ns, b_ks, mm, nn, kk, bf16=0):
+        P = ctypes.c_void_p * 3
+        outs = []
+        for zero in (0, 1):           # one workgroup per tile (C overwritten) / K split over workgroups (C cleared by the caller)
+            c = [(torch.zeros if zero else torch.empty)(mm, nn, device=DEV) for _ in range(3)]
+            _lib.call('repmode_gemm3', P(*[t.data_ptr() for t in a_list]), a_ms, a_ks, P(*[t.data_ptr() for t in b_list]), b_ns, b_ks,
+                      P(*[t.data_ptr() for t in c]), nn, mm, nn, kk, zero, bf16, torch.cuda.current_stream().cuda_stream)
+            outs.append([t.cpu().double() for t in c])
+        for u, v in zip(*outs):
+            assert rel_err(u, v) < 1e-5
+        return outs[1]
+
+    x = [torch.randn(m, k, generator=gen) for _ in range(3)]          # [M][K]
+    w = [torch.randn(n, k, generator=gen) for _ in range(3)]          # [N][K]
+    g = [torch.randn(m, n, generator=gen) for _ in range(3)]          # [M][N]
+    xd, wd, gd = [t.to(DEV) for t in x], [t.to(DEV) for t in w], [t.to(DEV) for t in g]
+    for got, a, b in zip(run(xd, k, 1, wd, k, 1, m, n, k), x, w):                      # forward: X W^T
+        assert rel_err(got, a.double() @ b.double().t()) < 1e-5
+    for got, a, b in zip(run(gd, 1, n, xd, 1, k, n, k, m), g, x):                      # filter gradient: G^T X  [N][K]
+        assert rel_err(got, a.double().t() @ b.double()) < 1e-5
+    for got, a, b in zip(run(gd, n, 1, wd, 1, k, m, k, n), g, w):                      # data gradient: G W  [M][K]
+        assert rel_err(got, a.double() @ b.double()) < 1e-5
+    # bf16 matrix cores: operands exactly representable in bf16 -> only the accumulation order differs
+    xb, wb, gb = [t.bfloat16().float() for t in x], [t.bfloat16().float() for t in w], [t.bfloat16().float() for t in g]
+    xbd, wbd, gbd = [t.to(DEV) for t in xb], [t.to(DEV) for t in wb], [t.to(DEV) for t in gb]
+    for got, a, b in zip(run(xbd, k, 1, wbd, k, 1, m, n, k, bf16=1), xb, wb):
+        assert rel_err(got, a.double() @ b.double().t()) < 1e-5
+    for got, a, b in zip(run(gbd, 1, n, xbd, 1, k, n, k, m, bf16=1), gb, xb):
+        assert rel_err(got, a.double().t() @ b.double()) < 1e-5
+    for got, a, b in zip(run(gbd, n, 1, wbd, 1, k, m, k, n, bf16=1), gb, wb):
+        assert rel_err(got, a.double() @ b.double()) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 2, 4, 4, 64), (3, 4, 8, 8, 32), (1, 1, 3, 5, 8)])
+def test_box_expand(shape, dtype):
+    """[x | box3(x) | box5(x)] from one launch against the separate copy + box-mean kernels."""
+    import ctypes
+    from repmode_amd import _lib
+    ops = _ops()
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape))).to(dtype).to(DEV)
+    out = torch.empty((3,) + shape, device=DEV)
+    n, d, h, w, c = shape
+    _lib.call('repmode_box_expand', x.data_ptr(), ops.dtype_code(dtype), out.data_ptr(), n, d, h, w, c, torch.cuda.current_stream().cuda_stream)
+    xf = x.float()
+    assert torch.equal(out[0], xf)
+    assert rel_err(out[1].cpu(), ops.box_sum(in3=xf).cpu()) < 1e-6
+    assert rel_err(out[2].cpu(), ops.box_sum(in5=xf).cpu()) < 1e-6
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('co,ci,nslots', [(32, 32, 3), (64, 48, 12), (7, 5, 2), (1, 16, 8), (32, 1, 20)])
+def test_gate_softmax_inside_gatrep(co, ci, nslots, dtype):
+    """repmode_gatrep_fwd_gate (gate softmax computed by the merging workgroups, one launch) against the two launches:
+    identical filters in both layouts, and g_out equal to the gate kernel's (the same expression evaluated per thread)."""
+    ops = _ops()
+    from repmode_amd import _lib
+    gen = torch.Generator().manual_seed(co * 31 + ci + nslots)
+    k5, k3, k1, a3, a5, gw, gb = [t.to(DEV) for t in _rand_experts(co, ci, gen)]
+    gw = torch.randn(5 * co, 24, generator=gen).to(DEV)
+    tasks = torch.randperm(24, generator=gen)[:nslots].sort().values.to(torch.int32).to(DEV)
+    g_ref = torch.empty(nslots, 5, co, device=DEV)
+    _lib.call('repmode_gate_softmax', gw.data_ptr(), gb.data_ptr(), tasks.data_ptr(), nslots, 24, co, g_ref.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    wf_ref, wd_ref = ops.gatrep_merge(k5, k3, k1, a3, a5, g_ref, dtype, want_wf=True, want_wd=True)
+    code = ops.dtype_code(dtype)
+    g = torch.zeros_like(g_ref)
+    wf, wd = torch.empty_like(wf_ref), torch.empty_like(wd_ref)
+    _lib.call('repmode_gatrep_fwd_gate', k5.data_ptr(), k3.data_ptr(), k1.data_ptr(), a3.data_ptr(), a5.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+              tasks.data_ptr(), nslots, 24, co, ci, code, g.data_ptr(), wf.data_ptr(), wd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rel_err(g.cpu(), g_ref.cpu()) < 1e-6
+    assert rel_err(wf.float().cpu(), wf_ref.float().cpu()) < (1e-6 if dtype == torch.float32 else 8e-3)
+    assert rel_err(wd.float().cpu(), wd_ref.float().cpu()) < (1e-6 if dtype == torch.float32 else 8e-3)
