@@ -81,6 +81,15 @@ int repmode_gatrep_fwd_gate(const float* k5, const float* k3, const float* k1, c
                             const float* gate_w, const float* gate_b, const int32_t* slot_task, int nslots, int num_tasks,
                             int co, int ci, int dtype, float* g_out, void* wf, void* wd, void* stream);
 
+/* repmode_gatrep_fwd_gate for several MoDE blocks in ONE launch (a train step merges all its blocks' forward filters before
+ * the first convolution: they depend on parameters and tasks only).  Every pointer argument but slot_task is a HOST array
+ * of nblocks entries (device pointers / channel counts per block); wd[i] may be NULL.  nblocks <= REPMODE_GATREP_MULTI_MAX. */
+#define REPMODE_GATREP_MULTI_MAX 19
+int repmode_gatrep_fwd_multi(int nblocks, const float* const* k5, const float* const* k3, const float* const* k1,
+                             const float* const* a3, const float* const* a5, const float* const* gate_w,
+                             const float* const* gate_b, const int* co, const int* ci, const int32_t* slot_task, int nslots,
+                             int num_tasks, int dtype, float* const* g_out, void* const* wf, void* const* wd, void* stream);
+
 /* ---- conv: RepMode.py:204-208 (train, per-sample filter) and :209-210 (eval, one filter) ----
  * y[n] = cross-correlation of x[n] with w[sample_slot[n]], 5^3, stride 1, zero pad 2, no bias.
  * x: [N][D][H][W][Cin] dtype;  w: fragment-major merged filter of nslots slots (rows = Cout, red = Cin);

@@ -54,7 +54,8 @@ FAMILIES = [('conv5_igemm level 0-1', 'conv5_igemm_kernel<unsigned short, Cfg<4,
             ('expert_frags', 'expert_frags'), ('gate softmax / backward', 'gate_'), ('BatchNorm+ReLU', 'bn_'),
             ('k2s2 (stride-2 stages)', 'k2'), ('Adam (fused)', 'FusedAdam'), ('box_sum', 'box_sum'),
             ('expert_mix', 'expert_mix'), ('tap_transpose', 'tap_transpose'), ('thin-layer helpers', 'shift5'),
-            ('thin-layer helpers', 'thin_pack'), ('rocBLAS (1x1 experts)', 'Cijk'), ('cat', 'CatArray'),
+            ('thin-layer helpers', 'thin_pack'), ('1x1 experts (gemm3)', 'gemm3'), ('box_sum', 'box_expand'),
+            ('loss (fused MSE)', 'mse_'), ('crop + flip', 'crop_flip'), ('rocBLAS', 'Cijk'), ('cat', 'CatArray'),
             ('pooled memset / fills', 'FillFunctor'), ('other PyTorch elementwise', 'at::native')]
 
 

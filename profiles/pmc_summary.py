@@ -1,28 +1,40 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 PMC passes (one counter per pass, as MI355X_MICROARCH.md prescribes) into
-per-kernel HBM traffic per launch.
+"""Summarise rocprofv3 PMC passes (one counter set per pass, as MI355X_MICROARCH.md prescribes) into per-kernel-family HBM
+traffic per launch and MFMA utilisation.
 
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_FETCH_SIZE -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-prof
-    rocprofv3 --pmc WRITE_SIZE ...                                   (separate run)
-    python profiles/pmc_summary.py gpurun_out > profiles/rNN_pmc_traffic.json
+    python profiles/pmc_summary.py <dir with pmc_FETCH_SIZE/, pmc_WRITE_SIZE/, pmc_MFMA/> <batch> <dtype>  > profiles/rNN_pmc_traffic.json
 
-FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE
-reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, which is how these
-kernels read -> the read side is doubled.  WRITE_SIZE is used as reported (uncalibrated).
+FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly half
+of the bytes of a wide (16 B/lane) coalesced streaming read, which is how these kernels read -> the read side is doubled.
+WRITE_SIZE is used as reported (uncalibrated).  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024
+SIMDs), the gfx94x formula of rocprofv3's MfmaUtil (no gfx950 section ships with ROCm 7.2), summed over the family's
+launches.  The output carries the hash of the kernel sources (bench.kernel_source_hash) the passes were taken on: bench.py
+only quotes `traffic` from a file whose hash matches the build it runs.
 """
 import collections
 import csv
 import glob
 import json
+import os
 import sys
 
-KINDS = ['conv5_igemm', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd']
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+KINDS = ['conv5_igemm', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd', 'bn_', 'k2s2', 'gemm3', 'multi_tensor_apply']
 
 
-def load(d, counter):
-    f = sorted(glob.glob('%s/pmc_%s/*/*_counter_collection.csv' % (d, counter)))[-1]
+def rows(d, name):
+    fs = sorted(glob.glob('%s/pmc_%s/**/*_counter_collection.csv' % (d, name), recursive=True))
+    if not fs:
+        return []
+    return list(csv.DictReader(open(fs[-1])))
+
+
+def per_kind(rs, counter):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(f)):
+    for r in rs:
+        if r['Counter_Name'] != counter:
+            continue
         for k in KINDS:
             if k in r['Kernel_Name']:
                 agg[k][0] += 1
@@ -31,18 +43,28 @@ def load(d, counter):
 
 
 def main():
-    d = sys.argv[1]
-    rd, wr = load(d, 'FETCH_SIZE'), load(d, 'WRITE_SIZE')
-    out = {}
+    d, batch, dtype = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    import bench
+    rd, wr = per_kind(rows(d, 'FETCH_SIZE'), 'FETCH_SIZE'), per_kind(rows(d, 'WRITE_SIZE'), 'WRITE_SIZE')
+    mf = rows(d, 'MFMA')
+    busy, act = per_kind(mf, 'SQ_VALU_MFMA_BUSY_CYCLES'), per_kind(mf, 'GRBM_GUI_ACTIVE')
+    out = {'kernel_source_hash': bench.kernel_source_hash(), 'batch': batch, 'dtype': dtype,
+           'command': 'rocprofv3 --pmc <counter(s)> --kernel-trace --output-format csv -- python bench.py --batch %d --steps 1 --warmup 1 '
+                      '--no-cpu-baseline --no-prof --no-fwd   (one pass per counter set: FETCH_SIZE | WRITE_SIZE | '
+                      'SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)' % batch}
     for k in KINDS:
         n = rd[k][0]
         if not n:
             continue
         read_b = 2.0 * rd[k][1] * 1024 / n
         write_b = wr[k][1] * 1024 / max(wr[k][0], 1)
-        out[k] = {'launches_profiled': n, 'hbm_read_bytes_per_launch': read_b, 'hbm_write_bytes_per_launch': write_b,
-                  'hbm_bytes_per_launch': read_b + write_b,
-                  'note': 'FETCH_SIZE x2 (gfx950 wide-load correction) + WRITE_SIZE, KiB -> bytes, averaged over launches'}
+        e = {'launches_profiled': n, 'hbm_read_bytes_per_launch': read_b, 'hbm_write_bytes_per_launch': write_b,
+             'hbm_bytes_per_launch': read_b + write_b,
+             'note': 'FETCH_SIZE x2 (gfx950 wide-load correction) + WRITE_SIZE, KiB -> bytes, averaged over launches'}
+        if act[k][1] > 0:
+            e['mfma_util_percent'] = 100.0 * busy[k][1] / (act[k][1] * 1024)
+            e['mfma_note'] = 'sum SQ_VALU_MFMA_BUSY_CYCLES / (sum GRBM_GUI_ACTIVE x 1024 SIMDs) over %d launches' % act[k][0]
+        out[k] = e
     print(json.dumps(out, indent=1))
 
 

@@ -26,6 +26,7 @@ _SIGNATURES = {
     'repmode_padded_channels': [_I, _I, _I],
     'repmode_gate_softmax': [_P, _P, _P, _I, _I, _I, _P, _P],
     'repmode_gatrep_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    'repmode_gatrep_fwd_multi': [_I] + [_P] * 10 + [_I, _I, _I] + [_P] * 4,
     'repmode_gatrep_fwd_gate': [_P] * 8 + [_I] * 5 + [_P] * 4,
     'repmode_conv5': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_ex': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -575,6 +575,101 @@ extern "C" int repmode_gatrep_fwd_gate(const float* k5, const float* k3, const f
 }
 
 // ------------------------------------------------------------------------------------------------
+// Gate softmax + GatRep forward of SEVERAL MoDE blocks in one launch.  The forward filters depend on the parameters and
+// the batch's tasks only, not on activations, so a train step can merge all its blocks before the first convolution; on
+// the shallow levels these launches are 17-27 us of latency each for a few MB, which one grid amortises.
+namespace {
+constexpr int GM_MAX = REPMODE_GATREP_MULTI_MAX;
+template <typename T>
+struct GatrepMultiArgs {
+  const float* k5[GM_MAX]; const float* k3[GM_MAX]; const float* k1[GM_MAX]; const float* a3[GM_MAX]; const float* a5[GM_MAX];
+  const float* gate_w[GM_MAX]; const float* gate_b[GM_MAX];
+  float* g_out[GM_MAX];
+  T* wf[GM_MAX]; T* wd[GM_MAX];
+  int co[GM_MAX], ci[GM_MAX], nwf[GM_MAX], nrt_f[GM_MAX], nkc_f[GM_MAX], ts_f[GM_MAX], nrt_d[GM_MAX], nkc_d[GM_MAX], ts_d[GM_MAX];
+  int first[GM_MAX + 1];          // first workgroup of each block (prefix sums)
+  int nblocks, nslots, num_tasks;
+  const int32_t* slot_task;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gatrep_fwd_multi_kernel(GatrepMultiArgs<T> a) {
+  __shared__ GatrepFwdLds<T> L;
+  int i = 0;
+  while (i + 1 < a.nblocks && (int)blockIdx.x >= a.first[i + 1]) ++i;       // (uniform; at most GM_MAX - 1 steps)
+  int b = blockIdx.x - a.first[i];
+  const GateSrc gs{nullptr, a.gate_w[i], a.gate_b[i], a.slot_task, a.num_tasks, a.g_out[i]};
+  if (b < a.nwf[i]) {
+    const int kc = b % a.nkc_f[i]; b /= a.nkc_f[i];
+    const int rt = b % a.nrt_f[i];
+    gatrep_fwd_body<T, false>(L, a.k5[i], a.k3[i], a.k1[i], a.a3[i], a.a5[i], gs, a.nslots, a.co[i], a.ci[i], a.nrt_f[i], a.nkc_f[i],
+                              a.ts_f[i], a.wf[i], kc, rt, b / a.nrt_f[i]);
+  } else {
+    b -= a.nwf[i];
+    const int kc = b % a.nkc_d[i]; b /= a.nkc_d[i];
+    const int rt = b % a.nrt_d[i];
+    gatrep_fwd_body<T, true>(L, a.k5[i], a.k3[i], a.k1[i], a.a3[i], a.a5[i], gs, a.nslots, a.co[i], a.ci[i], a.nrt_d[i], a.nkc_d[i],
+                             a.ts_d[i], a.wd[i], kc, rt, b / a.nrt_d[i]);
+  }
+}
+
+template <typename T>
+int gatrep_fwd_multi_t(int nblocks, const float* const* k5, const float* const* k3, const float* const* k1, const float* const* a3,
+                       const float* const* a5, const float* const* gate_w, const float* const* gate_b, const int* co, const int* ci,
+                       const int32_t* slot_task, int nslots, int num_tasks, int dtype, float* const* g_out, void* const* wf,
+                       void* const* wd, hipStream_t s) {
+  constexpr int KC = FragGeom<T>::KC;
+  GatrepMultiArgs<T> a{};
+  a.nblocks = nblocks; a.nslots = nslots; a.num_tasks = num_tasks; a.slot_task = slot_task;
+  long total = 0;
+  double bytes = 0;
+  for (int i = 0; i < nblocks; ++i) {
+    RM_REQUIRE(k5[i] && k3[i] && k1[i] && a3[i] && a5[i] && gate_w[i] && gate_b[i] && g_out[i] && wf[i], "gatrep_fwd_multi: null pointer (block %d)", i);
+    RM_REQUIRE(co[i] > 0 && ci[i] > 0, "gatrep_fwd_multi: bad shape (block %d)", i);
+    a.k5[i] = k5[i]; a.k3[i] = k3[i]; a.k1[i] = k1[i]; a.a3[i] = a3[i]; a.a5[i] = a5[i];
+    a.gate_w[i] = gate_w[i]; a.gate_b[i] = gate_b[i]; a.g_out[i] = g_out[i];
+    a.wf[i] = static_cast<T*>(wf[i]); a.wd[i] = static_cast<T*>(wd[i]);
+    a.co[i] = co[i]; a.ci[i] = ci[i];
+    a.nrt_f[i] = repmode_padded_channels(co[i], dtype, 0) / 32; a.nkc_f[i] = repmode_padded_channels(ci[i], dtype, 1) / KC;
+    a.ts_f[i] = (long)a.nkc_f[i] * a.nrt_f[i] * 8 < 512 ? 4 : 1;
+    a.nwf[i] = a.nkc_f[i] * a.nrt_f[i] * 8 * a.ts_f[i];
+    long nwd = 0;
+    a.nrt_d[i] = a.nkc_d[i] = a.ts_d[i] = 1;
+    if (wd[i]) {
+      a.nrt_d[i] = repmode_padded_channels(ci[i], dtype, 0) / 32; a.nkc_d[i] = repmode_padded_channels(co[i], dtype, 1) / KC;
+      a.ts_d[i] = (long)a.nkc_d[i] * a.nrt_d[i] * 8 < 512 ? 4 : 1;
+      nwd = (long)a.nkc_d[i] * a.nrt_d[i] * 8 * a.ts_d[i];
+    }
+    a.first[i] = (int)total;
+    total += a.nwf[i] + nwd;
+    bytes += (double)co[i] * ci[i] * (155.0 * 4 + 125.0 * nslots * sizeof(T) * (wd[i] ? 2 : 1));
+  }
+  a.first[nblocks] = (int)total;
+  RM_REQUIRE(total > 0 && total < (1L << 31), "gatrep_fwd_multi: grid out of range");
+  repmode_prof_begin(REPMODE_PROF_GATREP_FWD, bytes, s);
+  hipLaunchKernelGGL((gatrep_fwd_multi_kernel<T>), dim3((unsigned)total), dim3(256), 0, s, a);
+  RM_LAUNCH_CHECK("gatrep_fwd_multi");
+  repmode_prof_end(s);
+  return REPMODE_OK;
+}
+}  // namespace
+
+extern "C" int repmode_gatrep_fwd_multi(int nblocks, const float* const* k5, const float* const* k3, const float* const* k1,
+                                        const float* const* a3, const float* const* a5, const float* const* gate_w,
+                                        const float* const* gate_b, const int* co, const int* ci, const int32_t* slot_task,
+                                        int nslots, int num_tasks, int dtype, float* const* g_out, void* const* wf,
+                                        void* const* wd, void* stream) {
+  RM_REQUIRE(k5 && k3 && k1 && a3 && a5 && gate_w && gate_b && co && ci && slot_task && g_out && wf && wd, "gatrep_fwd_multi: null pointer");
+  RM_REQUIRE(nblocks > 0 && nblocks <= GM_MAX, "gatrep_fwd_multi: 1..%d blocks per call, got %d", GM_MAX, nblocks);
+  RM_REQUIRE(nslots > 0 && num_tasks > 0, "gatrep_fwd_multi: bad shape");
+  RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "gatrep_fwd_multi: bad dtype %d", dtype);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == REPMODE_F32)
+    return gatrep_fwd_multi_t<float>(nblocks, k5, k3, k1, a3, a5, gate_w, gate_b, co, ci, slot_task, nslots, num_tasks, dtype, g_out, wf, wd, s);
+  return gatrep_fwd_multi_t<bf16_t>(nblocks, k5, k3, k1, a3, a5, gate_w, gate_b, co, ci, slot_task, nslots, num_tasks, dtype, g_out, wf, wd, s);
+}
+
+// ------------------------------------------------------------------------------------------------
 // The raw 5x5x5 and 3x3x3 experts in the conv kernels' fragment-major bf16 layouts, for the per-expert
 // formulation of the deep levels (ops._ModeConv3dUnmerged): two "slots" that are not merged with anything,
 //   slot 0 = conv5x5 expert (125 taps),

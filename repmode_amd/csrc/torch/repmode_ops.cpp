@@ -280,6 +280,12 @@ int64_t g_bn_epilogue = []() {
   const char* e = std::getenv("REPMODE_BN_EPILOGUE");
   return e ? (int64_t)std::atoi(e) : (int64_t)1;
 }();
+// All merged blocks' forward filters (gate softmax + GatRep) from ONE launch at the start of a training forward pass
+// (prepare_filters); REPMODE_PREPARE=0: every block merges its own filter when it runs
+bool g_prepare = []() {
+  const char* e = std::getenv("REPMODE_PREPARE");
+  return e ? std::atoi(e) != 0 : true;
+}();
 bool g_overlap = []() {
   const char* e = std::getenv("REPMODE_OVERLAP");
   return e ? std::atoi(e) != 0 : false;
@@ -553,7 +559,7 @@ bool take_prepared(const Tensor& k5, int64_t rows, at::ScalarType dt, bool unmer
     g_prep.erase(it);
   }
   if (e.rows != rows || e.dt != dt || e.unmerged != unmerged || (want_wd && !e.wd.defined())) return false;
-  RM_HIP_CHECK(hipStreamWaitEvent(c10::hip::getCurrentHIPStream(k5.device().index()).stream(), e.ev, 0));
+  if (e.ev) RM_HIP_CHECK(hipStreamWaitEvent(c10::hip::getCurrentHIPStream(k5.device().index()).stream(), e.ev, 0));
   out->g = e.g;
   out->wf = e.wf;
   out->wd = want_wd ? e.wd : Tensor();
@@ -1300,10 +1306,53 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
     std::lock_guard<std::mutex> lock(g_prep_mu);
     g_prep.clear();                        // (entries a failed forward left behind)
   }
-  if (!g_overlap || nb == 0) return;
+  if (nb == 0 || !g_prepare) return;
   require_hip(k5[0], "parameters");
   const at::ScalarType dt = code_dtype(dtype);
   DeviceGuard guard(k5[0].device());
+  if (!g_overlap) {
+    // in line, on the caller's stream: the gate softmax + GatRep of every block that takes the merged formulation as ONE
+    // launch (repmode_gatrep_fwd_multi); the per-expert blocks lay their experts out themselves
+    Plan plan = make_plan(slot_task, sample_slot, sample_task, nslots, num_tasks, training, 0);
+    const int code = dtype_code(dt);
+    std::vector<const float*> p5, p3, p1, pa3, pa5, pgw, pgb;
+    std::vector<float*> pg;
+    std::vector<void*> pwf, pwd;
+    std::vector<int> cos, cis;
+    std::vector<PrepEntry> ents;
+    std::vector<void*> keys;
+    std::vector<Tensor> keep;          // contiguous copies (if any) must outlive the launch call
+    for (size_t i = 0; i < nb; ++i) {
+      if (plan.training && plan.nslots > 2 && w_in[i] <= g_unmerged_max_w) continue;
+      Tensor t[7] = {k5[i].contiguous(), k3[i].contiguous(), k1[i].contiguous(), a3[i].contiguous(), a5[i].contiguous(),
+                     gw[i].contiguous(), gb[i].contiguous()};
+      for (auto& x : t) keep.push_back(x);
+      const int64_t co = t[0].size(0), ci = t[0].size(1);
+      PrepEntry e;
+      e.dt = dt;
+      e.unmerged = false;
+      e.rows = plan.nslots;
+      e.g = at::empty({plan.nslots, E, co}, t[0].options());
+      e.wf = at::empty({plan.nslots, TAPS, padded(co, code, false), padded(ci, code, true)}, t[0].options().dtype(dt));
+      if (need_dx[i]) e.wd = at::empty({plan.nslots, TAPS, padded(ci, code, false), padded(co, code, true)}, t[0].options().dtype(dt));
+      p5.push_back(t[0].data_ptr<float>()); p3.push_back(t[1].data_ptr<float>()); p1.push_back(t[2].data_ptr<float>());
+      pa3.push_back(t[3].data_ptr<float>()); pa5.push_back(t[4].data_ptr<float>());
+      pgw.push_back(t[5].data_ptr<float>()); pgb.push_back(t[6].data_ptr<float>());
+      pg.push_back(e.g.data_ptr<float>()); pwf.push_back(e.wf.data_ptr()); pwd.push_back(e.wd.defined() ? e.wd.data_ptr() : nullptr);
+      cos.push_back((int)co); cis.push_back((int)ci);
+      ents.push_back(e);
+      keys.push_back(t[0].data_ptr());
+    }
+    for (size_t b0 = 0; b0 < ents.size(); b0 += REPMODE_GATREP_MULTI_MAX) {
+      const int cnt = (int)std::min<size_t>(REPMODE_GATREP_MULTI_MAX, ents.size() - b0);
+      RM_CALL(repmode_gatrep_fwd_multi, cnt, p5.data() + b0, p3.data() + b0, p1.data() + b0, pa3.data() + b0, pa5.data() + b0,
+              pgw.data() + b0, pgb.data() + b0, cos.data() + b0, cis.data() + b0, plan.slot_task.data_ptr<int32_t>(), (int)plan.nslots,
+              (int)plan.num_tasks, code, pg.data() + b0, pwf.data() + b0, pwd.data() + b0, stream_handle());
+    }
+    std::lock_guard<std::mutex> lock(g_prep_mu);
+    for (size_t i = 0; i < ents.size(); ++i) g_prep[keys[i]] = ents[i];
+    return;
+  }
   const int dev = k5[0].device().index();
   SideStreams& ss = side_streams(dev);
   const c10::hip::HIPStream main_s = c10::hip::getCurrentHIPStream(dev);
@@ -1357,7 +1406,7 @@ void op_finish_prepared(const Tensor& like) {
     any = !g_prep.empty();
     g_prep.clear();
   }
-  if (!any || !like.is_cuda()) return;
+  if (!any || !like.is_cuda() || !g_overlap) return;
   const int dev = like.device().index();
   SideStreams& ss = side_streams(dev);
   RM_HIP_CHECK(hipEventRecord(ss.prep_fork_ev, ss.prep.stream()));
@@ -1368,6 +1417,7 @@ void op_set_unmerged_max_w(int64_t w) { g_unmerged_max_w = w; }
 void op_set_dual_launch(bool on) { g_dual_launch = on; }
 int64_t op_get_unmerged_max_w() { return g_unmerged_max_w; }
 void op_set_overlap(bool on) { g_overlap = on; }
+void op_set_prepare(bool on) { g_prepare = on; }
 bool op_get_overlap() { return g_overlap; }
 
 void op_zero_pool_begin(const std::string& key, const Tensor& like) { g_pool.begin(key, like); }
@@ -1450,6 +1500,7 @@ TORCH_LIBRARY(repmode, m) {
   m.def("set_dual_launch(bool on) -> ()", &rm::op_set_dual_launch);
   m.def("get_unmerged_max_w() -> int", &rm::op_get_unmerged_max_w);
   m.def("set_overlap(bool on) -> ()", &rm::op_set_overlap);
+  m.def("set_prepare(bool on) -> ()", &rm::op_set_prepare);
   m.def("get_overlap() -> bool", &rm::op_get_overlap);
   m.def("zero_pool_begin(str key, Tensor like) -> ()", &rm::op_zero_pool_begin);
   m.def("zero_pool_end() -> ()", &rm::op_zero_pool_end);

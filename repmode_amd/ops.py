@@ -82,6 +82,12 @@ def set_bn_epilogue(mask):
     torch_ops().set_bn_epilogue(int(mask))
 
 
+def set_prepare(on):
+    """A training forward pass merges the forward filters of all its merged-formulation blocks with ONE launch up front
+    (they depend on parameters and tasks only; default) or block by block (REPMODE_PREPARE=0)."""
+    torch_ops().set_prepare(bool(on))
+
+
 def set_dual_launch(on):
     """Per-expert formulation: the 5x5x5 and the 3x3x3 expert's convolutions as one launch (default) or two."""
     torch_ops().set_dual_launch(bool(on))

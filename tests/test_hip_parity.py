@@ -1253,3 +1253,35 @@ def test_gate_softmax_inside_gatrep(co, ci, nslots, dtype):
     assert rel_err(g.cpu(), g_ref.cpu()) < 1e-6
     assert rel_err(wf.float().cpu(), wf_ref.float().cpu()) < (1e-6 if dtype == torch.float32 else 8e-3)
     assert rel_err(wd.float().cpu(), wd_ref.float().cpu()) < (1e-6 if dtype == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_filters_prepared_in_one_launch(dtype):
+    """A training step whose merged-formulation blocks get their forward filters from ONE launch at the start of the forward
+    pass (repmode_gatrep_fwd_multi through prepare_filters) against the same step merging block by block: same loss, same
+    gradients (the filters are bit-identical; what differs is the order of float atomics downstream)."""
+    ops = _ops()
+    from repmode_amd.nn_modules.RepMode import Net
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 1, 16, 32, 32, generator=gen).to(DEV)
+    tgt = torch.randn(4, 1, 16, 32, 32, generator=gen).to(DEV)
+    tasks = [1, 4, 9, 4]                       # three distinct tasks: the deep levels take the per-expert formulation
+    res = []
+    for prepare in (True, False, False):
+        ops.set_prepare(prepare)
+        torch.manual_seed(0)
+        net = Net(Opts(), mult_chan=4, dtype=dtype).to(DEV).train()
+        loss = torch.nn.functional.mse_loss(net(x, tasks), tgt)
+        loss.backward()
+        res.append((float(loss), {k: p.grad.float().cpu() for k, p in net.named_parameters()}))
+    ops.set_prepare(True)
+    assert abs(res[0][0] - res[1][0]) < (1e-5 if dtype == torch.float32 else 2e-3) * abs(res[1][0])
+    gmax = max(float(v.abs().max()) for v in res[1][1].values())
+
+    def worst(a, b):
+        return max(float((a[k] - b[k]).norm()) / max(float(b[k].norm()), 1e-2 * gmax * b[k].numel() ** 0.5) for k in b)
+
+    # run-to-run spread of two identical block-by-block steps (float atomics; in bf16 a flipped rounding / ReLU mask of this
+    # tiny network's first layer is a large part of its 4-channel gradient) bounds what the one-launch step may differ by
+    noise = worst(res[2][1], res[1][1])
+    assert worst(res[0][1], res[1][1]) <= max(3 * noise, 2e-2), (worst(res[0][1], res[1][1]), noise)
