@@ -304,6 +304,11 @@ int repmode_mse_loss(const float* out, const float* target, const int32_t* sampl
                      float* dout, float* sums_ws, float* loss, float* loss_sample, float* task_mean, float* task_count,
                      void* stream);
 
+/* repmode_expert_frags for several blocks (both roles) in ONE launch; pointer arguments are HOST arrays of nblocks entries,
+ * wd[i] may be NULL.  nblocks <= REPMODE_GATREP_MULTI_MAX. */
+int repmode_expert_frags_multi(int nblocks, const float* const* k5, const float* const* k3, const int* co, const int* ci,
+                               void* const* wf, void* const* wd, void* stream);
+
 /* ---- measurement: per-launch HIP-event timing of the library's kernels on their own stream.
  * repmode_prof_enable(1) clears the records and starts recording every kind, (2) records conv5_igemm only
  * (least perturbation of the timed region), (0) stops.  repmode_prof_summary()

@@ -60,6 +60,7 @@ _SIGNATURES = {
     'repmode_expert_frags': [_P, _P, _I, _I, _P, _P, _P],
     'repmode_crop_flip': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     'repmode_mse_loss': [_P, _P, _P, _I, _c.c_long, _I, _P, _P, _P, _P, _P, _P, _P],
+    'repmode_expert_frags_multi': [_I, _P, _P, _P, _P, _P, _P, _P],
     'repmode_prof_enable': [_I],
     'repmode_prof_pause': [_I],
     'repmode_prof_summary': [_I, _P, _P, _P],

@@ -74,6 +74,14 @@ __device__ unsigned long long g_conv_timing[64 * 64];
 #define RM_SCHED_FENCE() do {} while (0)
 #endif
 
+// Experiment (REPMODE_EXTRA_FLAGS=-DRM_CONV_PRIO): s_setprio 1 for the MFMA (tap) phase of a chunk, 0 for its staging
+// phase -- with two workgroups per CU one is usually staging while the other multiplies (cdna_hip_programming.md T5).
+#ifdef RM_CONV_PRIO
+#define RM_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define RM_PRIO(p) do {} while (0)
+#endif
+
 #ifndef CONV_SPLIT_TARGET
 #define CONV_SPLIT_TARGET 512
 #endif
@@ -268,6 +276,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
     }
     __syncthreads();
     RM_STAMP((chunk - c_begin) * 4 + 2);
+    RM_PRIO(1);     // (RM_CONV_PRIO builds) the tap phase outranks the co-resident workgroup's staging phase
 
     // ---- 125 taps from the staged image.  Filter fragments are prefetched from L2 one (dz,dy)
     // row (5 taps) ahead when one channel sub-tile is held (CW == 1), one tap ahead otherwise
@@ -391,6 +400,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
         dy = dyn;
       }
     }
+    RM_PRIO(0);
     RM_STAMP((chunk - c_begin) * 4 + 3);
   }
 

@@ -208,6 +208,14 @@ __device__ __forceinline__ uint32_t bf16_elem(const u32x4& v, int k) {
   return (k & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
+// Experiment (REPMODE_EXTRA_FLAGS=-DRM_WGRAD_PRIO): s_setprio 1 around a tile's MFMAs (the co-resident workgroup is
+// transposing its next tile into LDS meanwhile)
+#ifdef RM_WGRAD_PRIO
+#define RM_WPRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define RM_WPRIO(p) do {} while (0)
+#endif
+
 #ifdef RM_CONV_TIMING
 // developer build only (REPMODE_EXTRA_FLAGS=-DRM_CONV_TIMING): shader-clock stamps of the first workgroups'
 // phases, read back with repmode_debug_wgrad_timing (tools/wgrad_phase_timing.py)
@@ -398,7 +406,9 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
       RM_WSTAMP(tl_ * 3 + 1);
       have = advance();
       if (have) fetch();   // in flight during the MFMAs below
+      RM_WPRIO(1);
       mma_tile();
+      RM_WPRIO(0);
       RM_WSTAMP(tl_ * 3 + 2);
 #ifdef RM_CONV_TIMING
       ++tl_;

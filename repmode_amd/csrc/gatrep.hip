@@ -683,14 +683,17 @@ namespace {
 constexpr int XF_ROWS = 8, XF_KC = 16, XF_COUPLES = XF_ROWS * XF_KC / 2;   // 64 couples of adjacent reduction channels
 constexpr int XF_S5 = XF_COUPLES + 1;                                       // padded LDS row (u32): conflict-free transposed writes
 
+struct XfLds {
+  uint32_t s5[TAPS * XF_S5];
+  uint32_t s3[27 * XF_S5];
+};
+
 template <bool WRITE_WD>
-__global__ __launch_bounds__(256) void expert_frags_kernel(const float* __restrict__ k5, const float* __restrict__ k3,
-                                                           int co_n, int ci_n, int nrt, int nkc,
-                                                           bf16_t* __restrict__ wout) {
-  __shared__ uint32_t s5[TAPS * XF_S5];
-  __shared__ uint32_t s3[27 * XF_S5];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kc = blockIdx.x, rt = blockIdx.y, q = blockIdx.z;       // q: which 8 rows of the 32-row tile
+__device__ __forceinline__ void expert_frags_body(XfLds& L, const float* __restrict__ k5, const float* __restrict__ k3, int co_n,
+                                                  int ci_n, int nrt, int nkc, bf16_t* __restrict__ wout, int kc, int rt, int q) {
+  uint32_t* s5 = L.s5;
+  uint32_t* s3 = L.s3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;       // q: which 8 rows of the 32-row tile
   // ---- stage: wave w takes couples w, w+4, ...; a couple = elements (row, red) and (row, red + 1)
   constexpr int NB = 4;                                             // couples in flight per wave
   for (int c0 = wave; c0 < XF_COUPLES; c0 += 4 * NB) {
@@ -736,7 +739,68 @@ __global__ __launch_bounds__(256) void expert_frags_kernel(const float* __restri
     }
   }
 }
+
+template <bool WRITE_WD>
+__global__ __launch_bounds__(256) void expert_frags_kernel(const float* __restrict__ k5, const float* __restrict__ k3,
+                                                           int co_n, int ci_n, int nrt, int nkc,
+                                                           bf16_t* __restrict__ wout) {
+  __shared__ XfLds L;
+  expert_frags_body<WRITE_WD>(L, k5, k3, co_n, ci_n, nrt, nkc, wout, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// several blocks' experts, both roles, in one launch (the per-expert levels of a train step: see repmode_gatrep_fwd_multi)
+constexpr int XM_MAX = REPMODE_GATREP_MULTI_MAX;
+struct XfMultiArgs {
+  const float* k5[XM_MAX]; const float* k3[XM_MAX];
+  bf16_t* wf[XM_MAX]; bf16_t* wd[XM_MAX];
+  int co[XM_MAX], ci[XM_MAX], nrt_f[XM_MAX], nkc_f[XM_MAX], nrt_d[XM_MAX], nkc_d[XM_MAX], nwf[XM_MAX];
+  int first[XM_MAX + 1];
+  int nblocks;
+};
+__global__ __launch_bounds__(256) void expert_frags_multi_kernel(XfMultiArgs a) {
+  __shared__ XfLds L;
+  int i = 0;
+  while (i + 1 < a.nblocks && (int)blockIdx.x >= a.first[i + 1]) ++i;
+  int b = blockIdx.x - a.first[i];
+  if (b < a.nwf[i]) {
+    const int kc = b % a.nkc_f[i]; b /= a.nkc_f[i];
+    expert_frags_body<false>(L, a.k5[i], a.k3[i], a.co[i], a.ci[i], a.nrt_f[i], a.nkc_f[i], a.wf[i], kc, b % a.nrt_f[i], b / a.nrt_f[i]);
+  } else {
+    b -= a.nwf[i];
+    const int kc = b % a.nkc_d[i]; b /= a.nkc_d[i];
+    expert_frags_body<true>(L, a.k5[i], a.k3[i], a.co[i], a.ci[i], a.nrt_d[i], a.nkc_d[i], a.wd[i], kc, b % a.nrt_d[i], b / a.nrt_d[i]);
+  }
+}
 }  // namespace
+
+extern "C" int repmode_expert_frags_multi(int nblocks, const float* const* k5, const float* const* k3, const int* co, const int* ci,
+                                          void* const* wf, void* const* wd, void* stream) {
+  RM_REQUIRE(k5 && k3 && co && ci && wf && wd, "expert_frags_multi: null pointer");
+  RM_REQUIRE(nblocks > 0 && nblocks <= XM_MAX, "expert_frags_multi: 1..%d blocks per call, got %d", XM_MAX, nblocks);
+  XfMultiArgs a{};
+  a.nblocks = nblocks;
+  long total = 0;
+  double bytes = 0;
+  for (int i = 0; i < nblocks; ++i) {
+    RM_REQUIRE(k5[i] && k3[i] && wf[i] && co[i] > 0 && ci[i] > 0, "expert_frags_multi: bad block %d", i);
+    a.k5[i] = k5[i]; a.k3[i] = k3[i]; a.wf[i] = static_cast<bf16_t*>(wf[i]); a.wd[i] = static_cast<bf16_t*>(wd[i]);
+    a.co[i] = co[i]; a.ci[i] = ci[i];
+    a.nrt_f[i] = repmode_padded_channels(co[i], REPMODE_BF16, 0) / 32; a.nkc_f[i] = repmode_padded_channels(ci[i], REPMODE_BF16, 1) / 16;
+    a.nrt_d[i] = repmode_padded_channels(ci[i], REPMODE_BF16, 0) / 32; a.nkc_d[i] = repmode_padded_channels(co[i], REPMODE_BF16, 1) / 16;
+    a.nwf[i] = a.nkc_f[i] * a.nrt_f[i] * 4;
+    a.first[i] = (int)total;
+    total += a.nwf[i] + (wd[i] ? (long)a.nkc_d[i] * a.nrt_d[i] * 4 : 0);
+    bytes += (double)co[i] * ci[i] * (152.0 * 4 + (125.0 + 45.0) * 2 * (wd[i] ? 2 : 1));
+  }
+  a.first[nblocks] = (int)total;
+  RM_REQUIRE(total < (1L << 31), "expert_frags_multi: grid too large");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  repmode_prof_begin(REPMODE_PROF_GATREP_FWD, bytes, s);
+  hipLaunchKernelGGL(expert_frags_multi_kernel, dim3((unsigned)total), dim3(256), 0, s, a);
+  RM_LAUNCH_CHECK("expert_frags_multi");
+  repmode_prof_end(s);
+  return REPMODE_OK;
+}
 
 // wf: [2][125][CoP/32][CiP/16][32][16] bf16 (rows = co), wd: [2][125][CiP/32][CoP/16][32][16] (rows = ci, taps
 // flipped); either may be NULL.  Slot 1 is valid on the centre3 rows only (see above).

@@ -819,7 +819,7 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     std::pair<Tensor, Tensor> fr;
     Merged pm;
     if (take_prepared(k5, plan.n, x_cl.scalar_type(), true, need_dx, &pm)) {
-      gn = pm.g;
+      gn = pm.g.defined() ? pm.g : gate_softmax(gw, gb, plan.sample_task, plan.n, plan.num_tasks, co);
       fr = {pm.wf, pm.wd};
     } else {
       gn = gate_softmax(gw, gb, plan.sample_task, plan.n, plan.num_tasks, co);
@@ -1322,6 +1322,38 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
     std::vector<PrepEntry> ents;
     std::vector<void*> keys;
     std::vector<Tensor> keep;          // contiguous copies (if any) must outlive the launch call
+    // ... and the raw 5x5x5 / 3x3x3 experts of every per-expert block in the conv kernels' layout as another one
+    // (repmode_expert_frags_multi; bf16 only -- float32 lays them out through GatRep with one-hot gates, block by block)
+    {
+      std::vector<const float*> x5, x3;
+      std::vector<void*> xwf, xwd;
+      std::vector<int> xco, xci;
+      std::vector<PrepEntry> xe;
+      std::vector<void*> xk;
+      for (size_t i = 0; i < nb && dt == at::kBFloat16; ++i) {
+        if (!(plan.training && plan.nslots > 2 && w_in[i] <= g_unmerged_max_w)) continue;
+        Tensor K5 = k5[i].contiguous(), K3 = k3[i].contiguous();
+        keep.push_back(K5); keep.push_back(K3);
+        const int64_t co = K5.size(0), ci = K5.size(1);
+        PrepEntry e;
+        e.dt = dt;
+        e.unmerged = true;
+        e.rows = plan.n;
+        e.wf = at::empty({2, TAPS, padded(co, code, false), padded(ci, code, true)}, K5.options().dtype(dt));
+        if (need_dx[i]) e.wd = at::empty({2, TAPS, padded(ci, code, false), padded(co, code, true)}, K5.options().dtype(dt));
+        x5.push_back(K5.data_ptr<float>()); x3.push_back(K3.data_ptr<float>());
+        xwf.push_back(e.wf.data_ptr()); xwd.push_back(e.wd.defined() ? e.wd.data_ptr() : nullptr);
+        xco.push_back((int)co); xci.push_back((int)ci);
+        xe.push_back(e); xk.push_back(K5.data_ptr());
+      }
+      for (size_t b0 = 0; b0 < xe.size(); b0 += REPMODE_GATREP_MULTI_MAX) {
+        const int cnt = (int)std::min<size_t>(REPMODE_GATREP_MULTI_MAX, xe.size() - b0);
+        RM_CALL(repmode_expert_frags_multi, cnt, x5.data() + b0, x3.data() + b0, xco.data() + b0, xci.data() + b0, xwf.data() + b0,
+                xwd.data() + b0, stream_handle());
+      }
+      std::lock_guard<std::mutex> lock(g_prep_mu);
+      for (size_t i = 0; i < xe.size(); ++i) g_prep[xk[i]] = xe[i];
+    }
     for (size_t i = 0; i < nb; ++i) {
       if (plan.training && plan.nslots > 2 && w_in[i] <= g_unmerged_max_w) continue;
       Tensor t[7] = {k5[i].contiguous(), k3[i].contiguous(), k1[i].contiguous(), a3[i].contiguous(), a5[i].contiguous(),

@@ -120,13 +120,29 @@ class Model(object):
         state['nn_state'] = {k: v.cpu() for k, v in state['nn_state'].items()}
         torch.save(state, path_save)
 
-    def load_state(self, path_load):
+    def load_state(self, path_load, gpu_ids=None):
+        """fnet_model.py:82-94: the checkpoint decides the network (``nn_module``, ``opts``), the model is rebuilt from it
+        and moved to ``gpu_ids``.  The reference's default ``gpu_ids=-1`` means the CPU, which this build does not have:
+        ``None`` (default) keeps the model's current device; a negative id raises like the constructor does."""
         state = torch.load(path_load, map_location='cpu', weights_only=False)
+        if gpu_ids is not None:
+            ids = [gpu_ids] if isinstance(gpu_ids, int) else list(gpu_ids)
+            if ids[0] < 0:
+                raise RuntimeError('repmode_amd.Model needs a HIP device; there is no CPU path')
+            self.gpu_ids = ids
+            self.device = torch.device('cuda', ids[0])
+        if state.get('nn_module') is not None:
+            self.nn_module = state['nn_module']
+        if state.get('opts') is not None:
+            self.opts = state['opts']
+            self.opts.gpu_ids = self.gpu_ids[0]
+        self._init_model()
         self.net.load_state_dict(state['nn_state'])
         if 'optimizer_state' in state:
             self.optimizer.load_state_dict(state['optimizer_state'])
         self.count_iter = state.get('count_iter', 0)
         self.count_epoch = state.get('count_epoch', 0)
+        self._graphs, self._graph_pool = {}, None           # (captured steps hold the previous network's tensors)
 
     # ---- training step: fnet_model.py:96-132
     def _train_step(self, signal, target, task):
