@@ -154,6 +154,13 @@ int repmode_conv5_wgrad_part(const void* x, const void* dy, const int32_t* sampl
                              int d, int h, int wdim, int cin, int cin_total, int ci_off, int cout, int dtype,
                              int centre3, void* stream);
 
+/* Two filter gradients over the same input x in ONE launch (bf16; all samples in one slot): dw_a from dy_a with mode_a,
+ * dw_b from dy_b with mode_b (modes as repmode_conv5_wgrad_ex: 0 / 1 tap-major all taps / planes dz 1..3, 2 / 3 the experts'
+ * own layouts; bit 3 on both or neither: the outputs are already zero).  The per-expert formulation's 5x5x5 and 3x3x3
+ * experts' filter gradients. */
+int repmode_conv5_wgrad_dual(const void* x, const void* dy_a, const void* dy_b, float* dw_a, float* dw_b, int n, int d, int h,
+                             int wdim, int cin, int cout, int mode_a, int mode_b, void* stream);
+
 /* ---- the same filter gradient when one channel count is 1 (first layer Cin = 1, last layer Cout = 1): the
  * 125 taps take the place of the missing channel dimension.  bf16 only.  a: [N][D][H][W][C], b: [N][D][H][W],
  * dw: float [nslots][125][C] (== the general layout with the unit dimension dropped), overwritten.

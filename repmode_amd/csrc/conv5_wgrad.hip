@@ -37,6 +37,13 @@ struct WgradArgs {
   int prezeroed;   // dw is known to be all zero already: no memset before the atomics
   int CinTot, ci_off;   // layout 0: dw rows have CinTot input channels and this call fills [ci_off, ci_off + Cin)
                         // (the two halves of a skip connection's filter gradient); CinTot == Cin, ci_off == 0 otherwise
+  // Second job of a dual launch (repmode_conv5_wgrad_dual, bf16 kernels): workgroups [grid0, gridDim) compute another
+  // output gradient's filter gradient over the same input -- the 3x3x3 expert's beside the 5x5x5 expert's in the
+  // per-expert formulation.  grid0 == 0: single job.
+  int grid0;
+  const void* dy2;
+  float* dw2;
+  int dz_lo2, ndz2, layout2, direct2, nchunks2, tiles_per_block2;
 };
 
 template <typename T>
@@ -247,9 +254,20 @@ __global__ __launch_bounds__(256, 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
   const int cq = wave & 1, ciq = wave >> 1;
   const int l15 = lane & 15, kg = lane >> 4;
 
+  // dual launch: the second job's workgroups take its parameters (uniform per workgroup: scalar selects)
+  int bid_raw = blockIdx.x, grid_n = gridDim.x;
+  if (a.grid0 > 0) {
+    if (bid_raw >= a.grid0) {
+      bid_raw -= a.grid0; grid_n -= a.grid0;
+      a.dy = a.dy2; a.dw = a.dw2; a.dz_lo = a.dz_lo2; a.ndz = a.ndz2; a.layout = a.layout2; a.direct = a.direct2;
+      a.nchunks = a.nchunks2; a.tiles_per_block = a.tiles_per_block2;
+    } else {
+      grid_n = a.grid0;
+    }
+  }
   // the five dz workgroups of one voxel chunk read the same dy / x tiles: adjacent logical ids, and
   // xcd_remap keeps adjacent ids on one XCD, so they share those tiles through one L2
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int bid = xcd_remap(bid_raw, grid_n);
   const int dz = a.dz_lo + bid % a.ndz; bid /= a.ndz;
   const int chunk = bid % a.nchunks; bid /= a.nchunks;
   const int cit = bid % a.ncit;      bid /= a.ncit;
@@ -562,17 +580,26 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
     RM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv5_wgrad_bf16_kernel<TZ, TY, TX, true>, 256, 0));
     resident = (long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
   }
-  const long fixed = (long)a.nslots * a.ncot * a.ncit * a.ndz;
   // (from one workgroup per CU-slot-half on, keep whole voxel ranges together: direct stores, no memset, no atomics)
-  long want_chunks = (fixed >= WGRAD_DIRECT_MIN || fixed >= resident) ? 1 : (resident * WGRAD_ROUNDS) / fixed;
-  if (want_chunks < 1) want_chunks = 1;
-  if (want_chunks > a.ntiles) want_chunks = a.ntiles;
-  a.tiles_per_block = ceil_div(a.ntiles, (int)want_chunks);
-  a.nchunks = ceil_div(a.ntiles, a.tiles_per_block);
-  a.direct = a.nchunks == 1;
-  const long grid = fixed * a.nchunks;
-  RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
+  auto plan = [&](int ndz, int* tiles_per_block, int* nchunks, int* direct) -> long {
+    const long fixed = (long)a.nslots * a.ncot * a.ncit * ndz;
+    long want_chunks = (fixed >= WGRAD_DIRECT_MIN || fixed >= resident) ? 1 : (resident * WGRAD_ROUNDS) / fixed;
+    if (want_chunks < 1) want_chunks = 1;
+    if (want_chunks > a.ntiles) want_chunks = a.ntiles;
+    *tiles_per_block = ceil_div(a.ntiles, (int)want_chunks);
+    *nchunks = ceil_div(a.ntiles, *tiles_per_block);
+    *direct = *nchunks == 1;
+    return fixed * *nchunks;
+  };
+  long grid = plan(a.ndz, &a.tiles_per_block, &a.nchunks, &a.direct);
   if (!a.direct && !a.prezeroed) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * a.Cout * a.CinTot * sizeof(float), s));
+  if (a.dy2) {                       // dual launch: the second job is planned the same way, its workgroups follow the first's
+    a.grid0 = (int)grid;
+    grid += plan(a.ndz2, &a.tiles_per_block2, &a.nchunks2, &a.direct2);
+    RM_REQUIRE(a.layout2 == 0 || a.direct2, "conv5_wgrad_dual: job 2 cannot write the expert layout with atomics");
+    if (!a.direct2 && !a.prezeroed) RM_HIP(hipMemsetAsync(a.dw2, 0, (size_t)REPMODE_TAPS * a.Cout * a.CinTot * sizeof(float), s));
+  }
+  RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
   repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, s);
   const size_t sample_bytes = (size_t)a.D * a.H * a.W * (a.Cin > a.Cout ? a.Cin : a.Cout) * 2;
   // (levels with W < 16 hand a workgroup only a tile or two per sample: nothing to overlap, and the old loop is ~15 % faster there)
@@ -663,6 +690,41 @@ extern "C" int repmode_conv5_wgrad_part(const void* x, const void* dy, const int
   }
   repmode_prof_end(s);
   RM_LAUNCH_CHECK("conv5_wgrad");
+  return REPMODE_OK;
+}
+
+// Two filter gradients over the SAME input in one launch (bf16, every sample in one slot): the per-expert formulation's
+// 5x5x5 expert (dy_a: its gate-scaled output gradient) and 3x3x3 expert (dy_b).  mode_a / mode_b as repmode_conv5_wgrad_ex's
+// mode word (0 / 1 tap-major, 2 / 3 the experts' own layouts, bit 3: dw cleared by the caller).  The 3x3x3 job alone is a
+// latency-bound launch (27 taps, three planes); behind the 5x5x5 job's workgroups in one grid it fills their tail.
+extern "C" int repmode_conv5_wgrad_dual(const void* x, const void* dy_a, const void* dy_b, float* dw_a, float* dw_b, int n, int d,
+                                        int h, int wdim, int cin, int cout, int mode_a, int mode_b, void* stream) {
+  RM_REQUIRE(x && dy_a && dy_b && dw_a && dw_b, "conv5_wgrad_dual: null pointer");
+  RM_REQUIRE(n > 0 && d > 0 && h > 0 && wdim > 0 && cin > 0 && cout > 0, "conv5_wgrad_dual: bad shape");
+  RM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy_a & 15) == 0 && ((uintptr_t)dy_b & 15) == 0, "conv5_wgrad_dual: pointers must be 16-byte aligned");
+  RM_REQUIRE(((mode_a ^ mode_b) & 8) == 0, "conv5_wgrad_dual: both outputs cleared by the caller, or neither");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  WgradArgs a{};
+  a.x = x; a.dy = dy_a; a.dw = dw_a; a.dy2 = dy_b; a.dw2 = dw_b; a.sample_slot = nullptr;
+  a.N = n; a.D = d; a.H = h; a.W = wdim; a.Cin = cin; a.Cout = cout;
+  a.CinTot = cin; a.ci_off = 0;
+  a.ncot = ceil_div(cout, 32);
+  a.ncit = ceil_div(cin, 32);
+  a.nslots = 1;
+  a.prezeroed = (mode_a & 8) ? 1 : 0;
+  const int ma = mode_a & 7, mb = mode_b & 7;
+  RM_REQUIRE(ma >= 0 && ma <= 3 && mb >= 0 && mb <= 3, "conv5_wgrad_dual: bad mode");
+  a.dz_lo = (ma == 1 || ma == 3) ? 1 : 0;   a.ndz = (ma == 1 || ma == 3) ? 3 : 5;   a.layout = ma == 2 ? 1 : (ma == 3 ? 2 : 0);
+  a.dz_lo2 = (mb == 1 || mb == 3) ? 1 : 0;  a.ndz2 = (mb == 1 || mb == 3) ? 3 : 5;  a.layout2 = mb == 2 ? 1 : (mb == 3 ? 2 : 0);
+  int rc;
+  if (wdim >= 32 && h >= 8) rc = launch_wgrad_bf16<1, 8, 32>(a, n, s);
+  else if (wdim >= 32) rc = launch_wgrad_bf16<1, 4, 32>(a, n, s);
+  else if (wdim >= 16) rc = launch_wgrad_bf16<1, 8, 16>(a, n, s);
+  else if (wdim >= 8) rc = launch_wgrad_bf16<2, 8, 8>(a, n, s);
+  else rc = launch_wgrad_bf16<2, 4, 8>(a, n, s);
+  if (rc != REPMODE_OK) return rc;
+  repmode_prof_end(s);
+  RM_LAUNCH_CHECK("conv5_wgrad_dual");
   return REPMODE_OK;
 }
 

@@ -276,6 +276,10 @@ bool g_dual_launch = []() {
 //      epilogue.  The pass it removes streams a tensor that is still in the 256 MB Infinity Cache at full rate (11-25 us
 //      per layer); the epilogue's cross-lane reduction and atomics run inside the MFMA-bound, power-capped conv launch
 //      and cost more than that.
+bool g_dual_wgrad = []() {          // (REPMODE_DUAL_WGRAD=0: the two filter gradients of a per-expert block as two launches)
+  const char* e = std::getenv("REPMODE_DUAL_WGRAD");
+  return e ? std::atoi(e) != 0 : true;
+}();
 int64_t g_bn_epilogue = []() {
   const char* e = std::getenv("REPMODE_BN_EPILOGUE");
   return e ? (int64_t)std::atoi(e) : (int64_t)1;
@@ -891,10 +895,26 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
       // atomics) write the parameters' [Co][Ci][taps] layout directly; the others accumulate tap-major + one transpose launch.
       const int64_t tiles = ((co + 31) / 32) * ((ci + 31) / 32);
       Tensor lo0 = lo[0], lo1 = lo[1];
-      if (dt == at::kBFloat16 && tiles * 5 >= 512) dk5 = conv5_wgrad_expert_layout(x_cl, lo0, s0, co, 5, grad_out(k5));
-      else dk5 = tap_transpose(conv5_wgrad(x_cl, lo0, s0, 1, co)[0], k5.sizes(), grad_out(k5));
-      if (dt == at::kBFloat16 && tiles * 3 >= 512) dk3 = conv5_wgrad_expert_layout(x_cl, lo1, s0, co, 3, grad_out(k3));
-      else dk3 = tap_transpose(conv5_wgrad(x_cl, lo1, s0, 1, co, true)[0], k3.sizes(), grad_out(k3));
+      const bool direct5 = dt == at::kBFloat16 && tiles * 5 >= 512, direct3 = dt == at::kBFloat16 && tiles * 3 >= 512;
+      if (dt == at::kBFloat16 && g_dual_launch && g_dual_wgrad) {
+        // both experts' filter gradients from ONE launch (the 3x3x3 job alone is 27 taps on three planes: latency)
+        dk5 = grad_out(k5);
+        dk3 = grad_out(k3);
+        Tensor t5, t3;                       // tap-major accumulators of the jobs that cannot store directly
+        bool pre = true;
+        if (!direct5) { auto tk = g_pool.take({1, TAPS, co, ci}, x_cl); t5 = tk.first; pre = pre && tk.second; }
+        if (!direct3) { auto tk = g_pool.take({1, TAPS, co, ci}, x_cl); t3 = tk.first; pre = pre && tk.second; }
+        RM_CALL(repmode_conv5_wgrad_dual, x_cl.data_ptr(), lo0.data_ptr(), lo1.data_ptr(), direct5 ? dk5.data_ptr<float>() : t5.data_ptr<float>(),
+                direct3 ? dk3.data_ptr<float>() : t3.data_ptr<float>(), (int)n, (int)d, (int)h, (int)w, (int)ci, (int)co,
+                (direct5 ? 2 : 0) | (pre ? 8 : 0), (direct3 ? 3 : 1) | (pre ? 8 : 0), stream_handle());
+        if (!direct5) tap_transpose(t5[0], k5.sizes(), dk5);
+        if (!direct3) tap_transpose(t3[0], k3.sizes(), dk3);
+      } else {
+        if (direct5) dk5 = conv5_wgrad_expert_layout(x_cl, lo0, s0, co, 5, grad_out(k5));
+        else dk5 = tap_transpose(conv5_wgrad(x_cl, lo0, s0, 1, co)[0], k5.sizes(), grad_out(k5));
+        if (direct3) dk3 = conv5_wgrad_expert_layout(x_cl, lo1, s0, co, 3, grad_out(k3));
+        else dk3 = tap_transpose(conv5_wgrad(x_cl, lo1, s0, 1, co, true)[0], k3.sizes(), grad_out(k3));
+      }
       // the 1x1 experts' filter gradients dW_e[co][ci] = sum_m G_e[m][co] X_e[m][ci], straight into the parameters' gradients
       // (K = all voxel rows: split over workgroups when the three outputs can come pre-zeroed out of the step's pool --
       // not when they are slices of a data-parallel reducer's bucket)
