@@ -141,7 +141,9 @@ struct Cfg {
 // contiguous float stores / atomics (used for the float output, in particular the split-K atomics,
 // which otherwise touch one cache line per lane).
 // PAIR: the two-tensor form (repmode_conv5_pair); a separate instantiation keeps the one-tensor kernels free of its selects
-template <typename T, typename C, bool SWAP, bool PAIR>
+// DXC: the dx-centre mode (one tap per (dz, dy) row: the thin first / last layers) as its own instantiation, so that
+// neither path carries the other's registers and branches
+template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false>
 __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   constexpr int KV = Elem<T>::KV;
   constexpr int KC = 2 * KV;
@@ -224,8 +226,8 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
     // The first filter row of the chunk is requested before the halo staging, not behind its barrier: the two
     // fetches are independent, and after a kernel boundary both come from HBM / MALL, not L2.
     u32x4 a_first[5];
-    if constexpr (CW == 1) {
-      if (!a.dxc) {
+    if constexpr (CW == 1 && !DXC) {
+      {
 #pragma unroll
         for (int dx = 0; dx < 5; ++dx)
           a_first[dx] = *reinterpret_cast<const u32x4*>(wrow[0] + (size_t)((dz_lo * 5 + dy_lo) * 5 + dx) * tap_stride +
@@ -285,8 +287,51 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
       return *reinterpret_cast<const u32x4*>(wrow[cs] + (size_t)tap * tap_stride + (size_t)chunk * (32 * KC));
     };
     int dz = dz_lo, dy = dy_lo;
-    if (a.dxc) {
-      // one tap per (dz, dy) row (the thin first / last layers, whose x taps were folded into channels)
+    if constexpr (DXC && CW == 1) {
+      // one tap per (dz, dy) row (the thin first / last layers, whose x taps were folded into channels): a whole dz plane's
+      // filter fragments (its <= 5 dy rows) are in flight while the previous plane is multiplied -- one fragment per row,
+      // fetched a row ahead, left this path waiting on L2 latency for every tap (first layer: 140 us for 8.4 GFLOP)
+      u32x4 a_cur[5], a_nxt[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int dyy = min(dy_lo + i, dy_hi);
+        a_cur[i] = wfrag(0, (dz_lo * 5 + dyy) * 5 + 2);
+      }
+      u32x4 b_cur[VW], b_nxt[VW];
+#pragma unroll
+      for (int vs = 0; vs < VW; ++vs) b_cur[vs] = lds[vbase[vs] + (dz_lo * BYH + dy_lo) * BXH + 2];
+      for (int dzc = dz_lo; dzc <= dz_hi; ++dzc) {
+        const bool more_z = dzc < dz_hi;
+        if (more_z) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            const int dyy = min(dy_lo + i, dy_hi);
+            a_nxt[i] = wfrag(0, ((dzc + 1) * 5 + dyy) * 5 + 2);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          if (i < ndy) {
+            // the voxel fragment of the next row: next dy of this plane, or the first row of the next plane
+            const bool last_row = i + 1 >= ndy;
+            const int dzn = last_row ? (more_z ? dzc + 1 : dzc) : dzc;
+            const int dyn = last_row ? (more_z ? dy_lo : dy_lo + i) : dy_lo + i + 1;
+#pragma unroll
+            for (int vs = 0; vs < VW; ++vs) b_nxt[vs] = lds[vbase[vs] + (dzn * BYH + dyn) * BXH + 2];
+#pragma unroll
+            for (int vs = 0; vs < VW; ++vs) {
+              if constexpr (SWAP) Elem<T>::mma(b_cur[vs], a_cur[i], acc[0][vs]);
+              else Elem<T>::mma(a_cur[i], b_cur[vs], acc[0][vs]);
+            }
+#pragma unroll
+            for (int vs = 0; vs < VW; ++vs) b_cur[vs] = b_nxt[vs];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) a_cur[i] = a_nxt[i];
+      }
+    } else if constexpr (DXC) {
+      // one tap per (dz, dy) row, several channel sub-tiles per wave: one row ahead
       u32x4 a_c[CW], a_n[CW], b_c[VW], b_n[VW];
 #pragma unroll
       for (int cs = 0; cs < CW; ++cs) a_c[cs] = wfrag(cs, (dz * 5 + dy) * 5 + 2);
@@ -538,7 +583,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   RM_STAMP(60);
 }
 
-template <typename T, typename C, bool SWAP, bool PAIR>
+template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false>
 int launch_cfg(ConvArgs a, hipStream_t stream) {
   a.nbz = ceil_div(a.D, C::BZ);
   a.nby = ceil_div(a.H, C::BY);
@@ -562,7 +607,7 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   int dev = 0;
   RM_HIP(hipGetDevice(&dev));
   if (!((attr_set.load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_igemm_kernel<T, C, SWAP, PAIR>),
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_igemm_kernel<T, C, SWAP, PAIR, DXC>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
   }
@@ -578,7 +623,7 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   const double alg = a.dxc ? 2.0 * a.N * a.D * a.H * a.W * 25.0 * (a.Cin == 8 ? 5.0 * a.Cout : (double)a.Cin * a.Cout)
                            : a.tap_lo ? 0.0 : 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS;
   repmode_prof_begin(REPMODE_PROF_CONV5, alg, stream);
-  hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP, PAIR>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP, PAIR, DXC>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
   repmode_prof_end(stream);
   RM_LAUNCH_CHECK("conv5_igemm");
   return REPMODE_OK;
@@ -600,6 +645,16 @@ int dispatch_tile(ConvArgs a, hipStream_t stream) {
 
 template <typename T, bool SWAP>
 int dispatch(ConvArgs a, hipStream_t stream) {
+  if (a.dxc) {
+    // the thin layers (x taps folded into channels): bf16, one tensor in and out, on the two widest tiles
+    if constexpr (sizeof(T) == 2) {
+      RM_REQUIRE(a.Cin1 == 0 && a.Cout1 == 0, "conv5: the dx-centre mode takes one input and one output tensor");
+      if (a.W >= 32) return launch_cfg<T, CfgX32, SWAP, false, true>(a, stream);
+      return launch_cfg<T, CfgX16, SWAP, false, true>(a, stream);
+    } else {
+      RM_REQUIRE(false, "conv5: the dx-centre mode is a bf16 path");
+    }
+  }
   if (a.Cin1 > 0 || a.Cout1 > 0) return dispatch_tile<T, SWAP, true>(a, stream);
   return dispatch_tile<T, SWAP, false>(a, stream);
 }
