@@ -142,6 +142,9 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='patches per GPU (default: 8 on one GPU = configs[1], 24 per rank on several = configs[3])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-inputs', action='store_true', help='inputs start in pinned host memory every step (PCIe-inclusive rate)')
+    ap.add_argument('--device-volumes', action='store_true',
+                    help='every step draws a fresh batch from device-resident volumes (repmode_amd.data.DeviceVolumes: random crop + '
+                         'flips like the reference\'s data_aug, one launch) instead of re-using one synthetic batch')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events')
     ap.add_argument('--no-fwd', action='store_true', help='skip the forward-only measurement')
     ap.add_argument('--graph', action='store_true', help='replay the train step as one HIP graph (N = 1; DESIGN.md 3.5)')
@@ -175,6 +178,23 @@ def main():
         # would; never the headline `value` (inputs resident in HBM), reported in DESIGN.md section 5
         signal, target = signal.cpu().pin_memory(), target.cpu().pin_memory()
     task = (torch.arange(b) + rank * b) % NUM_TASKS            # CPU int tensor, like the DataLoader's
+    volumes = None
+    if args.device_volumes:
+        # the input side of SURVEY 8f.4 inside the timed region: 12 synthetic 64x160x160 volume pairs (one per task) live in
+        # HBM; each step crops + flips a new batch of them (numpy draws in the reference's order, one HIP launch)
+        import numpy as np
+        from repmode_amd.data import DeviceVolumes
+        volumes = DeviceVolumes(device, PATCH, 0.5)
+        for t_ in range(NUM_TASKS):
+            v = torch.randn(2, 64, 160, 160, generator=torch.Generator().manual_seed(t_))
+            volumes.add(v[0], v[1], t_)
+        rng = np.random.RandomState(rank)
+        vol_idx = [int(t_) for t_ in task]
+
+    def next_batch():
+        if volumes is None:
+            return signal, target, task
+        return volumes.sample_batch(vol_idx, rng)
 
     def barrier():
         if world > 1:
@@ -182,7 +202,7 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        model.do_train_iter(signal, target, task)
+        model.do_train_iter(*next_batch())
     barrier()
     # HIP events around the dominant kernel's launches only by default, and on every PROF_EVERY-th timed step (each
     # event pair costs ~4 us of stream time: ~0.5 ms per step if every launch of every step were bracketed)
@@ -201,7 +221,7 @@ def main():
             # the convolutions on a second stream, an event pair would time the pair of kernels, not the kernel
             ops_.set_overlap(overlap and not on)
         # (a profiled step is launched kernel by kernel: the library's event pairs are not part of a captured graph)
-        model.do_train_iter(signal, target, task, eager=not args.no_prof and on)
+        model.do_train_iter(*next_batch(), eager=not args.no_prof and on)
     t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (includes waiting on a full queue)
     barrier()
     dt = time.perf_counter() - t0
@@ -239,7 +259,8 @@ def main():
         'scaling': 'weak',
         'vs_baseline': None,
         'dtype': args.dtype,
-        'data': 'synthetic' + (' (inputs in pinned host memory every step: PCIe-inclusive)' if args.host_inputs else ''),
+        'data': 'synthetic' + (' (inputs in pinned host memory every step: PCIe-inclusive)' if args.host_inputs else '') +
+                (' (a fresh crop + flip batch from device-resident volumes every step)' if args.device_volumes else ''),
         'config': {'workload': 'RepMode U-Net (mult_chan 32, 12 tasks, 123.9M params) full train step '
                                '(fwd + bwd + Adam), batch %d x 1x32x64x64 per GPU (%s)'
                                % (b, 'BASELINE configs[1]' if (world == 1 and b == BATCH_1GPU) else

@@ -26,6 +26,7 @@
 #include "common.h"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace {
 
@@ -595,8 +596,10 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   const int nchunks = a.CinP / (2 * Elem<T>::KV);
   long base = (long)(a.dual ? 2 * a.N : a.N) * a.nbz * a.nby * a.nbx * a.ncot;
   int ks = 1;
+  static const int min_chunks = []() { const char* e = getenv("REPMODE_CONV_MIN_CHUNKS"); return e ? atoi(e) : 4; }();
+  static const int split_target = []() { const char* e = getenv("REPMODE_CONV_SPLIT_TARGET"); return e ? atoi(e) : CONV_SPLIT_TARGET; }();
   if (SWAP && !a.bias && !a.relu) {   // (a bias / ReLU epilogue needs the whole sum in one workgroup)
-    while (ks * 4 <= nchunks && base * ks < CONV_SPLIT_TARGET && ks < 64) ks *= 2;
+    while (ks * min_chunks <= nchunks && base * ks < split_target && ks < 64) ks *= 2;
   }
   RM_REQUIRE(!a.stats || !SWAP, "conv5: output statistics need the element-typed output path (bf16 input, not out_f32)");
   a.ksplit = ks;

@@ -4,6 +4,7 @@ cd "$(dirname "$0")/.."; S=gpurun_out/r02; D=profiles
 cp $S/bench_line.json $D/r02_bench_line.json
 cp $S/bench_line_driver_args.json $D/r02_bench_line_driver_args.json
 cp $S/bench_line_b24.json $D/r02_bench_line_b24.json
+cp $S/bench_line_device_volumes.json $D/r02_bench_line_device_volumes.json
 cp $S/kernel_stats_b8.csv $D/r02_bench_kernel_stats.csv
 cp $S/kernel_stats_b24.csv $D/r02_b24_kernel_stats.csv
 cp $S/trace_summary_b8.txt $D/r02_bench_trace_summary.txt

@@ -7,6 +7,7 @@ python bench.py > $O/bench_line.json 2> $O/bench.err
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_line_driver_args.json 2>> $O/bench.err
 python bench.py --no-cpu-baseline --no-fwd --prof-all --dump-launches $O/launches_last_step.json > $O/bench_profall.json 2>> $O/bench.err
 python bench.py --no-cpu-baseline --batch 24 --steps 40 --warmup 10 > $O/bench_line_b24.json 2>> $O/bench.err
+python bench.py --no-cpu-baseline --no-fwd --device-volumes > $O/bench_line_device_volumes.json 2>> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 for b in 8 24; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_b$b -- python $R/bench.py --batch $b --no-cpu-baseline --no-prof --no-fwd --steps 10 --warmup 3 > $O/trace_b$b.log 2>&1
