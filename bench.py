@@ -155,7 +155,12 @@ def main():
     from repmode_amd import _lib, ops as ops_, distributed as dist_
     from repmode_amd.model import Model
 
-    rank, world, local = dist_.init_from_env()
+    # REPMODE_BENCH_SHARE_GPU=1: developer check of the N > 1 code path on a one-GPU box -- every rank on cuda:0, gloo
+    # transport (RCCL refuses two ranks on one device); never a measurement
+    share_gpu = bool(os.environ.get('REPMODE_BENCH_SHARE_GPU'))
+    if share_gpu:
+        os.environ['LOCAL_RANK'] = '0'
+    rank, world, local = dist_.init_from_env(backend='gloo' if share_gpu else None)
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch N>1 through torch.distributed.run' % (args.gpus, world))
     if not torch.cuda.is_available():

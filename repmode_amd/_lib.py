@@ -10,7 +10,8 @@ import torch  # noqa: F401  -- FIRST: torch bundles its own libamdhip64.so.7; im
 # librepmode_hip.so makes that the single HIP runtime of the process (same soname as /opt/rocm's copy).
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librepmode_hip.so')
+# REPMODE_LIB: a developer's variant build of the kernel library (tools/ab_variant.sh, tools/conv_phase_timing.py)
+LIB_PATH = os.environ.get('REPMODE_LIB') or os.path.join(_HERE, 'librepmode_hip.so')
 
 F32, BF16 = 0, 1
 ABI_VERSION = 3
