@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define REPMODE_ABI_VERSION 3
+#define REPMODE_ABI_VERSION 4
 
 /* element types of activations / merged filters */
 #define REPMODE_F32 0  /* float in, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)          */
@@ -193,6 +193,24 @@ int repmode_gatrep_bwd(const float* dw, const float* k5, const float* k3, const 
                        int nslots, int num_tasks, int co, int ci, float* dk5, float* dk3,
                        float* dk1, float* da3, float* da5, float* dgate_w, float* dgate_b,
                        float* dg_ws, void* stream);
+/* flags & REPMODE_DEFER: the gate part (softmax Jacobian + Linear gradients, dgate_w / dgate_b) is not launched but
+ * queued on the stream, see "Deferred small jobs" below. */
+int repmode_gatrep_bwd_ex(const float* dw, const float* k5, const float* k3, const float* k1,
+                          const float* a3, const float* a5, const float* g, const int32_t* slot_task,
+                          int nslots, int num_tasks, int co, int ci, float* dk5, float* dk3,
+                          float* dk1, float* da3, float* da5, float* dgate_w, float* dgate_b,
+                          float* dg_ws, int flags, void* stream);
+
+/* ---- Deferred small jobs.  On the backward pass of a MoDE block (autograd of RepMode.py:171-214) the gate backward
+ * and the layout transposes of the filter gradients are a few microseconds of work each, behind a kernel boundary that
+ * costs as much; the block's data-gradient convolution, which does not depend on them, is launched right after.  An
+ * `_ex` entry point called with REPMODE_DEFER queues its job on the stream instead of launching it; the next
+ * repmode_conv5 / _ex / _pair / _epi launch on the same stream (same device) runs every queued job in its first
+ * workgroups, repmode_tail_flush launches what is still queued as one kernel (no-op when the queue is empty; at most 3
+ * jobs wait, a 4th push runs the 3 before it).  The caller must issue one of the two before anything reads a deferred
+ * job's outputs or overwrites its inputs.  Results are identical to the immediate form (same code). */
+#define REPMODE_DEFER 1
+int repmode_tail_flush(void* stream);
 
 /* ---- BatchNorm3d + ReLU of the MoDE block's `subsequent_layer` (RepMode.py:146-149, :212) and of the
  * stride-2 down/up stages (RepMode.py:80-84, 97-101), on a channels-last tensor viewed as [m][c].
@@ -279,11 +297,14 @@ int repmode_box_expand(const void* x, int dtype, float* out, int n, int d, int h
  * for the m = Co*Ci channel pairs; ntaps_out = 125 (all taps), 27 (the centred 3x3x3 taps of the [125][m] input)
  * or 8 (the 2x2x2 stride-2 filters, input [8][m]). */
 int repmode_tap_transpose(const float* in, float* out, long m, int ntaps_out, void* stream);
+int repmode_tap_transpose_ex(const float* in, float* out, long m, int ntaps_out, int flags /* REPMODE_DEFER */, void* stream);
 /* Softmax Jacobian + gate Linear gradients (autograd of RepMode.py:198-200) from gate-probability gradients
  * dg[s][5][Co]: dgate_w [5*Co][T], dgate_b [5*Co], overwritten.  (repmode_gatrep_bwd does this itself; the
  * per-expert formulation calls it with one "slot" per sample.) */
 int repmode_gate_bwd(const float* g, const float* dg, const int32_t* slot_task, int nslots, int num_tasks, int co,
                      float* dgate_w, float* dgate_b, void* stream);
+int repmode_gate_bwd_ex(const float* g, const float* dg, const int32_t* slot_task, int nslots, int num_tasks, int co,
+                        float* dgate_w, float* dgate_b, int flags /* REPMODE_DEFER */, void* stream);
 /* The raw conv5x5 / conv3x3 experts (RepMode.py:131-134) as two un-merged "slots" of the conv kernels' bf16
  * fragment-major layout, for the per-expert formulation: slot 0 = K5; slot 1 = K3 on its centred support,
  * of which ONLY the taps with dz, dy in [1,3] are written (what repmode_conv5_ex reads with centre3 set).

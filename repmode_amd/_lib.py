@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('REPMODE_LIB') or os.path.join(_HERE, 'librepmode_hip.so')
 
 F32, BF16 = 0, 1
-ABI_VERSION = 3
+DEFER = 1        # REPMODE_DEFER: queue the job for the next conv5 launch on the stream (include/repmode_hip.h)
+ABI_VERSION = 4
 
 _c = ctypes
 _P = _c.c_void_p
@@ -42,6 +43,8 @@ _SIGNATURES = {
     'repmode_thin_pack': [_P, _P, _I, _I, _I, _P],
     'repmode_unshift5': [_P, _P, _c.c_long, _I, _P],
     'repmode_gatrep_bwd': [_P] * 8 + [_I] * 4 + [_P] * 9,
+    'repmode_gatrep_bwd_ex': [_P] * 8 + [_I] * 4 + [_P] * 8 + [_I, _P],
+    'repmode_tail_flush': [_P],
     'repmode_bn_relu_fwd': [_P] * 8 + [_c.c_long, _I, _c.c_float, _c.c_float, _I, _I, _I, _P],
     'repmode_bn_relu_fwd_ex': [_P] * 8 + [_c.c_long, _I, _c.c_float, _c.c_float, _I, _I, _I, _I, _P],
     'repmode_bn_relu_bwd': [_P] * 8 + [_c.c_long, _I, _I, _I, _I, _P],
@@ -58,7 +61,9 @@ _SIGNATURES = {
     'repmode_box_sum': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'repmode_box_sum_ex': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'repmode_tap_transpose': [_P, _P, _c.c_long, _I, _P],
+    'repmode_tap_transpose_ex': [_P, _P, _c.c_long, _I, _I, _P],
     'repmode_gate_bwd': [_P, _P, _P, _I, _I, _I, _P, _P, _P],
+    'repmode_gate_bwd_ex': [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P],
     'repmode_expert_frags': [_P, _P, _I, _I, _P, _P, _P],
     'repmode_crop_flip': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     'repmode_mse_loss': [_P, _P, _P, _I, _c.c_long, _I, _P, _P, _P, _P, _P, _P, _P],

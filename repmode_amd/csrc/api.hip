@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "common.h"
+#include "tail_jobs.h"
 #include <map>
 #include <mutex>
 #include <utility>
@@ -106,6 +107,65 @@ int repmode_bn_scratch_half(hipStream_t s) {
   const int mine = h;
   h ^= 1;
   return mine;
+}
+
+// ---- deferred small jobs (tail_jobs.h): per (device, stream) queue, taken by the next conv5 launch on the stream
+namespace {
+std::mutex g_tail_mu;
+std::map<std::pair<int, hipStream_t>, TailJobs> g_tail;
+
+__global__ __launch_bounds__(TAIL_THREADS) void tail_jobs_kernel(TailJobs t) {
+  __shared__ float lds[TAIL_LDS_BYTES / 4];
+  tail_run(t, blockIdx.x, threadIdx.x, lds);
+}
+}  // namespace
+
+void repmode_tail_take(hipStream_t s, TailJobs* out) {
+  out->njobs = 0;
+  out->nblocks = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(g_tail_mu);
+  auto it = g_tail.find({dev, s});
+  if (it == g_tail.end() || it->second.njobs == 0) return;
+  *out = it->second;
+  out->nblocks = (out->nblocks + 7) & ~7;
+  it->second.njobs = 0;
+  it->second.nblocks = 0;
+}
+
+int repmode_tail_launch(const TailJobs& t, hipStream_t s) {
+  if (t.njobs == 0) return REPMODE_OK;
+  hipLaunchKernelGGL(tail_jobs_kernel, dim3((unsigned)t.nblocks), dim3(TAIL_THREADS), 0, s, t);
+  RM_LAUNCH_CHECK("tail_jobs");
+  return REPMODE_OK;
+}
+
+int repmode_tail_push(const TailJob& job, hipStream_t s) {
+  RM_REQUIRE(job.nblocks > 0 && (job.kind == 1 || job.kind == 2), "tail_push: bad job");
+  int dev = 0;
+  RM_HIP(hipGetDevice(&dev));
+  TailJobs full;
+  full.njobs = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_tail_mu);
+    TailJobs& q = g_tail[{dev, s}];
+    if (q.njobs == TAIL_MAX_JOBS) {       // no host launch came by: run what is queued, then queue this one
+      full = q;
+      full.nblocks = (full.nblocks + 7) & ~7;
+      q.njobs = 0;
+      q.nblocks = 0;
+    }
+    q.job[q.njobs++] = job;
+    q.nblocks += job.nblocks;
+  }
+  return repmode_tail_launch(full, s);
+}
+
+extern "C" int repmode_tail_flush(void* stream) {
+  TailJobs t;
+  repmode_tail_take(static_cast<hipStream_t>(stream), &t);
+  return repmode_tail_launch(t, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int repmode_prof_enable(int on) {

@@ -12,6 +12,7 @@
 // live in L2, so the kernel is a direct gather: one thread per (voxel, 4 channels), 27 / 125 float4
 // loads.  Memory-bound on L2, a few tens of microseconds; not on the MFMA path.
 #include "common.h"
+#include "tail_jobs.h"
 
 namespace {
 
@@ -315,27 +316,27 @@ namespace {
 __global__ __launch_bounds__(256) void tap_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, long M,
                                                             int ntaps_out) {
   __shared__ float tile[125 * 65];
-  const long m0 = (long)blockIdx.x * 64;
-  const int ncol = (int)min((long)64, M - m0);
-  for (int i = threadIdx.x; i < ntaps_out * 64; i += 256) {
-    const int t = i / 64, col = i % 64;
-    int tap = t;
-    if (ntaps_out == 27) tap = ((t / 9 + 1) * 5 + (t / 3) % 3 + 1) * 5 + t % 3 + 1;
-    if (col < ncol) tile[t * 65 + col] = in[(size_t)tap * M + m0 + col];
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < ncol * ntaps_out; i += 256) {
-    const int col = i / ntaps_out, t = i % ntaps_out;
-    out[(size_t)m0 * ntaps_out + i] = tile[t * 65 + col];
-  }
+  // (the body is shared with the deferred form that rides in a conv5 launch: tail_jobs.h)
+  tail_tap_transpose(in, out, M, ntaps_out, tile, blockIdx.x, threadIdx.x);
 }
 }  // namespace
 
-extern "C" int repmode_tap_transpose(const float* in, float* out, long m, int ntaps_out, void* stream) {
+extern "C" int repmode_tap_transpose_ex(const float* in, float* out, long m, int ntaps_out, int flags, void* stream) {
   RM_REQUIRE(in && out, "tap_transpose: null pointer");
   RM_REQUIRE(m > 0 && (ntaps_out == 125 || ntaps_out == 27 || ntaps_out == 8), "tap_transpose: bad shape");
+  if (flags & REPMODE_DEFER) {
+    TailJob j{};
+    j.kind = 2;
+    j.nblocks = (int)((m + 63) / 64);
+    j.in0 = in; j.io1 = out; j.m = m; j.p0 = ntaps_out;
+    return repmode_tail_push(j, static_cast<hipStream_t>(stream));
+  }
   hipLaunchKernelGGL(tap_transpose_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      in, out, m, ntaps_out);
   RM_LAUNCH_CHECK("tap_transpose");
   return REPMODE_OK;
+}
+
+extern "C" int repmode_tap_transpose(const float* in, float* out, long m, int ntaps_out, void* stream) {
+  return repmode_tap_transpose_ex(in, out, m, ntaps_out, 0, stream);
 }

@@ -24,6 +24,7 @@
 //   * epilogue: the 32x32 accumulator tile holds 4 consecutive output channels per lane per
 //     register quad -> 8-byte (bf16) / 16-byte (f32) channel-contiguous stores.
 #include "common.h"
+#include "tail_jobs.h"
 
 #include <atomic>
 #include <cstdlib>
@@ -117,6 +118,9 @@ struct ConvArgs {
   // 2 N samples (the two gate-scaled output gradients), else both jobs read sample v % N; dual & 4: the output holds
   // 2 N samples (the two expert outputs), else both jobs ADD into sample v % N.
   int dual;
+  // deferred small jobs (tail_jobs.h) that ride in this launch: workgroups [0, tail.nblocks) run them, the convolution's
+  // workgroups follow (tail.nblocks is a multiple of 8, so their workgroup -> XCD map is unchanged)
+  TailJobs tail;
 };
 
 // Tile configuration.  BZ*BY*BX output voxels = 32 * WV * VW; 32 * WC * CW output channels.
@@ -162,7 +166,14 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   const int khalf = lane >> 5;
   const int l31 = lane & 31;
 
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  if (a.tail.nblocks) {
+    if ((int)blockIdx.x < a.tail.nblocks) {
+      tail_run(a.tail, blockIdx.x, tid, reinterpret_cast<float*>(smem));
+      return;
+    }
+  }
+  const int conv_block = blockIdx.x - a.tail.nblocks, conv_blocks = gridDim.x - a.tail.nblocks;
+  int bid = xcd_remap(conv_block, conv_blocks);
   const int kz = bid % a.ksplit;  bid /= a.ksplit;
   const int cot = bid % a.ncot;   bid /= a.ncot;
   const int bx = bid % a.nbx;     bid /= a.nbx;
@@ -490,7 +501,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ssum[cs][r] = 0.f; ssq[cs][r] = 0.f; }
       // put the zeros back into the BatchNorm scratch half the previous call used (what bn_stats_kernel does)
-      for (int i = blockIdx.x * NT + tid; i < (int)REPMODE_SCRATCH_BN_HALF; i += gridDim.x * NT) a.stats_clear[i] = 0.f;
+      for (int i = conv_block * NT + tid; i < (int)REPMODE_SCRATCH_BN_HALF; i += conv_blocks * NT) a.stats_clear[i] = 0.f;
     }
 #pragma unroll
     for (int vs = 0; vs < VW; ++vs) {
@@ -564,7 +575,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
     if (want_stats) {
       // lanes with equal khalf hold the same 16 channels of different voxels: butterfly over the 32 lanes, then one lane
       // per half-wave adds the wave's totals to this workgroup's slice (BatchNorm's slice layout, bnrelu.hip)
-      float* slice = a.stats + (size_t)(blockIdx.x & 15) * 2 * Cout;
+      float* slice = a.stats + (size_t)(conv_block & 15) * 2 * Cout;
 #pragma unroll
       for (int cs = 0; cs < CW; ++cs) {
 #pragma unroll
@@ -603,15 +614,19 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   }
   RM_REQUIRE(!a.stats || !SWAP, "conv5: output statistics need the element-typed output path (bf16 input, not out_f32)");
   a.ksplit = ks;
-  const long grid = base * ks;
+  // small jobs deferred to this launch (tail_jobs.h) become its first workgroups
+  repmode_tail_take(stream, &a.tail);
+  const long grid = base * ks + a.tail.nblocks;
   RM_REQUIRE(grid > 0 && grid < (1L << 31), "conv5: grid %ld out of range", grid);
+  constexpr int LDS_BYTES = C::LDS_BYTES > TAIL_LDS_BYTES ? C::LDS_BYTES : TAIL_LDS_BYTES;   // (level 4's tile is smaller than a job's)
+  const int lds_bytes = a.tail.nblocks ? LDS_BYTES : C::LDS_BYTES;
   // per instantiation and per device (one bit each; a racing second thread at worst repeats the idempotent call)
   static std::atomic<unsigned> attr_set{0};
   int dev = 0;
   RM_HIP(hipGetDevice(&dev));
   if (!((attr_set.load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_igemm_kernel<T, C, SWAP, PAIR, DXC>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
   }
   if ((ks > 1 || (a.dual && !(a.dual & 4))) && !a.accum) {
@@ -626,7 +641,7 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   const double alg = a.dxc ? 2.0 * a.N * a.D * a.H * a.W * 25.0 * (a.Cin == 8 ? 5.0 * a.Cout : (double)a.Cin * a.Cout)
                            : a.tap_lo ? 0.0 : 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS;
   repmode_prof_begin(REPMODE_PROF_CONV5, alg, stream);
-  hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP, PAIR, DXC>), dim3((unsigned)grid), dim3(C::NT), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP, PAIR, DXC>), dim3((unsigned)grid), dim3(C::NT), lds_bytes, stream, a);
   repmode_prof_end(stream);
   RM_LAUNCH_CHECK("conv5_igemm");
   return REPMODE_OK;

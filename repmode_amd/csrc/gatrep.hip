@@ -11,6 +11,7 @@
 // Backward is the autograd of the same lines: expert gradients, gate-probability gradients
 // (reduced over ci and taps), then the softmax Jacobian and the gate Linear's weight/bias grads.
 #include "common.h"
+#include "tail_jobs.h"
 
 namespace {
 
@@ -303,30 +304,8 @@ constexpr int GATE_BWD_THREADS = 32 * E;
 __global__ __launch_bounds__(GATE_BWD_THREADS) void gate_bwd_kernel(
     const float* __restrict__ g, float* __restrict__ dg, const int32_t* __restrict__ slot_task, int nslots,
     int num_tasks, int co_n, float* __restrict__ dgate_w, float* __restrict__ dgate_b, int clear) {
-  const int idx = blockIdx.x * GATE_BWD_THREADS + threadIdx.x;
-  const int o = idx / E, e = idx % E;
-  const bool on = o < co_n;
-  if (on) {
-    float* wrow = dgate_w + ((size_t)e * co_n + o) * num_tasks;
-    for (int t = 0; t < num_tasks; ++t) wrow[t] = 0.f;
-    float bsum = 0.f;
-    for (int s = 0; s < nslots; ++s) {
-      const float* gs = g + (size_t)s * E * co_n + o;
-      const float* ds = dg + (size_t)s * E * co_n + o;
-      float dot = 0.f;
-#pragma unroll
-      for (int k = 0; k < E; ++k) dot += gs[k * co_n] * ds[k * co_n];
-      const float dl = gs[e * co_n] * (ds[e * co_n] - dot);
-      atomicAdd(&wrow[slot_task[s]], dl);   // (atomic only to keep the slot iterations independent)
-      bsum += dl;
-    }
-    dgate_b[e * co_n + o] = bsum;
-  }
-  if (clear) {
-    __syncthreads();
-    if (on)
-      for (int s = 0; s < nslots; ++s) dg[((size_t)s * E + e) * co_n + o] = 0.f;
-  }
+  // (the body is shared with the deferred form that rides in a conv5 launch: tail_jobs.h)
+  tail_gate_bwd(g, dg, slot_task, nslots, num_tasks, co_n, dgate_w, dgate_b, clear, blockIdx.x, threadIdx.x);
 }
 
 
@@ -828,21 +807,41 @@ extern "C" int repmode_expert_frags(const float* k5, const float* k3, int co, in
 
 // Softmax-Jacobian + gate Linear gradients alone, from gate-probability gradients dg[s][5][Co] (used by the
 // per-expert formulation, where "slots" are the samples themselves and dg[n][e][o] = <dy[n], P_e[n]>).
-extern "C" int repmode_gate_bwd(const float* g, const float* dg, const int32_t* slot_task, int nslots, int num_tasks,
-                                int co, float* dgate_w, float* dgate_b, void* stream) {
-  RM_REQUIRE(g && dg && slot_task && dgate_w && dgate_b, "gate_bwd: null pointer");
-  RM_REQUIRE(nslots > 0 && num_tasks > 0 && co > 0, "gate_bwd: bad shape");
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(co, 32)), dim3(GATE_BWD_THREADS), 0, static_cast<hipStream_t>(stream), g,
-                     const_cast<float*>(dg), slot_task, nslots, num_tasks, co, dgate_w, dgate_b, 0);
+// One launch of the gate backward, or (defer) one queued job for the next conv5 launch on the stream
+static int gate_bwd_launch(const float* g, float* dg, const int32_t* slot_task, int nslots, int num_tasks, int co, float* dgate_w,
+                           float* dgate_b, int clear, bool defer, hipStream_t s) {
+  if (defer) {
+    TailJob j{};
+    j.kind = 1;
+    j.nblocks = ceil_div(co, 32);
+    j.in0 = g; j.io1 = dg; j.ids = slot_task; j.out2 = dgate_w; j.out3 = dgate_b;
+    j.p0 = nslots; j.p1 = num_tasks; j.p2 = co; j.p3 = clear;
+    return repmode_tail_push(j, s);
+  }
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(co, 32)), dim3(GATE_BWD_THREADS), 0, s, g, dg, slot_task, nslots, num_tasks, co,
+                     dgate_w, dgate_b, clear);
   RM_LAUNCH_CHECK("gate_bwd");
   return REPMODE_OK;
 }
 
-extern "C" int repmode_gatrep_bwd(const float* dw, const float* k5, const float* k3, const float* k1,
-                                  const float* a3, const float* a5, const float* g, const int32_t* slot_task,
-                                  int nslots, int num_tasks, int co, int ci, float* dk5, float* dk3, float* dk1,
-                                  float* da3, float* da5, float* dgate_w, float* dgate_b, float* dg_ws,
-                                  void* stream) {
+extern "C" int repmode_gate_bwd_ex(const float* g, const float* dg, const int32_t* slot_task, int nslots, int num_tasks,
+                                   int co, float* dgate_w, float* dgate_b, int flags, void* stream) {
+  RM_REQUIRE(g && dg && slot_task && dgate_w && dgate_b, "gate_bwd: null pointer");
+  RM_REQUIRE(nslots > 0 && num_tasks > 0 && co > 0, "gate_bwd: bad shape");
+  return gate_bwd_launch(g, const_cast<float*>(dg), slot_task, nslots, num_tasks, co, dgate_w, dgate_b, 0, (flags & REPMODE_DEFER) != 0,
+                         static_cast<hipStream_t>(stream));
+}
+
+extern "C" int repmode_gate_bwd(const float* g, const float* dg, const int32_t* slot_task, int nslots, int num_tasks,
+                                int co, float* dgate_w, float* dgate_b, void* stream) {
+  return repmode_gate_bwd_ex(g, dg, slot_task, nslots, num_tasks, co, dgate_w, dgate_b, 0, stream);
+}
+
+extern "C" int repmode_gatrep_bwd_ex(const float* dw, const float* k5, const float* k3, const float* k1,
+                                     const float* a3, const float* a5, const float* g, const int32_t* slot_task,
+                                     int nslots, int num_tasks, int co, int ci, float* dk5, float* dk3, float* dk1,
+                                     float* da3, float* da5, float* dgate_w, float* dgate_b, float* dg_ws, int flags,
+                                     void* stream) {
   RM_REQUIRE(dw && k5 && k3 && k1 && a3 && a5 && g && slot_task, "gatrep_bwd: null input");
   RM_REQUIRE(dk5 && dk3 && dk1 && da3 && da5 && dgate_w && dgate_b && dg_ws, "gatrep_bwd: null output");
   RM_REQUIRE(nslots > 0 && num_tasks > 0 && co > 0 && ci > 0, "gatrep_bwd: bad shape");
@@ -870,9 +869,17 @@ extern "C" int repmode_gatrep_bwd(const float* dw, const float* k5, const float*
     hipLaunchKernelGGL(gatrep_bwd_kernel<2>, dim3(ceil_div(ci, GF_CT), co), dim3(GF_THREADS), 0, s, dw, k5, k3, k1, a3, a5,
                        g, nslots, co, ci, dk5, dk3, dk1, da3, da5, dg);
   RM_LAUNCH_CHECK("gatrep_bwd");
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3(ceil_div(co, 32)), dim3(GATE_BWD_THREADS), 0, s, g, dg, slot_task, nslots,
-                     num_tasks, co, dgate_w, dgate_b, clear);
+  // the gate backward: its own launch, or (REPMODE_DEFER) the first workgroups of the next conv5 launch on this stream
+  const int rc = gate_bwd_launch(g, dg, slot_task, nslots, num_tasks, co, dgate_w, dgate_b, clear, (flags & REPMODE_DEFER) != 0, s);
   repmode_prof_end(s);
-  RM_LAUNCH_CHECK("gate_bwd");
-  return REPMODE_OK;
+  return rc;
+}
+
+extern "C" int repmode_gatrep_bwd(const float* dw, const float* k5, const float* k3, const float* k1,
+                                  const float* a3, const float* a5, const float* g, const int32_t* slot_task,
+                                  int nslots, int num_tasks, int co, int ci, float* dk5, float* dk3, float* dk1,
+                                  float* da3, float* da5, float* dgate_w, float* dgate_b, float* dg_ws,
+                                  void* stream) {
+  return repmode_gatrep_bwd_ex(dw, k5, k3, k1, a3, a5, g, slot_task, nslots, num_tasks, co, ci, dk5, dk3, dk1, da3, da5, dgate_w,
+                               dgate_b, dg_ws, 0, stream);
 }

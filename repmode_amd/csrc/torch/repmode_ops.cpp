@@ -294,6 +294,13 @@ bool g_overlap = []() {
   const char* e = std::getenv("REPMODE_OVERLAP");
   return e ? std::atoi(e) != 0 : false;
 }();
+// Deferred small jobs (csrc/tail_jobs.h): on the backward pass a block's gate backward and gradient-layout transposes are
+// queued and run in the first workgroups of the block's data-gradient convolution instead of as launches of their own
+// (a dependent kernel boundary costs 4-5 us; ~25 launches per step).  REPMODE_TAIL=0 / set_tail_jobs(False): launch each.
+bool g_tail = []() {
+  const char* e = std::getenv("REPMODE_TAIL");
+  return e ? std::atoi(e) != 0 : true;
+}();
 
 // ------------------------------------------------------------------------------------------------------------
 // thin wrappers of the C ABI (allocation + argument marshalling)
@@ -470,10 +477,11 @@ Tensor conv5_wgrad_expert_layout(const Tensor& x_cl, const Tensor& dy_cl, const 
   return out;
 }
 
-Tensor tap_transpose(const Tensor& dw_taps, at::IntArrayRef shape, Tensor out) {
+Tensor tap_transpose(const Tensor& dw_taps, at::IntArrayRef shape, Tensor out, bool defer = false) {
   const int64_t co = shape[0], ci = shape[1], k = shape[2];
   TORCH_CHECK(out.sizes() == shape && out.scalar_type() == at::kFloat && out.is_contiguous(), "tap_transpose: bad output");
-  RM_CALL(repmode_tap_transpose, dw_taps.data_ptr<float>(), out.data_ptr<float>(), (long)(co * ci), (int)(k * k * k), stream_handle());
+  RM_CALL(repmode_tap_transpose_ex, dw_taps.data_ptr<float>(), out.data_ptr<float>(), (long)(co * ci), (int)(k * k * k),
+          defer ? REPMODE_DEFER : 0, stream_handle());
   return out;
 }
 
@@ -604,17 +612,19 @@ Merged merged_filters(const Tensor& k5, const Tensor& k3, const Tensor& k1, cons
 
 // GatRep backward: per-slot filter gradient dw [S, 125, Co, Ci] -> (dk5, dk3, dk1, da3, da5, dgate_w, dgate_b)
 std::vector<Tensor> filter_and_expert_grads(const Tensor& dw, const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3,
-                                            const Tensor& a5, const Tensor& g, const Plan& plan) {
+                                            const Tensor& a5, const Tensor& g, const Plan& plan, bool defer_gate = false) {
   const int64_t co = k5.size(0), ci = k5.size(1);
   Tensor dk5 = grad_out(k5), dk3 = grad_out(k3), dk1 = grad_out(k1), da3 = grad_out(a3), da5 = grad_out(a5);
   Tensor dgw = at::empty({E * co, plan.num_tasks}, k5.options());
   Tensor dgb = at::empty({E * co}, k5.options());
   Tensor dg_ws = at::empty_like(g);
-  RM_CALL(repmode_gatrep_bwd, dw.data_ptr<float>(), k5.data_ptr<float>(), k3.data_ptr<float>(), k1.data_ptr<float>(),
+  // defer_gate: the gate part rides in the caller's data-gradient conv launch (the library defers only when its
+  // accumulator is its own scratch, so dg_ws may go out of scope here)
+  RM_CALL(repmode_gatrep_bwd_ex, dw.data_ptr<float>(), k5.data_ptr<float>(), k3.data_ptr<float>(), k1.data_ptr<float>(),
           a3.data_ptr<float>(), a5.data_ptr<float>(), g.data_ptr<float>(), plan.slot_task.data_ptr<int32_t>(), (int)plan.nslots,
           (int)plan.num_tasks, (int)co, (int)ci, dk5.data_ptr<float>(), dk3.data_ptr<float>(), dk1.data_ptr<float>(),
           da3.data_ptr<float>(), da5.data_ptr<float>(), dgw.data_ptr<float>(), dgb.data_ptr<float>(), dg_ws.data_ptr<float>(),
-          stream_handle());
+          defer_gate ? REPMODE_DEFER : 0, stream_handle());
   return {dk5, dk3, dk1, da3, da5, dgw, dgb};
 }
 
@@ -672,7 +682,8 @@ struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
     Fork fork(need_dx && (whole || g_overlap), x_cl);
     fork.to_side();
     if (whole) dw = conv5_wgrad(x_cl, dy, plan.sample_slot, plan.nslots, co);
-    std::vector<Tensor> pg = filter_and_expert_grads(dw, k5, k3, k1, a3, a5, g, plan);
+    const bool defer = g_tail && need_dx && !(whole || g_overlap);      // (one stream: the data-gradient conv below hosts the job)
+    std::vector<Tensor> pg = filter_and_expert_grads(dw, k5, k3, k1, a3, a5, g, plan, defer);
     fork.to_main();
     Tensor dx;
     if (need_dx) {
@@ -681,6 +692,7 @@ struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
       if (dt == at::kBFloat16 && co == 1 && ci != 1) dx = thin_conv_in1(dy, wd, plan.sample_slot, ci, f32);   // last layer: dy has one channel
       else if (dt == at::kBFloat16 && ci == 1 && co != 1) dx = thin_conv_out1(dy, wd, plan.sample_slot);
       else dx = conv5(dy, wd, plan.sample_slot, ci, f32);
+      if (defer) RM_CALL(repmode_tail_flush, stream_handle());      // (nothing left unless the conv above was not reached)
       if (dx.scalar_type() != dt) dx = dx.to(dt);
     }
     fork.join();
@@ -761,7 +773,8 @@ struct ModeConvPair : public torch::autograd::Function<ModeConvPair> {
     Fork fork(wd.defined() && (whole || g_overlap), xa);      // (as ModeConvMerged::backward)
     fork.to_side();
     if (whole) filter_grad();
-    std::vector<Tensor> pg = filter_and_expert_grads(dw, k5, k3, k1, a3, a5, g, plan);
+    const bool defer = g_tail && wd.defined() && !(whole || g_overlap);
+    std::vector<Tensor> pg = filter_and_expert_grads(dw, k5, k3, k1, a3, a5, g, plan, defer);
     fork.to_main();
     Tensor dxa, dxb;
     if (wd.defined()) {
@@ -786,6 +799,7 @@ struct ModeConvPair : public torch::autograd::Function<ModeConvPair> {
       }
       RM_CALL(repmode_conv5_pair, dy.data_ptr(), nullptr, 0, wd.data_ptr(), plan.sample_slot.data_ptr<int32_t>(), dxa.data_ptr(),
               dxb.data_ptr(), (int)ca, (int)n, (int)d, (int)h, (int)w_, (int)co, (int)ci, code, f32 ? 1 : 0, flags, stream_handle());
+      if (defer) RM_CALL(repmode_tail_flush, stream_handle());
       if (dxa.scalar_type() != dt) {
         dxa = dxa.to(dt);
         dxb = dxb.to(dt);
@@ -882,14 +896,16 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
             stream_handle());
     Tensor dgw = at::empty({E * co, num_tasks}, k5.options());
     Tensor dgb = at::empty({E * co}, k5.options());
-    RM_CALL(repmode_gate_bwd, gn.data_ptr<float>(), dg.data_ptr<float>(), sample_task.data_ptr<int32_t>(), (int)n, (int)num_tasks, (int)co,
-            dgw.data_ptr<float>(), dgb.data_ptr<float>(), stream_handle());
     Tensor s0 = single_slot(n, 0, x_cl), s1 = single_slot(n, 1, x_cl);
     const bool need_dx = ctx->needs_input_grad(0) && wd2.defined();
+    // the gate backward and the two layout transposes below ride in the data-gradient conv's launch (one stream only)
+    const bool defer = g_tail && need_dx && !forks(x_cl) && g_dual_launch;
+    RM_CALL(repmode_gate_bwd_ex, gn.data_ptr<float>(), dg.data_ptr<float>(), sample_task.data_ptr<int32_t>(), (int)n, (int)num_tasks, (int)co,
+            dgw.data_ptr<float>(), dgb.data_ptr<float>(), defer ? REPMODE_DEFER : 0, stream_handle());
     // the expert gradients do not depend on the data gradient: second stream
     Fork fork(need_dx && forks(x_cl), x_cl);
     fork.to_side();
-    Tensor dk5, dk3, dk1, da3, da5;
+    Tensor dk5, dk3, dk1, da3, da5, keep5, keep3;
     {
       // filter gradients of the gate-scaled dy, all samples in one slot.  Large layers (every workgroup owns its outputs: no
       // atomics) write the parameters' [Co][Ci][taps] layout directly; the others accumulate tap-major + one transpose launch.
@@ -907,8 +923,10 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
         RM_CALL(repmode_conv5_wgrad_dual, x_cl.data_ptr(), lo0.data_ptr(), lo1.data_ptr(), direct5 ? dk5.data_ptr<float>() : t5.data_ptr<float>(),
                 direct3 ? dk3.data_ptr<float>() : t3.data_ptr<float>(), (int)n, (int)d, (int)h, (int)w, (int)ci, (int)co,
                 (direct5 ? 2 : 0) | (pre ? 8 : 0), (direct3 ? 3 : 1) | (pre ? 8 : 0), stream_handle());
-        if (!direct5) tap_transpose(t5[0], k5.sizes(), dk5);
-        if (!direct3) tap_transpose(t3[0], k3.sizes(), dk3);
+        if (!direct5) tap_transpose(t5[0], k5.sizes(), dk5, defer);
+        if (!direct3) tap_transpose(t3[0], k3.sizes(), dk3, defer);
+        keep5 = t5;             // (a deferred job reads them from inside the data-gradient conv's launch)
+        keep3 = t3;
       } else {
         if (direct5) dk5 = conv5_wgrad_expert_layout(x_cl, lo0, s0, co, 5, grad_out(k5));
         else dk5 = tap_transpose(conv5_wgrad(x_cl, lo0, s0, 1, co)[0], k5.sizes(), grad_out(k5));
@@ -943,6 +961,7 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
       Tensor dxf;
       if (g_dual_launch) {
         dxf = conv5(lo.view({2 * n, d, h, w, co}), wd2, s0, ci, true, c10::nullopt, false, false, false, nullptr, DUAL_IN2);
+        if (defer) RM_CALL(repmode_tail_flush, stream_handle());
       } else {
         dxf = conv5(lo0, wd2, s0, ci, true);
         conv5(lo1, wd2, s1, ci, true, dxf, true, true);
@@ -1469,6 +1488,7 @@ void op_set_unmerged_max_w(int64_t w) { g_unmerged_max_w = w; }
 void op_set_dual_launch(bool on) { g_dual_launch = on; }
 int64_t op_get_unmerged_max_w() { return g_unmerged_max_w; }
 void op_set_overlap(bool on) { g_overlap = on; }
+void op_set_tail_jobs(bool on) { g_tail = on; }
 void op_set_prepare(bool on) { g_prepare = on; }
 bool op_get_overlap() { return g_overlap; }
 
@@ -1552,6 +1572,7 @@ TORCH_LIBRARY(repmode, m) {
   m.def("set_dual_launch(bool on) -> ()", &rm::op_set_dual_launch);
   m.def("get_unmerged_max_w() -> int", &rm::op_get_unmerged_max_w);
   m.def("set_overlap(bool on) -> ()", &rm::op_set_overlap);
+  m.def("set_tail_jobs(bool on) -> ()", &rm::op_set_tail_jobs);
   m.def("set_prepare(bool on) -> ()", &rm::op_set_prepare);
   m.def("get_overlap() -> bool", &rm::op_get_overlap);
   m.def("zero_pool_begin(str key, Tensor like) -> ()", &rm::op_zero_pool_begin);

@@ -100,6 +100,12 @@ def set_overlap(on):
     torch_ops().set_overlap(bool(on))
 
 
+def set_tail_jobs(on):
+    """Backward pass: a block's gate backward and gradient-layout transposes ride in the first workgroups of the block's
+    data-gradient conv launch (default, csrc/tail_jobs.h) instead of being launched on their own (REPMODE_TAIL=0)."""
+    torch_ops().set_tail_jobs(bool(on))
+
+
 def get_overlap():
     return bool(torch_ops().get_overlap())
 

@@ -1285,3 +1285,113 @@ def test_filters_prepared_in_one_launch(dtype):
     # tiny network's first layer is a large part of its 4-channel gradient) bounds what the one-launch step may differ by
     noise = worst(res[2][1], res[1][1])
     assert worst(res[0][1], res[1][1]) <= max(3 * noise, 2e-2), (worst(res[0][1], res[1][1]), noise)
+
+
+@pytest.mark.parametrize('w_extent,dtype', [(32, torch.bfloat16), (8, torch.bfloat16), (4, torch.bfloat16), (8, torch.float32)])
+def test_deferred_jobs_ride_in_a_conv_launch(w_extent, dtype):
+    """REPMODE_DEFER (csrc/tail_jobs.h): a gate backward and two layout transposes queued on the stream come out of the next
+    conv5 launch -- or of repmode_tail_flush -- bit for bit as from their own launches, and the hosting convolution's
+    result is the one it gives alone (every tile configuration hosts: the level-4 tile borrows a larger LDS allocation)."""
+    from repmode_amd import _lib, ops
+    gen = torch.Generator().manual_seed(w_extent)
+    st = torch.cuda.current_stream().cuda_stream
+    nslots, ntasks, co, ci = 5, 12, 48, 32
+    g = torch.softmax(torch.randn(nslots, 5, co, generator=gen), 1).to(DEV)
+    dg = torch.randn(nslots, 5, co, generator=gen).to(DEV)
+    slot_task = torch.tensor([3, 7, 0, 11, 5], dtype=torch.int32, device=DEV)
+    t125 = torch.randn(125, co * ci, generator=gen).to(DEV)
+
+    def jobs(flags):
+        dgw = torch.full((5 * co, ntasks), 7.0, device=DEV)
+        dgb = torch.full((5 * co,), 7.0, device=DEV)
+        o125 = torch.full((co * ci, 125), 7.0, device=DEV)
+        o27 = torch.full((co * ci, 27), 7.0, device=DEV)
+        _lib.call('repmode_gate_bwd_ex', g.data_ptr(), dg.data_ptr(), slot_task.data_ptr(), nslots, ntasks, co, dgw.data_ptr(),
+                  dgb.data_ptr(), flags, st)
+        _lib.call('repmode_tap_transpose_ex', t125.data_ptr(), o125.data_ptr(), co * ci, 125, flags, st)
+        _lib.call('repmode_tap_transpose_ex', t125.data_ptr(), o27.data_ptr(), co * ci, 27, flags, st)
+        return dgw, dgb, o125, o27
+
+    ref = jobs(0)
+    torch.cuda.synchronize()
+    # gate backward of the softmax + Linear (RepMode.py:198-200) in float64
+    # softmax Jacobian: dz = g * (dg - <g, dg>); dgate_b = sum over slots, dgate_w[:, task(s)] += dz[s]
+    gd, dgd = g.cpu().double(), dg.cpu().double()
+    dz = gd * (dgd - (gd * dgd).sum(1, keepdim=True))
+    exp_b = dz.sum(0).reshape(-1)
+    exp_w = torch.zeros(5 * co, ntasks, dtype=torch.float64)
+    for s_, t_ in enumerate(slot_task.cpu().tolist()):
+        exp_w[:, t_] += dz[s_].reshape(-1)
+    assert rel_err(ref[1].cpu().double(), exp_b) < 1e-5 and rel_err(ref[0].cpu().double(), exp_w) < 1e-5
+    assert torch.equal(ref[2].cpu(), t125.cpu().t().contiguous())
+
+    # the host convolution alone
+    n, d, h = 2, 4 if w_extent <= 8 else 8, w_extent if w_extent <= 8 else 8
+    code = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+    x = torch.randn(n, d, h, w_extent, ci, generator=gen).to(DEV).to(dtype)
+    wf = (torch.randn(2, 125, _lib.padded_channels(co, code, False), _lib.padded_channels(ci, code, True), generator=gen) * 0.05).to(DEV).to(dtype)
+    slots = torch.tensor([1, 0], dtype=torch.int32, device=DEV)
+    y_alone = ops.conv5(x, wf, slots, co, out_f32=(w_extent < 32)).clone()
+    # queued, then hosted by the conv
+    got = jobs(_lib.DEFER)
+    torch.cuda.synchronize()
+    assert float(got[1].min()) == 7.0 and float(got[2].min()) == 7.0           # nothing ran yet
+    y_host = ops.conv5(x, wf, slots, co, out_f32=(w_extent < 32))
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    if w_extent >= 32:
+        assert torch.equal(y_host, y_alone)
+    else:
+        assert rel_err(y_host.float().cpu(), y_alone.float().cpu()) < 1e-5          # (split-K float atomics: order-dependent rounding)
+    # queued, then flushed; a second flush is a no-op
+    got = jobs(_lib.DEFER)
+    _lib.call('repmode_tail_flush', st)
+    _lib.call('repmode_tail_flush', st)
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    # a fourth job pushes the three queued ones out
+    got = jobs(_lib.DEFER)
+    o8 = torch.full((co * ci, 8), 7.0, device=DEV)
+    _lib.call('repmode_tap_transpose_ex', t125.data_ptr(), o8.data_ptr(), co * ci, 8, _lib.DEFER, st)
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    assert float(o8.min()) == 7.0
+    _lib.call('repmode_tail_flush', st)
+    torch.cuda.synchronize()
+    assert torch.equal(o8.cpu(), t125[:8].cpu().t().contiguous())
+
+
+def test_train_step_with_and_without_deferred_jobs():
+    """The backward pass with the gate backward / layout transposes riding in the data-gradient convs (default) gives the
+    gradients of the launch-by-launch form: same kernels' code (bit-exact at kernel level, test above), so the two may
+    differ by what two launch-by-launch runs differ by (the order of float atomics, amplified by the batch-norm chain)."""
+    from repmode_amd import ops
+    from repmode_amd.model import Model
+    gen = torch.Generator().manual_seed(3)
+    # 16x64x64: the deepest level keeps 32 values per BatchNorm channel (well conditioned); 4 tasks -> per-expert deep levels
+    x = torch.randn(4, 1, 16, 64, 64, generator=gen)
+    t = torch.randn(4, 1, 16, 64, 64, generator=gen)
+    tasks = torch.tensor([1, 4, 9, 11])
+    res, losses = [], []
+    try:
+        for on in (True, False, False):
+            ops.set_tail_jobs(on)
+            torch.manual_seed(0)
+            m = Model(Opts(), lr=1e-4, gpu_ids=0, mult_chan=4, dtype=torch.float32)
+            _, loss_sample = m.do_train_iter(x, t, tasks)
+            losses.append(float(loss_sample.mean()))
+            res.append({k: p.grad.detach().float().cpu() for k, p in m.net.named_parameters()})
+    finally:
+        ops.set_tail_jobs(True)
+    assert abs(losses[0] - losses[1]) <= 1e-5 * abs(losses[1])          # (the forward pass is the same code path)
+    gmax = max(float(v.abs().max()) for v in res[1].values())
+
+    def worst(a, b):
+        return max(float((a[k] - b[k]).norm()) / max(float(b[k].norm()), 1e-2 * gmax * b[k].numel() ** 0.5) for k in b)
+
+    noise = worst(res[2], res[1])
+    assert worst(res[0], res[1]) <= max(5 * noise, 1e-1), (worst(res[0], res[1]), noise)
+    assert all(torch.isfinite(v).all() for v in res[0].values())
