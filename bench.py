@@ -216,6 +216,7 @@ def main():
         _lib.prof_enable(1 if (args.prof_all or args.dump_launches) else 2)
     profiled_steps = 0
     overlap = ops_.get_overlap()
+    hosted = ops_.get_tail_jobs()
     t0 = time.perf_counter()
     for step in range(args.steps):
         if not args.no_prof:
@@ -225,6 +226,10 @@ def main():
             # a step whose launches are timed one by one runs them one after the other: with the GatRep kernels beside
             # the convolutions on a second stream, an event pair would time the pair of kernels, not the kernel
             ops_.set_overlap(overlap and not on)
+            # likewise the small jobs that otherwise ride in the first workgroups of the data-gradient conv launches (gate
+            # backward, layout transposes: csrc/tail_jobs.h) are launched on their own on such a step, so that the events
+            # around a conv5_igemm launch time the convolution alone
+            ops_.set_tail_jobs(hosted and not on)
         # (a profiled step is launched kernel by kernel: the library's event pairs are not part of a captured graph)
         model.do_train_iter(*next_batch(), eager=not args.no_prof and on)
     t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (includes waiting on a full queue)
@@ -232,6 +237,7 @@ def main():
     dt = time.perf_counter() - t0
     dt = dist_.max_over_ranks(dt, device)
     ops_.set_overlap(overlap)
+    ops_.set_tail_jobs(hosted)
     loss = float(model.last_loss)
     # what ENQUEUEING one step costs the host: timed with the GPU idle at the start of the step, so that nothing waits
     # on a full queue (over many back-to-back steps the host runs ahead until the runtime blocks it, and

@@ -51,9 +51,10 @@ def main():
     mf = rows(d, 'MFMA')
     busy, act = per_kind(mf, 'SQ_VALU_MFMA_BUSY_CYCLES'), per_kind(mf, 'GRBM_GUI_ACTIVE')
     out = {'kernel_source_hash': bench.kernel_source_hash(), 'batch': batch, 'dtype': dtype,
-           'command': 'rocprofv3 --pmc <counter(s)> --kernel-trace --output-format csv -- python bench.py --batch %d --steps 1 --warmup 1 '
+           'command': 'REPMODE_TAIL=0 rocprofv3 --pmc <counter(s)> --kernel-trace --output-format csv -- python bench.py --batch %d --steps 1 --warmup 1 '
                       '--no-cpu-baseline --no-prof --no-fwd   (one pass per counter set: FETCH_SIZE | WRITE_SIZE | '
-                      'SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)' % batch}
+                      'SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; REPMODE_TAIL=0: the conv launches alone, without the small jobs they '
+                      'otherwise host -- what bench.py times on its event-timed steps)' % batch}
     for k in KINDS:
         n = rd[k][0]
         if not n:

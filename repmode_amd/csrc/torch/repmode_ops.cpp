@@ -1489,6 +1489,7 @@ void op_set_dual_launch(bool on) { g_dual_launch = on; }
 int64_t op_get_unmerged_max_w() { return g_unmerged_max_w; }
 void op_set_overlap(bool on) { g_overlap = on; }
 void op_set_tail_jobs(bool on) { g_tail = on; }
+bool op_get_tail_jobs() { return g_tail; }
 void op_set_prepare(bool on) { g_prepare = on; }
 bool op_get_overlap() { return g_overlap; }
 
@@ -1573,6 +1574,7 @@ TORCH_LIBRARY(repmode, m) {
   m.def("get_unmerged_max_w() -> int", &rm::op_get_unmerged_max_w);
   m.def("set_overlap(bool on) -> ()", &rm::op_set_overlap);
   m.def("set_tail_jobs(bool on) -> ()", &rm::op_set_tail_jobs);
+  m.def("get_tail_jobs() -> bool", &rm::op_get_tail_jobs);
   m.def("set_prepare(bool on) -> ()", &rm::op_set_prepare);
   m.def("get_overlap() -> bool", &rm::op_get_overlap);
   m.def("zero_pool_begin(str key, Tensor like) -> ()", &rm::op_zero_pool_begin);

@@ -106,6 +106,10 @@ def set_tail_jobs(on):
     torch_ops().set_tail_jobs(bool(on))
 
 
+def get_tail_jobs():
+    return bool(torch_ops().get_tail_jobs())
+
+
 def get_overlap():
     return bool(torch_ops().get_overlap())
 

@@ -7,6 +7,10 @@ cp $S/bench_line_b24.json $D/r02_bench_line_b24.json
 cp $S/bench_line_device_volumes.json $D/r02_bench_line_device_volumes.json
 cp $S/kernel_stats_b8.csv $D/r02_bench_kernel_stats.csv
 cp $S/kernel_stats_b24.csv $D/r02_b24_kernel_stats.csv
+cp $S/kernel_stats_alone_b8.csv $D/r02_bench_kernel_stats_conv_alone.csv
+cp $S/kernel_stats_alone_b24.csv $D/r02_b24_kernel_stats_conv_alone.csv
+cp $S/trace_summary_alone_b8.txt $D/r02_bench_trace_summary_conv_alone.txt
+cp $S/trace_summary_alone_b24.txt $D/r02_b24_trace_summary_conv_alone.txt
 cp $S/trace_summary_b8.txt $D/r02_bench_trace_summary.txt
 cp $S/trace_summary_b24.txt $D/r02_b24_trace_summary.txt
 cp $S/pmc_traffic_b8.json $D/r02_pmc_traffic.json
