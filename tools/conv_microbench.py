@@ -20,7 +20,7 @@ code = _lib.BF16
 x = torch.randn(n, d, h, w, cin, device=dev).bfloat16()
 wf = (torch.randn(8, 125, _lib.padded_channels(cout, code, False), _lib.padded_channels(cin, code, True), device=dev) * 0.02).bfloat16()
 slots = torch.arange(n, dtype=torch.int32, device=dev)
-for _ in range(1500):                        # ~0.4 s: let the clocks settle under load (power-capped part)
+for _ in range(int(os.environ.get("CONV_WARM", "1500"))):                        # ~0.4 s: let the clocks settle under load (power-capped part)
     y = ops.conv5(x, wf, slots, cout, out_f32)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -15,16 +15,17 @@ cin, cout, d, h, w = (args + [32, 32, 32, 64, 64][len(args):])[:5]
 n, dev = 8, 'cuda:0'
 x = torch.randn(n, d, h, w, cin, device=dev).bfloat16()
 dy = torch.randn(n, d, h, w, cout, device=dev).bfloat16()
-plan = ops.TaskPlan([0, 1, 2, 3, 4, 5, 0, 1], 12, dev)
-for _ in range(600):                         # let the clocks settle under load
+plan = ops.TaskPlan(list(range(8)), 12, dev)      # 8 slots, one sample each: the bench configuration
+WARM, REPS = (int(v) for v in os.environ.get('WGRAD_ITERS', '600,1000').split(','))
+for _ in range(WARM):                        # let the clocks settle under load
     dw = ops.conv5_wgrad(x, dy, plan, cout)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(1000):
+for _ in range(REPS):
     dw = ops.conv5_wgrad(x, dy, plan, cout)
 e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 1000
+ms = e0.elapsed_time(e1) / REPS
 print('wgrad %d->%d %dx%dx%d: %.1f us, %.1f TFLOP/s' % (cin, cout, d, h, w, ms * 1e3, 2.0 * n * d * h * w * cin * cout * 125 / ms / 1e9))
 lib = _lib.load()
 if not hasattr(lib, 'repmode_debug_wgrad_timing'):
