@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256, TX == 16 ? WGRAD_TX16_OCC : 2) void conv5_wgra
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cq = wave & 1, ciq = wave >> 1;
   const int l15 = lane & 15, kg = lane >> 4;
+  RM_WSTAMP(59);
 
   // dual launch: the second job's workgroups take its parameters (uniform per workgroup: scalar selects)
   int bid_raw = blockIdx.x, grid_n = gridDim.x;
@@ -541,6 +542,7 @@ __global__ __launch_bounds__(256, TX == 16 ? WGRAD_TX16_OCC : 2) void conv5_wgra
   }
   }
   }
+  RM_WSTAMP(60);
   if (a.layout != 0 && a.direct) {
     // The experts' own layout ([co][ci][125] or, K3, [co][ci][27]): a (co, ci) pair's 25 taps of this dz plane are
     // 100 contiguous bytes.  Straight from the accumulators that is 4-byte stores 500 B apart (measured 5x slower
@@ -601,6 +603,10 @@ __global__ __launch_bounds__(256, TX == 16 ? WGRAD_TX16_OCC : 2) void conv5_wgra
       }
     }
   }
+#ifdef RM_CONV_TIMING
+  __builtin_amdgcn_s_waitcnt(0);      // (stamp 61 after the stores have left)
+#endif
+  RM_WSTAMP(61);
 }
 
 #ifdef RM_CONV_TIMING

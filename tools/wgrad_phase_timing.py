@@ -41,4 +41,4 @@ for b in (0, 1, 8, 33, 63):
         s = row[it * 3:it * 3 + 3]
         if s[2] <= t0: break
         out.append('t%d +%d stage %d mma %d' % (it, s[0] - t0, s[1] - s[0], s[2] - s[1]))
-    print('wg %2d | ' % b + ' | '.join(out))
+    print('wg %2d | ' % b + ' | '.join(out) + ' | kernel start %d, loop end +%d, kernel end +%d' % (row[59] - t0, row[60] - t0, row[61] - t0))
