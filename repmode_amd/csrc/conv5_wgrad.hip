@@ -236,9 +236,6 @@ __device__ __forceinline__ uint32_t bf16_elem(const u32x4& v, int k) {
 
 // The next B-operand window is requested behind a scheduling fence: without it the scheduler sinks a window's two LDS
 // loads to just before the s_waitcnt of the code that consumes them (-DRM_WGRAD_NOSCHED).
-#ifndef WGRAD_TX16_OCC
-#define WGRAD_TX16_OCC 2
-#endif
 #ifdef RM_WGRAD_NOSCHED
 #define RM_WSCHED_FENCE() do {} while (0)
 #else
@@ -264,8 +261,8 @@ __device__ unsigned long long g_wgrad_timing[64 * 64];
 // before the MFMAs of the current one and only transposed into LDS after them.  Without it the phase timing
 // (tools/wgrad_phase_timing.py) showed ~7k cycles of serialized load->LDS staging next to ~5k cycles of MFMAs
 // per tile.  !VEC keeps the simple stage-then-compute loop with per-element loads.
-template <int TZ, int TY, int TX, bool VEC>
-__global__ __launch_bounds__(256, TX == 16 ? WGRAD_TX16_OCC : 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {   // (TX = 16, level 2: 640 workgroups want 3 per CU)
+template <int TZ, int TY, int TX, bool VEC, bool DENSE = false>
+__global__ __launch_bounds__(256, DENSE ? 3 : 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
   using G = WgTile<TZ, TY, TX>;
   constexpr int TV = G::TV, HY = G::HY, RG = G::RG, NGX = G::NGX, ROW_C = G::ROW_C, DYS = G::DYS;
   __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
@@ -340,16 +337,17 @@ __global__ __launch_bounds__(256, TX == 16 ? WGRAD_TX16_OCC : 2) void conv5_wgra
     };
     u32x4 lo_n;
     u32x2 hi_n;
-    window(0, lo_n, hi_n);
+    if (!DENSE) window(0, lo_n, hi_n);
 #pragma unroll
     for (int w = 0; w < TZ * NWROW; ++w) {
       const int zz = w / NWROW, rr = w % NWROW;
       u32x4 lo = lo_n;
       u32x2 hi = hi_n;
+      if (DENSE) window(w, lo, hi);              // (three workgroups per CU: no register room to run a window ahead)
       // From here on the window is a register value (opaque to the optimiser, which otherwise re-reads parts of it from
       // LDS to assemble the shifted operands)
       asm volatile("" : "+v"(lo), "+v"(hi));
-      if (w + 1 < TZ * NWROW) window(w + 1, lo_n, hi_n);
+      if (!DENSE && w + 1 < TZ * NWROW) window(w + 1, lo_n, hi_n);
       RM_WSCHED_FENCE();      // keep the request ahead of this window's MFMAs (the scheduler sinks it to its use otherwise)
       const uint32_t a10 = __builtin_amdgcn_alignbit(lo.y, lo.x, 16);
       const uint32_t a21 = __builtin_amdgcn_alignbit(lo.z, lo.y, 16);
@@ -633,44 +631,77 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   a.nty = ceil_div(a.H, TY);
   a.ntx = ceil_div(a.W, TX);
   a.ntiles = ceil_div(a.D, TZ) * a.nty * a.ntx;
-  // split the voxel range over workgroups only as far as needed to fill the chip (>= 2 workgroups per
-  // CU): every extra chunk costs one more f32 atomic per output element, which dominates on levels
-  // with few voxels and many channels
-  // The grid is sized to a whole number of "rounds" of the workgroups that are resident at once (occupancy x CUs):
-  // 1040 workgroups on 512 slots run as two full rounds plus a third for 16 stragglers (measured: level 0,
-  // 434 us at 26 chunks vs 385 us at 52).
-  static long resident = 0;   // per instantiation
-  if (!resident) {
+  // The voxel range of a (slot, co tile, ci tile, dz plane) is split over `nchunks` workgroups (float atomics from 2 on).
+  // The grid runs as rounds of the workgroups resident at once (occupancy x CUs), and a workgroup's fixed costs (first
+  // fetch, ~24 k cycles of epilogue = 3.5 tiles of 8x32 voxels, 6 of the smaller ones; more with atomics) are comparable to
+  // a short tile loop: candidates are priced as rounds x (overhead + tiles per workgroup), in tile units.  Same box, old
+  // rule (two rounds' worth of workgroups) -> priced, batch 8: level 0 254 -> 239 us, level 1 (32 -> 64) 112 -> 80,
+  // (64 -> 64) 148 -> 131, level 2 (64 -> 128) 96 -> 83.
+  const bool vec = (a.Cin & 7) == 0 && (a.Cout & 7) == 0 && a.W >= WGRAD_PIPE_MINW &&
+                   (size_t)a.D * a.H * a.W * (a.Cin > a.Cout ? a.Cin : a.Cout) * 2 < ((size_t)1 << 31);
+  static long resident2 = 0, resident3 = 0;   // per instantiation: the regular kernel / the three-per-CU form (8x16 tile only)
+  if (!resident2) {
     int per_cu = 0, cus = 0, dev = 0;
     RM_HIP(hipGetDevice(&dev));
     RM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (TX == 16) {
+      RM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv5_wgrad_bf16_kernel<TZ, TY, TX, true, TX == 16>, 256, 0));
+      resident3 = (long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+    }
     RM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv5_wgrad_bf16_kernel<TZ, TY, TX, true>, 256, 0));
-    resident = (long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+    resident2 = (long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
   }
-  // (from one workgroup per CU-slot-half on, keep whole voxel ranges together: direct stores, no memset, no atomics)
-  auto plan = [&](int ndz, int* tiles_per_block, int* nchunks, int* direct) -> long {
+  const double ov = TX >= 32 ? 3.5 : 6.0;
+  const double tiles = (double)a.ntiles * (n > a.nslots ? (double)n / a.nslots : 1.0);
+  // best chunk count of a job of `ndz` planes on `resident` slots; returns its price
+  auto price = [&](int ndz, long resident, long* chunks) -> double {
     const long fixed = (long)a.nslots * a.ncot * a.ncit * ndz;
-    long want_chunks = (fixed >= WGRAD_DIRECT_MIN || fixed >= resident) ? 1 : (resident * WGRAD_ROUNDS) / fixed;
-    if (want_chunks < 1) want_chunks = 1;
-    if (want_chunks > a.ntiles) want_chunks = a.ntiles;
+    double best = 1e30;
+    *chunks = 1;
+    for (long nc = 1; nc <= 64 && nc <= a.ntiles; ++nc) {
+      const double rounds = (double)((fixed * nc + resident - 1) / resident);
+      const double cost = rounds * ((nc > 1 ? ov + 2.0 : ov) + (double)((long)((tiles + nc - 1) / nc)));
+      if (cost < best * 0.97) { best = cost; *chunks = nc; }
+    }
+    return best;
+  };
+  // The 8x16 tile (level 2) has a second form with three workgroups per CU (168 registers: no window ahead, a few
+  // spilled dwords): a slower round of 1.5x the workgroups.  It pays when it saves a round -- 640 workgroups (8 slots,
+  // 128 -> 128) are one round of 768 instead of two of 512: 88 -> 77 us; 960 (12 slots) are two rounds either way:
+  // 189 -> 235 us -- so both forms are priced, the dense one at 1.25 per round.
+  bool dense = false;
+  if (TX == 16 && vec && resident3 > resident2) {
+    long c2, c3;
+    double p2 = price(a.ndz, resident2, &c2), p3 = 1.25 * price(a.ndz, resident3, &c3);
+    if (a.dy2) { p2 += price(a.ndz2, resident2, &c2); p3 += 1.25 * price(a.ndz2, resident3, &c3); }
+    dense = p3 < p2;
+  }
+  const long resident = dense ? resident3 : resident2;
+  auto plan = [&](int ndz, int layout, int* tiles_per_block, int* nchunks, int* direct) -> long {
+    const long fixed = (long)a.nslots * a.ncot * a.ncit * ndz;
+    long want_chunks = 1;
+    // (the experts' own layout is written by whole-range workgroups only: atomics 500 bytes apart are 5x slower than
+    // the tile loop they would shorten)
+    if (layout == 0) price(ndz, resident, &want_chunks);
     *tiles_per_block = ceil_div(a.ntiles, (int)want_chunks);
     *nchunks = ceil_div(a.ntiles, *tiles_per_block);
     *direct = *nchunks == 1;
     return fixed * *nchunks;
   };
-  long grid = plan(a.ndz, &a.tiles_per_block, &a.nchunks, &a.direct);
+  long grid = plan(a.ndz, a.layout, &a.tiles_per_block, &a.nchunks, &a.direct);
   if (!a.direct && !a.prezeroed) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * a.Cout * a.CinTot * sizeof(float), s));
   if (a.dy2) {                       // dual launch: the second job is planned the same way, its workgroups follow the first's
     a.grid0 = (int)grid;
-    grid += plan(a.ndz2, &a.tiles_per_block2, &a.nchunks2, &a.direct2);
+    grid += plan(a.ndz2, a.layout2, &a.tiles_per_block2, &a.nchunks2, &a.direct2);
     RM_REQUIRE(a.layout2 == 0 || a.direct2, "conv5_wgrad_dual: job 2 cannot write the expert layout with atomics");
     if (!a.direct2 && !a.prezeroed) RM_HIP(hipMemsetAsync(a.dw2, 0, (size_t)REPMODE_TAPS * a.Cout * a.CinTot * sizeof(float), s));
   }
   RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
   repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, s);
-  const size_t sample_bytes = (size_t)a.D * a.H * a.W * (a.Cin > a.Cout ? a.Cin : a.Cout) * 2;
-  // (levels with W < 16 hand a workgroup only a tile or two per sample: nothing to overlap, and the old loop is ~15 % faster there)
-  if ((a.Cin & 7) == 0 && (a.Cout & 7) == 0 && a.W >= WGRAD_PIPE_MINW && sample_bytes < ((size_t)1 << 31))
+  // (levels with W < 16 hand a workgroup only a tile or two per sample: nothing to overlap, and the plain loop is ~15 % faster there)
+  if (vec && dense)
+    hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true, TX == 16>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  else if (vec)
     hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, false>), dim3((unsigned)grid), dim3(256), 0, s, a);

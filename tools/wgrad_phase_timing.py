@@ -12,10 +12,11 @@ if os.environ.get('REPMODE_LIB'):          # A/B against another build of the li
 
 args = [int(a) for a in sys.argv[1:]]
 cin, cout, d, h, w = (args + [32, 32, 32, 64, 64][len(args):])[:5]
-n, dev = 8, 'cuda:0'
+n, dev = int(os.environ.get('WGRAD_N', '8')), 'cuda:0'
+nslots = int(os.environ.get('WGRAD_SLOTS', '8'))
 x = torch.randn(n, d, h, w, cin, device=dev).bfloat16()
 dy = torch.randn(n, d, h, w, cout, device=dev).bfloat16()
-plan = ops.TaskPlan(list(range(8)), 12, dev)      # 8 slots, one sample each: the bench configuration
+plan = ops.TaskPlan([i % nslots for i in range(n)], 12, dev)      # default: 8 slots, one sample each (the bench configuration)
 WARM, REPS = (int(v) for v in os.environ.get('WGRAD_ITERS', '600,1000').split(','))
 for _ in range(WARM):                        # let the clocks settle under load
     dw = ops.conv5_wgrad(x, dy, plan, cout)
