@@ -172,6 +172,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
 #pragma unroll
   for (int k = 0; k < CV; ++k) { s[k] = 0.f; ss[k] = 0.f; }
   if (active) {
+    // Shifted sums: S1 = sum (x - x0), S2 = sum (x - x0)^2 with x0 = the channel's value in row 0 (every workgroup reads
+    // the same row; bn_apply_relu_kernel adds it back).  var = S2/M - (S1/M)^2 then cancels digits of (mean - x0)^2, not of
+    // mean^2: a channel whose |mean| is 1e3 standard deviations keeps its variance.
+    float x0[CV];
+    load_row<T, CV>(x, c0, C, vec, x0);
     // 4 rows per iteration, loads issued before use: the pass is bandwidth-bound only with enough bytes in flight
     const long stride = (long)gridDim.x * g.rows_per_iter;
     long r = (long)blockIdx.x * g.rows_per_iter + r0;
@@ -182,13 +187,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int k = 0; k < CV; ++k) { s[k] += v[u][k]; ss[k] += v[u][k] * v[u][k]; }
+        for (int k = 0; k < CV; ++k) { const float d = v[u][k] - x0[k]; s[k] += d; ss[k] += d * d; }
     }
     for (; r < M; r += stride) {
       float v[CV];
       load_row<T, CV>(x + r * C, c0, C, vec, v);
 #pragma unroll
-      for (int k = 0; k < CV; ++k) { s[k] += v[k]; ss[k] += v[k] * v[k]; }
+      for (int k = 0; k < CV; ++k) { const float d = v[k] - x0[k]; s[k] += d; ss[k] += d * d; }
     }
   }
   block_commit(lds, s, ss, c0, C, active, sums);
@@ -202,13 +207,15 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_relu_kernel(
     const TI* __restrict__ x, TO* __restrict__ out, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ sums, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ save_mean,
-    float* __restrict__ save_invstd, float eps, float momentum, int training, long M, int C) {
+    float* __restrict__ save_invstd, float eps, float momentum, int training, long M, int C, int shifted) {
   __shared__ float sc[BN_MAXC], sh[BN_MAXC];
   for (int c = threadIdx.x; c < C; c += BN_THREADS) {
     float mean, invstd;
     if (training) {
-      mean = slice_total(sums, c, C) / (float)M;
-      const float var = fmaxf(slice_total(sums, C + c, C) / (float)M - mean * mean, 0.f);
+      // shifted: the sums are of (x - x0[c]), x0 = row 0 (bn_stats_kernel); else of x itself (the conv epilogue's)
+      const float m1 = slice_total(sums, c, C) / (float)M;
+      const float var = fmaxf(slice_total(sums, C + c, C) / (float)M - m1 * m1, 0.f);
+      mean = shifted ? m1 + to_f32<TI>(x[c]) : m1;
       invstd = rsqrtf(var + eps);
       if (blockIdx.x == 0) {
         const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
@@ -554,9 +561,10 @@ extern "C" int repmode_bn_relu_fwd_ex(const void* x, void* out, const float* gam
       hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const bf16_t*)x, m, c, own, other);
     RM_LAUNCH_CHECK("bn_stats");
   }
+  const int shifted = (training && stats_half < 0) ? 1 : 0;     // bn_stats_kernel's sums are relative to row 0
 #define RM_BN_APPLY(TI, TO)                                                                                      \
   hipLaunchKernelGGL((bn_apply_relu_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (TO*)out, \
-                     gamma, beta, own, running_mean, running_var, save_mean, save_invstd, eps, momentum, training, m, c)
+                     gamma, beta, own, running_mean, running_var, save_mean, save_invstd, eps, momentum, training, m, c, shifted)
   if (in_dtype == REPMODE_F32 && out_dtype == REPMODE_F32) RM_BN_APPLY(float, float);
   else if (in_dtype == REPMODE_F32) RM_BN_APPLY(float, bf16_t);
   else if (out_dtype == REPMODE_F32) RM_BN_APPLY(bf16_t, float);
