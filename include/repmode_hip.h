@@ -211,6 +211,10 @@ int repmode_gatrep_bwd_ex(const float* dw, const float* k5, const float* k3, con
  * job's outputs or overwrites its inputs.  Results are identical to the immediate form (same code). */
 #define REPMODE_DEFER 1
 int repmode_tail_flush(void* stream);
+/* Drops the stream's queued jobs WITHOUT running them: error recovery -- if a call failed between a deferral and the
+ * launch meant to host it, the queue holds jobs whose buffers may be gone (the operator library calls this at the start of
+ * every train step and of every MoDE backward node; a no-op when nothing is queued). */
+int repmode_tail_discard(void* stream);
 
 /* ---- BatchNorm3d + ReLU of the MoDE block's `subsequent_layer` (RepMode.py:146-149, :212) and of the
  * stride-2 down/up stages (RepMode.py:80-84, 97-101), on a channels-last tensor viewed as [m][c].

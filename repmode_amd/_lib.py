@@ -45,6 +45,7 @@ _SIGNATURES = {
     'repmode_gatrep_bwd': [_P] * 8 + [_I] * 4 + [_P] * 9,
     'repmode_gatrep_bwd_ex': [_P] * 8 + [_I] * 4 + [_P] * 8 + [_I, _P],
     'repmode_tail_flush': [_P],
+    'repmode_tail_discard': [_P],
     'repmode_bn_relu_fwd': [_P] * 8 + [_c.c_long, _I, _c.c_float, _c.c_float, _I, _I, _I, _P],
     'repmode_bn_relu_fwd_ex': [_P] * 8 + [_c.c_long, _I, _c.c_float, _c.c_float, _I, _I, _I, _I, _P],
     'repmode_bn_relu_bwd': [_P] * 8 + [_c.c_long, _I, _I, _I, _I, _P],

@@ -162,6 +162,13 @@ int repmode_tail_push(const TailJob& job, hipStream_t s) {
   return repmode_tail_launch(full, s);
 }
 
+// Drops what is queued without running it: after a failed call the queue may hold jobs whose tensors are gone.
+extern "C" int repmode_tail_discard(void* stream) {
+  TailJobs t;
+  repmode_tail_take(static_cast<hipStream_t>(stream), &t);
+  return REPMODE_OK;
+}
+
 extern "C" int repmode_tail_flush(void* stream) {
   TailJobs t;
   repmode_tail_take(static_cast<hipStream_t>(stream), &t);

@@ -661,6 +661,7 @@ struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    RM_CALL(repmode_tail_discard, stream_handle());      // (jobs a failed call left queued must not ride in this node's convs)
     auto sv = ctx->get_saved_variables();
     const Tensor &x_cl = sv[0], &k5 = sv[1], &k3 = sv[2], &k1 = sv[3], &a3 = sv[4], &a5 = sv[5], &g = sv[6];
     Tensor wd = sv[7];
@@ -742,6 +743,7 @@ struct ModeConvPair : public torch::autograd::Function<ModeConvPair> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    RM_CALL(repmode_tail_discard, stream_handle());      // (jobs a failed call left queued must not ride in this node's convs)
     auto sv = ctx->get_saved_variables();
     const Tensor &xa = sv[0], &xb = sv[1], &k5 = sv[2], &k3 = sv[3], &k1 = sv[4], &a3 = sv[5], &a5 = sv[6], &g = sv[7];
     Tensor wd = sv[8];
@@ -874,6 +876,7 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    RM_CALL(repmode_tail_discard, stream_handle());      // (jobs a failed call left queued must not ride in this node's convs)
     auto sv = ctx->get_saved_variables();
     const Tensor &x_cl = sv[0], &k5 = sv[1], &k3 = sv[2], &k1 = sv[3], &a3 = sv[4], &a5 = sv[5], &gn = sv[6], &xb = sv[7], &p = sv[8];
     Tensor wd2 = sv[9];
@@ -1493,7 +1496,13 @@ bool op_get_tail_jobs() { return g_tail; }
 void op_set_prepare(bool on) { g_prepare = on; }
 bool op_get_overlap() { return g_overlap; }
 
-void op_zero_pool_begin(const std::string& key, const Tensor& like) { g_pool.begin(key, like); }
+void op_zero_pool_begin(const std::string& key, const Tensor& like) {
+  if (like.is_cuda()) {       // start of a train step: nothing a failed step deferred may ride in this step's convs
+    DeviceGuard guard(like.device());
+    RM_CALL(repmode_tail_discard, stream_handle());
+  }
+  g_pool.begin(key, like);
+}
 void op_zero_pool_end() { g_pool.end(); }
 bool op_zero_pool_has_plan(const std::string& key) {
   std::lock_guard<std::mutex> lock(g_pool.mu);

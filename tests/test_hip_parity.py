@@ -1397,6 +1397,13 @@ def test_deferred_jobs_ride_in_a_conv_launch(w_extent, dtype):
     _lib.call('repmode_tail_flush', st)
     torch.cuda.synchronize()
     assert torch.equal(o8.cpu(), t125[:8].cpu().t().contiguous())
+    # error recovery: queued jobs can be dropped without running (their buffers may be gone after a failed call)
+    got = jobs(_lib.DEFER)
+    _lib.call('repmode_tail_discard', st)
+    _lib.call('repmode_tail_flush', st)
+    ops.conv5(x, wf, slots, co, out_f32=(w_extent < 32))
+    torch.cuda.synchronize()
+    assert float(got[1].min()) == 7.0 and float(got[2].min()) == 7.0 and float(got[3].min()) == 7.0
 
 
 def test_train_step_with_and_without_deferred_jobs():
