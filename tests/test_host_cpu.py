@@ -207,3 +207,25 @@ def test_seeded_init_matches_reference_fixture():
         assert sorted(k for k in sd if sd[k].dtype.is_floating_point) == keys
         finger = np.asarray([float(sd[k].double().sum()) for k in keys])
         assert np.array_equal(finger, g['state_fingerprint']), cls
+
+
+def test_wgrad_lds_layout_is_conflict_free_in_the_bank_model():
+    """The filter-gradient kernel's LDS layout (csrc/conv5_wgrad.hip, WgTile) against the bank model of ds_read_b128
+    (tools/lds_bank_check.py): no lane group of any B-window or A-fragment read of any tile puts two lanes on one
+    16-byte slot; round 1's layout cost every read one extra cycle per lane group.  The model restates the kernel's
+    constants, so the source is checked to still carry them."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('lds_bank_check', os.path.join(root, 'tools', 'lds_bank_check.py'))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    src = open(os.path.join(root, 'repmode_amd', 'csrc', 'conv5_wgrad.hip')).read()
+    for line in ('static constexpr int RG = TX >= 32 ? 8 : TX >= 16 ? 4 : 2;',
+                 'static constexpr bool SWZ = TX < 16;',
+                 'static constexpr int ROW_C = TZ * HY * RG * 16 + 32;',
+                 'static constexpr int DYS = TV * 2 + 32;'):
+        assert line in src, line
+    for t in chk.TILES:
+        assert ('conv5_wgrad_bf16_kernel<%d, %d, %d' % t) in src or ('launch_wgrad_bf16<%d, %d, %d>' % t) in src, t
+        assert chk.wgrad_x(*t) == 0 and chk.wgrad_dy(*t) == 0, t
+        assert chk.round1_x(*t) == 4 * 5 * t[0] * t[1] * t[2] // 32        # one extra cycle per lane group and read
