@@ -19,9 +19,10 @@ Workloads (BASELINE.json ``configs``):
   ``--batch B`` overrides the per-GPU batch for either.
 
 Also reported in the same line:
-  roofline      the conv5_igemm kernel (forward + data-gradient launches): algorithmic FLOPs (the layer's merged
-                125-tap convolution, 2 * voxels * Cin * Cout * 125, once per layer and direction) / HIP-event
-                duration on the launch stream, against the dense bf16 MFMA peak.  ``traffic``: HBM bytes per
+  roofline      the conv5_igemm kernel (forward + data-gradient launches of levels 0-2, the dominant kernel): algorithmic
+                FLOPs (the layer's merged 125-tap convolution, 2 * voxels * Cin * Cout * 125, once per layer and
+                direction) / HIP-event duration on the launch stream, against the dense bf16 MFMA peak;
+                ``all_conv_kernels``: the same over conv5_igemm + conv5_deep (levels 3-4) + the one-channel layers' kernels.  ``traffic``: HBM bytes per
                 launch from rocprofv3 PMC passes of THIS build (profiles/*_pmc_traffic.json carries the hash of
                 the kernel sources it was taken on), else null.
   fwd           forward only (BASELINE's ">= 40 % MFMA on fused GatRep+Conv3d forward"): voxels/s of the whole
@@ -54,6 +55,7 @@ NUM_TASKS = 12
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
 FWD_FLOP_PER_VOXEL = 2083520.0                    # whole forward; MoDE convs alone 2,072,000
 FWD_CONV_FLOP_PER_VOXEL = 2072000.0
+CONV_KINDS = ('conv5_igemm', 'conv5_deep', 'conv5_thin')     # the forward / data-gradient convolution kernels of the MoDE blocks
 
 
 class Opts:
@@ -252,7 +254,7 @@ def main():
     torch.cuda.synchronize()
     train_prof = {}
     if not args.no_prof and rank == 0:
-        for kind in ('conv5_igemm', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd'):
+        for kind in ('conv5_igemm', 'conv5_deep', 'conv5_thin', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd'):
             train_prof[kind] = _lib.prof_summary(kind)
         train_recs = _lib.prof_records() if args.dump_launches else None
     _lib.prof_enable(False)
@@ -322,7 +324,8 @@ def main():
             for _ in range(2):
                 net(signal, task)
             torch.cuda.synchronize()
-        n_c, ms_c, fl_c = _lib.prof_summary('conv5_igemm')
+        # every forward convolution launch of the MoDE blocks: conv5_igemm, the deep levels' conv5_deep, the thin layers' own
+        n_c, ms_c, fl_c = (sum(v) for v in zip(*(_lib.prof_summary(k) for k in CONV_KINDS)))
         n_g, ms_g, _ = _lib.prof_summary('gatrep_fwd')
         _lib.prof_enable(False)
         vps = b * PATCH[0] * PATCH[1] * PATCH[2] * kf / dt_f
@@ -331,7 +334,8 @@ def main():
         out['fwd'] = {'value': vps, 'unit': 'voxels/s', 'ms_per_pass': 1e3 * dt_f / kf,
                       'whole_pass_tflops': vps * FWD_FLOP_PER_VOXEL / 1e12,
                       'whole_pass_frac': vps * FWD_FLOP_PER_VOXEL / 1e12 / peak,
-                      'gatrep_conv_unit': {'what': 'gate softmax + GatRep (+ expert layout) + conv5_igemm launches of one forward pass, '
+                      'gatrep_conv_unit': {'what': 'gate softmax + GatRep (+ expert layout) + every MoDE convolution launch (conv5_igemm, conv5_deep, '
+                                                   'the one-channel layers\' kernels) of one forward pass, '
                                                    'event-timed; FLOPs = the MoDE convs\' algorithmic 2*V*Cin*Cout*125',
                                            'conv_ms': ms_c / 2, 'gatrep_ms': ms_g / 2, 'conv_launches': n_c // 2,
                                            'gatrep_launches': n_g // 2, 'achieved': unit_tflops, 'peak': peak,
@@ -354,6 +358,12 @@ def main():
                                'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_file,
                                'launches': n, 'avg_launch_ms': ms / max(n, 1),
                                'flops_per_launch': flops / max(n, 1)}
+            # all forward / data-gradient convolution kernels together (the dominant one above + the deep levels' + the thin layers')
+            n_a, ms_a, fl_a = (sum(v) for v in zip(*(train_prof[k] for k in CONV_KINDS)))
+            out['roofline']['all_conv_kernels'] = {'kernels': [k for k in CONV_KINDS if train_prof[k][0]], 'launches': n_a,
+                                                   'achieved': (fl_a / (ms_a * 1e-3) / 1e12) if ms_a > 0 else 0.0,
+                                                   'frac': (fl_a / (ms_a * 1e-3) / 1e12 / peak) if ms_a > 0 else 0.0,
+                                                   'ms_per_step': ms_a / max(profiled_steps, 1)}
             out['kernels'] = kinds
             if args.dump_launches:
                 per = len(train_recs) // max(profiled_steps, 1)

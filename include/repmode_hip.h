@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define REPMODE_ABI_VERSION 4
+#define REPMODE_ABI_VERSION 5
 
 /* element types of activations / merged filters */
 #define REPMODE_F32 0  /* float in, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)          */
@@ -112,6 +112,22 @@ int repmode_conv5(const void* x, const void* w, const int32_t* sample_slot, void
 int repmode_conv5_ex(const void* x, const void* w, const int32_t* sample_slot, void* y, int n, int d,
                      int h, int wdim, int cin, int cout, int dtype, int out_f32, int centre3,
                      void* stream);
+
+/* The two convolutions of the per-expert formulation of a MoDE block (RepMode.py:171-192 by linearity:
+ * y[n] = sum_e g[n,e,:] * conv(x[n], K_e), the F.conv3d of :204-208 once per conv expert instead of once per merged
+ * filter) on the deep U-Net levels (x extent <= 8), bf16, as ONE uniform grid -- every workgroup runs the 5x5x5 expert's
+ * 125 taps and the 3x3x3 expert's 27 taps over the same staged input, for several samples at a time (csrc/conv5_deep.hip).
+ *   w: repmode_expert_frags' two slots (wf for the forward form, wd for the data-gradient form).
+ *   forward form  (flags bit 0 clear): x [n][d][h][w][cin] bf16 -> y [2 n][d][h][w][cout] float: P5 = conv(x, K5) in
+ *                 samples 0 .. n-1, P3 = conv(x, pad(K3)) in n .. 2n-1.
+ *   data-gradient form (bit 0 set):   x [2 n][...][cin] bf16 (the two gate-scaled output gradients G5, G3)
+ *                 -> y [n][...][cout] float = conv(G5, w slot 0) + conv(G3, w slot 1).
+ *   flags bit 1: y is all zero already (the kernel accumulates input-channel slices with float atomics); else the call
+ *   clears it.  Deferred small jobs (REPMODE_DEFER) ride in this launch as in repmode_conv5_ex.
+ * repmode_conv5_deep_supported(): 1 when the shape is one this kernel takes (bf16, x extent <= 8, cin % 8 == 0). */
+int repmode_conv5_deep(const void* x, const void* w, float* y, int n, int d, int h, int wdim, int cin, int cout, int flags,
+                       void* stream);
+int repmode_conv5_deep_supported(int wdim, int cin, int dtype);
 
 /* The same convolution with the input and / or the output channels split over two tensors: a U-Net skip connection
  * without the concatenated copy (RepMode.py:106 torch.cat((x_skip, up), 1)).  Input channels [0, cin1) are read from
@@ -342,8 +358,8 @@ int repmode_expert_frags_multi(int nblocks, const float* const* k5, const float*
                                void* const* wf, void* const* wd, void* stream);
 
 /* ---- measurement: per-launch HIP-event timing of the library's kernels on their own stream.
- * repmode_prof_enable(1) clears the records and starts recording every kind, (2) records conv5_igemm only
- * (least perturbation of the timed region), (0) stops.  repmode_prof_summary()
+ * repmode_prof_enable(1) clears the records and starts recording every kind, (2) records the convolution kernels only
+ * (conv5_igemm, conv5_deep, the thin layers'; least perturbation of the timed region), (0) stops.  repmode_prof_summary()
  * synchronises the recorded events and returns, for one kernel kind, the number of launches, the
  * summed duration (ms) and the summed algorithmic work (FLOPs for the conv kernels, bytes for GatRep). */
 #define REPMODE_PROF_CONV5 0    /* conv5_igemm (forward and data-gradient launches) */
@@ -351,7 +367,9 @@ int repmode_expert_frags_multi(int nblocks, const float* const* k5, const float*
 #define REPMODE_PROF_GATREP_FWD 2
 #define REPMODE_PROF_GATREP_BWD 3
 #define REPMODE_PROF_WGRAD_THIN 4 /* conv5_wgrad_thin */
-#define REPMODE_PROF_KINDS 5
+#define REPMODE_PROF_CONV5_DEEP 5 /* conv5_deep (per-expert formulation, deep levels) */
+#define REPMODE_PROF_CONV5_THIN 6 /* the one-channel first / last layers' own kernels */
+#define REPMODE_PROF_KINDS 7
 int repmode_prof_enable(int on);
 /* Suspend (1) / resume (0) recording; the records so far are kept (sampling a subset of the steps). */
 int repmode_prof_pause(int paused);

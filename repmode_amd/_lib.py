@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('REPMODE_LIB') or os.path.join(_HERE, 'librepmode_hip.
 
 F32, BF16 = 0, 1
 DEFER = 1        # REPMODE_DEFER: queue the job for the next conv5 launch on the stream (include/repmode_hip.h)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c = ctypes
 _P = _c.c_void_p
@@ -32,6 +32,8 @@ _SIGNATURES = {
     'repmode_gatrep_fwd_gate': [_P] * 8 + [_I] * 5 + [_P] * 4,
     'repmode_conv5': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_ex': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_conv5_deep': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_conv5_deep_supported': [_I, _I, _I],
     'repmode_conv5_pair': [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_epi': [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P],
     'repmode_conv5_wgrad': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -151,11 +153,12 @@ def device_arch(dev=0):
     return buf.value.decode()
 
 
-PROF_KINDS = {'conv5_igemm': 0, 'conv5_wgrad': 1, 'gatrep_fwd': 2, 'gatrep_bwd': 3, 'conv5_wgrad_thin': 4}
+PROF_KINDS = {'conv5_igemm': 0, 'conv5_wgrad': 1, 'gatrep_fwd': 2, 'gatrep_bwd': 3, 'conv5_wgrad_thin': 4, 'conv5_deep': 5,
+              'conv5_thin': 6}
 
 
 def prof_enable(on):
-    """False/0: off; True/1: every kernel kind; 2: conv5_igemm only."""
+    """False/0: off; True/1: every kernel kind; 2: the forward / data-gradient convolution kernels only."""
     call('repmode_prof_enable', int(on))
 
 

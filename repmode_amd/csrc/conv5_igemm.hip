@@ -118,6 +118,7 @@ struct ConvArgs {
   // 2 N samples (the two gate-scaled output gradients), else both jobs read sample v % N; dual & 4: the output holds
   // 2 N samples (the two expert outputs), else both jobs ADD into sample v % N.
   int dual;
+  int wide;            // element-typed bf16 output: 16-byte stores through v_permlane32_swap (see the epilogue)
   // deferred small jobs (tail_jobs.h) that ride in this launch: workgroups [0, tail.nblocks) run them, the convolution's
   // workgroups follow (tail.nblocks is a multiple of 8, so their workgroup -> XCD map is unchanged)
   TailJobs tail;
@@ -148,7 +149,8 @@ struct Cfg {
 // PAIR: the two-tensor form (repmode_conv5_pair); a separate instantiation keeps the one-tensor kernels free of its selects
 // DXC: the dx-centre mode (one tap per (dz, dy) row: the thin first / last layers) as its own instantiation, so that
 // neither path carries the other's registers and branches
-template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false>
+// ROWSTAT: the row-stationary tap loop (4 x 4 x 32 bricks only, see the loop's comment)
+template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false, bool ROWSTAT = false>
 __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   constexpr int KV = Elem<T>::KV;
   constexpr int KC = 2 * KV;
@@ -241,9 +243,11 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
     if constexpr (CW == 1 && !DXC) {
       {
 #pragma unroll
-        for (int dx = 0; dx < 5; ++dx)
-          a_first[dx] = *reinterpret_cast<const u32x4*>(wrow[0] + (size_t)((dz_lo * 5 + dy_lo) * 5 + dx) * tap_stride +
-                                                        (size_t)chunk * (32 * KC));
+        for (int i = 0; i < 5; ++i) {
+          // (row-stationary loop: the five dy taps of (dz_lo, dx = 0); else the five dx taps of the first row)
+          const int tap = ROWSTAT ? (dz_lo * 5 + i) * 5 : (dz_lo * 5 + dy_lo) * 5 + i;
+          a_first[i] = *reinterpret_cast<const u32x4*>(wrow[0] + (size_t)tap * tap_stride + (size_t)chunk * (32 * KC));
+        }
       }
     }
     RM_STAMP((chunk - c_begin) * 4 + 0);
@@ -372,6 +376,46 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
         dz = dzn;
         dy = dyn;
       }
+    } else if constexpr (ROWSTAT) {
+      // Row-stationary order (4 x 4 x 32 bricks: a wave owns the four y rows of one z plane, sub-tile vs = row).  For a
+      // fixed (dz, dx) the voxel fragment of halo row y' = vs + dy serves every (vs, dy) pair that lands on it: EIGHT
+      // LDS reads (y' = 0..7) and five filter fragments (dy = 0..4) feed TWENTY MFMAs -- 0.4 ds_read_b128 per MFMA
+      // instead of 1.0 in the tap-major order below, same filter traffic.  The next group's 8 + 5 fragments are
+      // requested before this group's MFMAs (double buffers: 104 registers + 64 accumulators).  Halo rows outside the
+      // volume are zero in LDS, so all five dy are always taken (no skipped-tap bookkeeping); dz keeps its range.
+      static_assert(CW == 1 && VW == 4 && BY == 4 && BX == 32 && C::WV == 4, "row-stationary loop: 4 x 4 x 32 bricks");
+      const int vb0 = vbase[0];
+      u32x4 a_cur[5], a_nxt[5], b_cur[8], b_nxt[8];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) a_cur[i] = a_first[i];
+#pragma unroll
+      for (int yy = 0; yy < 8; ++yy) b_cur[yy] = lds[vb0 + (dz_lo * BYH + yy) * BXH];
+      for (int dzc = dz_lo; dzc <= dz_hi; ++dzc) {
+        const bool more_z = dzc < dz_hi;
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          // next group: (dzc, dx + 1), or (dzc + 1, 0); on the very last group a harmless reload of this one
+          const int dzn = (dx < 4) ? dzc : (more_z ? dzc + 1 : dzc);
+          const int dxn = (dx < 4) ? dx + 1 : (more_z ? 0 : 4);
+#pragma unroll
+          for (int i = 0; i < 5; ++i) a_nxt[i] = wfrag(0, (dzn * 5 + i) * 5 + dxn);
+#pragma unroll
+          for (int yy = 0; yy < 8; ++yy) b_nxt[yy] = lds[vb0 + (dzn * BYH + yy) * BXH + dxn];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int dyy = 0; dyy < 5; ++dyy)
+#pragma unroll
+            for (int vs = 0; vs < 4; ++vs) {
+              if constexpr (SWAP) Elem<T>::mma(b_cur[vs + dyy], a_cur[dyy], acc[0][vs]);
+              else Elem<T>::mma(a_cur[dyy], b_cur[vs + dyy], acc[0][vs]);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 5; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+          for (int yy = 0; yy < 8; ++yy) b_cur[yy] = b_nxt[yy];
+        }
+      }
     } else if constexpr (CW == 1) {
       u32x4 a_cur[5], a_nxt[5];
 #pragma unroll
@@ -494,6 +538,56 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   } else {
     // rows = output channels (4 consecutive per register quad), column = this lane's voxel; T output
     const bool want_stats = a.stats != nullptr;
+    bool stored = false;
+    if constexpr (sizeof(T) == 2) {
+      if (a.wide && !want_stats) {
+        // 16-byte stores (cdna_hip_programming.md T21): lane i holds channels 8q .. 8q+3 of its voxel, lane i + 32 channels
+        // 8q+4 .. 8q+7.  One v_permlane32_swap per packed dword of the quad pair (q, q+1) leaves 8 consecutive channels of
+        // quad q in the lower and of quad q + 1 in the upper half-wave: half as many store instructions for the same bytes
+        // (the host sets `wide` only when every 16-channel group lies inside one output tensor).
+#pragma unroll
+        for (int vs = 0; vs < VW; ++vs) {
+          const int m = (wv * VW + vs) * 32 + l31;
+          const int lx = m % BX, ly = (m / BX) % BY, lz = m / (BX * BY);
+          const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
+          const bool inside = gz < D && gy < H && gx < W;
+          const size_t vox = ((size_t)(n_out * D + gz) * H + gy) * W + gx;
+#pragma unroll
+          for (int cs = 0; cs < CW; ++cs) {
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+              const int co16 = cot * C::COT + (wc * CW + cs) * 32 + 16 * qp;     // first channel of this 16-channel group
+              if (co16 >= Cout) continue;                                          // (wave-uniform)
+              uint32_t pk[2][2];
+#pragma unroll
+              for (int g = 0; g < 2; ++g) {
+                const int q = 2 * qp + g;
+                float v0 = acc[cs][vs][4 * q + 0], v1 = acc[cs][vs][4 * q + 1];
+                float v2 = acc[cs][vs][4 * q + 2], v3 = acc[cs][vs][4 * q + 3];
+                if (a.bias) {
+                  const float* bp = a.bias + co16 + 8 * g + 4 * khalf;
+                  v0 += bp[0]; v1 += bp[1]; v2 += bp[2]; v3 += bp[3];
+                }
+                if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                pk[g][0] = pack_bf16x2(v0, v1);
+                pk[g][1] = pack_bf16x2(v2, v3);
+              }
+              // vdst = quad q's dword, src = quad q + 1's: the upper half of vdst swaps with the lower half of src
+              const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+              const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+              if (!inside) continue;
+              const bool out2 = Cout1 > 0 && co16 >= Cout1;
+              const int Cout_ = Cout1 > 0 ? (out2 ? Cout - Cout1 : Cout1) : Cout;
+              const int co = (out2 ? co16 - Cout1 : co16) + 8 * khalf;
+              bf16_t* yp = static_cast<bf16_t*>(out2 ? a.y2 : a.y) + vox * Cout_ + co;
+              *reinterpret_cast<u32x4*>(yp) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+            }
+          }
+        }
+        stored = true;
+      }
+    }
+    if (!stored) {
     float ssum[CW][16], ssq[CW][16];
     if (want_stats) {
 #pragma unroll
@@ -591,11 +685,12 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
         }
       }
     }
+    }   // (!stored)
   }
   RM_STAMP(60);
 }
 
-template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false>
+template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false, bool ROWSTAT = false>
 int launch_cfg(ConvArgs a, hipStream_t stream) {
   a.nbz = ceil_div(a.D, C::BZ);
   a.nby = ceil_div(a.H, C::BY);
@@ -625,7 +720,7 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   int dev = 0;
   RM_HIP(hipGetDevice(&dev));
   if (!((attr_set.load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_igemm_kernel<T, C, SWAP, PAIR, DXC>),
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_igemm_kernel<T, C, SWAP, PAIR, DXC, ROWSTAT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
   }
@@ -641,7 +736,7 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   const double alg = a.dxc ? 2.0 * a.N * a.D * a.H * a.W * 25.0 * (a.Cin == 8 ? 5.0 * a.Cout : (double)a.Cin * a.Cout)
                            : a.tap_lo ? 0.0 : 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS;
   repmode_prof_begin(REPMODE_PROF_CONV5, alg, stream);
-  hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP, PAIR, DXC>), dim3((unsigned)grid), dim3(C::NT), lds_bytes, stream, a);
+  hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP, PAIR, DXC, ROWSTAT>), dim3((unsigned)grid), dim3(C::NT), lds_bytes, stream, a);
   repmode_prof_end(stream);
   RM_LAUNCH_CHECK("conv5_igemm");
   return REPMODE_OK;
@@ -653,9 +748,17 @@ using CfgX16 = Cfg<4, 4, 16, 2, 2, 4, 1>;      // 256 voxels x 64 channels   (le
 using CfgX8 = Cfg<4, 8, 8, 2, 2, 4, 1>;        // 256 voxels x 64 channels   (level 3)
 using CfgX4 = Cfg<2, 4, 4, 1, 4, 1, 1>;        // 32 voxels x 128 channels   (level 4)
 
+// REPMODE_CONV_ROWSTAT (default 1): the row-stationary tap loop on the 4 x 4 x 32 tile (full 5x5x5 support only)
+static const int g_rowstat = []() { const char* e = getenv("REPMODE_CONV_ROWSTAT"); return e ? atoi(e) : 1; }();
+// REPMODE_CONV_WIDE (default 1): 16-byte bf16 stores through v_permlane32_swap
+static const int g_wide = []() { const char* e = getenv("REPMODE_CONV_WIDE"); return e ? atoi(e) : 1; }();
+
 template <typename T, bool SWAP, bool PAIR>
 int dispatch_tile(ConvArgs a, hipStream_t stream) {
-  if (a.W >= 32) return launch_cfg<T, CfgX32, SWAP, PAIR>(a, stream);
+  if (a.W >= 32) {
+    if (g_rowstat && a.tap_lo == 0 && a.tap_hi == 4 && !a.dual) return launch_cfg<T, CfgX32, SWAP, PAIR, false, true>(a, stream);
+    return launch_cfg<T, CfgX32, SWAP, PAIR>(a, stream);
+  }
   if (a.W >= 16) return launch_cfg<T, CfgX16, SWAP, PAIR>(a, stream);
   if (a.W >= 8) return launch_cfg<T, CfgX8, SWAP, PAIR>(a, stream);
   return launch_cfg<T, CfgX4, SWAP, PAIR>(a, stream);
@@ -786,6 +889,7 @@ static int conv5_common(const void* x, const void* x2, int cin1, const void* w, 
   }
   if (dtype == REPMODE_F32) return dispatch<float, true>(a, s);
   if (a.out_f32) return dispatch<bf16_t, true>(a, s);
+  a.wide = g_wide && !want_stats && (cout1 > 0 ? (cout1 % 16 == 0 && (cout - cout1) % 16 == 0) : cout % 16 == 0);
   return dispatch<bf16_t, false>(a, s);
 }
 

@@ -276,6 +276,12 @@ bool g_dual_launch = []() {
 //      epilogue.  The pass it removes streams a tensor that is still in the 256 MB Infinity Cache at full rate (11-25 us
 //      per layer); the epilogue's cross-lane reduction and atomics run inside the MFMA-bound, power-capped conv launch
 //      and cost more than that.
+// The per-expert levels' two convolutions through their own uniform-grid kernel (csrc/conv5_deep.hip) instead of the
+// general kernel's dual-expert launch; REPMODE_DEEP=0 / set_deep_conv(False): the dual-expert launch
+bool g_deep = []() {
+  const char* e = std::getenv("REPMODE_DEEP");
+  return e ? std::atoi(e) != 0 : true;
+}();
 bool g_dual_wgrad = []() {          // (REPMODE_DUAL_WGRAD=0: the two filter gradients of a per-expert block as two launches)
   const char* e = std::getenv("REPMODE_DUAL_WGRAD");
   return e ? std::atoi(e) != 0 : true;
@@ -863,8 +869,16 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
       gemm3(am, ci, 1, bm, ci, 1, cm, co, n * d * h * w, co, ci, pre, x_cl.scalar_type() == at::kBFloat16);      // (P lives in the step's pre-zeroed pool tensor)
     }
     fork.to_main();
-    if (g_dual_launch) conv5(x_cl, fr.first, s0, co, true, p.narrow(0, 0, 2).view({2 * n, d, h, w, co}), false, pre, false, nullptr, DUAL_OUT2);
-    else conv5(x_cl, fr.first, s0, co, true, p[0], false, pre);
+    const bool deep = g_deep && g_dual_launch && repmode_conv5_deep_supported((int)w, (int)ci, dtype_code(x_cl.scalar_type())) != 0;
+    if (deep) {
+      Tensor p2 = p.narrow(0, 0, 2);
+      RM_CALL(repmode_conv5_deep, x_cl.data_ptr(), fr.first.data_ptr(), p2.data_ptr<float>(), (int)n, (int)d, (int)h, (int)w, (int)ci, (int)co,
+              pre ? 2 : 0, stream_handle());
+    } else if (g_dual_launch) {
+      conv5(x_cl, fr.first, s0, co, true, p.narrow(0, 0, 2).view({2 * n, d, h, w, co}), false, pre, false, nullptr, DUAL_OUT2);
+    } else {
+      conv5(x_cl, fr.first, s0, co, true, p[0], false, pre);
+    }
     fork.join();
     Tensor y = at::empty({n, d, h, w, co}, x_cl.options().dtype(at::kFloat));
     RM_CALL(repmode_expert_mix_fwd, p.data_ptr<float>(), gn.data_ptr<float>(), y.data_ptr<float>(), (int)n, (long)(d * h * w), (int)co,
@@ -962,7 +976,14 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     if (need_dx) {
       Tensor lo0 = lo[0], lo1 = lo[1];
       Tensor dxf;
-      if (g_dual_launch) {
+      if (g_deep && g_dual_launch && repmode_conv5_deep_supported((int)w, (int)co, dtype_code(dt)) != 0) {
+        // (float accumulation target out of the step's pre-zeroed pool, as conv5 takes its own)
+        auto tk = g_pool.take({n, d, h, w, ci}, x_cl);
+        dxf = tk.first;
+        RM_CALL(repmode_conv5_deep, lo.data_ptr(), wd2.data_ptr(), dxf.data_ptr<float>(), (int)n, (int)d, (int)h, (int)w, (int)co, (int)ci,
+                1 | (tk.second ? 2 : 0), stream_handle());
+        if (defer) RM_CALL(repmode_tail_flush, stream_handle());
+      } else if (g_dual_launch) {
         dxf = conv5(lo.view({2 * n, d, h, w, co}), wd2, s0, ci, true, c10::nullopt, false, false, false, nullptr, DUAL_IN2);
         if (defer) RM_CALL(repmode_tail_flush, stream_handle());
       } else {
@@ -1489,6 +1510,8 @@ void op_finish_prepared(const Tensor& like) {
 void op_set_bn_epilogue(int64_t mask) { g_bn_epilogue = mask; }
 void op_set_unmerged_max_w(int64_t w) { g_unmerged_max_w = w; }
 void op_set_dual_launch(bool on) { g_dual_launch = on; }
+void op_set_deep_conv(bool on) { g_deep = on; }
+bool op_get_deep_conv() { return g_deep; }
 int64_t op_get_unmerged_max_w() { return g_unmerged_max_w; }
 void op_set_overlap(bool on) { g_overlap = on; }
 void op_set_tail_jobs(bool on) { g_tail = on; }
@@ -1580,6 +1603,8 @@ TORCH_LIBRARY(repmode, m) {
   m.def("set_bn_epilogue(int mask) -> ()", &rm::op_set_bn_epilogue);
   m.def("set_unmerged_max_w(int w) -> ()", &rm::op_set_unmerged_max_w);
   m.def("set_dual_launch(bool on) -> ()", &rm::op_set_dual_launch);
+  m.def("set_deep_conv(bool on) -> ()", &rm::op_set_deep_conv);
+  m.def("get_deep_conv() -> bool", &rm::op_get_deep_conv);
   m.def("get_unmerged_max_w() -> int", &rm::op_get_unmerged_max_w);
   m.def("set_overlap(bool on) -> ()", &rm::op_set_overlap);
   m.def("set_tail_jobs(bool on) -> ()", &rm::op_set_tail_jobs);

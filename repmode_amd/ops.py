@@ -93,6 +93,16 @@ def set_dual_launch(on):
     torch_ops().set_dual_launch(bool(on))
 
 
+def set_deep_conv(on):
+    """Per-expert levels: the two experts' convolutions through the uniform-grid kernel of csrc/conv5_deep.hip (default)
+    or the general kernel's dual-expert launch (REPMODE_DEEP=0)."""
+    torch_ops().set_deep_conv(bool(on))
+
+
+def get_deep_conv():
+    return bool(torch_ops().get_deep_conv())
+
+
 def set_overlap(on):
     """Overlap of the HBM-bound GatRep kernels with the convolutions on the library's own streams (the step's filter
     preparation beside the first convolutions, a layer's GatRep backward beside its data-gradient conv).  Off by default
@@ -276,6 +286,29 @@ def conv5(x_cl, w, sample_slot, cout, out_f32=False, out=None, centre3=False, ac
     assert not accumulate or out_dtype == torch.float32
     _lib.call('repmode_conv5_ex', _ptr(x_cl), _ptr(w), _ptr(sample_slot), _ptr(y), n, d, h, wd_, cin, cout, code,
               1 if out_dtype == torch.float32 else 0, (1 if centre3 else 0) | (2 if accumulate else 0) | (4 if dxc else 0), _stream())
+    return y
+
+
+def conv5_deep_supported(x_cl):
+    """Whether ``conv5_deep`` takes this input (bf16, x extent <= 8, channels a multiple of 8)."""
+    return bool(_lib.load().repmode_conv5_deep_supported(x_cl.shape[3], x_cl.shape[4], dtype_code(x_cl.dtype))) \
+        if x_cl.dtype in (torch.float32, torch.bfloat16) else False
+
+
+def conv5_deep(x_cl, w2, cout, two_in=False, out=None, zeroed=False):
+    """The per-expert formulation's two convolutions on a deep level as one uniform grid (csrc/conv5_deep.hip).
+    ``w2``: ``expert_frags``' two slots.  Forward form: x [N,...] -> float [2N, ...] (P5, then P3); data-gradient form
+    (``two_in``): x [2N, ...] (G5, then G3) -> float [N, ...] = conv(G5, slot 0) + conv(G3, slot 1)."""
+    nn, d, h, wd_, cin = x_cl.shape
+    n = nn // 2 if two_in else nn
+    shape = (n if two_in else 2 * n, d, h, wd_, cout)
+    if out is None:
+        y = torch.empty(shape, dtype=torch.float32, device=x_cl.device)
+    else:
+        y = out
+        assert tuple(y.shape) == shape and y.dtype == torch.float32 and y.is_contiguous()
+    _lib.call('repmode_conv5_deep', _ptr(x_cl), _ptr(w2), _ptr(y), n, d, h, wd_, cin, cout,
+              (1 if two_in else 0) | (2 if zeroed else 0), _stream())
     return y
 
 

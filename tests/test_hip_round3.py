@@ -1,0 +1,130 @@
+"""Round-3 kernels against the CPU oracle (through the C ABI): the deep levels' uniform-grid convolution pair
+(csrc/conv5_deep.hip), the row-stationary tap loop and 16-byte stores of conv5_igemm, the one-channel layers' own kernels.
+Needs a real MI355X: every test is marked ``gpu``.  Tolerances as tests/test_hip_parity.py states them."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from oracle import repmode_oracle as orc
+from test_hip_parity import DEV, TOL_BF16_ACC, _kc, _layout_wf, _ops, _rand_experts
+
+pytestmark = pytest.mark.gpu
+
+
+DEEP_CASES = [
+    # (n, (d, h, w), ci, co)
+    (8, (2, 4, 4), 64, 128),      # level-4 tile: four samples per workgroup, two groups
+    (5, (1, 2, 2), 32, 32),       # smaller than the level-4 brick, a ragged last group
+    (24, (2, 4, 4), 32, 64),      # batch 24: six groups (forward) / twelve (data gradient)
+    (3, (4, 8, 8), 48, 96),       # level-3 tile, channel counts that are no tile multiples
+    (2, (4, 8, 8), 128, 256),     # level-3 tile at a real layer's width (8 input-channel chunks, split 8 ways)
+    (3, (2, 4, 8), 16, 40),       # level-3 tile on a volume smaller than its brick
+    (2, (6, 10, 8), 16, 32),      # several bricks per sample (no skipped taps: the zero halo does it)
+]
+
+
+@pytest.mark.parametrize('case', DEEP_CASES)
+def test_conv5_deep_vs_oracle(case):
+    """Forward form (P5 = conv(x, K5), P3 = conv(x, pad K3)) and data-gradient form (conv(G5, flip K5^T) + conv(G3, flip
+    pad(K3)^T)) of repmode_conv5_deep against the oracle's F.conv3d on bf16-rounded operands (float accumulation on both
+    sides: 1e-4)."""
+    ops = _ops()
+    n, shape, ci, co = case
+    gen = torch.Generator().manual_seed(n * 1000 + ci + co + shape[2])
+    k5, k3 = _rand_experts(co, ci, gen)[:2]
+    k5r, k3r = k5.bfloat16().float(), k3.bfloat16().float()
+    x = torch.randn(n, ci, *shape, generator=gen).bfloat16().float()
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    assert ops.conv5_deep_supported(x_cl)
+    wf, wd = ops.expert_frags(k5.to(DEV), k3.to(DEV), torch.bfloat16, want_wd=True)
+    # ---- forward form, output cleared by the call and handed over pre-zeroed
+    p5_ref = F.conv3d(x, k5r, padding=2)
+    p3_ref = F.conv3d(x, k3r, padding=1)
+    for zeroed in (False, True):
+        out = torch.zeros(2 * n, *shape, co, device=DEV) if zeroed else torch.full((2 * n, *shape, co), 7.0, device=DEV)
+        y = ops.conv5_deep(x_cl, wf, co, two_in=False, out=out, zeroed=zeroed)
+        y = y.permute(0, 4, 1, 2, 3).cpu()
+        assert rel_err(y[:n], p5_ref) < TOL_BF16_ACC, '5x5x5 expert'
+        assert rel_err(y[n:], p3_ref) < TOL_BF16_ACC, '3x3x3 expert'
+    # ---- data-gradient form: dx = d/dx [<conv(x, K5), G5> + <conv(x, pad K3), G3>]
+    g = torch.randn(2 * n, co, *shape, generator=gen).bfloat16().float()
+    dx_ref = F.conv_transpose3d(g[:n], k5r, padding=2) + F.conv_transpose3d(g[n:], k3r, padding=1)
+    g_cl = g.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    assert ops.conv5_deep_supported(g_cl)
+    dx = ops.conv5_deep(g_cl, wd, ci, two_in=True)
+    assert rel_err(dx.permute(0, 4, 1, 2, 3).cpu(), dx_ref) < TOL_BF16_ACC, 'data gradient'
+
+
+@pytest.mark.parametrize('ci,co,shape,n', [(64, 64, (2, 4, 4), 8), (48, 96, (4, 8, 8), 3), (256, 128, (4, 8, 8), 8)])
+def test_deep_conv_in_the_operator(ci, co, shape, n):
+    """The per-expert block through the operator library with the deep kernel (default) and with the general kernel's
+    dual-expert launch: output, data gradient and every parameter gradient agree (bf16: an atomics-order difference can
+    flip a rounding), and the deep form matches the oracle's block."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(ci + co + n)
+    ps = _rand_experts(co, ci, gen)
+    tasks = [(5 * i + 2) % 12 for i in range(n)]
+    x = torch.randn(n, *shape, ci, generator=gen).bfloat16()
+    r = torch.randn(n, *shape, co, generator=gen)
+    res = []
+    try:
+        for deep in (True, False):
+            ops.set_deep_conv(deep)
+            dev = [p.to(DEV).requires_grad_(True) for p in ps]
+            xd = x.to(DEV).requires_grad_(True)
+            plan = ops.TaskPlan(tasks, 12, DEV, training=True)
+            y = ops.mode_conv3d(xd, *dev, plan, mode='unmerged')
+            (y.float() * r.to(DEV)).sum().backward()
+            res.append([y.detach().float().cpu(), xd.grad.float().cpu()] + [p.grad.cpu() for p in dev])
+    finally:
+        ops.set_deep_conv(True)
+    for a, b in zip(res[0], res[1]):
+        assert rel_err(a, b) < 1e-2
+    # the oracle's block on the bf16-rounded operands
+    xr = x.float().permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
+    pr = [p.clone().requires_grad_(True) for p in ps]
+    y_ref = orc.mode_conv_pre_bn(xr, *pr, torch.tensor(tasks), training=True)
+    (y_ref * r.permute(0, 4, 1, 2, 3)).sum().backward()
+    assert rel_err(res[0][0].permute(0, 4, 1, 2, 3), y_ref.detach()) < 2e-2
+    assert rel_err(res[0][1].permute(0, 4, 1, 2, 3), xr.grad) < 2e-2
+    for got, p in zip(res[0][2:], pr):
+        assert rel_err(got, p.grad) < 2e-2
+
+
+ROWSTAT_CASES = [
+    # (N, D, H, W, Cin, Cout): the 4 x 4 x 32 tile (row-stationary tap loop), ragged in every direction
+    (1, 6, 10, 40, 16, 48),
+    (2, 5, 9, 35, 24, 32),
+    (1, 4, 4, 64, 32, 64),
+    (2, 3, 7, 33, 40, 16),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', ROWSTAT_CASES)
+def test_conv5_wide_volumes_vs_oracle(case, dtype):
+    """conv5_igemm on volumes with x extent >= 32 (row-stationary tap loop; bf16 output through 16-byte permlane-swapped
+    stores when the channel count allows) against the oracle, float and element-typed output."""
+    ops = _ops()
+    from repmode_amd import _lib
+    n, d, h, w, cin, cout = case
+    gen = torch.Generator().manual_seed(sum(case))
+    nslots = 2
+    slots = torch.tensor([i % nslots for i in range(n)], dtype=torch.int32)
+    x = torch.randn(n, cin, d, h, w, generator=gen).to(dtype).float()
+    wt = (torch.randn(nslots, cout, cin, 5, 5, 5, generator=gen) / np.sqrt(cin * 125)).to(dtype).float()
+    y_ref = orc.conv_per_sample(x, wt[slots.long()])
+    code = ops.dtype_code(dtype)
+    wf = _layout_wf(wt, _lib.padded_channels(cout, code, False), _lib.padded_channels(cin, code, True), _kc(dtype)).to(DEV, dtype)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype)
+    y = ops.conv5(x_cl, wf, slots.to(DEV), cout, out_f32=True)
+    assert rel_err(y.permute(0, 4, 1, 2, 3).cpu(), y_ref) < TOL_BF16_ACC
+    if dtype == torch.bfloat16:
+        yb = ops.conv5(x_cl, wf, slots.to(DEV), cout, out_f32=False)
+        assert yb.dtype == torch.bfloat16
+        assert rel_err(yb.float().permute(0, 4, 1, 2, 3).cpu(), y_ref) < 6e-3
+        # the 16-byte stores put every channel where the 8-byte ones would: the float output rounded once, up to the
+        # summation order of the two kernels' operand roles
+        assert rel_err(yb.float().cpu(), y.cpu()) < 5e-3
