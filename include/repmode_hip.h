@@ -129,6 +129,20 @@ int repmode_conv5_deep(const void* x, const void* w, float* y, int n, int d, int
                        void* stream);
 int repmode_conv5_deep_supported(int wdim, int cin, int dtype);
 
+/* The one-channel ends of the network as kernels of their own (csrc/thin_conv.hip; bf16).
+ * repmode_conv5_thin_in1: ONE input channel -- the first block's convolution (RepMode.py:27, Net's first MoDEConv(1, 32))
+ *   with its forward filter wf, or the last block's input gradient (RepMode.py:42 conv_out, autograd of :204-208) with its
+ *   data-gradient filter wd.  x: [n][d][h][w] bf16; w: fragment-major [slots][125][coutP/32][1][32][16]; y:
+ *   [n][d][h][w][cout] bf16 (out_f32 == 0) or float.  bias != NULL / relu: y = max(acc + bias[co], 0) (an eval-mode BatchNorm
+ *   folded into filter and bias, RepMode.py:209-212).  The 125 taps are the GEMM's reduction dimension.
+ * repmode_conv5_thin_out1: ONE output channel -- conv_out's forward (RepMode.py:42) with wf, or the first block's input
+ *   gradient with wd (row 0 of the 32-row tile real).  x: [n][d][h][w][cin] bf16; y: [n][d][h][w] float.  The 25 (dz, dy)
+ *   tap rows are the GEMM's row dimension; the diagonal sum over taps stays inside a lane. */
+int repmode_conv5_thin_in1(const void* x, const void* w, const int32_t* sample_slot, void* y, int n, int d, int h, int wdim,
+                           int cout, int out_f32, const float* bias, int relu, void* stream);
+int repmode_conv5_thin_out1(const void* x, const void* w, const int32_t* sample_slot, float* y, int n, int d, int h, int wdim,
+                            int cin, void* stream);
+
 /* The same convolution with the input and / or the output channels split over two tensors: a U-Net skip connection
  * without the concatenated copy (RepMode.py:106 torch.cat((x_skip, up), 1)).  Input channels [0, cin1) are read from
  * x ([N][D][H][W][cin1]), [cin1, cin) from x2; output channels [0, cout1) are written to y ([...][cout1]), the rest

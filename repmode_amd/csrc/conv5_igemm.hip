@@ -748,9 +748,13 @@ using CfgX16 = Cfg<4, 4, 16, 2, 2, 4, 1>;      // 256 voxels x 64 channels   (le
 using CfgX8 = Cfg<4, 8, 8, 2, 2, 4, 1>;        // 256 voxels x 64 channels   (level 3)
 using CfgX4 = Cfg<2, 4, 4, 1, 4, 1, 1>;        // 32 voxels x 128 channels   (level 4)
 
-// REPMODE_CONV_ROWSTAT (default 1): the row-stationary tap loop on the 4 x 4 x 32 tile (full 5x5x5 support only)
-static const int g_rowstat = []() { const char* e = getenv("REPMODE_CONV_ROWSTAT"); return e ? atoi(e) : 1; }();
-// REPMODE_CONV_WIDE (default 1): 16-byte bf16 stores through v_permlane32_swap
+// REPMODE_CONV_ROWSTAT=1: the row-stationary tap loop on the 4 x 4 x 32 tile (full 5x5x5 support only).  Built, measured,
+// OFF: same box, interleaved, us per launch tap-major / row-stationary: 32->32 237.2 / 256.1, 64->32 471.1 / 498.7,
+// 64->64 (level 1) 119.8 / 126.1, 128->64 228.7 / 234.2; train step 12.49 / 12.68 ms.  2.5 x fewer LDS reads buy nothing
+// (the LDS is not what the tap loop waits for) and the 104 registers of double buffers cost a spill in the staging phase.
+static const int g_rowstat = []() { const char* e = getenv("REPMODE_CONV_ROWSTAT"); return e ? atoi(e) : 0; }();
+// REPMODE_CONV_WIDE (default 1): 16-byte bf16 stores through v_permlane32_swap (same box, interleaved: 237.2 -> 235.2 us on
+// 32->32 at level 0, 471.1 -> 467.0 on 64->32; train step 12.49 -> 12.44 ms)
 static const int g_wide = []() { const char* e = getenv("REPMODE_CONV_WIDE"); return e ? atoi(e) : 1; }();
 
 template <typename T, bool SWAP, bool PAIR>

@@ -282,6 +282,16 @@ bool g_deep = []() {
   const char* e = std::getenv("REPMODE_DEEP");
   return e ? std::atoi(e) != 0 : true;
 }();
+// The FORWARD pair goes through conv5_deep only where it measured faster than the dual-expert launch (same box, us per
+// launch deep / dual, batch 8: 128->256 50.0 / 41.8, 256->256 82.1 / 60.5, 512->256 121.1 / 109.7, level 4 32.3 / 28.1 and
+// 48.6 / 47.6; batch 24: 114.9 / 96.6, 155.4 / 166.3, 272.2 / 322.2, level 4 62.0 / 46.9 and 117.7 / 87.1): two float outputs
+// double its atomics, and a uniform grid leaves no short jobs whose atomics overlap the long jobs' MFMAs.  Rule: the
+// level-3 tile with samples x input channels >= REPMODE_DEEP_FWD_MIN (default 6000; 0: always, also level 4).  The
+// data-gradient form (one output) wins everywhere: 244 vs 288 us over the five layers at batch 8.
+int64_t g_deep_fwd_min = []() {
+  const char* e = std::getenv("REPMODE_DEEP_FWD_MIN");
+  return e ? (int64_t)std::atoll(e) : (int64_t)6000;
+}();
 bool g_dual_wgrad = []() {          // (REPMODE_DUAL_WGRAD=0: the two filter gradients of a per-expert block as two launches)
   const char* e = std::getenv("REPMODE_DUAL_WGRAD");
   return e ? std::atoi(e) != 0 : true;
@@ -438,14 +448,39 @@ Tensor shift5(const Tensor& t_cl) {
   return out;
 }
 
-// conv5 for a ONE-channel input: the five x taps become channels, 25 instead of 125 taps (csrc/thin.hip)
+// The one-channel layers through their own kernels (csrc/thin_conv.hip); REPMODE_THIN=0 / set_thin_kernels(False): round 2's
+// form (x taps folded into channels / rows around the general kernel's dx-centre mode, csrc/thin.hip)
+bool g_thin = []() {
+  const char* e = std::getenv("REPMODE_THIN");
+  return e ? std::atoi(e) != 0 : true;
+}();
+
+// conv5 for a ONE-channel input (the first layer's forward, the last layer's data gradient)
 Tensor thin_conv_in1(const Tensor& x_cl, const Tensor& w, const Tensor& sample_slot, int64_t cout, bool out_f32, const Epi* epi = nullptr) {
+  if (g_thin && !(epi && epi->stats)) {
+    Tensor x1 = x_cl.contiguous();
+    const int64_t n = x1.size(0), d = x1.size(1), h = x1.size(2), w_ = x1.size(3);
+    Tensor y = at::empty({n, d, h, w_, cout}, x1.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
+    const bool bias = epi && epi->bias.defined();
+    RM_CALL(repmode_conv5_thin_in1, x1.data_ptr(), w.data_ptr(), sample_slot.data_ptr<int32_t>(), y.data_ptr(), (int)n, (int)d, (int)h, (int)w_,
+            (int)cout, out_f32 ? 1 : 0, bias ? epi->bias.data_ptr<float>() : nullptr, (epi && epi->relu) ? 1 : 0, stream_handle());
+    tl_stats_half = -1;
+    return y;
+  }
+  // the five x taps become channels, 25 instead of 125 taps (csrc/thin.hip)
   return conv5(shift5(x_cl.contiguous()), thin_pack(w, false), sample_slot, cout, out_f32, c10::nullopt, false, false, true, epi);
 }
 
-// conv5 for ONE output channel: the five x taps become output rows, then a 5-tap diagonal sum.  float [N,D,H,W,1]
+// conv5 for ONE output channel.  float [N,D,H,W,1]
 Tensor thin_conv_out1(const Tensor& x_cl, const Tensor& w, const Tensor& sample_slot) {
   const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), w_ = x_cl.size(3);
+  if (g_thin) {
+    Tensor y = at::empty({n, d, h, w_, 1}, x_cl.options().dtype(at::kFloat));
+    RM_CALL(repmode_conv5_thin_out1, x_cl.data_ptr(), w.data_ptr(), sample_slot.data_ptr<int32_t>(), y.data_ptr<float>(), (int)n, (int)d, (int)h,
+            (int)w_, (int)x_cl.size(4), stream_handle());
+    return y;
+  }
+  // the five x taps become output rows, then a 5-tap diagonal sum (csrc/thin.hip)
   Tensor y5 = conv5(x_cl, thin_pack(w, true), sample_slot, 5, true, c10::nullopt, false, false, true);
   Tensor y = at::empty({n, d, h, w_, 1}, x_cl.options().dtype(at::kFloat));
   RM_CALL(repmode_unshift5, y5.data_ptr<float>(), y.data_ptr<float>(), (long)(n * d * h), (int)w_, stream_handle());
@@ -869,7 +904,8 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
       gemm3(am, ci, 1, bm, ci, 1, cm, co, n * d * h * w, co, ci, pre, x_cl.scalar_type() == at::kBFloat16);      // (P lives in the step's pre-zeroed pool tensor)
     }
     fork.to_main();
-    const bool deep = g_deep && g_dual_launch && repmode_conv5_deep_supported((int)w, (int)ci, dtype_code(x_cl.scalar_type())) != 0;
+    const bool deep = g_deep && g_dual_launch && repmode_conv5_deep_supported((int)w, (int)ci, dtype_code(x_cl.scalar_type())) != 0 &&
+                      (g_deep_fwd_min == 0 || (w > 4 && n * ci >= g_deep_fwd_min));
     if (deep) {
       Tensor p2 = p.narrow(0, 0, 2);
       RM_CALL(repmode_conv5_deep, x_cl.data_ptr(), fr.first.data_ptr(), p2.data_ptr<float>(), (int)n, (int)d, (int)h, (int)w, (int)ci, (int)co,
@@ -1511,6 +1547,8 @@ void op_set_bn_epilogue(int64_t mask) { g_bn_epilogue = mask; }
 void op_set_unmerged_max_w(int64_t w) { g_unmerged_max_w = w; }
 void op_set_dual_launch(bool on) { g_dual_launch = on; }
 void op_set_deep_conv(bool on) { g_deep = on; }
+void op_set_deep_fwd_min(int64_t v) { g_deep_fwd_min = v; }
+void op_set_thin_kernels(bool on) { g_thin = on; }
 bool op_get_deep_conv() { return g_deep; }
 int64_t op_get_unmerged_max_w() { return g_unmerged_max_w; }
 void op_set_overlap(bool on) { g_overlap = on; }
@@ -1604,6 +1642,8 @@ TORCH_LIBRARY(repmode, m) {
   m.def("set_unmerged_max_w(int w) -> ()", &rm::op_set_unmerged_max_w);
   m.def("set_dual_launch(bool on) -> ()", &rm::op_set_dual_launch);
   m.def("set_deep_conv(bool on) -> ()", &rm::op_set_deep_conv);
+  m.def("set_deep_fwd_min(int v) -> ()", &rm::op_set_deep_fwd_min);
+  m.def("set_thin_kernels(bool on) -> ()", &rm::op_set_thin_kernels);
   m.def("get_deep_conv() -> bool", &rm::op_get_deep_conv);
   m.def("get_unmerged_max_w() -> int", &rm::op_get_unmerged_max_w);
   m.def("set_overlap(bool on) -> ()", &rm::op_set_overlap);

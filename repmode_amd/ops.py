@@ -99,8 +99,20 @@ def set_deep_conv(on):
     torch_ops().set_deep_conv(bool(on))
 
 
+def set_deep_fwd_min(v):
+    """Forward pair through conv5_deep only on the level-3 tile with samples x input channels >= v (0: always)."""
+    torch_ops().set_deep_fwd_min(int(v))
+
+
 def get_deep_conv():
     return bool(torch_ops().get_deep_conv())
+
+
+def set_thin_kernels(on):
+    """The one-channel first / last layers through their own kernels (csrc/thin_conv.hip; default) or round 2's fold of the x
+    taps around the general kernel (REPMODE_THIN=0).  The operator library's switch (the ``thin_conv_*`` wrappers here
+    take ``folded``)."""
+    torch_ops().set_thin_kernels(bool(on))
 
 
 def set_overlap(on):
@@ -329,17 +341,32 @@ def _shift5(t_cl):
     return out
 
 
-def thin_conv_in1(x_cl, w, sample_slot, cout, out_f32=False):
-    """conv5 for a ONE-channel input (bf16 filter ``w`` [S, 125, CoP, 16]): the five x taps become channels and the
-    general kernel runs 25 instead of 125 taps (csrc/thin.hip).  Used for the first layer's forward and (with the
-    data-gradient filter) for the last layer's data gradient."""
-    return conv5(_shift5(x_cl.contiguous()), _thin_pack(w, False), sample_slot, cout, out_f32, dxc=True)
+def thin_conv_in1(x_cl, w, sample_slot, cout, out_f32=False, bias=None, relu=False, folded=False):
+    """conv5 for a ONE-channel input (bf16 filter ``w`` [S, 125, CoP, 16]): the first layer's forward and (with the
+    data-gradient filter) the last layer's data gradient.  Default: the layer's own kernel (csrc/thin_conv.hip: the 125
+    taps are the GEMM's reduction dimension); ``folded``: round 2's form -- the five x taps become channels and the general
+    kernel runs 25 instead of 125 taps (csrc/thin.hip)."""
+    if folded:
+        assert bias is None and not relu
+        return conv5(_shift5(x_cl.contiguous()), _thin_pack(w, False), sample_slot, cout, out_f32, dxc=True)
+    n, d, h, w_, c1 = x_cl.shape
+    assert c1 == 1 and x_cl.dtype == torch.bfloat16 and x_cl.is_contiguous()
+    y = torch.empty((n, d, h, w_, cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x_cl.device)
+    _lib.call('repmode_conv5_thin_in1', _ptr(x_cl), _ptr(w), _ptr(sample_slot), _ptr(y), n, d, h, w_, cout, 1 if out_f32 else 0,
+              _ptr(bias) if bias is not None else None, 1 if relu else 0, _stream())
+    return y
 
 
-def thin_conv_out1(x_cl, w, sample_slot):
-    """conv5 for ONE output channel (bf16 filter ``w`` [S, 125, 32, CiP]): the five x taps become output rows, then a
-    5-tap diagonal sum (csrc/thin.hip).  Returns float [N, D, H, W, 1]."""
-    n, d, h, w_, _ = x_cl.shape
+def thin_conv_out1(x_cl, w, sample_slot, folded=False):
+    """conv5 for ONE output channel (bf16 filter ``w`` [S, 125, 32, CiP]).  Default: the layer's own kernel
+    (csrc/thin_conv.hip: the 25 (dz, dy) tap rows are the GEMM's row dimension); ``folded``: round 2's form -- the five x
+    taps become output rows of the general kernel, then a 5-tap diagonal sum (csrc/thin.hip).  Returns float [N, D, H, W, 1]."""
+    n, d, h, w_, cin = x_cl.shape
+    if not folded:
+        assert x_cl.dtype == torch.bfloat16 and x_cl.is_contiguous()
+        y = torch.empty((n, d, h, w_, 1), dtype=torch.float32, device=x_cl.device)
+        _lib.call('repmode_conv5_thin_out1', _ptr(x_cl), _ptr(w), _ptr(sample_slot), _ptr(y), n, d, h, w_, cin, _stream())
+        return y
     y5 = conv5(x_cl, _thin_pack(w, True), sample_slot, 5, out_f32=True, dxc=True)
     y = torch.empty((n, d, h, w_, 1), dtype=torch.float32, device=x_cl.device)
     _lib.call('repmode_unshift5', _ptr(y5), _ptr(y), n * d * h, w_, _stream())

@@ -442,36 +442,61 @@ def test_box_sum(shape):
     assert got.dtype == torch.bfloat16 and rel_err(got.float().cpu(), want - c1) < 5e-3
 
 
-@pytest.mark.parametrize('shape', [(2, 4, 8, 32), (1, 3, 5, 7), (2, 8, 16, 64)])
+@pytest.mark.parametrize('shape', [(2, 4, 8, 32), (1, 3, 5, 7), (2, 8, 16, 64), (3, 6, 9, 70)])
 def test_thin_convs_match_general_kernel(shape):
-    """The 1-channel ends of the net with their x taps folded into channels / rows (csrc/thin.hip) vs the same merged
-    filters through the general conv kernel."""
+    """The 1-channel ends of the net through their own kernels (csrc/thin_conv.hip) and through round 2's fold of the x taps
+    into channels / rows (csrc/thin.hip) vs the same merged filters through the general conv kernel -- and vs the ORACLE's
+    per-sample F.conv3d on the bf16-rounded merged filter (RepMode.py:204-208)."""
     ops = _ops()
     n, d, h, w = shape
     gen = torch.Generator().manual_seed(sum(shape))
-    plan = ops.TaskPlan([i % 3 for i in range(n)], 4, DEV)
+    tasks = [i % 3 for i in range(n)]
+    plan = ops.TaskPlan(tasks, 4, DEV)
+    slots = plan.sample_slot.cpu().long()
     def experts(co, ci):
-        return [torch.randn(co, ci, k, k, k, generator=gen).to(DEV) * 0.2 for k in (5, 3, 1, 1, 1)]
-    # first layer: 1 -> 24
-    e = experts(24, 1)
-    g = torch.softmax(torch.randn(plan.nslots, 5, 24, generator=gen), dim=1).to(DEV)
-    wf, _ = ops.gatrep_merge(*e, g, torch.bfloat16)
-    x = torch.randn(n, d, h, w, 1, generator=gen).bfloat16().to(DEV)
-    ref = ops.conv5(x, wf, plan.sample_slot, 24, out_f32=True)
-    got = ops.thin_conv_in1(x, wf, plan.sample_slot, 24, out_f32=True)
-    assert rel_err(got.cpu(), ref.cpu()) < 1e-5
+        return [torch.randn(co, ci, k, k, k, generator=gen) * 0.2 for k in (5, 3, 1, 1, 1)]
+    def oracle_filter(e, g):
+        return orc.merge_filters(orc.expert_bank(*e), g).bfloat16().float()          # [S, Co, Ci, 5, 5, 5]
+    # first layer: 1 -> 24 (and 1 -> 32: the 16-byte store path)
+    for co in (24, 32):
+        e = experts(co, 1)
+        g = torch.softmax(torch.randn(plan.nslots, 5, co, generator=gen), dim=1)
+        wf, _ = ops.gatrep_merge(*[t.to(DEV) for t in e], g.to(DEV), torch.bfloat16)
+        xc = torch.randn(n, d, h, w, 1, generator=gen).bfloat16()
+        x = xc.to(DEV)
+        ref = ops.conv5(x, wf, plan.sample_slot, co, out_f32=True)
+        y_or = orc.conv_per_sample(xc.float().permute(0, 4, 1, 2, 3), oracle_filter(e, g)[slots]).permute(0, 2, 3, 4, 1)
+        for folded in (False, True):
+            got = ops.thin_conv_in1(x, wf, plan.sample_slot, co, out_f32=True, folded=folded)
+            assert rel_err(got.cpu(), ref.cpu()) < 5e-5, folded
+            assert rel_err(got.cpu(), y_or) < 1e-3, folded
+        got = ops.thin_conv_in1(x, wf, plan.sample_slot, co, out_f32=False)
+        assert got.dtype == torch.bfloat16 and rel_err(got.float().cpu(), ref.cpu()) < 6e-3
+        bias = torch.randn(co, generator=gen).to(DEV)
+        got = ops.thin_conv_in1(x, wf, plan.sample_slot, co, out_f32=False, bias=bias, relu=True)
+        assert rel_err(got.float().cpu(), torch.relu(ref + bias).cpu()) < 6e-3
     # last layer: 40 -> 1, forward and data gradient
     e = experts(1, 40)
-    g = torch.softmax(torch.randn(plan.nslots, 5, 1, generator=gen), dim=1).to(DEV)
-    wf, wd = ops.gatrep_merge(*e, g, torch.bfloat16, want_wf=True, want_wd=True)
-    x = torch.randn(n, d, h, w, 40, generator=gen).bfloat16().to(DEV)
+    g = torch.softmax(torch.randn(plan.nslots, 5, 1, generator=gen), dim=1)
+    wf, wd = ops.gatrep_merge(*[t.to(DEV) for t in e], g.to(DEV), torch.bfloat16, want_wf=True, want_wd=True)
+    xc = torch.randn(n, d, h, w, 40, generator=gen).bfloat16()
+    x = xc.to(DEV)
     ref = ops.conv5(x, wf, plan.sample_slot, 1, out_f32=True)
-    got = ops.thin_conv_out1(x, wf, plan.sample_slot)
-    assert rel_err(got.cpu(), ref.cpu()) < 1e-5
-    dy = torch.randn(n, d, h, w, 1, generator=gen).bfloat16().to(DEV)
+    w_or = oracle_filter(e, g)
+    y_or = orc.conv_per_sample(xc.float().permute(0, 4, 1, 2, 3), w_or[slots]).permute(0, 2, 3, 4, 1)
+    for folded in (False, True):
+        got = ops.thin_conv_out1(x, wf, plan.sample_slot, folded=folded)
+        assert rel_err(got.cpu(), ref.cpu()) < 5e-5, folded
+        assert rel_err(got.cpu(), y_or) < 1e-3, folded
+    dyc = torch.randn(n, d, h, w, 1, generator=gen).bfloat16()
+    dy = dyc.to(DEV)
     ref = ops.conv5(dy, wd, plan.sample_slot, 40, out_f32=True)
-    got = ops.thin_conv_in1(dy, wd, plan.sample_slot, 40, out_f32=True)
-    assert rel_err(got.cpu(), ref.cpu()) < 1e-5
+    dx_or = torch.cat([torch.nn.functional.conv_transpose3d(dyc[i:i + 1].float().permute(0, 4, 1, 2, 3), w_or[slots[i]], padding=2)
+                       for i in range(n)]).permute(0, 2, 3, 4, 1)
+    for folded in (False, True):
+        got = ops.thin_conv_in1(dy, wd, plan.sample_slot, 40, out_f32=True, folded=folded)
+        assert rel_err(got.cpu(), ref.cpu()) < 5e-5, folded
+        assert rel_err(got.cpu(), dx_or) < 1e-3, folded
 
 
 @pytest.mark.parametrize('co,ci', [(32, 32), (40, 24), (7, 5), (64, 96)])

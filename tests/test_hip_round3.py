@@ -70,6 +70,7 @@ def test_deep_conv_in_the_operator(ci, co, shape, n):
     r = torch.randn(n, *shape, co, generator=gen)
     res = []
     try:
+        ops.set_deep_fwd_min(0)                # (the forward form on every shape, not only where it is the faster one)
         for deep in (True, False):
             ops.set_deep_conv(deep)
             dev = [p.to(DEV).requires_grad_(True) for p in ps]
@@ -80,6 +81,7 @@ def test_deep_conv_in_the_operator(ci, co, shape, n):
             res.append([y.detach().float().cpu(), xd.grad.float().cpu()] + [p.grad.cpu() for p in dev])
     finally:
         ops.set_deep_conv(True)
+        ops.set_deep_fwd_min(6000)
     for a, b in zip(res[0], res[1]):
         assert rel_err(a, b) < 1e-2
     # the oracle's block on the bf16-rounded operands
