@@ -83,7 +83,9 @@ int repmode_gatrep_fwd_gate(const float* k5, const float* k3, const float* k1, c
 
 /* repmode_gatrep_fwd_gate for several MoDE blocks in ONE launch (a train step merges all its blocks' forward filters before
  * the first convolution: they depend on parameters and tasks only).  Every pointer argument but slot_task is a HOST array
- * of nblocks entries (device pointers / channel counts per block); wd[i] may be NULL.  nblocks <= REPMODE_GATREP_MULTI_MAX. */
+ * of nblocks entries (device pointers / channel counts per block); wd[i] may be NULL; so may wf[i] (and then g_out[i]) when
+ * wd[i] is given: the data-gradient filters alone, which a train step asks for where its backward pass starts.
+ * nblocks <= REPMODE_GATREP_MULTI_MAX. */
 #define REPMODE_GATREP_MULTI_MAX 19
 int repmode_gatrep_fwd_multi(int nblocks, const float* const* k5, const float* const* k3, const float* const* k1,
                              const float* const* a3, const float* const* a5, const float* const* gate_w,
@@ -367,7 +369,7 @@ int repmode_mse_loss(const float* out, const float* target, const int32_t* sampl
                      void* stream);
 
 /* repmode_expert_frags for several blocks (both roles) in ONE launch; pointer arguments are HOST arrays of nblocks entries,
- * wd[i] may be NULL.  nblocks <= REPMODE_GATREP_MULTI_MAX. */
+ * wd[i] may be NULL, or wf[i] when wd[i] is given.  nblocks <= REPMODE_GATREP_MULTI_MAX. */
 int repmode_expert_frags_multi(int nblocks, const float* const* k5, const float* const* k3, const int* co, const int* ci,
                                void* const* wf, void* const* wd, void* stream);
 

@@ -19,10 +19,13 @@ def short(name):
 
 def main():
     d = sys.argv[1]
-    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     stats = glob.glob(d + '/**/*_kernel_stats.csv', recursive=True)[0]
     trace = glob.glob(d + '/**/*_kernel_trace.csv', recursive=True)[0]
     rows = list(csv.DictReader(open(stats)))
+    tr = list(csv.DictReader(open(trace)))
+    # train steps in the trace: counted from the trace itself (a step ends with a run of consecutive fused-Adam launches;
+    # bench.py runs warm-up + timed + 5 host-enqueue-timing steps), the command-line number only as a fall-back
+    steps = count_steps(tr) or (int(sys.argv[2]) if len(sys.argv) > 2 else 3)
     tot = sum(float(r['TotalDurationNs']) for r in rows)
     print('== per-kernel totals over %d traced steps (%.2f ms/step of GPU time) ==' % (steps, tot / 1e6 / steps))
     for r in rows[:24]:
@@ -34,8 +37,7 @@ def main():
         calls = sum(int(r['Calls']) for r in ig)
         print('conv5_igemm_kernel, all %d instantiations: %d calls, %.1f us average  (compare bench.py roofline.avg_launch_ms)'
               % (len(ig), calls, sum(float(r['TotalDurationNs']) for r in ig) / calls / 1e3))
-    tr = list(csv.DictReader(open(trace)))
-    for key in ('conv5_igemm', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd', 'bn_', 'k2s2', 'expert_mix', 'box_sum'):
+    for key in ('conv5_igemm', 'conv5_deep', 'thin_', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd', 'bn_', 'k2s2', 'expert_mix', 'box_sum'):
         ks = [r for r in tr if key in r['Kernel_Name']]
         if not ks:
             continue
@@ -44,7 +46,9 @@ def main():
     families(tr)
 
 
-FAMILIES = [('conv5_igemm level 0-1', 'conv5_igemm_kernel<unsigned short, Cfg<4, 4, 32'),
+FAMILIES = [('conv5_deep level 3 (per-expert pair)', 'conv5_deep_kernel<DCfg<4, 8, 8'), ('conv5_deep level 4 (per-expert pair)', 'conv5_deep_kernel<DCfg<2, 4, 4'),
+            ('thin layers (own kernels)', 'thin_in1_kernel'), ('thin layers (own kernels)', 'thin_out1_kernel'),
+            ('conv5_igemm level 0-1', 'conv5_igemm_kernel<unsigned short, Cfg<4, 4, 32'),
             ('conv5_igemm level 2', 'conv5_igemm_kernel<unsigned short, Cfg<4, 4, 16'),
             ('conv5_igemm level 3', 'conv5_igemm_kernel<unsigned short, Cfg<4, 8, 8'),
             ('conv5_igemm level 4', 'conv5_igemm_kernel<unsigned short, Cfg<2, 4, 4'),
@@ -59,17 +63,26 @@ FAMILIES = [('conv5_igemm level 0-1', 'conv5_igemm_kernel<unsigned short, Cfg<4,
             ('pooled memset / fills', 'FillFunctor'), ('other PyTorch elementwise', 'at::native')]
 
 
-def families(tr):
-    """GPU time per train step by kernel family and U-Net level, over the steady steps of the trace (a step ends with
-    its last fused-Adam launch; the first three steps are skipped), plus the idle time between launches."""
+def adam_step_ends(tr):
+    """Indices (in start-time order) of the last fused-Adam launch of every train step, and the sorted trace."""
     tr = sorted(tr, key=lambda r: int(r['Start_Timestamp']))
-    adam = [i for i, r in enumerate(tr) if 'FusedAdam' in r['Kernel_Name']]
+    adam = [i for i, r in enumerate(tr) if 'FusedAdam' in r['Kernel_Name'] or 'adam_' in r['Kernel_Name']]
     if len(adam) < 2:
-        return
+        return tr, []
     per = 1
     while per < len(adam) and adam[per] == adam[per - 1] + 1:
         per += 1                                   # Adam launches per step (consecutive dispatches)
-    ends = [adam[i] for i in range(per - 1, len(adam), per)]
+    return tr, [adam[i] for i in range(per - 1, len(adam), per)]
+
+
+def count_steps(tr):
+    return len(adam_step_ends(tr)[1])
+
+
+def families(tr):
+    """GPU time per train step by kernel family and U-Net level, over the steady steps of the trace (a step ends with
+    its last fused-Adam launch; the first three steps are skipped), plus the idle time between launches."""
+    tr, ends = adam_step_ends(tr)
     if len(ends) < 6:
         return
     t, c, n, idle = {}, {}, 0, 0.0

@@ -113,7 +113,7 @@ def load():
     return lib
 
 
-TORCH_LIB_PATH = os.path.join(_HERE, 'librepmode_torch.so')
+TORCH_LIB_PATH = os.environ.get('REPMODE_TORCH_LIB') or os.path.join(_HERE, 'librepmode_torch.so')
 _torch_ops_loaded = False
 
 
@@ -123,7 +123,15 @@ def load_torch_ops():
     global _torch_ops_loaded
     if _torch_ops_loaded:
         return
-    load()                      # librepmode_hip.so first (the operator library links against it)
+    lib = load()                # librepmode_hip.so first (the operator library links against it)
+    if os.environ.get('REPMODE_LIB') and not os.environ.get('REPMODE_TORCH_LIB'):
+        # the operator library links librepmode_hip.so BY NAME (rpath $ORIGIN): with only the ctypes handle redirected, the
+        # network path would run the in-tree kernels next to a second copy of the library's state
+        raise RepModeHipError('REPMODE_LIB selects a variant kernel library for the ctypes layer only; the operator seam needs '
+                              'REPMODE_TORCH_LIB = a librepmode_torch.so built against it (csrc/build.sh with REPMODE_OUT / '
+                              'REPMODE_TORCH_OUT in one directory)')
+    if lib.repmode_abi_version() != ABI_VERSION:
+        raise RepModeHipError('ABI mismatch: library %d, binding %d' % (lib.repmode_abi_version(), ABI_VERSION))
     if not os.path.exists(TORCH_LIB_PATH):
         raise RepModeHipError(
             'librepmode_torch.so not found at %s -- build it with `python -c "import __graft_entry__ as g; g.build()"`. '

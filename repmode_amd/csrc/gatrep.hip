@@ -603,7 +603,8 @@ int gatrep_fwd_multi_t(int nblocks, const float* const* k5, const float* const* 
   long total = 0;
   double bytes = 0;
   for (int i = 0; i < nblocks; ++i) {
-    RM_REQUIRE(k5[i] && k3[i] && k1[i] && a3[i] && a5[i] && gate_w[i] && gate_b[i] && g_out[i] && wf[i], "gatrep_fwd_multi: null pointer (block %d)", i);
+    RM_REQUIRE(k5[i] && k3[i] && k1[i] && a3[i] && a5[i] && gate_w[i] && gate_b[i] && (wf[i] || wd[i]) && (g_out[i] || !wf[i]),
+               "gatrep_fwd_multi: null pointer (block %d)", i);
     RM_REQUIRE(co[i] > 0 && ci[i] > 0, "gatrep_fwd_multi: bad shape (block %d)", i);
     a.k5[i] = k5[i]; a.k3[i] = k3[i]; a.k1[i] = k1[i]; a.a3[i] = a3[i]; a.a5[i] = a5[i];
     a.gate_w[i] = gate_w[i]; a.gate_b[i] = gate_b[i]; a.g_out[i] = g_out[i];
@@ -611,7 +612,7 @@ int gatrep_fwd_multi_t(int nblocks, const float* const* k5, const float* const* 
     a.co[i] = co[i]; a.ci[i] = ci[i];
     a.nrt_f[i] = repmode_padded_channels(co[i], dtype, 0) / 32; a.nkc_f[i] = repmode_padded_channels(ci[i], dtype, 1) / KC;
     a.ts_f[i] = (long)a.nkc_f[i] * a.nrt_f[i] * 8 < 512 ? 4 : 1;
-    a.nwf[i] = a.nkc_f[i] * a.nrt_f[i] * 8 * a.ts_f[i];
+    a.nwf[i] = wf[i] ? a.nkc_f[i] * a.nrt_f[i] * 8 * a.ts_f[i] : 0;      // (no forward filter asked for: the data-gradient role only)
     long nwd = 0;
     a.nrt_d[i] = a.nkc_d[i] = a.ts_d[i] = 1;
     if (wd[i]) {
@@ -621,7 +622,7 @@ int gatrep_fwd_multi_t(int nblocks, const float* const* k5, const float* const* 
     }
     a.first[i] = (int)total;
     total += a.nwf[i] + nwd;
-    bytes += (double)co[i] * ci[i] * (155.0 * 4 + 125.0 * nslots * sizeof(T) * (wd[i] ? 2 : 1));
+    bytes += (double)co[i] * ci[i] * (155.0 * 4 + 125.0 * nslots * sizeof(T) * ((wf[i] ? 1 : 0) + (wd[i] ? 1 : 0)));
   }
   a.first[nblocks] = (int)total;
   RM_REQUIRE(total > 0 && total < (1L << 31), "gatrep_fwd_multi: grid out of range");
@@ -761,15 +762,15 @@ extern "C" int repmode_expert_frags_multi(int nblocks, const float* const* k5, c
   long total = 0;
   double bytes = 0;
   for (int i = 0; i < nblocks; ++i) {
-    RM_REQUIRE(k5[i] && k3[i] && wf[i] && co[i] > 0 && ci[i] > 0, "expert_frags_multi: bad block %d", i);
+    RM_REQUIRE(k5[i] && k3[i] && (wf[i] || wd[i]) && co[i] > 0 && ci[i] > 0, "expert_frags_multi: bad block %d", i);
     a.k5[i] = k5[i]; a.k3[i] = k3[i]; a.wf[i] = static_cast<bf16_t*>(wf[i]); a.wd[i] = static_cast<bf16_t*>(wd[i]);
     a.co[i] = co[i]; a.ci[i] = ci[i];
     a.nrt_f[i] = repmode_padded_channels(co[i], REPMODE_BF16, 0) / 32; a.nkc_f[i] = repmode_padded_channels(ci[i], REPMODE_BF16, 1) / 16;
     a.nrt_d[i] = repmode_padded_channels(ci[i], REPMODE_BF16, 0) / 32; a.nkc_d[i] = repmode_padded_channels(co[i], REPMODE_BF16, 1) / 16;
-    a.nwf[i] = a.nkc_f[i] * a.nrt_f[i] * 4;
+    a.nwf[i] = wf[i] ? a.nkc_f[i] * a.nrt_f[i] * 4 : 0;
     a.first[i] = (int)total;
     total += a.nwf[i] + (wd[i] ? (long)a.nkc_d[i] * a.nrt_d[i] * 4 : 0);
-    bytes += (double)co[i] * ci[i] * (152.0 * 4 + (125.0 + 45.0) * 2 * (wd[i] ? 2 : 1));
+    bytes += (double)co[i] * ci[i] * (152.0 * 4 + (125.0 + 45.0) * 2 * ((wf[i] ? 1 : 0) + (wd[i] ? 1 : 0)));
   }
   a.first[nblocks] = (int)total;
   RM_REQUIRE(total < (1L << 31), "expert_frags_multi: grid too large");

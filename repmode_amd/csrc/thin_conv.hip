@@ -361,11 +361,13 @@ __global__ __launch_bounds__(256, 2) void thin_out1_kernel(ThinOutArgs a) {
 }
 
 static const int g_thin_wide = []() { const char* e = getenv("REPMODE_CONV_WIDE"); return e ? atoi(e) : 1; }();
-// bricks per workgroup: enough workgroups for four per CU, at most 8 bricks each (the filter fragments are re-read per workgroup)
+// bricks per workgroup: two workgroups per CU (254 registers: that is what fits), at most 8 bricks each (the filter fragments
+// are re-read per workgroup).  Same box, batch 8 of 32x64x64 (2048 bricks), us per launch at 2 / 4 / 8 bricks per workgroup:
+// 65.4 / 52.4 / 64.6 (first layer), 64.2 / 50.3 / 63.8 (last layer's data gradient); the fold around the general kernel: 70.6.
 static int thin_per_wg(int nbricks) {
   static const int forced = []() { const char* e = getenv("REPMODE_THIN_PER_WG"); return e ? atoi(e) : 0; }();
   if (forced > 0) return forced;
-  int per = (nbricks + 1023) / 1024;
+  int per = (nbricks + 511) / 512;
   return per < 1 ? 1 : (per > 8 ? 8 : per);
 }
 

@@ -86,10 +86,14 @@ class Model(object):
     def _init_model(self):
         if self.nn_module != 'RepMode':
             raise ValueError('only the RepMode network is provided (got %r)' % self.nn_module)
-        self.net = _repmode.Net(self.opts, mult_chan=self.mult_chan, dtype=self.dtype).to(self.device)
         from . import distributed as dist_
         from . import ops as ops_
+        # a rebuild (load_state): the previous network's reducer hooks / communication buckets and DDP wrapper go first
+        if getattr(self, 'reducer', None) is not None:
+            self.reducer.remove()
+            ops_.set_grad_sink(None)
         self.ddp = self.reducer = None
+        self.net = _repmode.Net(self.opts, mult_chan=self.mult_chan, dtype=self.dtype).to(self.device)
         if self.distributed in ('reducer', 'reducer-always'):
             # gradients are produced inside the communication buckets and averaged under backward (distributed.py);
             # measured equal to the stock wrapper on one rank, not yet run on eight -> opt-in
@@ -135,7 +139,7 @@ class Model(object):
             self.nn_module = state['nn_module']
         if state.get('opts') is not None:
             self.opts = state['opts']
-            self.opts.gpu_ids = self.gpu_ids[0]
+        self.opts.gpu_ids = self.gpu_ids[0]                  # (also when the checkpoint carries no opts)
         self._init_model()
         self.net.load_state_dict(state['nn_state'])
         if 'optimizer_state' in state:
@@ -177,6 +181,8 @@ class Model(object):
         ``do_train_iter``.  The values were computed on the device during the step; THIS call copies them to the host
         (one synchronisation, when and if the caller wants the numbers -- the reference pays ~4 per iteration)."""
         import pandas as pd
+        if self._last_log is None:
+            raise RuntimeError('loss_log(): no train iteration has run yet')
         loss, loss_sample, task_mean, task_count, tasks = self._last_log
         names = self.opts.adopted_datasets
         per = loss_sample.float().cpu().numpy()

@@ -108,6 +108,12 @@ def get_deep_conv():
     return bool(torch_ops().get_deep_conv())
 
 
+def set_wd_lazy(on):
+    """A training step's data-gradient filters (wd) are allocated by ``prepare_filters`` and produced by ONE launch where the
+    backward pass starts (default) instead of next to the forward filters in the forward pass's launch (REPMODE_WD_LAZY=0)."""
+    torch_ops().set_wd_lazy(bool(on))
+
+
 def set_thin_kernels(on):
     """The one-channel first / last layers through their own kernels (csrc/thin_conv.hip; default) or round 2's fold of the x
     taps around the general kernel (REPMODE_THIN=0).  The operator library's switch (the ``thin_conv_*`` wrappers here
@@ -384,15 +390,15 @@ def conv5_wgrad(x_cl, dy_cl, plan, cout, centre3=False, expert_layout=None, out=
         _lib.call('repmode_conv5_wgrad_ex', _ptr(x_cl), _ptr(dy_cl), _ptr(plan.sample_slot), 1, _ptr(dw),
                   n, d, h, wd_, cin, cout, dtype_code(x_cl.dtype), 2 if k == 5 else 3, _stream())
         return dw
-    dw, pre = torch.empty((plan.nslots, TAPS, cout, cin), dtype=torch.float32, device=x_cl.device), False
+    dw = torch.empty((plan.nslots, TAPS, cout, cin), dtype=torch.float32, device=x_cl.device)      # (cleared by the call)
     if x_cl.dtype == torch.bfloat16 and (cin == 1) != (cout == 1) and not centre3:
         # thin layer: taps stand in for the missing channel dimension (conv5_wgrad_thin)
         a_t, b_t, c, flip = (dy_cl, x_cl, cout, 0) if cin == 1 else (x_cl, dy_cl, cin, 1)
         _lib.call('repmode_conv5_wgrad_thin', _ptr(a_t), _ptr(b_t), _ptr(plan.sample_slot), plan.nslots, _ptr(dw),
-                  n, d, h, wd_, c, flip | (2 if pre else 0), _stream())
+                  n, d, h, wd_, c, flip, _stream())
         return dw
     _lib.call('repmode_conv5_wgrad_ex', _ptr(x_cl), _ptr(dy_cl), _ptr(plan.sample_slot), plan.nslots, _ptr(dw),
-              n, d, h, wd_, cin, cout, dtype_code(x_cl.dtype), (1 if centre3 else 0) | (8 if pre else 0), _stream())
+              n, d, h, wd_, cin, cout, dtype_code(x_cl.dtype), 1 if centre3 else 0, _stream())
     return dw
 
 
@@ -608,22 +614,16 @@ def expert_mix_fwd(p, gn):
 
 
 def expert_mix_bwd(dy, p, gn, dtype):
-    """(dg [N,5,Co], dye_lo [2,N,D,H,W,Co] in ``dtype``, dye_hi [3, M(+pad), Co] float) from dy, the expert outputs and
-    g; M = N*D*H*W voxel rows.  dye_hi's three matrices feed batched GEMMs; rocBLAS picks a pathological kernel when
-    such a GEMM has exactly 256 x 256 (or 128 x 256) outputs (118 us instead of 18), so for small M each matrix gets
-    8 rows of zero padding."""
+    """(dg [N,5,Co], dye_lo [2,N,D,H,W,Co] in ``dtype``, dye_hi [3, M, Co] float) from dy, the expert outputs and g;
+    M = N*D*H*W voxel rows.  dye_lo: the two conv experts' gate-scaled output gradients (operands of the conv kernels),
+    dye_hi: the three 1x1 experts' (operands of repmode_gemm3)."""
     _, n, d, h, w, co = p.shape
     m = n * d * h * w
-    pad = 8 if m <= 512 else 0
-    dg, pre = torch.empty((n, NUM_EXPERTS, co), dtype=torch.float32, device=p.device), False
+    dg = torch.empty((n, NUM_EXPERTS, co), dtype=torch.float32, device=p.device)
     lo = torch.empty((2, n, d, h, w, co), dtype=dtype, device=p.device)
-    if pad:
-        hi = torch.empty((3, m + pad, co), dtype=torch.float32, device=p.device)
-        hi[:, m:].zero_()
-    else:
-        hi = torch.empty((3, m, co), dtype=torch.float32, device=p.device)
-    _lib.call('repmode_expert_mix_bwd_ex', _ptr(dy), _ptr(p), _ptr(gn), _ptr(dg), _ptr(lo), _ptr(hi), (m + pad) * co, n,
-              d * h * w, co, dtype_code(dtype) | (16 if pre else 0), _stream())
+    hi = torch.empty((3, m, co), dtype=torch.float32, device=p.device)
+    _lib.call('repmode_expert_mix_bwd_ex', _ptr(dy), _ptr(p), _ptr(gn), _ptr(dg), _ptr(lo), _ptr(hi), m * co, n,
+              d * h * w, co, dtype_code(dtype), _stream())
     return dg, lo, hi
 
 

@@ -130,3 +130,40 @@ def test_conv5_wide_volumes_vs_oracle(case, dtype):
         # the 16-byte stores put every channel where the 8-byte ones would: the float output rounded once, up to the
         # summation order of the two kernels' operand roles
         assert rel_err(yb.float().cpu(), y.cpu()) < 5e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_data_gradient_filters_at_the_start_of_backward(dtype):
+    """prepare_filters only allocates the data-gradient filters; the first backward node launches them all (WdBatch in the
+    operator library).  Same kernels, same inputs: every gradient of a whole-network step agrees with the step whose forward
+    launch wrote them (up to the float atomics' order), also when a second forward pass replaced the first one's batch before
+    its backward ran (each block then produces its own filter)."""
+    from conftest import Opts
+    from repmode_amd.nn_modules.RepMode import Net
+    ops = _ops()
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 1, 16, 32, 32, generator=gen).to(DEV)
+    tgt = torch.randn(4, 1, 16, 32, 32, generator=gen).to(DEV)
+    tasks = [3, 7, 11, 3]                                  # three distinct tasks: the deep levels take the per-expert form
+    torch.manual_seed(0)
+    net = Net(Opts(), mult_chan=4, dtype=dtype).to(DEV).train()
+
+    def grads(lazy, interleave=False):
+        ops.set_wd_lazy(lazy)
+        net.zero_grad(set_to_none=True)
+        y = net(x, tasks)
+        if interleave:                                      # two more forward passes push the first one's batch out
+            for _ in range(2):
+                net(x.flip(0), tasks[::-1])
+        torch.nn.functional.mse_loss(y, tgt).backward()
+        return [p.grad.detach().float().cpu().clone() for p in net.parameters()]
+
+    try:
+        ref = grads(False)
+        for got in (grads(True), grads(True, interleave=True)):
+            gmax = max(float(r.abs().max()) for r in ref)
+            for a, b in zip(got, ref):
+                tol = 2e-3 if dtype == torch.float32 else 5e-2
+                assert float((a - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-2 * gmax)
+    finally:
+        ops.set_wd_lazy(True)
