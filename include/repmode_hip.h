@@ -131,6 +131,16 @@ int repmode_conv5_deep(const void* x, const void* w, float* y, int n, int d, int
                        void* stream);
 int repmode_conv5_deep_supported(int wdim, int cin, int dtype);
 
+/* EXPERIMENT, not on the product path: the forward convolution of a merged-formulation block with
+ * GatRep INSIDE the kernel (RepMode.py:171-192 fused into :204-208): the filter fragment of every tap is built in registers
+ * from the experts' un-merged bf16 fragments w2 (repmode_expert_frags), the 1x1 experts' float parameters k1 / a3 / a5
+ * [cout][cin] and the gate probabilities gates [nslots][5][cout]; no merged filter is written to or read from HBM.  bf16
+ * input, float output y [n][d][h][w][cout] (flags bit 1: y is zero already and is added to), cin % 8 == 0, the 4 x 4 x 16
+ * tile.  Kept for the A/B against repmode_gatrep_fwd + repmode_conv5 (tools/merge_ab.py, profiles/r03_merge_ab.txt). */
+int repmode_conv5_merged(const void* x, const void* w2, const float* k1, const float* a3, const float* a5, const float* gates,
+                         const int32_t* sample_slot, float* y, int n, int d, int h, int wdim, int cin, int cout, int flags,
+                         void* stream);
+
 /* The one-channel ends of the network as kernels of their own (csrc/thin_conv.hip; bf16).
  * repmode_conv5_thin_in1: ONE input channel -- the first block's convolution (RepMode.py:27, Net's first MoDEConv(1, 32))
  *   with its forward filter wf, or the last block's input gradient (RepMode.py:42 conv_out, autograd of :204-208) with its

@@ -36,6 +36,7 @@ _SIGNATURES = {
     'repmode_conv5_deep_supported': [_I, _I, _I],
     'repmode_conv5_thin_in1': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'repmode_conv5_thin_out1': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'repmode_conv5_merged': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_pair': [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_epi': [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P],
     'repmode_conv5_wgrad': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -51,8 +51,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 pair, round-to-nearest-even: ONE v_cvt_pk_bf16_f32 on gfx950 (the software form above is ~10
+// VALU operations per element)
+typedef __bf16 rm_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rm_bf16x2));
 }
 
 template <typename T>

@@ -119,6 +119,12 @@ struct ConvArgs {
   // 2 N samples (the two expert outputs), else both jobs ADD into sample v % N.
   int dual;
   int wide;            // element-typed bf16 output: 16-byte stores through v_permlane32_swap (see the epilogue)
+  // MERGE kernels only: w = the experts' two un-merged slots (repmode_expert_frags), the 1x1 experts' parameters [Cout][Cin]
+  // and the gate probabilities g[slot][5][Cout]
+  const float* mk1;
+  const float* ma3;
+  const float* ma5;
+  const float* gates;
   // deferred small jobs (tail_jobs.h) that ride in this launch: workgroups [0, tail.nblocks) run them, the convolution's
   // workgroups follow (tail.nblocks is a multiple of 8, so their workgroup -> XCD map is unchanged)
   TailJobs tail;
@@ -150,7 +156,8 @@ struct Cfg {
 // DXC: the dx-centre mode (one tap per (dz, dy) row: the thin first / last layers) as its own instantiation, so that
 // neither path carries the other's registers and branches
 // ROWSTAT: the row-stationary tap loop (4 x 4 x 32 bricks only, see the loop's comment)
-template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false, bool ROWSTAT = false>
+// MERGE: the filter fragment is MERGED IN THE KERNEL from the experts (the A/B experiment of repmode_conv5_merged below)
+template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false, bool ROWSTAT = false, bool MERGE = false>
 __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   constexpr int KV = Elem<T>::KV;
   constexpr int KC = 2 * KV;
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   const T* __restrict__ xn2 = Cin1 > 0 ? static_cast<const T*>(a.x2) + (size_t)n * D * H * W * (Cin - Cin1) : nullptr;
   // filter layout (fragment-major): [slot][tap][co tile (32)][ci chunk (KC)][32][KC]; a lane's 16 bytes
   // of an A fragment are bytes [16 lane, 16 lane + 16) of the 1 KiB tile
-  const T* __restrict__ wsl = static_cast<const T*>(a.w) + (size_t)slot * REPMODE_TAPS * CoutP * CinP;
+  const T* __restrict__ wsl = static_cast<const T*>(a.w) + (size_t)(MERGE ? 0 : slot) * REPMODE_TAPS * CoutP * CinP;
   const size_t tap_stride = (size_t)CoutP * CinP;
   const int nkc = CinP / KC, nrt = CoutP / 32;
 
@@ -376,6 +383,103 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
         dz = dzn;
         dy = dyn;
       }
+    } else if constexpr (MERGE) {
+      // GatRep INSIDE the conv (RepMode.py:171-192 fused with :204-208, what BASELINE's north star words as "fuse"): the
+      // filter fragment of a tap is built in registers from the raw 5x5x5 / 3x3x3 expert fragments (bf16, shared by every
+      // sample: slots 0 / 1 of repmode_expert_frags), the three 1x1 experts' values of this lane's (co, 8 ci) and the
+      // sample's five gate probabilities:   W = g0 K5 + [centre 27] (g1 K3 + g3 A3 / 27) + [centre] g2 K1 + g4 A5 / 125.
+      // No merged filter is written to or read from HBM; the price is ~20 (36 on the 27 centre taps) VALU operations per
+      // fragment next to the 4 MFMAs it feeds.
+      static_assert(sizeof(T) == 2 && CW == 1, "in-kernel merge: bf16, one channel sub-tile per wave");
+      const int co_c = min(cot * C::COT + wc * 32 + l31, Cout - 1);
+      const float* gp = a.gates + (size_t)slot * 5 * Cout + co_c;
+      const float g0 = gp[0], g1 = gp[Cout], g2 = gp[2 * Cout], g3 = gp[3 * Cout], g4 = gp[4 * Cout];
+      float cA[8], cB[8], cC[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ci = ci0 + khalf * 8 + i;
+        const bool ok = ci < Cin;
+        const size_t o = (size_t)co_c * Cin + (ok ? ci : 0);
+        cA[i] = ok ? g4 * (a.ma5[o] * (1.0f / 125.0f)) : 0.f;
+        cB[i] = ok ? cA[i] + g3 * (a.ma3[o] * (1.0f / 27.0f)) : 0.f;
+        cC[i] = ok ? cB[i] + g2 * a.mk1[o] : 0.f;
+      }
+      const size_t slot1 = (size_t)REPMODE_TAPS * tap_stride;          // the 3x3x3 expert's slot
+      auto merge = [&](const u32x4& r5, const u32x4& r3, int cls) -> u32x4 {      // cls 0: outside the centre 27, 1: inside, 2: the centre tap
+        const uint32_t w5[4] = {r5.x, r5.y, r5.z, r5.w}, w3[4] = {r3.x, r3.y, r3.z, r3.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float lo = g0 * __uint_as_float(w5[q] << 16), hi = g0 * __uint_as_float(w5[q] & 0xffff0000u);
+          if (cls == 0) {
+            lo += cA[2 * q]; hi += cA[2 * q + 1];
+          } else {
+            lo = fmaf(g1, __uint_as_float(w3[q] << 16), lo); hi = fmaf(g1, __uint_as_float(w3[q] & 0xffff0000u), hi);
+            lo += (cls == 2 ? cC[2 * q] : cB[2 * q]); hi += (cls == 2 ? cC[2 * q + 1] : cB[2 * q + 1]);
+          }
+          o[q] = pack_bf16x2(lo, hi);
+        }
+        return u32x4{o[0], o[1], o[2], o[3]};
+      };
+      u32x4 a_cur[5], a_nxt[5], c_cur[3], c_nxt[3];
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) a_cur[dx] = a_first[dx];
+      {
+        const bool rowc = dz >= 1 && dz <= 3 && dy >= 1 && dy <= 3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c_cur[j] = u32x4{0u, 0u, 0u, 0u};
+        if (rowc) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            c_cur[j] = *reinterpret_cast<const u32x4*>(wrow[0] + slot1 + (size_t)((dz * 5 + dy) * 5 + 1 + j) * tap_stride + (size_t)chunk * (32 * KC));
+        }
+      }
+      u32x4 b_cur[VW], b_nxt[VW];
+      {
+        const int rowoff0 = (dz * BYH + dy) * BXH;
+#pragma unroll
+        for (int vs = 0; vs < VW; ++vs) b_cur[vs] = lds[vbase[vs] + rowoff0];
+      }
+      for (int row = 0; row < nrows; ++row) {
+        int dzn = dz, dyn = dy + 1;
+        if (dyn > dy_hi) { dyn = dy_lo; dzn = dz + 1; }
+        const bool more = row + 1 < nrows;
+        const bool rowc = dz >= 1 && dz <= 3 && dy >= 1 && dy <= 3;
+        const bool rowc_n = more && dzn >= 1 && dzn <= 3 && dyn >= 1 && dyn <= 3;
+        if (more) {
+#pragma unroll
+          for (int dx = 0; dx < 5; ++dx) a_nxt[dx] = wfrag(0, (dzn * 5 + dyn) * 5 + dx);
+          if (rowc_n) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              c_nxt[j] = *reinterpret_cast<const u32x4*>(wrow[0] + slot1 + (size_t)((dzn * 5 + dyn) * 5 + 1 + j) * tap_stride + (size_t)chunk * (32 * KC));
+          }
+        }
+        const int rowoff = (dz * BYH + dy) * BXH;
+        const int rowoff_n = more ? (dzn * BYH + dyn) * BXH : rowoff;
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          const int offn = (dx < 4) ? rowoff + dx + 1 : rowoff_n;
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) b_nxt[vs] = lds[vbase[vs] + offn];
+          u32x4 wm;
+          if (rowc && dx >= 1 && dx <= 3) wm = merge(a_cur[dx], c_cur[dx - 1], (dz == 2 && dy == 2 && dx == 2) ? 2 : 1);
+          else wm = merge(a_cur[dx], a_cur[dx], 0);
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) {
+            if constexpr (SWAP) Elem<T>::mma(b_cur[vs], wm, acc[0][vs]);
+            else Elem<T>::mma(wm, b_cur[vs], acc[0][vs]);
+          }
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) b_cur[vs] = b_nxt[vs];
+        }
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) a_cur[dx] = a_nxt[dx];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c_cur[j] = c_nxt[j];
+        dz = dzn;
+        dy = dyn;
+      }
     } else if constexpr (ROWSTAT) {
       // Row-stationary order (4 x 4 x 32 bricks: a wave owns the four y rows of one z plane, sub-tile vs = row).  For a
       // fixed (dz, dx) the voxel fragment of halo row y' = vs + dy serves every (vs, dy) pair that lands on it: EIGHT
@@ -416,6 +520,85 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
           for (int yy = 0; yy < 8; ++yy) b_cur[yy] = b_nxt[yy];
         }
       }
+#ifdef RM_CONV_PRE2
+    } else if constexpr (CW == 1) {
+      // Experiment (REPMODE_EXTRA_FLAGS=-DRM_CONV_PRE2 [-DRM_CONV_BPRE2], tools/ab_variant.sh): the PMC pass of the level-0
+      // launch (tools/pmc_conv.sh) shows 31 % of the wave cycles parked in s_waitcnt / barriers and only 4 % stalled on LDS
+      // issue -- the filter fragments, requested ONE row (5 taps) ahead from L2, are the suspect.  Here they are requested
+      // TWO rows ahead (+20 registers); RM_CONV_BPRE2: the voxel fragments two taps ahead as well (+16).
+      u32x4 a_cur[5], a_n1[5], a_n2[5];
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) a_cur[dx] = a_first[dx];
+      auto next_row = [&](int& z, int& y) { if (++y > dy_hi) { y = dy_lo; ++z; } };
+      {
+        int z1 = dz, y1 = dy;
+        next_row(z1, y1);
+        if (nrows > 1) {
+#pragma unroll
+          for (int dx = 0; dx < 5; ++dx) a_n1[dx] = wfrag(0, (z1 * 5 + y1) * 5 + dx);
+        }
+      }
+#ifdef RM_CONV_BPRE2
+      u32x4 b0[VW], b1[VW], b2[VW];
+      {
+        const int rowoff0 = (dz * BYH + dy) * BXH;
+#pragma unroll
+        for (int vs = 0; vs < VW; ++vs) { b0[vs] = lds[vbase[vs] + rowoff0]; b1[vs] = lds[vbase[vs] + rowoff0 + 1]; }
+      }
+#else
+      u32x4 b_cur[VW], b_nxt[VW];
+      {
+        const int rowoff0 = (dz * BYH + dy) * BXH;
+#pragma unroll
+        for (int vs = 0; vs < VW; ++vs) b_cur[vs] = lds[vbase[vs] + rowoff0];
+      }
+#endif
+      for (int row = 0; row < nrows; ++row) {
+        int dzn = dz, dyn = dy;
+        next_row(dzn, dyn);
+        int dzn2 = dzn, dyn2 = dyn;
+        next_row(dzn2, dyn2);
+        const bool more = row + 1 < nrows, more2 = row + 2 < nrows;
+        if (more2) {
+#pragma unroll
+          for (int dx = 0; dx < 5; ++dx) a_n2[dx] = wfrag(0, (dzn2 * 5 + dyn2) * 5 + dx);
+        }
+        const int rowoff = (dz * BYH + dy) * BXH;
+        const int rowoff_n = more ? (dzn * BYH + dyn) * BXH : rowoff;
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+#ifdef RM_CONV_BPRE2
+          const int off2 = (dx < 3) ? rowoff + dx + 2 : rowoff_n + (dx - 3);       // the tap after next (clamped on the last row)
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) b2[vs] = lds[vbase[vs] + off2];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) {
+            if constexpr (SWAP) Elem<T>::mma(b0[vs], a_cur[dx], acc[0][vs]);
+            else Elem<T>::mma(a_cur[dx], b0[vs], acc[0][vs]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) { b0[vs] = b1[vs]; b1[vs] = b2[vs]; }
+#else
+          const int offn = (dx < 4) ? rowoff + dx + 1 : rowoff_n;
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) b_nxt[vs] = lds[vbase[vs] + offn];
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) {
+            if constexpr (SWAP) Elem<T>::mma(b_cur[vs], a_cur[dx], acc[0][vs]);
+            else Elem<T>::mma(a_cur[dx], b_cur[vs], acc[0][vs]);
+          }
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) b_cur[vs] = b_nxt[vs];
+#endif
+        }
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) { a_cur[dx] = a_n1[dx]; a_n1[dx] = a_n2[dx]; }
+        dz = dzn;
+        dy = dyn;
+      }
+#else
     } else if constexpr (CW == 1) {
       u32x4 a_cur[5], a_nxt[5];
 #pragma unroll
@@ -458,6 +641,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
         dz = dzn;
         dy = dyn;
       }
+#endif
     } else {
       u32x4 a_cur[CW], a_nxt[CW];
 #pragma unroll
@@ -690,7 +874,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   RM_STAMP(60);
 }
 
-template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false, bool ROWSTAT = false>
+template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false, bool ROWSTAT = false, bool MERGE = false>
 int launch_cfg(ConvArgs a, hipStream_t stream) {
   a.nbz = ceil_div(a.D, C::BZ);
   a.nby = ceil_div(a.H, C::BY);
@@ -720,7 +904,7 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   int dev = 0;
   RM_HIP(hipGetDevice(&dev));
   if (!((attr_set.load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_igemm_kernel<T, C, SWAP, PAIR, DXC, ROWSTAT>),
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_igemm_kernel<T, C, SWAP, PAIR, DXC, ROWSTAT, MERGE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
   }
@@ -736,7 +920,7 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   const double alg = a.dxc ? 2.0 * a.N * a.D * a.H * a.W * 25.0 * (a.Cin == 8 ? 5.0 * a.Cout : (double)a.Cin * a.Cout)
                            : a.tap_lo ? 0.0 : 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS;
   repmode_prof_begin(REPMODE_PROF_CONV5, alg, stream);
-  hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP, PAIR, DXC, ROWSTAT>), dim3((unsigned)grid), dim3(C::NT), lds_bytes, stream, a);
+  hipLaunchKernelGGL((conv5_igemm_kernel<T, C, SWAP, PAIR, DXC, ROWSTAT, MERGE>), dim3((unsigned)grid), dim3(C::NT), lds_bytes, stream, a);
   repmode_prof_end(stream);
   RM_LAUNCH_CHECK("conv5_igemm");
   return REPMODE_OK;
@@ -904,3 +1088,25 @@ extern "C" int repmode_debug_conv_timing(unsigned long long* out) {
   return 0;
 }
 #endif
+
+// EXPERIMENT: the forward convolution of a merged-formulation MoDE block with
+// GatRep inside the kernel -- no merged filter in HBM.  w2: repmode_expert_frags' two slots (shared by all samples), k1 / a3 /
+// a5: the 1x1 experts' parameters [cout][cin] float, gates: [nslots][5][cout] float (repmode_gate_softmax), y: float
+// [n][d][h][w][cout] (flags bit 1: add to y, which is zero already; else cleared / overwritten).  bf16, the 4 x 4 x 16 tile
+// (level 2 of the network).  Measured against repmode_gatrep_fwd + repmode_conv5 by tools/merge_ab.py; not on the product path.
+extern "C" int repmode_conv5_merged(const void* x, const void* w2, const float* k1, const float* a3, const float* a5, const float* gates,
+                                    const int32_t* sample_slot, float* y, int n, int d, int h, int wdim, int cin, int cout, int flags,
+                                    void* stream) {
+  RM_REQUIRE(x && w2 && k1 && a3 && a5 && gates && sample_slot && y, "conv5_merged: null pointer");
+  RM_REQUIRE(n > 0 && d > 0 && h > 0 && wdim > 0 && cin > 0 && cout > 0 && cin % 8 == 0, "conv5_merged: bad shape (cin %% 8 == 0)");
+  ConvArgs a{};
+  a.x = x; a.w = w2; a.sample_slot = sample_slot; a.y = y;
+  a.N = n; a.D = d; a.H = h; a.W = wdim; a.Cin = cin; a.Cout = cout;
+  a.CinP = repmode_padded_channels(cin, REPMODE_BF16, 1);
+  a.CoutP = repmode_padded_channels(cout, REPMODE_BF16, 0);
+  a.out_f32 = 1;
+  a.tap_lo = 0; a.tap_hi = 4;
+  a.accum = (flags & 2) ? 1 : 0;
+  a.mk1 = k1; a.ma3 = a3; a.ma5 = a5; a.gates = gates;
+  return launch_cfg<bf16_t, CfgX16, true, false, false, false, true>(a, static_cast<hipStream_t>(stream));
+}

@@ -585,88 +585,7 @@ std::unordered_map<EvalKey, std::pair<Tensor, Tensor>, EvalKeyHash> g_eval;
 
 struct Merged {
   Tensor g, wf, wd;
-  Tensor wd_flag;       // defined: wd is not filled yet -- see WdBatch / ensure_wd
 };
-
-// The data-gradient filters (wd: rows = ci, taps flipped) of a training step are not needed before its backward pass.
-// prepare_filters therefore only ALLOCATES them and records what is needed to produce them; the first backward node of the
-// step that wants one launches them all (ensure_wd): the forward pass -- BASELINE's "GatRep + conv forward" unit -- writes
-// half the merged-filter bytes, inference never writes wd at all, and the filters are produced right before the kernels
-// that read them.  `flag` is a one-element CPU tensor shared by the blocks of a step (0: not launched yet); a batch that is
-// no longer registered (a later forward pass replaced it) makes the block produce its own filter.
-struct WdBatch {
-  std::vector<Tensor> k5, k3, k1, a3, a5, gw, gb, wd;      // merged-formulation blocks
-  std::vector<int> co, ci;
-  std::vector<Tensor> x5, x3, xwd;                         // per-expert blocks
-  std::vector<int> xco, xci;
-  Tensor slot_task;
-  int64_t nslots = 0, num_tasks = 0;
-  int code = 0;
-};
-std::mutex g_wd_mu;
-std::unordered_map<void*, std::shared_ptr<WdBatch>> g_wd_batches;       // key: the flag tensor's storage
-std::vector<void*> g_wd_order;                                           // registration order (the oldest is dropped beyond 2)
-bool g_wd_lazy = []() {
-  const char* e = std::getenv("REPMODE_WD_LAZY");
-  return e ? std::atoi(e) != 0 : true;
-}();
-
-void register_wd_batch(const Tensor& flag, std::shared_ptr<WdBatch> b) {
-  std::lock_guard<std::mutex> lock(g_wd_mu);
-  g_wd_batches[flag.data_ptr()] = std::move(b);
-  g_wd_order.push_back(flag.data_ptr());
-  while (g_wd_order.size() > 2) {
-    g_wd_batches.erase(g_wd_order.front());
-    g_wd_order.erase(g_wd_order.begin());
-  }
-}
-
-// true: every filter of the flag's batch has been launched (now or earlier); false: the batch is gone -- the caller
-// produces its own filter
-bool ensure_wd(const Tensor& flag) {
-  std::shared_ptr<WdBatch> b;
-  {
-    std::lock_guard<std::mutex> lock(g_wd_mu);
-    if (flag.data_ptr<int64_t>()[0] != 0) return true;
-    auto it = g_wd_batches.find(flag.data_ptr());
-    if (it == g_wd_batches.end()) return false;
-    b = it->second;
-    g_wd_batches.erase(it);
-    for (size_t i = 0; i < g_wd_order.size(); ++i)
-      if (g_wd_order[i] == flag.data_ptr()) { g_wd_order.erase(g_wd_order.begin() + i); break; }
-    flag.data_ptr<int64_t>()[0] = 1;
-  }
-  {
-    const size_t nb = b->wd.size();
-    std::vector<const float*> p5(nb), p3(nb), p1(nb), pa3(nb), pa5(nb), pgw(nb), pgb(nb);
-    std::vector<float*> pg(nb, nullptr);
-    std::vector<void*> pwf(nb, nullptr), pwd(nb);
-    for (size_t i = 0; i < nb; ++i) {
-      p5[i] = b->k5[i].data_ptr<float>(); p3[i] = b->k3[i].data_ptr<float>(); p1[i] = b->k1[i].data_ptr<float>();
-      pa3[i] = b->a3[i].data_ptr<float>(); pa5[i] = b->a5[i].data_ptr<float>();
-      pgw[i] = b->gw[i].data_ptr<float>(); pgb[i] = b->gb[i].data_ptr<float>();
-      pwd[i] = b->wd[i].data_ptr();
-    }
-    for (size_t b0 = 0; b0 < nb; b0 += REPMODE_GATREP_MULTI_MAX) {
-      const int cnt = (int)std::min<size_t>(REPMODE_GATREP_MULTI_MAX, nb - b0);
-      RM_CALL(repmode_gatrep_fwd_multi, cnt, p5.data() + b0, p3.data() + b0, p1.data() + b0, pa3.data() + b0, pa5.data() + b0, pgw.data() + b0,
-              pgb.data() + b0, b->co.data() + b0, b->ci.data() + b0, b->slot_task.data_ptr<int32_t>(), (int)b->nslots, (int)b->num_tasks, b->code,
-              pg.data() + b0, pwf.data() + b0, pwd.data() + b0, stream_handle());
-    }
-  }
-  {
-    const size_t nb = b->xwd.size();
-    std::vector<const float*> x5(nb), x3(nb);
-    std::vector<void*> xwf(nb, nullptr), xwd(nb);
-    for (size_t i = 0; i < nb; ++i) { x5[i] = b->x5[i].data_ptr<float>(); x3[i] = b->x3[i].data_ptr<float>(); xwd[i] = b->xwd[i].data_ptr(); }
-    for (size_t b0 = 0; b0 < nb; b0 += REPMODE_GATREP_MULTI_MAX) {
-      const int cnt = (int)std::min<size_t>(REPMODE_GATREP_MULTI_MAX, nb - b0);
-      RM_CALL(repmode_expert_frags_multi, cnt, x5.data() + b0, x3.data() + b0, b->xco.data() + b0, b->xci.data() + b0, xwf.data() + b0,
-              xwd.data() + b0, stream_handle());
-    }
-  }
-  return true;
-}
 
 // Filters prepared ahead of the forward pass on the `prep` stream (op prepare_filters): they depend on the parameters and
 // the batch's tasks only, not on activations, so all 19 blocks' gate softmax + GatRep (or expert layout) launches are
@@ -674,7 +593,6 @@ bool ensure_wd(const Tensor& flag) {
 // behind the entry's event) or, when there is none that fits, computes the filters itself.
 struct PrepEntry {
   Tensor g, wf, wd;
-  Tensor wd_flag;            // defined: wd is allocated but produced where the backward pass starts (WdBatch)
   hipEvent_t ev = nullptr;
   int64_t rows = 0;          // slots (merged) or samples (per-expert)
   at::ScalarType dt = at::kFloat;
@@ -699,7 +617,6 @@ bool take_prepared(const Tensor& k5, int64_t rows, at::ScalarType dt, bool unmer
   out->g = e.g;
   out->wf = e.wf;
   out->wd = want_wd ? e.wd : Tensor();
-  out->wd_flag = want_wd ? e.wd_flag : Tensor();
   return true;
 }
 // fold_scale (eval only): per-output-channel factor gamma / sqrt(running_var + eps) of the BatchNorm behind the block; it
@@ -759,18 +676,6 @@ std::vector<Tensor> filter_and_expert_grads(const Tensor& dw, const Tensor& k5, 
 // ------------------------------------------------------------------------------------------------------------
 // autograd nodes.  Input order of every MoDE function: activations first, then k5 k3 k1 a3 a5 gate_w gate_b.
 
-// A merged block's data-gradient filter before its backward pass uses it: launched with the rest of its step's (ensure_wd),
-// or -- the step's batch is gone -- by this block alone from its saved gate probabilities.
-void merged_wd_ready(AutogradContext* ctx, const Tensor& wd, const Tensor& k5, const Tensor& k3, const Tensor& k1, const Tensor& a3,
-                     const Tensor& a5, const Tensor& g) {
-  auto it = ctx->saved_data.find("wd_flag");
-  if (it == ctx->saved_data.end() || !wd.defined()) return;
-  if (ensure_wd(it->second.toTensor())) return;
-  RM_CALL(repmode_gatrep_fwd, k5.data_ptr<float>(), k3.data_ptr<float>(), k1.data_ptr<float>(), a3.data_ptr<float>(), a5.data_ptr<float>(),
-          g.data_ptr<float>(), (int)g.size(0), (int)k5.size(0), (int)k5.size(1), dtype_code(wd.scalar_type()), nullptr, wd.data_ptr(),
-          stream_handle());
-}
-
 // Fused gate-softmax + GatRep + per-slot 5^3 convolution (the "merged" formulation), forward and backward.
 struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
   static Tensor forward(AutogradContext* ctx, Tensor x_cl, Tensor k5, Tensor k3, Tensor k1, Tensor a3, Tensor a5, Tensor gw, Tensor gb,
@@ -797,7 +702,6 @@ struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
     ctx->saved_data["sample_slot"] = plan.sample_slot;
     ctx->saved_data["nslots"] = plan.nslots;
     ctx->saved_data["num_tasks"] = plan.num_tasks;
-    if (m.wd_flag.defined()) ctx->saved_data["wd_flag"] = m.wd_flag;
     return y;
   }
 
@@ -806,7 +710,6 @@ struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
     auto sv = ctx->get_saved_variables();
     const Tensor &x_cl = sv[0], &k5 = sv[1], &k3 = sv[2], &k1 = sv[3], &a3 = sv[4], &a5 = sv[5], &g = sv[6];
     Tensor wd = sv[7];
-    merged_wd_ready(ctx, wd, k5, k3, k1, a3, a5, g);
     Plan plan;
     plan.slot_task = ctx->saved_data["slot_task"].toTensor();
     plan.sample_slot = ctx->saved_data["sample_slot"].toTensor();
@@ -881,7 +784,6 @@ struct ModeConvPair : public torch::autograd::Function<ModeConvPair> {
     ctx->saved_data["sample_slot"] = plan.sample_slot;
     ctx->saved_data["nslots"] = plan.nslots;
     ctx->saved_data["num_tasks"] = plan.num_tasks;
-    if (m.wd_flag.defined()) ctx->saved_data["wd_flag"] = m.wd_flag;
     return y;
   }
 
@@ -890,7 +792,6 @@ struct ModeConvPair : public torch::autograd::Function<ModeConvPair> {
     auto sv = ctx->get_saved_variables();
     const Tensor &xa = sv[0], &xb = sv[1], &k5 = sv[2], &k3 = sv[3], &k1 = sv[4], &a3 = sv[5], &a5 = sv[6], &g = sv[7];
     Tensor wd = sv[8];
-    merged_wd_ready(ctx, wd, k5, k3, k1, a3, a5, g);
     Plan plan;
     plan.slot_task = ctx->saved_data["slot_task"].toTensor();
     plan.sample_slot = ctx->saved_data["sample_slot"].toTensor();
@@ -982,11 +883,9 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     Tensor gn;                                                                            // g per SAMPLE [N, 5, Co]
     std::pair<Tensor, Tensor> fr;
     Merged pm;
-    Tensor wd_flag;
     if (take_prepared(k5, plan.n, x_cl.scalar_type(), true, need_dx, &pm)) {
       gn = pm.g.defined() ? pm.g : gate_softmax(gw, gb, plan.sample_task, plan.n, plan.num_tasks, co);
       fr = {pm.wf, pm.wd};
-      wd_flag = pm.wd_flag;
     } else {
       gn = gate_softmax(gw, gb, plan.sample_task, plan.n, plan.num_tasks, co);
       fr = expert_frags(k5, k3, x_cl.scalar_type(), need_dx);
@@ -1027,7 +926,6 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     ctx->save_for_backward({x_cl, k5, k3, k1, a3, a5, gn, xb, p, fr.second.defined() ? fr.second : Tensor()});
     ctx->saved_data["sample_task"] = plan.sample_task;
     ctx->saved_data["num_tasks"] = plan.num_tasks;
-    if (wd_flag.defined()) ctx->saved_data["wd_flag"] = wd_flag;
     return y;
   }
 
@@ -1036,12 +934,6 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     auto sv = ctx->get_saved_variables();
     const Tensor &x_cl = sv[0], &k5 = sv[1], &k3 = sv[2], &k1 = sv[3], &a3 = sv[4], &a5 = sv[5], &gn = sv[6], &xb = sv[7], &p = sv[8];
     Tensor wd2 = sv[9];
-    {
-      auto it = ctx->saved_data.find("wd_flag");
-      if (it != ctx->saved_data.end() && wd2.defined() && !ensure_wd(it->second.toTensor()))
-        RM_CALL(repmode_expert_frags, k5.data_ptr<float>(), k3.data_ptr<float>(), (int)k5.size(0), (int)k5.size(1), nullptr, wd2.data_ptr(),
-                stream_handle());
-    }
     const Tensor sample_task = ctx->saved_data["sample_task"].toTensor();
     const int64_t num_tasks = ctx->saved_data["num_tasks"].toInt();
     const int64_t co = k5.size(0), ci = k5.size(1);
@@ -1529,18 +1421,6 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
     // launch (repmode_gatrep_fwd_multi); the per-expert blocks lay their experts out themselves
     Plan plan = make_plan(slot_task, sample_slot, sample_task, nslots, num_tasks, training, 0);
     const int code = dtype_code(dt);
-    // the data-gradient filters: allocated here, launched where the backward pass starts (WdBatch)
-    const bool lazy = g_wd_lazy && training;
-    Tensor wd_flag;
-    std::shared_ptr<WdBatch> batch;
-    if (lazy) {
-      wd_flag = at::zeros({1}, at::TensorOptions().dtype(at::kLong).device(at::kCPU));
-      batch = std::make_shared<WdBatch>();
-      batch->slot_task = plan.slot_task;
-      batch->nslots = plan.nslots;
-      batch->num_tasks = plan.num_tasks;
-      batch->code = code;
-    }
     std::vector<const float*> p5, p3, p1, pa3, pa5, pgw, pgb;
     std::vector<float*> pg;
     std::vector<void*> pwf, pwd;
@@ -1567,13 +1447,8 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
         e.rows = plan.n;
         e.wf = at::empty({2, TAPS, padded(co, code, false), padded(ci, code, true)}, K5.options().dtype(dt));
         if (need_dx[i]) e.wd = at::empty({2, TAPS, padded(ci, code, false), padded(co, code, true)}, K5.options().dtype(dt));
-        if (lazy && e.wd.defined()) {
-          e.wd_flag = wd_flag;
-          batch->x5.push_back(K5); batch->x3.push_back(K3); batch->xwd.push_back(e.wd);
-          batch->xco.push_back((int)co); batch->xci.push_back((int)ci);
-        }
         x5.push_back(K5.data_ptr<float>()); x3.push_back(K3.data_ptr<float>());
-        xwf.push_back(e.wf.data_ptr()); xwd.push_back((e.wd.defined() && !lazy) ? e.wd.data_ptr() : nullptr);
+        xwf.push_back(e.wf.data_ptr()); xwd.push_back(e.wd.defined() ? e.wd.data_ptr() : nullptr);
         xco.push_back((int)co); xci.push_back((int)ci);
         xe.push_back(e); xk.push_back(K5.data_ptr());
       }
@@ -1598,16 +1473,10 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
       e.g = at::empty({plan.nslots, E, co}, t[0].options());
       e.wf = at::empty({plan.nslots, TAPS, padded(co, code, false), padded(ci, code, true)}, t[0].options().dtype(dt));
       if (need_dx[i]) e.wd = at::empty({plan.nslots, TAPS, padded(ci, code, false), padded(co, code, true)}, t[0].options().dtype(dt));
-      if (lazy && e.wd.defined()) {
-        e.wd_flag = wd_flag;
-        batch->k5.push_back(t[0]); batch->k3.push_back(t[1]); batch->k1.push_back(t[2]); batch->a3.push_back(t[3]); batch->a5.push_back(t[4]);
-        batch->gw.push_back(t[5]); batch->gb.push_back(t[6]); batch->wd.push_back(e.wd);
-        batch->co.push_back((int)co); batch->ci.push_back((int)ci);
-      }
       p5.push_back(t[0].data_ptr<float>()); p3.push_back(t[1].data_ptr<float>()); p1.push_back(t[2].data_ptr<float>());
       pa3.push_back(t[3].data_ptr<float>()); pa5.push_back(t[4].data_ptr<float>());
       pgw.push_back(t[5].data_ptr<float>()); pgb.push_back(t[6].data_ptr<float>());
-      pg.push_back(e.g.data_ptr<float>()); pwf.push_back(e.wf.data_ptr()); pwd.push_back((e.wd.defined() && !lazy) ? e.wd.data_ptr() : nullptr);
+      pg.push_back(e.g.data_ptr<float>()); pwf.push_back(e.wf.data_ptr()); pwd.push_back(e.wd.defined() ? e.wd.data_ptr() : nullptr);
       cos.push_back((int)co); cis.push_back((int)ci);
       ents.push_back(e);
       keys.push_back(t[0].data_ptr());
@@ -1618,7 +1487,6 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
               pgw.data() + b0, pgb.data() + b0, cos.data() + b0, cis.data() + b0, plan.slot_task.data_ptr<int32_t>(), (int)plan.nslots,
               (int)plan.num_tasks, code, pg.data() + b0, pwf.data() + b0, pwd.data() + b0, stream_handle());
     }
-    if (lazy && (!batch->wd.empty() || !batch->xwd.empty())) register_wd_batch(wd_flag, batch);
     std::lock_guard<std::mutex> lock(g_prep_mu);
     for (size_t i = 0; i < ents.size(); ++i) g_prep[keys[i]] = ents[i];
     return;
@@ -1686,7 +1554,6 @@ void op_set_bn_epilogue(int64_t mask) { g_bn_epilogue = mask; }
 void op_set_unmerged_max_w(int64_t w) { g_unmerged_max_w = w; }
 void op_set_dual_launch(bool on) { g_dual_launch = on; }
 void op_set_deep_conv(bool on) { g_deep = on; }
-void op_set_wd_lazy(bool on) { g_wd_lazy = on; }
 void op_set_deep_fwd_min(int64_t v) { g_deep_fwd_min = v; }
 void op_set_thin_kernels(bool on) { g_thin = on; }
 bool op_get_deep_conv() { return g_deep; }
@@ -1782,7 +1649,6 @@ TORCH_LIBRARY(repmode, m) {
   m.def("set_unmerged_max_w(int w) -> ()", &rm::op_set_unmerged_max_w);
   m.def("set_dual_launch(bool on) -> ()", &rm::op_set_dual_launch);
   m.def("set_deep_conv(bool on) -> ()", &rm::op_set_deep_conv);
-  m.def("set_wd_lazy(bool on) -> ()", &rm::op_set_wd_lazy);
   m.def("set_deep_fwd_min(int v) -> ()", &rm::op_set_deep_fwd_min);
   m.def("set_thin_kernels(bool on) -> ()", &rm::op_set_thin_kernels);
   m.def("get_deep_conv() -> bool", &rm::op_get_deep_conv);

@@ -108,12 +108,6 @@ def get_deep_conv():
     return bool(torch_ops().get_deep_conv())
 
 
-def set_wd_lazy(on):
-    """A training step's data-gradient filters (wd) are allocated by ``prepare_filters`` and produced by ONE launch where the
-    backward pass starts (default) instead of next to the forward filters in the forward pass's launch (REPMODE_WD_LAZY=0)."""
-    torch_ops().set_wd_lazy(bool(on))
-
-
 def set_thin_kernels(on):
     """The one-channel first / last layers through their own kernels (csrc/thin_conv.hip; default) or round 2's fold of the x
     taps around the general kernel (REPMODE_THIN=0).  The operator library's switch (the ``thin_conv_*`` wrappers here
@@ -327,6 +321,17 @@ def conv5_deep(x_cl, w2, cout, two_in=False, out=None, zeroed=False):
         assert tuple(y.shape) == shape and y.dtype == torch.float32 and y.is_contiguous()
     _lib.call('repmode_conv5_deep', _ptr(x_cl), _ptr(w2), _ptr(y), n, d, h, wd_, cin, cout,
               (1 if two_in else 0) | (2 if zeroed else 0), _stream())
+    return y
+
+
+def conv5_merged(x_cl, w2, k1, a3, a5, g, sample_slot, cout):
+    """EXPERIMENT (not on the product path): the forward conv of a merged-formulation block with GatRep inside the kernel --
+    ``w2`` = ``expert_frags``' two un-merged slots, ``k1 / a3 / a5`` the 1x1 experts' parameters, ``g`` [S, 5, Co] the gate
+    probabilities.  bf16 in, float out."""
+    n, d, h, wd_, cin = x_cl.shape
+    y = torch.empty((n, d, h, wd_, cout), dtype=torch.float32, device=x_cl.device)
+    _lib.call('repmode_conv5_merged', _ptr(x_cl), _ptr(w2), _ptr(k1), _ptr(a3), _ptr(a5), _ptr(g), _ptr(sample_slot), _ptr(y),
+              n, d, h, wd_, cin, cout, 0, _stream())
     return y
 
 
