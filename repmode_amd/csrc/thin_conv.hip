@@ -49,8 +49,9 @@ struct ThinInArgs {
 };
 
 template <bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void thin_in1_kernel(ThinInArgs a) {
+__global__ __launch_bounds__(256, 3) void thin_in1_kernel(ThinInArgs a) {
   __shared__ __attribute__((aligned(16))) bf16_t tile[2][TH_ELEMS];
+  __shared__ u32x4 filt[TIN_KSTEPS][64];        // the current slot's filter fragments, lane-major (15 KB): see the K mapping
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int khalf = lane >> 5, l31 = lane & 31;
   const int D = a.D, H = a.H, W = a.W, Cout = a.Cout;
@@ -94,7 +95,6 @@ __global__ __launch_bounds__(256, 2) void thin_in1_kernel(ThinInArgs a) {
   };
 
   for (int rt = 0; rt < nrt; ++rt) {          // (one output-channel tile of 32 at a time: the first layer has exactly one)
-    u32x4 af[TIN_KSTEPS];
     int slot_loaded = -1;
     bf16_t stage[TIN_STAGE];
     __syncthreads();                          // (pads zeroed / the previous tile's reads finished)
@@ -108,27 +108,27 @@ __global__ __launch_bounds__(256, 2) void thin_in1_kernel(ThinInArgs a) {
       const bool more = b + 1 < b_end;
       if (more) load_halo(b + 1, stage);      // the next brick's halo travels while this one is multiplied
       const int slot = a.sample_slot[n];
-      if (slot != slot_loaded) {
-        // filter fragments of this slot: element i = dx (5 real of 8).  (The opaque offset keeps the 75 tap addresses
-        // inside this block: computed up front they are loop invariants that cost 150 registers for the whole brick loop.)
-        const bf16_t* ws = a.w + (size_t)slot * REPMODE_TAPS * nrt * 512;
-        uint32_t lane_off = (uint32_t)(rt * 512 + l31 * 16);
-        asm volatile("" : "+v"(lane_off));
+      if (slot != slot_loaded) {              // (workgroup-uniform: every wave works on the same brick)
+        // this slot's filter fragments into LDS, by all 256 threads: fragment (step j, lane L): element i = dx (5 real of 8)
+        // of tap row (dz, dy).  Nobody reads `filt` here: the loop's closing barrier is behind every wave.
+        const bf16_t* ws = a.w + ((size_t)slot * REPMODE_TAPS * nrt + rt) * 512;
         const uint32_t tap_elems = (uint32_t)nrt * 512u;
-#pragma unroll
-        for (int j = 0; j < TIN_KSTEPS; ++j) {
+        for (int f = tid; f < TIN_KSTEPS * 64; f += 256) {
+          const int j = f >> 6, L = f & 63, kh = L >> 5;
           const int dz0 = j < 10 ? j / 5 : 4, dy = j < 10 ? j % 5 : j - 10;
-          const int dz = dz0 + 2 * khalf;
+          const int dz = dz0 + 2 * kh;
           uint32_t e[5] = {0u, 0u, 0u, 0u, 0u};
           if (dz < 5) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) e[i] = ws[lane_off + (uint32_t)((dz * 5 + dy) * 5 + i) * tap_elems];
+            for (int i = 0; i < 5; ++i) e[i] = ws[(uint32_t)((L & 31) * 16) + (uint32_t)((dz * 5 + dy) * 5 + i) * tap_elems];
           }
-          af[j] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4], 0u};
+          filt[j][L] = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4], 0u};
         }
         slot_loaded = slot;
+        __syncthreads();
       }
-      // ---- 13 K steps x 4 row segments (wave = z plane, segment = y row) of Toeplitz fragments
+      // ---- 15 K steps x 4 row segments (wave = z plane, segment = y row) of Toeplitz fragments, software-pipelined: the
+      // next step's filter fragment and raw dwords are requested before this step's MFMAs
       f32x16 acc[TB_Y];
 #pragma unroll
       for (int vs = 0; vs < TB_Y; ++vs)
@@ -136,19 +136,38 @@ __global__ __launch_bounds__(256, 2) void thin_in1_kernel(ThinInArgs a) {
         for (int r = 0; r < 16; ++r) acc[vs][r] = 0.f;
       const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile[buf]) + ((wave + 2 * khalf) * TH_Y) * (TH_PITCH / 2) + (l31 >> 1);
       const int sh = (l31 & 1) * 16;
-#pragma unroll
-      for (int j = 0; j < TIN_KSTEPS; ++j) {
+      auto load_raw = [&](int j, uint32_t (&raw)[TB_Y][5]) {
         const int dz0 = j < 10 ? j / 5 : 4, dy = j < 10 ? j % 5 : j - 10;
 #pragma unroll
         for (int vs = 0; vs < TB_Y; ++vs) {
           const int dw = (dz0 * TH_Y + vs + dy) * (TH_PITCH / 2);        // compile-time
-          const uint32_t d0 = t32[dw], d1 = t32[dw + 1], d2 = t32[dw + 2], d3 = t32[dw + 3], d4 = t32[dw + 4];
-          const u32x4 bf = u32x4{__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
-                                 __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh)};
-          acc[vs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[j]), __builtin_bit_cast(bf16x8, bf), acc[vs], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 5; ++i) raw[vs][i] = t32[dw + i];
         }
-        // (fence: left alone, the scheduler hoists the dword reads of all steps above the first MFMA)
-        if (j & 1) __builtin_amdgcn_sched_barrier(0);
+      };
+      u32x4 a_cur = filt[0][lane], a_nxt = a_cur;
+      uint32_t raw_cur[TB_Y][5], raw_nxt[TB_Y][5];
+      load_raw(0, raw_cur);
+#pragma unroll
+      for (int j = 0; j < TIN_KSTEPS; ++j) {
+        if (j + 1 < TIN_KSTEPS) {
+          a_nxt = filt[j + 1][lane];
+          load_raw(j + 1, raw_nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int vs = 0; vs < TB_Y; ++vs) {
+          const uint32_t* d = raw_cur[vs];
+          const u32x4 bf = u32x4{__builtin_amdgcn_alignbit(d[1], d[0], sh), __builtin_amdgcn_alignbit(d[2], d[1], sh),
+                                 __builtin_amdgcn_alignbit(d[3], d[2], sh), __builtin_amdgcn_alignbit(d[4], d[3], sh)};
+          acc[vs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur), __builtin_bit_cast(bf16x8, bf), acc[vs], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int vs = 0; vs < TB_Y; ++vs)
+#pragma unroll
+          for (int i = 0; i < 5; ++i) raw_cur[vs][i] = raw_nxt[vs][i];
       }
       // ---- epilogue: rows = output channels (4 consecutive per register quad), column = this lane's voxel
       const int gz = z0 + wave, gx = x0 + l31;
