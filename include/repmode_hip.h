@@ -292,7 +292,9 @@ int repmode_k2s2(const void* in, const void* w, void* out, int n, int d, int h, 
 int repmode_k2s2_wgrad(const void* coarse, const void* fine, float* dw, int n, int d, int h, int wdim, int ca,
                        int cb, void* stream);
 /* Same with the output written in the parameter's own layout (no permute copy afterwards):
- * param_layout 0: dw[8][A][B]; 1: dw[A][B][2][2][2]; 2: dw[B][A][2][2][2]. */
+ * param_layout bits 0-1: 0: dw[8][A][B]; 1: dw[A][B][2][2][2]; 2: dw[B][A][2][2][2].  Bit 2 (4): dw is zero already (the
+ * voxel range is split over workgroups that add with float atomics); bit 3 (8): coarse and fine are FLOAT32 tensors (the
+ * parity mode: exact float32 FMAs instead of the bf16 MFMA kernel). */
 int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float* dw, int n, int d, int h, int wdim, int ca,
                           int cb, int param_layout, void* stream);
 /* The fragment-major, zero-padded filter operand `w` of repmode_k2s2 from a float parameter tensor, one launch:

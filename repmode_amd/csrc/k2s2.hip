@@ -303,6 +303,67 @@ __global__ __launch_bounds__(256) void k2s2_wgrad_kernel(K2WArgs a) {
   }
 }
 
+// The same filter gradient for float32 tensors (the parity mode; round 2 used a library GEMM on gathered patches here, so
+// the float32 goldens never ran this build's own stride-2 filter gradient).  Exact float32 FMAs on the vector units: a
+// workgroup owns a 32 x 32 (a, b) tile of ONE tap and a chunk of the voxel range, stages 32 voxel rows of both tensors in
+// LDS and every thread accumulates a 2 x 2 patch.  Not a fast path: float32 is 1/16 of the bf16 rate everywhere.
+struct K2WArgsF {
+  const float* coarse;
+  const float* fine;
+  float* dw;
+  int param_layout;
+  long M;
+  int d, h, wd, A, B, rows_per_block;
+};
+
+__global__ __launch_bounds__(256) void k2s2_wgrad_f32_kernel(K2WArgsF a) {
+  __shared__ float sc[32][33], sf[32][33];
+  const int tid = threadIdx.x;
+  const int nbt = (a.B + 31) / 32;
+  const int at = blockIdx.y / nbt, bt = blockIdx.y % nbt, p = blockIdx.z;
+  const int ta = tid >> 4, tb = tid & 15;                 // this thread's outputs: a = 2 ta + {0,1}, b = 2 tb + {0,1}
+  const int lr = tid >> 3, lc = (tid & 7) * 4;            // staging: row lr, 4 consecutive channels from lc
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  const long m_begin = (long)blockIdx.x * a.rows_per_block, m_end = min(a.M, m_begin + a.rows_per_block);
+  for (long m0 = m_begin; m0 < m_end; m0 += 32) {
+    const long m = m0 + lr;
+    float vc[4] = {0.f, 0.f, 0.f, 0.f}, vf[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m < m_end) {
+      const float* cr = a.coarse + (size_t)m * a.A;
+      const float* fr = a.fine + fine_row(m, p, a.d, a.h, a.wd) * a.B;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ca = at * 32 + lc + k, cb = bt * 32 + lc + k;
+        if (ca < a.A) vc[k] = cr[ca];
+        if (cb < a.B) vf[k] = fr[cb];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sc[lr][lc + k] = vc[k]; sf[lr][lc + k] = vf[k]; }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const float a0 = sc[k][2 * ta], a1 = sc[k][2 * ta + 1], b0 = sf[k][2 * tb], b1 = sf[k][2 * tb + 1];
+      acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
+      acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int arow = at * 32 + 2 * ta + i, bcol = bt * 32 + 2 * tb + j;
+      if (arow < a.A && bcol < a.B) {
+        const size_t o = a.param_layout == 0 ? ((size_t)p * a.A + arow) * a.B + bcol
+                       : a.param_layout == 1 ? ((size_t)arow * a.B + bcol) * 8 + p
+                                             : ((size_t)bcol * a.A + arow) * 8 + p;
+        if (gridDim.x == 1) a.dw[o] = acc[i][j];
+        else unsafeAtomicAdd(a.dw + o, acc[i][j]);
+      }
+    }
+}
+
 }  // namespace
 
 // dw[8][A][B] (float, overwritten) = sum_m coarse[m][a] * fine[fine(m,p)][b].  coarse: [N][d][h][w][A] bf16,
@@ -321,11 +382,29 @@ extern "C" int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float
                                      int ca, int cb, int param_layout, void* stream) {
   RM_REQUIRE(coarse && fine && dw, "k2s2_wgrad: null pointer");
   const int prezeroed = param_layout & 4;        // bit 2: dw has been cleared by the caller
+  const int is_f32 = param_layout & 8;           // bit 3: coarse and fine are float32 tensors (parity mode)
   param_layout &= 3;
   RM_REQUIRE(param_layout >= 0 && param_layout <= 2, "k2s2_wgrad: bad layout %d", param_layout);
   RM_REQUIRE(n > 0 && d > 0 && h > 0 && wdim > 0 && ca > 0 && cb > 0, "k2s2_wgrad: bad shape");
   RM_REQUIRE(((uintptr_t)coarse & 15) == 0 && ((uintptr_t)fine & 15) == 0, "k2s2_wgrad: pointers must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (is_f32) {
+    K2WArgsF f{};
+    f.coarse = static_cast<const float*>(coarse); f.fine = static_cast<const float*>(fine); f.dw = dw;
+    f.param_layout = param_layout;
+    f.M = (long)n * d * h * wdim; f.d = d; f.h = h; f.wd = wdim; f.A = ca; f.B = cb;
+    const int tiles = ceil_div(ca, 32) * ceil_div(cb, 32);
+    long chunks = (K2W_TARGET_BLOCKS + 8L * tiles - 1) / (8L * tiles);      // enough workgroups to fill the chip
+    const long max_chunks = (f.M + 31) / 32;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    f.rows_per_block = (int)(((f.M + chunks - 1) / chunks + 31) / 32 * 32);
+    const int nchunks_f = (int)((f.M + f.rows_per_block - 1) / f.rows_per_block);
+    if (!prezeroed && nchunks_f > 1) RM_HIP(hipMemsetAsync(dw, 0, (size_t)8 * ca * cb * sizeof(float), s));
+    hipLaunchKernelGGL(k2s2_wgrad_f32_kernel, dim3(nchunks_f, tiles, 8), dim3(256), 0, s, f);
+    RM_LAUNCH_CHECK("k2s2_wgrad_f32");
+    return REPMODE_OK;
+  }
   K2WArgs a{};
   a.coarse = static_cast<const bf16_t*>(coarse); a.fine = static_cast<const bf16_t*>(fine); a.dw = dw;
   a.param_layout = param_layout;

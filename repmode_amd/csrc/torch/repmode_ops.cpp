@@ -1104,20 +1104,18 @@ Tensor k2s2(const Tensor& in_cl, const Tensor& w_frag, int64_t cout, bool scatte
 Tensor k2s2_wgrad_param(const Tensor& coarse_cl, const Tensor& fine_cl) {
   const int64_t n = coarse_cl.size(0), d = coarse_cl.size(1), h = coarse_cl.size(2), w = coarse_cl.size(3), ca = coarse_cl.size(4);
   const int64_t cb = fine_cl.size(4);
-  if (coarse_cl.scalar_type() == at::kBFloat16) {
-    // the kernel accumulates tap-major (atomics into the parameter layout, 32-byte stride, measured 5x slower); one small
-    // transpose launch behind it
-    auto tk = g_pool.take({8, ca, cb}, coarse_cl);
-    RM_CALL(repmode_k2s2_wgrad_ex, coarse_cl.data_ptr(), fine_cl.data_ptr(), tk.first.data_ptr<float>(), (int)n, (int)d, (int)h, (int)w,
-            (int)ca, (int)cb, tk.second ? 4 : 0, stream_handle());
-    Tensor dw = at::empty({ca, cb, 2, 2, 2}, coarse_cl.options().dtype(at::kFloat));
-    RM_CALL(repmode_tap_transpose, tk.first.data_ptr<float>(), dw.data_ptr<float>(), (long)(ca * cb), 8, stream_handle());
-    return dw;
-  }
-  // float32 (parity mode only): a library GEMM on gathered patches
-  Tensor g = fine_cl.view({n, d, 2, h, 2, w, 2, cb}).permute({0, 1, 3, 5, 2, 4, 6, 7}).reshape({-1, 8 * cb});   // [M, 8*B]
-  Tensor dw8 = at::matmul(coarse_cl.view({-1, ca}).t(), g).view({ca, 8, cb}).permute({1, 0, 2});             // [8, A, B]
-  return dw8.view({2, 2, 2, ca, cb}).permute({3, 4, 0, 1, 2}).contiguous();
+  // the kernel accumulates tap-major (atomics into the parameter layout, 32-byte stride, measured 5x slower); one small
+  // transpose launch behind it.  bf16: MFMA on LDS-transposed operands; float32 (parity mode): exact-f32 FMAs -- both this
+  // build's own kernels (csrc/k2s2.hip), so the float32 goldens verify the same code path shape.
+  const bool f32 = coarse_cl.scalar_type() == at::kFloat;
+  auto tk = g_pool.take({8, ca, cb}, coarse_cl);
+  Tensor acc8 = tk.first;
+  const bool zero = tk.second;
+  RM_CALL(repmode_k2s2_wgrad_ex, coarse_cl.data_ptr(), fine_cl.data_ptr(), acc8.data_ptr<float>(), (int)n, (int)d, (int)h, (int)w, (int)ca,
+          (int)cb, (zero ? 4 : 0) | (f32 ? 8 : 0), stream_handle());
+  Tensor dw = at::empty({ca, cb, 2, 2, 2}, coarse_cl.options().dtype(at::kFloat));
+  RM_CALL(repmode_tap_transpose, acc8.data_ptr<float>(), dw.data_ptr<float>(), (long)(ca * cb), 8, stream_handle());
+  return dw;
 }
 
 // Conv3d(C, C, kernel_size=2, stride=2, bias=False) on channels-last data (RepMode.py:81)

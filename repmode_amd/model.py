@@ -56,7 +56,7 @@ def patch_grid(img_size, patch_size, overlap=0.5):
 
 class Model(object):
     def __init__(self, opts, nn_module='RepMode', init_weights=True, lr=0.001, criterion_fn=torch.nn.MSELoss,
-                 gpu_ids=0, mult_chan=32, dtype=torch.bfloat16, distributed=False, hip_graph=False):
+                 gpu_ids=0, mult_chan=32, dtype=torch.bfloat16, distributed=False, hip_graph=False, grad_compress=None):
         self.opts = opts
         self.nn_module = nn_module
         self.lr = lr
@@ -70,6 +70,8 @@ class Model(object):
         self.mult_chan = mult_chan
         self.dtype = dtype
         self.distributed = distributed
+        # grad_compress='bf16' (or REPMODE_GRAD_COMPRESS=bf16): the gradient buckets cross the links as bfloat16
+        self.grad_compress = grad_compress or os.environ.get('REPMODE_GRAD_COMPRESS') or None
         # hip_graph: replay the whole train step (forward, backward, Adam: ~415 launches, 13 ms of host time) as ONE
         # HIP graph per (input shape, number of distinct tasks) -- see _graph_train_iter.  Single-GPU training only.
         self.hip_graph = bool(hip_graph)
@@ -97,9 +99,10 @@ class Model(object):
         if self.distributed in ('reducer', 'reducer-always'):
             # gradients are produced inside the communication buckets and averaged under backward (distributed.py);
             # measured equal to the stock wrapper on one rank, not yet run on eight -> opt-in
-            self.reducer = dist_.GradReducer(self.net, always_reduce=self.distributed == 'reducer-always')
+            self.reducer = dist_.GradReducer(self.net, always_reduce=self.distributed == 'reducer-always',
+                                             comm_dtype=torch.bfloat16 if self.grad_compress == 'bf16' else None)
         elif self.distributed:
-            self.ddp = dist_.wrap_ddp(self.net, self.device)
+            self.ddp = dist_.wrap_ddp(self.net, self.device, grad_compress=self.grad_compress)
         # process-wide (one training process per GPU): where the MoDE gradient kernels put the parameter gradients
         ops_.set_grad_sink(self.reducer)
         try:
