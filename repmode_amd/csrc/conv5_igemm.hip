@@ -242,6 +242,28 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
   const int c_end = (int)((long)(kz + 1) * nchunks / a.ksplit);
   const bool vec_ok = (Cin % KV) == 0;
 
+#ifdef RM_CONV_DMA
+  // Experiment (REPMODE_EXTRA_FLAGS=-DRM_CONV_DMA), measured and OFF: same box, interleaved, us per launch register path /
+  // LDS-DMA: 32->32 (level 0) 224.9 / 232.1, 64->32 457.8 / 488.8, 64->64 (level 1) 112.9 / 116.0, 128->64 216.9 / 223.7,
+  // level 2 float output 81.4 / 83.5 -- correct (zeros outside the volume included: the whole parity suite passes on it),
+  // but a 16-byte-per-lane gather through the DMA path moves fewer bytes per clock than the two register batches.
+  // LDS-DMA staging (buffer_load_dwordx4 ... lds): a wave instruction moves 64 halo voxels' 16-byte channel groups from
+  // global memory straight into 64 consecutive slots of one plane of the image -- no VGPR round trip, no ds_write pass, all
+  // of a wave's instructions of a chunk in flight together (the register path took two dependent batches).  Wave w fills
+  // plane w & 1, segments (w >> 1) + (NT / 128) k.  Per lane only the voxel index of each segment is kept (chunk invariant);
+  // positions outside the volume get an out-of-range offset: the buffer load returns zeros for them.
+  static_assert(VH % 64 == 0 && (NT / 64) % 2 == 0 && (VH / 64) % (NT / 128) == 0, "LDS-DMA staging: whole wave instructions per plane");
+  constexpr int DMA_K = (VH / 64) / (NT / 128);          // instructions per wave per chunk
+  int dma_vox[DMA_K];
+#pragma unroll
+  for (int k = 0; k < DMA_K; ++k) {
+    const int vh = ((wave >> 1) + (NT / 128) * k) * 64 + lane;
+    const int xx = vh % BXH, t2 = vh / BXH;
+    const int yy = t2 % BYH, zz = t2 / BYH;
+    const int gz = z0 + zz - 2, gy = y0 + yy - 2, gx = x0 + xx - 2;
+    dma_vox[k] = ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? (gz * H + gy) * W + gx : -1;
+  }
+#endif
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     const int ci0 = chunk * KC;
     // The first filter row of the chunk is requested before the halo staging, not behind its barrier: the two
@@ -266,37 +288,61 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
     const int csrc = Cin1 > 0 ? (from2 ? Cin - Cin1 : Cin1) : Cin;     // channel stride of the source tensor
     const int cbase = from2 ? Cin1 : 0;                                     // first channel the source holds
     constexpr int NITEMS = 2 * VH;
-    constexpr int UNR = (NITEMS + NT - 1) / NT >= 9 ? 9 : 4;   // loads in flight per thread per batch (latency-bound phase)
-    for (int it0 = 0; it0 < NITEMS; it0 += NT * UNR) {
-      u32x4 v[UNR];
+#ifdef RM_CONV_DMA
+    if (vec_ok) {
+      const int pl = wave & 1;
+      const int c = ci0 + pl * KV;
+      const size_t sample_bytes = (size_t)D * H * W * csrc * sizeof(T);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xsrc), 0, (int)sample_bytes, 0x00020000);
+      const int chan_off = (c - cbase) * (int)sizeof(T), vox_bytes = csrc * (int)sizeof(T);
+      const bool plane_live = c < Cin;
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int it = it0 + u * NT + tid;
-        v[u] = u32x4{0u, 0u, 0u, 0u};
-        if (it < NITEMS) {
-          const int pl = it & 1, vh = it >> 1;
-          const int xx = vh % BXH, t2 = vh / BXH;
-          const int yy = t2 % BYH, zz = t2 / BYH;
-          const int gz = z0 + zz - 2, gy = y0 + yy - 2, gx = x0 + xx - 2;
-          const int c = ci0 + pl * KV;
-          if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin) {
-            // (two-input mode: this chunk's channels lie entirely in one of the two tensors, Cin1 % KC == 0)
-            const T* p = xsrc + ((size_t)(gz * H + gy) * W + gx) * csrc + (c - cbase);
-            if (vec_ok) {
-              v[u] = *reinterpret_cast<const u32x4*>(p);
-            } else {
-              T e[KV];
+      for (int k = 0; k < DMA_K; ++k) {
+        const int seg = (wave >> 1) + (NT / 128) * k;
+        const int voff = (plane_live && dma_vox[k] >= 0) ? dma_vox[k] * vox_bytes + chan_off : 0x7fffffff;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + ((size_t)pl * PLS + seg * 64) * 16), 16,
+                                                 voff, 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else
+#endif
+    {
+#ifdef RM_CONV_DMA
+      constexpr int UNR = 1;     // (only channel counts that are no multiple of 8 (4) come here: one item at a time, few registers)
+#else
+      constexpr int UNR = (NITEMS + NT - 1) / NT >= 9 ? 9 : 4;   // loads in flight per thread per batch (latency-bound phase)
+#endif
+      for (int it0 = 0; it0 < NITEMS; it0 += NT * UNR) {
+        u32x4 v[UNR];
 #pragma unroll
-              for (int k = 0; k < KV; ++k) e[k] = (c + k < Cin) ? p[k] : (T)0;
-              v[u] = *reinterpret_cast<const u32x4*>(e);
+        for (int u = 0; u < UNR; ++u) {
+          const int it = it0 + u * NT + tid;
+          v[u] = u32x4{0u, 0u, 0u, 0u};
+          if (it < NITEMS) {
+            const int pl = it & 1, vh = it >> 1;
+            const int xx = vh % BXH, t2 = vh / BXH;
+            const int yy = t2 % BYH, zz = t2 / BYH;
+            const int gz = z0 + zz - 2, gy = y0 + yy - 2, gx = x0 + xx - 2;
+            const int c = ci0 + pl * KV;
+            if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin) {
+              // (two-input mode: this chunk's channels lie entirely in one of the two tensors, Cin1 % KC == 0)
+              const T* p = xsrc + ((size_t)(gz * H + gy) * W + gx) * csrc + (c - cbase);
+              if (vec_ok) {
+                v[u] = *reinterpret_cast<const u32x4*>(p);
+              } else {
+                T e[KV];
+#pragma unroll
+                for (int k = 0; k < KV; ++k) e[k] = (c + k < Cin) ? p[k] : (T)0;
+                v[u] = *reinterpret_cast<const u32x4*>(e);
+              }
             }
           }
         }
-      }
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int it = it0 + u * NT + tid;
-        if (it < NITEMS) lds[(it & 1) * PLS + (it >> 1)] = v[u];
+        for (int u = 0; u < UNR; ++u) {
+          const int it = it0 + u * NT + tid;
+          if (it < NITEMS) lds[(it & 1) * PLS + (it >> 1)] = v[u];
+        }
       }
     }
     __syncthreads();
