@@ -55,6 +55,14 @@ extern "C" {
 #define REPMODE_TAPS 125
 
 int repmode_abi_version(void);
+/* Deterministic mode (also: environment REPMODE_DETERMINISTIC=1 when the library is loaded): every float sum of the path gets
+ * a fixed order, so that two runs on the same inputs agree BITWISE -- no input-channel split of the convolutions (the
+ * per-expert pair goes through the general kernel), whole-range workgroups in the filter gradients, ordered in-workgroup
+ * reductions and one writer per partial-sum slice in BatchNorm, the gate-probability gradients tile after tile from one
+ * thread, one workgroup per sample in the loss ...  Costs the parallelism those splits buy.  Set it
+ * between steps, not while launches of the library are being issued from another thread. */
+int repmode_set_deterministic(int on);
+int repmode_get_deterministic(void);
 const char* repmode_last_error(void);
 /* name of device `dev`'s gcnArchName into buf; REPMODE_ENODEV when there is none */
 int repmode_device_arch(int dev, char* buf, int buflen);

@@ -25,6 +25,8 @@ _I = _c.c_int
 _SIGNATURES = {
     'repmode_abi_version': [],
     'repmode_device_arch': [_I, _c.c_char_p, _I],
+    'repmode_set_deterministic': [_I],
+    'repmode_get_deterministic': [],
     'repmode_padded_channels': [_I, _I, _I],
     'repmode_gate_softmax': [_P, _P, _P, _I, _I, _I, _P, _P],
     'repmode_gatrep_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],

@@ -1,6 +1,7 @@
 // api.hip -- error reporting, ABI/device queries and the naive diagnostic kernels.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -19,6 +20,15 @@ void repmode_set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+static int g_deterministic = []() { const char* e = getenv("REPMODE_DETERMINISTIC"); return e ? atoi(e) : 0; }();
+bool repmode_deterministic() { return g_deterministic != 0; }
+int repmode_det_cap(int site) {
+  static const int single = []() { const char* e = getenv("REPMODE_DET_SINGLE"); return e ? atoi(e) : 0; }();
+  return (single & site) ? 1 : 2;
+}
+extern "C" int repmode_set_deterministic(int on) { g_deterministic = on ? 1 : 0; return REPMODE_OK; }
+extern "C" int repmode_get_deterministic(void) { return g_deterministic; }
 
 extern "C" int repmode_abi_version(void) { return REPMODE_ABI_VERSION; }
 extern "C" const char* repmode_last_error(void) { return g_err; }

@@ -108,8 +108,26 @@ __device__ __forceinline__ Geom geom(int C) {
 }
 
 // sums[c] += sum_rows a(row, c) ; sums[C + c] += sum_rows b(row, c)
+// nsl: partial-sum slices in use -- BN_SLICES, or (deterministic mode) half as many as the grid has workgroups: two writers each
 __device__ __forceinline__ void block_commit(float* lds, const float* s, const float* ss, int c0, int C, bool active,
-                                             float* __restrict__ sums) {
+                                             float* __restrict__ sums, int nsl, bool det) {
+  if (det) {
+    // fixed summation order: every thread's partial sums through LDS, channel i's total = its row groups in order; the
+    // slice has at most two writers (grid <= 2 nsl): two addends on a zeroed entry commute
+    __shared__ float all[BN_THREADS * 2 * CV];
+    const int ngroups = (C + CV - 1) / CV, rows = BN_THREADS / ngroups;
+#pragma unroll
+    for (int k = 0; k < CV; ++k) { all[threadIdx.x * 2 * CV + k] = active ? s[k] : 0.f; all[threadIdx.x * 2 * CV + CV + k] = active ? ss[k] : 0.f; }
+    __syncthreads();
+    float* slice = sums + (size_t)(blockIdx.x % nsl) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) {
+      const int which = i / C, ch = i % C;
+      float t = 0.f;
+      for (int r = 0; r < rows; ++r) t += all[(r * ngroups + ch / CV) * 2 * CV + which * CV + ch % CV];
+      atomicAdd(&slice[i], t);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) lds[i] = 0.f;
   __syncthreads();
   // lanes l, l + ngroups, l + 2 ngroups ... of a wave hold the same channels: butterfly them together first, so
@@ -135,7 +153,7 @@ __device__ __forceinline__ void block_commit(float* lds, const float* s, const f
       }
   }
   __syncthreads();
-  float* slice = sums + (size_t)(blockIdx.x % BN_SLICES) * 2 * C;
+  float* slice = sums + (size_t)(blockIdx.x % nsl) * 2 * C;
   for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) atomicAdd(&slice[i], lds[i]);
 }
 
@@ -146,10 +164,14 @@ __device__ __forceinline__ void block_commit(float* lds, const float* s, const f
 // So a BatchNorm pass is two launches, with no finalize kernel and no memset.  (A "last workgroup finalizes"
 // variant inside the reduction kernels was tried and lost: the device-scope fence it needs writes back and
 // invalidates the XCD's L2 once per workgroup.)
-__device__ __forceinline__ float slice_total(const float* __restrict__ sums, int i, int C) {
+__device__ __forceinline__ float slice_total(const float* __restrict__ sums, int i, int C, int nsl) {
   float t = 0.f;
+  if (nsl == BN_SLICES) {
 #pragma unroll
-  for (int k = 0; k < BN_SLICES; ++k) t += sums[(size_t)k * 2 * C + i];
+    for (int k = 0; k < BN_SLICES; ++k) t += sums[(size_t)k * 2 * C + i];
+  } else {
+    for (int k = 0; k < nsl; ++k) t += sums[(size_t)k * 2 * C + i];
+  }
   return t;
 }
 
@@ -160,7 +182,7 @@ __device__ __forceinline__ void clear_other_half(float* __restrict__ other) {
 
 template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restrict__ x, long M, int C,
-                                                              float* __restrict__ sums, float* __restrict__ other) {
+                                                              float* __restrict__ sums, float* __restrict__ other, int nsl, int det) {
   __shared__ float lds[2 * BN_MAXC];
   clear_other_half(other);
   const Geom g = geom(C);
@@ -196,7 +218,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const T* __restric
       for (int k = 0; k < CV; ++k) { const float d = v[k] - x0[k]; s[k] += d; ss[k] += d * d; }
     }
   }
-  block_commit(lds, s, ss, c0, C, active, sums);
+  block_commit(lds, s, ss, c0, C, active, sums, nsl, det != 0);
 }
 
 // normalise + ReLU.  Prologue (every workgroup, through LDS): mean / invstd of all channels from the partial-sum
@@ -207,14 +229,14 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_relu_kernel(
     const TI* __restrict__ x, TO* __restrict__ out, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ sums, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ save_mean,
-    float* __restrict__ save_invstd, float eps, float momentum, int training, long M, int C, int shifted) {
+    float* __restrict__ save_invstd, float eps, float momentum, int training, long M, int C, int shifted, int nsl) {
   __shared__ float sc[BN_MAXC], sh[BN_MAXC];
   for (int c = threadIdx.x; c < C; c += BN_THREADS) {
     float mean, invstd;
     if (training) {
       // shifted: the sums are of (x - x0[c]), x0 = row 0 (bn_stats_kernel); else of x itself (the conv epilogue's)
-      const float m1 = slice_total(sums, c, C) / (float)M;
-      const float var = fmaxf(slice_total(sums, C + c, C) / (float)M - m1 * m1, 0.f);
+      const float m1 = slice_total(sums, c, C, nsl) / (float)M;
+      const float var = fmaxf(slice_total(sums, C + c, C, nsl) / (float)M - m1 * m1, 0.f);
       mean = shifted ? m1 + to_f32<TI>(x[c]) : m1;
       invstd = rsqrtf(var + eps);
       if (blockIdx.x == 0) {
@@ -258,7 +280,7 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
     const TI* __restrict__ x, const TO* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta, long M, int C,
-    float* __restrict__ sums, float* __restrict__ other) {
+    float* __restrict__ sums, float* __restrict__ other, int nsl, int det) {
   __shared__ float lds[2 * BN_MAXC];
   clear_other_half(other);
   const Geom g = geom(C);
@@ -307,7 +329,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(
       }
     }
   }
-  block_commit(lds, s, ss, c0, C, active, sums);
+  block_commit(lds, s, ss, c0, C, active, sums, nsl, det != 0);
 }
 
 // backward apply: dx = gamma * invstd * (dz - sum(dz)/M - xhat * sum(dz xhat)/M).  Prologue: every workgroup
@@ -317,10 +339,10 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(
     const TI* __restrict__ x, const TO* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ sums, float* __restrict__ totals, long M, int C, int training, TI* __restrict__ dx) {
+    const float* __restrict__ sums, float* __restrict__ totals, long M, int C, int training, TI* __restrict__ dx, int nsl) {
   __shared__ float tot[2 * BN_MAXC];
   for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) {
-    const float t = slice_total(sums, i, C);
+    const float t = slice_total(sums, i, C, nsl);
     tot[i] = t;
     if (blockIdx.x == 0) totals[i] = t;
   }
@@ -495,6 +517,19 @@ int grid_for_reduce(long M, int C) {
   return (int)blocks;
 }
 
+// partial-sum slices of a call: BN_SLICES; deterministic mode: as many as fit the scratch half (one writer each, more
+// workgroups for the large tensors, which have few channels)
+int slices_for(int C) {
+  if (!repmode_deterministic()) return BN_SLICES;
+  long n = (long)REPMODE_SCRATCH_BN_HALF / (2L * C);
+  return (int)(n > 256 ? 256 : (n < 1 ? 1 : n));
+}
+int grid_for_reduce_det(long M, int C, int nsl) {
+  const int g = grid_for_reduce(M, C);
+  const int cap = repmode_det_cap(RM_DET_BN) * nsl;
+  return repmode_deterministic() ? (g < cap ? g : cap) : g;      // (two writers per slice: two addends on the cleared entry)
+}
+
 int grid_for(long M, int C) {
   const int ngroups = (C + CV - 1) / CV;
   const int rows_per_iter = BN_THREADS / ngroups;
@@ -528,6 +563,8 @@ extern "C" int repmode_bn_relu_fwd_ex(const void* x, void* out, const float* gam
              "bn_relu_fwd: null pointer");
   RM_REQUIRE(m > 0 && c > 0 && c <= BN_MAXC, "bn_relu_fwd: bad shape (C <= %d)", BN_MAXC);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nsl = slices_for(c), det = repmode_deterministic() ? 1 : 0;
+  (void)det;
   const int grid = grid_for(m, c);
   float* own = nullptr;
   RM_REQUIRE(stats_half < 0 || (training && stats_half <= 1), "bn_relu_fwd: bad statistics half %d", stats_half);
@@ -556,15 +593,16 @@ extern "C" int repmode_bn_relu_fwd_ex(const void* x, void* out, const float* gam
     own = scratch + (size_t)half * REPMODE_SCRATCH_BN_HALF;
     float* other = scratch + (size_t)(1 - half) * REPMODE_SCRATCH_BN_HALF;
     if (in_dtype == REPMODE_F32)
-      hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const float*)x, m, c, own, other);
+      hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(grid_for_reduce_det(m, c, nsl)), dim3(BN_THREADS), 0, s, (const float*)x, m, c, own, other, nsl, det);
     else
-      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const bf16_t*)x, m, c, own, other);
+      hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid_for_reduce_det(m, c, nsl)), dim3(BN_THREADS), 0, s, (const bf16_t*)x, m, c, own, other, nsl, det);
     RM_LAUNCH_CHECK("bn_stats");
   }
   const int shifted = (training && stats_half < 0) ? 1 : 0;     // bn_stats_kernel's sums are relative to row 0
 #define RM_BN_APPLY(TI, TO)                                                                                      \
   hipLaunchKernelGGL((bn_apply_relu_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (TO*)out, \
-                     gamma, beta, own, running_mean, running_var, save_mean, save_invstd, eps, momentum, training, m, c, shifted)
+                     gamma, beta, own, running_mean, running_var, save_mean, save_invstd, eps, momentum, training, m, c, shifted, \
+                     stats_half >= 0 ? BN_SLICES : nsl)
   if (in_dtype == REPMODE_F32 && out_dtype == REPMODE_F32) RM_BN_APPLY(float, float);
   else if (in_dtype == REPMODE_F32) RM_BN_APPLY(float, bf16_t);
   else if (out_dtype == REPMODE_F32) RM_BN_APPLY(bf16_t, float);
@@ -581,6 +619,8 @@ extern "C" int repmode_bn_relu_bwd(const void* x, const void* dy, const float* g
   RM_REQUIRE(x && dy && gamma && beta && save_mean && save_invstd && dx && totals, "bn_relu_bwd: null pointer");
   RM_REQUIRE(m > 0 && c > 0 && c <= BN_MAXC, "bn_relu_bwd: bad shape (C <= %d)", BN_MAXC);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nsl = slices_for(c), det = repmode_deterministic() ? 1 : 0;
+  (void)det;
   const int grid = grid_for(m, c);
   if (bn_small(m, c)) {
     const dim3 g((unsigned)((c + CV - 1) / CV));
@@ -602,10 +642,10 @@ extern "C" int repmode_bn_relu_bwd(const void* x, const void* dy, const float* g
   float* other = scratch + (size_t)(1 - half) * REPMODE_SCRATCH_BN_HALF;
 #define RM_BN_BWD(TI, TO)                                                                                              \
   do {                                                                                                                 \
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<TI, TO>), dim3(grid_for_reduce(m, c)), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy, \
-                       save_mean, save_invstd, gamma, beta, m, c, own, other);                                         \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<TI, TO>), dim3(grid_for_reduce_det(m, c, nsl)), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy, \
+                       save_mean, save_invstd, gamma, beta, m, c, own, other, nsl, det);                               \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TI, TO>), dim3(grid), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy,  \
-                       save_mean, save_invstd, gamma, beta, own, totals, m, c, training, (TI*)dx);                          \
+                       save_mean, save_invstd, gamma, beta, own, totals, m, c, training, (TI*)dx, nsl);                     \
   } while (0)
   if (in_dtype == REPMODE_F32 && out_dtype == REPMODE_F32) RM_BN_BWD(float, float);
   else if (in_dtype == REPMODE_F32) RM_BN_BWD(float, bf16_t);

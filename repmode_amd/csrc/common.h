@@ -91,5 +91,16 @@ constexpr size_t REPMODE_SCRATCH_GATE_OFF = 2 * REPMODE_SCRATCH_BN_HALF;    // g
 int repmode_bn_scratch_half(hipStream_t s);
 void repmode_prof_end(hipStream_t s);
 
+// REPMODE_DETERMINISTIC=1 / repmode_set_deterministic(1): run-to-run bitwise reproducible results -- every float sum gets a
+// fixed order (no input-channel split of the convolutions, one workgroup per filter-gradient tile, ordered in-workgroup
+// reductions, one writer per BatchNorm partial-sum slice ...) at the price of the parallelism those splits buy.  A float
+// atomicAdd stays where at most two addends meet on a zeroed location (a + b is commutative; three are not associative).
+bool repmode_deterministic();
+// how many workgroups may add to one element of a cleared output in deterministic mode: 2 (a + b commutes), or 1 for the
+// sites named in REPMODE_DET_SINGLE (a bit mask, developer switch): 1 conv5 split, (2 gemm3: always 1,) 4 k2s2, 8 loss,
+// 16 expert_mix, 32 BatchNorm, 64 filter gradient
+enum { RM_DET_CONV = 1, RM_DET_GEMM3 = 2, RM_DET_K2S2 = 4, RM_DET_MSE = 8, RM_DET_MIX = 16, RM_DET_BN = 32, RM_DET_WGRAD = 64 };
+int repmode_det_cap(int site);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

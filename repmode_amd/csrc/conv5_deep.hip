@@ -316,6 +316,7 @@ using DCfgX4D = DCfg<2, 4, 4, 2, 1, 4, 2>;     // level 4 data gradient (two ima
 }  // namespace
 
 extern "C" int repmode_conv5_deep_supported(int wdim, int cin, int dtype) {
+  if (repmode_deterministic()) return 0;      // (its input-channel slices add with atomics: the general kernel without a split)
   return (dtype == REPMODE_BF16 && wdim > 0 && wdim <= 8 && cin > 0 && cin % 8 == 0) ? 1 : 0;
 }
 

@@ -934,8 +934,11 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   int ks = 1;
   static const int min_chunks = []() { const char* e = getenv("REPMODE_CONV_MIN_CHUNKS"); return e ? atoi(e) : 4; }();
   static const int split_target = []() { const char* e = getenv("REPMODE_CONV_SPLIT_TARGET"); return e ? atoi(e) : CONV_SPLIT_TARGET; }();
+  // (deterministic mode: at most TWO addends per element of the cleared output -- a + b is commutative, three slices'
+  // atomics would meet in any order; a dual launch whose two jobs share the output already has its two)
+  const int ks_max = !repmode_deterministic() ? 64 : (a.dual && !(a.dual & 4)) ? 1 : repmode_det_cap(RM_DET_CONV);
   if (SWAP && !a.bias && !a.relu) {   // (a bias / ReLU epilogue needs the whole sum in one workgroup)
-    while (ks * min_chunks <= nchunks && base * ks < split_target && ks < 64) ks *= 2;
+    while (ks * min_chunks <= nchunks && base * ks < split_target && ks < ks_max) ks *= 2;
   }
   RM_REQUIRE(!a.stats || !SWAP, "conv5: output statistics need the element-typed output path (bf16 input, not out_f32)");
   a.ksplit = ks;
@@ -1123,6 +1126,7 @@ static int conv5_common(const void* x, const void* x2, int cin1, const void* w, 
   }
   if (dtype == REPMODE_F32) return dispatch<float, true>(a, s);
   if (a.out_f32) return dispatch<bf16_t, true>(a, s);
+  RM_REQUIRE(!want_stats || !repmode_deterministic(), "conv5_epi: the statistics epilogue adds with atomics; not in deterministic mode");
   a.wide = g_wide && !want_stats && (cout1 > 0 ? (cout1 % 16 == 0 && (cout - cout1) % 16 == 0) : cout % 16 == 0);
   return dispatch<bf16_t, false>(a, s);
 }

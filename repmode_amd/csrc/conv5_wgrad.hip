@@ -658,7 +658,8 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
     const long fixed = (long)a.nslots * a.ncot * a.ncit * ndz;
     double best = 1e30;
     *chunks = 1;
-    for (long nc = 1; nc <= 64 && nc <= a.ntiles; ++nc) {
+    const long nc_max = repmode_deterministic() ? repmode_det_cap(RM_DET_WGRAD) : 64;      // (deterministic: at most two addends per element of the cleared dw)
+    for (long nc = 1; nc <= nc_max && nc <= a.ntiles; ++nc) {
       const double rounds = (double)((fixed * nc + resident - 1) / resident);
       const double cost = rounds * ((nc > 1 ? ov + 2.0 : ov) + (double)((long)((tiles + nc - 1) / nc)));
       if (cost < best * 0.97) { best = cost; *chunks = nc; }
@@ -776,6 +777,7 @@ extern "C" int repmode_conv5_wgrad_part(const void* x, const void* dy, const int
     const long fixed = (long)nslots * a.ncot * a.ncit * a.ndz;
     long want_chunks = (2048 + fixed - 1) / fixed;       // aim at >= 2048 workgroups
     if (want_chunks < 1) want_chunks = 1;
+    if (repmode_deterministic() && want_chunks > repmode_det_cap(RM_DET_WGRAD)) want_chunks = repmode_det_cap(RM_DET_WGRAD);
     if (want_chunks > a.ntiles) want_chunks = a.ntiles;
     a.tiles_per_block = ceil_div(a.ntiles, (int)want_chunks);
     a.nchunks = ceil_div(a.ntiles, a.tiles_per_block);
@@ -985,6 +987,7 @@ extern "C" int repmode_conv5_wgrad_thin(const void* a_t, const void* b_t, const 
   long want = (1024 + fixed - 1) / fixed;
   if (want > a.ntiles) want = a.ntiles;
   if (want < 1) want = 1;
+  if (repmode_deterministic() && want > repmode_det_cap(RM_DET_WGRAD)) want = repmode_det_cap(RM_DET_WGRAD);      // (deterministic: at most two addends per element of the cleared dw)
   a.tiles_per_block = ceil_div(a.ntiles, (int)want);
   a.nchunks = ceil_div(a.ntiles, a.tiles_per_block);
   if (!(flip & 2)) RM_HIP(hipMemsetAsync(dw, 0, (size_t)nslots * REPMODE_TAPS * c * sizeof(float), s));   // flip bit 1: dw already cleared

@@ -60,7 +60,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void expert_mix_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ p,
                                                              const float* __restrict__ g, float* __restrict__ dg,
                                                              T* __restrict__ dye_lo, float* __restrict__ dye_hi, int N,
-                                                             long V, int C, long vchunk, long hi_stride) {
+                                                             long V, int C, long vchunk, long hi_stride, int det) {
   __shared__ float red[E * 512];
   const int c4n = (C + 3) / 4;
   const int n = blockIdx.y;
@@ -96,6 +96,25 @@ __global__ __launch_bounds__(256) void expert_mix_bwd_kernel(const float* __rest
         else store4<float>(dye_hi + (e - 2) * (size_t)hi_stride + off, o, c, C, vec);
       }
     }
+  }
+  if (det) {
+    // deterministic mode (at most two workgroups per sample): the row groups' partial sums are added in row order, and the
+    // workgroup's total is ONE add onto the cleared dg
+    __shared__ float all[256 * E * 4];                    // [row r0][e][channel group cg][4]: rows * 5 * C <= 5120 floats
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) all[((size_t)(r0 * E + e) * c4n + cg) * 4 + k] = part[e][k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < E * C; i += 256) {
+      const int e = i / C, ch = i % C;
+      float t = 0.f;
+      for (int r = 0; r < rows; ++r) t += all[((size_t)(r * E + e) * c4n + ch / 4) * 4 + (ch & 3)];
+      atomicAdd(dg + (size_t)n * E * C + i, t);
+    }
+    return;
   }
   for (int i = threadIdx.x; i < E * C; i += 256) red[i] = 0.f;
   __syncthreads();
@@ -142,15 +161,17 @@ extern "C" int repmode_expert_mix_bwd_ex(const float* dy, const float* p, const 
   const int rows = 256 / ((c + 3) / 4);
   long chunks = (v + rows * 4 - 1) / (rows * 4);          // >= 4 rows iterations per workgroup
   if (chunks > 256) chunks = 256;
+  const int det = repmode_deterministic() ? 1 : 0;
   if (chunks < 1) chunks = 1;
+  if (det && chunks > repmode_det_cap(RM_DET_MIX)) chunks = repmode_det_cap(RM_DET_MIX);
   const long vchunk = (v + chunks - 1) / chunks;
   const dim3 grid((unsigned)((v + vchunk - 1) / vchunk), (unsigned)n);
   if (dtype == REPMODE_F32)
     hipLaunchKernelGGL(expert_mix_bwd_kernel<float>, grid, dim3(256), 0, s, dy, p, g, dg, static_cast<float*>(dye_lo), dye_hi,
-                       n, v, c, vchunk, hi_stride);
+                       n, v, c, vchunk, hi_stride, det);
   else
     hipLaunchKernelGGL(expert_mix_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, dy, p, g, dg, static_cast<bf16_t*>(dye_lo),
-                       dye_hi, n, v, c, vchunk, hi_stride);
+                       dye_hi, n, v, c, vchunk, hi_stride, det);
   RM_LAUNCH_CHECK("expert_mix_bwd");
   return REPMODE_OK;
 }

@@ -327,9 +327,16 @@ __global__ __launch_bounds__(GF_THREADS, SG > 2 ? 1 : 2) void gatrep_bwd_kernel(
   __shared__ float s3[GF_CT * 27];
   __shared__ float part[SG * 5][GF_THREADS];
   __shared__ float cross[3][SG][GF_CT];     // per-slot contributions to dk1 / da3 / da5 of each ci
+  __shared__ float sgb[64][E];
   const int tid = threadIdx.x;
   const int co = blockIdx.y;
-  const int c0 = blockIdx.x * GF_CT;
+  // A workgroup takes the 32-channel tiles bx, bx + gridDim.x, ... of its output channel.  Normally gridDim.x = the number of
+  // tiles (one each); deterministic mode launches gridDim.x = 1, so that ONE thread adds a (slot, expert, co) entry of dg tile
+  // after tile in program order (the tiles' atomics would otherwise meet in any order).
+  const int ntile = (ci_n + GF_CT - 1) / GF_CT;
+  for (int bx = blockIdx.x; bx < ntile; bx += gridDim.x) {
+  if (bx != (int)blockIdx.x) __syncthreads();          // (the previous tile's LDS reads are done)
+  const int c0 = bx * GF_CT;
   const int nlive = min(GF_CT, ci_n - c0);
   const size_t base = (size_t)co * ci_n + c0;
   const int c = tid & (GF_CT - 1), tq = tid / GF_CT;
@@ -353,7 +360,6 @@ __global__ __launch_bounds__(GF_THREADS, SG > 2 ? 1 : 2) void gatrep_bwd_kernel(
   const float w1 = live ? k1[oi] : 0.f;
   const float w3 = live ? a3[oi] * (1.0f / 27.0f) : 0.f;
   const float w5 = live ? a5[oi] * (1.0f / 125.0f) : 0.f;
-  __shared__ float sgb[64][E];
   {
     float v5[16], v3[4], vg[2];
 #pragma unroll
@@ -478,6 +484,7 @@ __global__ __launch_bounds__(GF_THREADS, SG > 2 ? 1 : 2) void gatrep_bwd_kernel(
   __syncthreads();
   for (int i = tid; i < nlive * TAPS; i += GF_THREADS) dk5[base * TAPS + i] = s5[i];
   for (int i = tid; i < nlive * 27; i += GF_THREADS) dk3[base * 27 + i] = s3[i];
+  }   // (tile loop)
 }
 
 }  // namespace
@@ -863,11 +870,12 @@ extern "C" int repmode_gatrep_bwd_ex(const float* dw, const float* k5, const flo
   repmode_prof_begin(REPMODE_PROF_GATREP_BWD, (double)co * ci * 4.0 * (125.0 * nslots + 2 * 155.0), s);
   // small layers are latency-bound: 8 slots' loads in flight per thread (one wave per SIMD); larger ones want
   // the occupancy of the 2-slot variant
+  const int gx = repmode_deterministic() ? 1 : ceil_div(ci, GF_CT);      // (deterministic: a workgroup walks all tiles of its co)
   if ((long)ceil_div(ci, GF_CT) * co <= 256)
-    hipLaunchKernelGGL(gatrep_bwd_kernel<8>, dim3(ceil_div(ci, GF_CT), co), dim3(GF_THREADS), 0, s, dw, k5, k3, k1, a3, a5,
+    hipLaunchKernelGGL(gatrep_bwd_kernel<8>, dim3(gx, co), dim3(GF_THREADS), 0, s, dw, k5, k3, k1, a3, a5,
                        g, nslots, co, ci, dk5, dk3, dk1, da3, da5, dg);
   else
-    hipLaunchKernelGGL(gatrep_bwd_kernel<2>, dim3(ceil_div(ci, GF_CT), co), dim3(GF_THREADS), 0, s, dw, k5, k3, k1, a3, a5,
+    hipLaunchKernelGGL(gatrep_bwd_kernel<2>, dim3(gx, co), dim3(GF_THREADS), 0, s, dw, k5, k3, k1, a3, a5,
                        g, nslots, co, ci, dk5, dk3, dk1, da3, da5, dg);
   RM_LAUNCH_CHECK("gatrep_bwd");
   // the gate backward: its own launch, or (REPMODE_DEFER) the first workgroups of the next conv5 launch on this stream

@@ -398,6 +398,7 @@ extern "C" int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float
     const long max_chunks = (f.M + 31) / 32;
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
+    if (repmode_deterministic() && chunks > repmode_det_cap(RM_DET_K2S2)) chunks = repmode_det_cap(RM_DET_K2S2);      // (deterministic: at most two addends per element of the cleared dw)
     f.rows_per_block = (int)(((f.M + chunks - 1) / chunks + 31) / 32 * 32);
     const int nchunks_f = (int)((f.M + f.rows_per_block - 1) / f.rows_per_block);
     if (!prezeroed && nchunks_f > 1) RM_HIP(hipMemsetAsync(dw, 0, (size_t)8 * ca * cb * sizeof(float), s));
@@ -414,6 +415,7 @@ extern "C" int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float
   long want = (K2W_TARGET_BLOCKS + (long)nat * nbt - 1) / ((long)nat * nbt);
   if (want > a.ntiles) want = a.ntiles;
   if (want < 1) want = 1;
+  if (repmode_deterministic() && want > repmode_det_cap(RM_DET_K2S2)) want = repmode_det_cap(RM_DET_K2S2);             // (deterministic: at most two addends per element of the cleared dw)
   a.tiles_per_block = ceil_div(a.ntiles, (int)want);
   const int nchunks = ceil_div(a.ntiles, a.tiles_per_block);
   if (!prezeroed) RM_HIP(hipMemsetAsync(dw, 0, (size_t)8 * ca * cb * sizeof(float), s));

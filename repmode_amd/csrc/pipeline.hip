@@ -152,6 +152,7 @@ extern "C" int repmode_mse_loss(const float* out, const float* target, const int
   long blocks = (v / 4 + MSE_THREADS * 4 - 1) / (MSE_THREADS * 4);
   if (blocks < 1) blocks = 1;
   if (blocks * n > 2048) blocks = (2048 + n - 1) / n;
+  if (repmode_deterministic() && blocks > repmode_det_cap(RM_DET_MSE)) blocks = repmode_det_cap(RM_DET_MSE);     // (two workgroups per sample: two addends on the cleared sum)
   hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3((unsigned)blocks, n), dim3(MSE_THREADS), 0, s, out, target, dout, sums_ws, v,
                      2.0f / ((float)n * (float)v));
   RM_LAUNCH_CHECK("mse_fwd_bwd");

@@ -108,6 +108,16 @@ def get_deep_conv():
     return bool(torch_ops().get_deep_conv())
 
 
+def set_deterministic(on):
+    """Run-to-run bitwise reproducible results (REPMODE_DETERMINISTIC=1): every float sum of the path gets a fixed order --
+    see ``repmode_set_deterministic`` in include/repmode_hip.h; slower (the splits it removes are there for parallelism)."""
+    _lib.call('repmode_set_deterministic', 1 if on else 0)
+
+
+def get_deterministic():
+    return bool(_lib.load().repmode_get_deterministic())
+
+
 def set_thin_kernels(on):
     """The one-channel first / last layers through their own kernels (csrc/thin_conv.hip; default) or round 2's fold of the x
     taps around the general kernel (REPMODE_THIN=0).  The operator library's switch (the ``thin_conv_*`` wrappers here
