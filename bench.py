@@ -89,6 +89,28 @@ def pmc_traffic(kind, batch, dtype):
     return None, None
 
 
+def conv5_igemm_algorithmic_bytes(batch, nslots):
+    """Algorithmic HBM bytes per train step of the launches that go through conv5_igemm_kernel at the default policy, and their
+    count: every tensor once -- bf16 input, output (bf16 on levels 0-1, float where the reduction is split: levels
+    2-4) and the filter (one per slot: 125 taps x Cin x Cout bf16; the per-expert pair of levels 3-4: 125 + 27 taps, shared by
+    the batch).  Levels 0-2: forward + data gradient of every merged block but the two one-channel layers (own kernels);
+    levels 3-4: the forward pair (their data gradient runs in conv5_deep)."""
+    v = [PATCH[0] * PATCH[1] * PATCH[2] // 8 ** l for l in range(5)]
+    merged = [(0, 32, 32), (0, 64, 32), (0, 32, 32), (1, 32, 64), (1, 64, 64), (1, 128, 64), (1, 64, 64),
+              (2, 64, 128), (2, 128, 128), (2, 256, 128), (2, 128, 128)]
+    pair = [(3, 128, 256), (3, 256, 256), (3, 512, 256), (3, 256, 256), (4, 256, 512), (4, 512, 512)]
+    total, n = 0.0, 0
+    for l, ci, co in merged:
+        osz = 2 if l < 2 else 4
+        for a, b in ((ci, co), (co, ci)):                       # forward, data gradient
+            total += batch * v[l] * (a * 2 + b * osz) + nslots * 125 * ci * co * 2
+            n += 1
+    for l, ci, co in pair:
+        total += batch * v[l] * (ci * 2 + 2 * co * 4) + (125 + 27) * ci * co * 2
+        n += 1
+    return total, n
+
+
 def cpu_baseline():
     """Oracle train step (forward + backward + Adam, fp32) on the host cores: batch 2 of the headline patches (two
     different tasks), up to 32 host threads (see below), >= 3 timed steps (8-15 s) of each organisation after a small warm-up -- the reference's
@@ -356,10 +378,13 @@ def main():
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             peak = PEAK_TFLOPS[args.dtype]
             traffic, traffic_file = pmc_traffic('conv5_igemm', b, args.dtype)
+            alg_bytes, alg_n = conv5_igemm_algorithmic_bytes(b, len(set(task.tolist())))
             out['roofline'] = {'kernel': 'conv5_igemm_kernel', 'bound': 'mfma', 'achieved': achieved, 'peak': peak,
                                'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_file,
                                'launches': n, 'avg_launch_ms': ms / max(n, 1),
-                               'flops_per_launch': flops / max(n, 1)}
+                               'flops_per_launch': flops / max(n, 1),
+                               'algorithmic_bytes_per_launch': alg_bytes / alg_n,
+                               'traffic_over_algorithmic': (traffic / (alg_bytes / alg_n)) if traffic else None}
             # all forward / data-gradient convolution kernels together (the dominant one above + the deep levels' + the thin layers')
             n_a, ms_a, fl_a = (sum(v) for v in zip(*(train_prof[k] for k in CONV_KINDS)))
             out['roofline']['all_conv_kernels'] = {'kernels': [k for k in CONV_KINDS if train_prof[k][0]], 'launches': n_a,

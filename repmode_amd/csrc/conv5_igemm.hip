@@ -157,8 +157,11 @@ struct Cfg {
 // neither path carries the other's registers and branches
 // ROWSTAT: the row-stationary tap loop (4 x 4 x 32 bricks only, see the loop's comment)
 // MERGE: the filter fragment is MERGED IN THE KERNEL from the experts (the A/B experiment of repmode_conv5_merged below)
+#ifndef RM_CONV_X16_WAVES
+#define RM_CONV_X16_WAVES 2     // (experiment: -DRM_CONV_X16_WAVES=3 asks for three waves per SIMD on the 4 x 4 x 16 tile)
+#endif
 template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false, bool ROWSTAT = false, bool MERGE = false>
-__global__ __launch_bounds__(C::NT, 2) void conv5_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(C::NT, (C::BX == 16 && !MERGE) ? RM_CONV_X16_WAVES : 2) void conv5_igemm_kernel(ConvArgs a) {
   constexpr int KV = Elem<T>::KV;
   constexpr int KC = 2 * KV;
   constexpr int BZ = C::BZ, BY = C::BY, BX = C::BX, VW = C::VW, CW = C::CW;
@@ -990,8 +993,13 @@ static const int g_rowstat = []() { const char* e = getenv("REPMODE_CONV_ROWSTAT
 // 32->32 at level 0, 471.1 -> 467.0 on 64->32; train step 12.49 -> 12.44 ms)
 static const int g_wide = []() { const char* e = getenv("REPMODE_CONV_WIDE"); return e ? atoi(e) : 1; }();
 
+// Experiment (REPMODE_CONV_X16_AT=<cout>): layers at least that wide in output channels take the 4 x 4 x 16 tile (256 voxels x 64
+// channels: two channel sub-tiles share a staged image) also when the volume is 32 or more voxels wide
+static const int g_x16_at = []() { const char* e = getenv("REPMODE_CONV_X16_AT"); return e ? atoi(e) : 0; }();
+
 template <typename T, bool SWAP, bool PAIR>
 int dispatch_tile(ConvArgs a, hipStream_t stream) {
+  if (a.W >= 32 && g_x16_at > 0 && a.Cout >= g_x16_at) return launch_cfg<T, CfgX16, SWAP, PAIR>(a, stream);
   if (a.W >= 32) {
     if (g_rowstat && a.tap_lo == 0 && a.tap_hi == 4 && !a.dual) return launch_cfg<T, CfgX32, SWAP, PAIR, false, true>(a, stream);
     return launch_cfg<T, CfgX32, SWAP, PAIR>(a, stream);
