@@ -310,22 +310,27 @@ __global__ __launch_bounds__(GATE_BWD_THREADS) void gate_bwd_kernel(
 
 
 // Expert gradients and gate-probability gradients from the per-slot filter gradient dw[s][tap][co][ci].
-// Block = (one co, 32 ci); thread = (ci = tid % 32, taps tid / 32 + 8k).  Reads of dw are 128-byte
+// Block = (one co, 32 ci); thread = (ci = tid % 32, taps tid / 32 + (NTH / 32) k).  Reads of dw are 128-byte
 // rows; expert gradients are accumulated over slots in registers and written back transposed through
 // LDS ([ci][taps] contiguous, the experts' layout); the per-slot gate-probability partial sums are
 // reduced over the block and added to dg[s][e][co] (one atomic per block, slot and expert).
-constexpr int GB_NT = 16;   // taps per thread: ceil(125 / 8)
-
-template <int SG>   // slots per reduction round
-__global__ __launch_bounds__(GF_THREADS, SG > 2 ? 1 : 2) void gatrep_bwd_kernel(
+// NTH threads: ci = tid % 32, tap group tq = tid / 32, taps tq + (NTH / 32) k.  Two shapes: 256 threads x 16 taps, 2 slots per
+// round (large layers: two or three workgroups per CU) and 512 threads x 8 taps, 8 slots per round (small layers: the launch
+// is one dependent chain of fetch -> reduce -> write, so a tile's work is spread over 8 waves).
+template <int NTH, int SG>   // threads per workgroup; slots per reduction round
+__global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void gatrep_bwd_kernel(
     const float* __restrict__ dw, const float* __restrict__ k5, const float* __restrict__ k3,
     const float* __restrict__ k1, const float* __restrict__ a3, const float* __restrict__ a5,
     const float* __restrict__ g, int nslots, int co_n, int ci_n, float* __restrict__ dk5,
     float* __restrict__ dk3, float* __restrict__ dk1, float* __restrict__ da3, float* __restrict__ da5,
     float* __restrict__ dg) {
+  constexpr int NQ = NTH / GF_CT;                 // tap groups
+  constexpr int NT = (TAPS + NQ - 1) / NQ;        // taps per thread
+  constexpr int NW = NTH / 64;                    // waves
+  constexpr int NV5 = (GF_CT * TAPS + NTH - 1) / NTH, NV3 = (GF_CT * 27 + NTH - 1) / NTH, NVG = (64 * E + NTH - 1) / NTH;
   __shared__ float s5[GF_CT * TAPS];        // k5 slab, later reused for the dk5 write-back
   __shared__ float s3[GF_CT * 27];
-  __shared__ float part[SG * 5][GF_THREADS];
+  __shared__ float part[SG * 5][NW][GF_CT]; // per-wave partial sums (the two tap groups of a wave already folded)
   __shared__ float cross[3][SG][GF_CT];     // per-slot contributions to dk1 / da3 / da5 of each ci
   __shared__ float sgb[64][E];
   const int tid = threadIdx.x;
@@ -342,52 +347,80 @@ __global__ __launch_bounds__(GF_THREADS, SG > 2 ? 1 : 2) void gatrep_bwd_kernel(
   const int c = tid & (GF_CT - 1), tq = tid / GF_CT;
   const bool live = c < nlive;
   const size_t oi = base + (live ? c : 0);
-  const size_t tap_stride = (size_t)co_n * ci_n;
+  const size_t tap_stride = (size_t)co_n * ci_n;            // (125 co ci < 2^30: checked by the launcher)
   // Every global load this workgroup needs before its first reduction is issued up front, BEFORE anything waits: the
-  // first round's filter gradients (SG x 16 per thread), the expert slabs, the 1x1 experts and the gate
+  // first round's filter gradients (SG x NT per thread), the expert slabs, the 1x1 experts and the gate
   // probabilities.  In the train step these are cold (the filter gradient was just written by another kernel): the
   // prologue used to be three dependent round trips to HBM (50-70 us per launch cold vs 25 us warm).
-  float dpre[SG][GB_NT];
+  // Addresses: buffer loads -- a descriptor at the first slot of the round, the slot's byte offset in an SGPR and a 32-bit
+  // per-lane offset per tap shared by all slots (per-load 64-bit addresses spilled).  Invalid taps and dead lanes load element
+  // 0 of the tile (a valid address) unmasked: everything such a value is multiplied into is a zero constant (below) or is
+  // never written back.
+  const float* __restrict__ dwt = dw + base;
+  const unsigned slot_bytes = (unsigned)(TAPS * tap_stride * sizeof(float));      // (8 slots < 4 GiB: checked by the launcher)
+  bool tap_on[NT];
+  int offk[NT];
 #pragma unroll
-  for (int j = 0; j < SG; ++j) {
-    const float* dws = dw + (size_t)min(j, nslots - 1) * TAPS * tap_stride + oi;
+  for (int k = 0; k < NT; ++k) {
+    tap_on[k] = tq + NQ * k < TAPS && live;
+    offk[k] = tap_on[k] ? (int)(((unsigned)(tq + NQ * k) * (unsigned)tap_stride + (unsigned)c) * sizeof(float)) : 0;
+  }
+  float dpre[SG][NT];
+  {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dwt), 0, -1, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < GB_NT; ++k) {
-      const int tap = tq + 8 * k;
-      dpre[j][k] = (tap < TAPS && live && j < nslots) ? dws[(size_t)tap * tap_stride] : 0.f;
-    }
+    for (int j = 0; j < SG; ++j)
+#pragma unroll
+      for (int k = 0; k < NT; ++k)
+        dpre[j][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, offk[k], min(j, nslots - 1) * slot_bytes, 0));
   }
   const float w1 = live ? k1[oi] : 0.f;
   const float w3 = live ? a3[oi] * (1.0f / 27.0f) : 0.f;
   const float w5 = live ? a5[oi] * (1.0f / 125.0f) : 0.f;
   {
-    float v5[16], v3[4], vg[2];
+    float v5[NV5], v3[NV3], vg[NVG];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { const int i = tid + j * GF_THREADS; v5[j] = i < nlive * TAPS ? k5[base * TAPS + i] : 0.f; }
+    for (int j = 0; j < NV5; ++j) { const int i = tid + j * NTH; v5[j] = i < nlive * TAPS ? k5[base * TAPS + i] : 0.f; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int i = tid + j * GF_THREADS; v3[j] = i < nlive * 27 ? k3[base * 27 + i] : 0.f; }
+    for (int j = 0; j < NV3; ++j) { const int i = tid + j * NTH; v3[j] = i < nlive * 27 ? k3[base * 27 + i] : 0.f; }
     // this output channel's gate probabilities for every slot (up to 64 slots through LDS: 320 values)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int i = tid + j * GF_THREADS;
+    for (int j = 0; j < NVG; ++j) {
+      const int i = tid + j * NTH;
       vg[j] = i < min(nslots, 64) * E ? g[((size_t)(i / E) * E + i % E) * co_n + co] : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { const int i = tid + j * GF_THREADS; if (i < GF_CT * TAPS) s5[i] = v5[j]; }
+    for (int j = 0; j < NV5; ++j) { const int i = tid + j * NTH; if (i < GF_CT * TAPS) s5[i] = v5[j]; }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int i = tid + j * GF_THREADS; if (i < GF_CT * 27) s3[i] = v3[j]; }
+    for (int j = 0; j < NV3; ++j) { const int i = tid + j * NTH; if (i < GF_CT * 27) s3[i] = v3[j]; }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { const int i = tid + j * GF_THREADS; if (i < 64 * E) sgb[i / E][i % E] = vg[j]; }
+    for (int j = 0; j < NVG; ++j) { const int i = tid + j * NTH; if (i < 64 * E) sgb[i / E][i % E] = vg[j]; }
   }
-  float acc5[GB_NT], acc3[GB_NT];
+  float acc5[NT], acc3[NT];
 #pragma unroll
-  for (int k = 0; k < GB_NT; ++k) { acc5[k] = 0.f; acc3[k] = 0.f; }
+  for (int k = 0; k < NT; ++k) { acc5[k] = 0.f; acc3[k] = 0.f; }
   float acc1 = 0.f, acca3 = 0.f, acca5 = 0.f;     // meaningful in threads tid < 32 only
   __syncthreads();
   // Slots are taken SG at a time: their filter-gradient loads are independent (all in flight together) and the
   // per-slot partial sums stay in registers until ONE block reduction per round.  (One load -> reduce -> barrier
   // round trip per slot made every launch 50-60 us whatever the layer size.)
   const int rj = tid / GF_CT;               // reduction phase: this thread reduces slot s0 + rj for ci c
+  // Per-tap constants of this thread, so that the slot loop below is branch-free (the unrolled slots x taps bodies with their
+  // own predicates and exec-mask juggling were ~9 k instructions per wave: the small layers' launches were bound by VALU
+  // issue, not by memory).  Invalid taps / dead lanes load d = 0 and carry zero constants.
+  constexpr int K_C = 62 / NQ;              // the centre tap (62) is tap tq + NQ k of thread group tq = 62 % NQ at k = K_C
+  float s5v[NT], s3v[NT], m1[NT], m3[NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const int tap = tq + NQ * k;
+    int t3;
+    const bool c3 = in_centre3(tap, t3) && tap_on[k];
+    s5v[k] = tap_on[k] ? s5[c * TAPS + tap] : 0.f;     // (dead lanes must not touch the uninitialised slab tail)
+    s3v[k] = c3 ? s3[c * 27 + t3] : 0.f;
+    m1[k] = tap_on[k] ? 1.f : 0.f;
+    m3[k] = c3 ? 1.f : 0.f;
+  }
+  const float mc = (tq == 62 % NQ && live) ? 1.f : 0.f;
   for (int s0 = 0; s0 < nslots; s0 += SG) {
     const int ns = min(SG, nslots - s0);
     float q[SG][5];
@@ -400,41 +433,48 @@ __global__ __launch_bounds__(GF_THREADS, SG > 2 ? 1 : 2) void gatrep_bwd_kernel(
         const bool in_lds = s < 64;
         const float* gs = g + (size_t)s * E * co_n + co;
         const float g0 = in_lds ? sgb[s][0] : gs[0], g1 = in_lds ? sgb[s][1] : gs[co_n];
-        const float* dws = dw + (size_t)s * TAPS * tap_stride + oi;
 #pragma unroll
-        for (int k = 0; k < GB_NT; ++k) {
-          const int tap = tq + 8 * k;
-          if (tap < TAPS && live) {      // dead lanes must not touch the (uninitialised) slab tail
-            const float d = s0 == 0 ? dpre[j][k] : dws[(size_t)tap * tap_stride];
-            int t3;
-            const bool c3 = in_centre3(tap, t3);
-            q[j][4] += d;
-            q[j][0] += s5[c * TAPS + tap] * d;
-            acc5[k] += g0 * d;
-            if (c3) {
-              q[j][3] += d;
-              q[j][1] += s3[c * 27 + t3] * d;
-              acc3[k] += g1 * d;
-              if (tap == 62) q[j][2] = d;
-            }
-          }
+        for (int k = 0; k < NT; ++k) {
+          const float d = dpre[j][k];
+          q[j][4] = fmaf(m1[k], d, q[j][4]);
+          q[j][0] = fmaf(s5v[k], d, q[j][0]);
+          q[j][3] = fmaf(m3[k], d, q[j][3]);
+          q[j][1] = fmaf(s3v[k], d, q[j][1]);
+          if (k == K_C) q[j][2] = fmaf(mc, d, q[j][2]);
+          acc5[k] = fmaf(g0, d, acc5[k]);          // (invalid taps, and for acc3 taps outside the centre cube: never written back)
+          acc3[k] = fmaf(g1, d, acc3[k]);
         }
       }
     }
+    // the next round's filter gradients are requested before this round's reduction
+    if (s0 + SG < nslots) {
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dwt + (size_t)(s0 + SG) * TAPS * tap_stride), 0, -1, 0x00020000);
+      const int nn = nslots - (s0 + SG);
+#pragma unroll
+      for (int j = 0; j < SG; ++j)
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+          dpre[j][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, offk[k], min(j, nn - 1) * slot_bytes, 0));
+    }
+    // the two tap groups of a wave (lanes l and l + 32: same ci) fold in registers; lanes 0..31 store the wave's sums
 #pragma unroll
     for (int j = 0; j < SG; ++j)
 #pragma unroll
-      for (int v = 0; v < 5; ++v) part[j * 5 + v][tid] = q[j][v];
+      for (int v = 0; v < 5; ++v) {
+        const float t = q[j][v] + __shfl_xor(q[j][v], 32);
+        if ((tid & 32) == 0) part[j * 5 + v][tid >> 6][c] = t;
+      }
     __syncthreads();
     {
-      // thread (c, rj): totals of slot s0 + rj for ci c over the 8 tap groups
+      // thread (c, rj): totals of slot s0 + rj for ci c over the waves
       float r[5];
 #pragma unroll
       for (int v = 0; v < 5; ++v) {
         r[v] = 0.f;
         if (rj < SG) {
 #pragma unroll
-          for (int t = 0; t < GF_THREADS / GF_CT; ++t) r[v] += part[rj * 5 + v][c + t * GF_CT];
+          for (int t = 0; t < NW; ++t) r[v] += part[rj * 5 + v][t][c];
         }
       }
       const int s = s0 + rj;
@@ -450,13 +490,15 @@ __global__ __launch_bounds__(GF_THREADS, SG > 2 ? 1 : 2) void gatrep_bwd_kernel(
         cross[2][rj][c] = g4 * r[4];
       }
       // dg[s][e][co] += sum over this block's ci (one atomic per block, slot and expert)
-      float e[E] = {r[0], r[1], w1 * r[2], w3 * r[3], w5 * r[4]};
+      if (rj < SG) {                       // (wave-uniform: rj is constant over a half-wave, SG is even)
+        float e[E] = {r[0], r[1], w1 * r[2], w3 * r[3], w5 * r[4]};
 #pragma unroll
-      for (int k = 0; k < E; ++k) {
-        float v = e[k];
+        for (int k = 0; k < E; ++k) {
+          float v = e[k];
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 32);
-        if (c == 0 && on) atomicAdd(dg + ((size_t)s * E + k) * co_n + co, v);
+          for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 32);
+          if (c == 0 && on) atomicAdd(dg + ((size_t)s * E + k) * co_n + co, v);
+        }
       }
     }
     __syncthreads();
@@ -473,8 +515,8 @@ __global__ __launch_bounds__(GF_THREADS, SG > 2 ? 1 : 2) void gatrep_bwd_kernel(
   }
   // write dk5 / dk3 back in the experts' [ci][taps] layout through LDS (slabs are contiguous)
 #pragma unroll
-  for (int k = 0; k < GB_NT; ++k) {
-    const int tap = tq + 8 * k;
+  for (int k = 0; k < NT; ++k) {
+    const int tap = tq + NQ * k;
     if (tap < TAPS) {
       s5[c * TAPS + tap] = acc5[k];
       int t3;
@@ -482,8 +524,8 @@ __global__ __launch_bounds__(GF_THREADS, SG > 2 ? 1 : 2) void gatrep_bwd_kernel(
     }
   }
   __syncthreads();
-  for (int i = tid; i < nlive * TAPS; i += GF_THREADS) dk5[base * TAPS + i] = s5[i];
-  for (int i = tid; i < nlive * 27; i += GF_THREADS) dk3[base * 27 + i] = s3[i];
+  for (int i = tid; i < nlive * TAPS; i += NTH) dk5[base * TAPS + i] = s5[i];
+  for (int i = tid; i < nlive * 27; i += NTH) dk3[base * 27 + i] = s3[i];
   }   // (tile loop)
 }
 
@@ -853,6 +895,7 @@ extern "C" int repmode_gatrep_bwd_ex(const float* dw, const float* k5, const flo
   RM_REQUIRE(dw && k5 && k3 && k1 && a3 && a5 && g && slot_task, "gatrep_bwd: null input");
   RM_REQUIRE(dk5 && dk3 && dk1 && da3 && da5 && dgate_w && dgate_b && dg_ws, "gatrep_bwd: null output");
   RM_REQUIRE(nslots > 0 && num_tasks > 0 && co > 0 && ci > 0, "gatrep_bwd: bad shape");
+  RM_REQUIRE((long)TAPS * co * ci < (1L << 27), "gatrep_bwd: 8 slots of the filter gradient must stay below 4 GiB (32-bit offsets)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   // dg accumulates in the library's zero scratch when it fits (gate_bwd puts the zeros back: no memset launch);
   // otherwise in the caller's dg_ws
@@ -868,15 +911,18 @@ extern "C" int repmode_gatrep_bwd_ex(const float* dw, const float* k5, const flo
     RM_HIP(hipMemsetAsync(dg_ws, 0, ndg * sizeof(float), s));
   }
   repmode_prof_begin(REPMODE_PROF_GATREP_BWD, (double)co * ci * 4.0 * (125.0 * nslots + 2 * 155.0), s);
-  // small layers are latency-bound: 8 slots' loads in flight per thread (one wave per SIMD); larger ones want
-  // the occupancy of the 2-slot variant
+  // Small layers (at most one workgroup per CU) are one dependent chain per launch: 512 threads per tile, 8 slots' loads in
+  // flight per thread.  Larger ones want the occupancy of the 256-thread, 2-slot shape.  Measured per launch, warm / cold
+  // (tools/gatrep_microbench.py under rocprofv3, 8 slots): 32x32 13.3 / 15.4 us, 64x64 13.9 / 19.4, 128x64 15.6 / 25.5 (512
+  // threads; 1024 x 4 slots: 16.7-22.0 / 20.0-30.3; 256 x 8: 15.8-18.3 / 18.2-28.3); 128x128 26.6 / 42.7, 128x256 49.9 / 79.6
+  // (256 x 2; 1024 x 4: 41.2-78.3 / 57.1-104.4; 512 x 4: 32.8-62.9 / 47.2-86.7).
   const int gx = repmode_deterministic() ? 1 : ceil_div(ci, GF_CT);      // (deterministic: a workgroup walks all tiles of its co)
   if ((long)ceil_div(ci, GF_CT) * co <= 256)
-    hipLaunchKernelGGL(gatrep_bwd_kernel<8>, dim3(gx, co), dim3(GF_THREADS), 0, s, dw, k5, k3, k1, a3, a5,
-                       g, nslots, co, ci, dk5, dk3, dk1, da3, da5, dg);
+    hipLaunchKernelGGL((gatrep_bwd_kernel<512, 8>), dim3(gx, co), dim3(512), 0, s, dw, k5, k3, k1, a3, a5, g, nslots, co, ci, dk5,
+                       dk3, dk1, da3, da5, dg);
   else
-    hipLaunchKernelGGL(gatrep_bwd_kernel<2>, dim3(gx, co), dim3(GF_THREADS), 0, s, dw, k5, k3, k1, a3, a5,
-                       g, nslots, co, ci, dk5, dk3, dk1, da3, da5, dg);
+    hipLaunchKernelGGL((gatrep_bwd_kernel<256, 2>), dim3(gx, co), dim3(256), 0, s, dw, k5, k3, k1, a3, a5, g, nslots, co, ci, dk5,
+                       dk3, dk1, da3, da5, dg);
   RM_LAUNCH_CHECK("gatrep_bwd");
   // the gate backward: its own launch, or (REPMODE_DEFER) the first workgroups of the next conv5 launch on this stream
   const int rc = gate_bwd_launch(g, dg, slot_task, nslots, num_tasks, co, dgate_w, dgate_b, clear, (flags & REPMODE_DEFER) != 0, s);

@@ -11,7 +11,7 @@ if os.environ.get('REPMODE_LIB'):
     _lib.LIB_PATH = os.environ['REPMODE_LIB']
 dev = 'cuda:0'
 plan = ops.TaskPlan([0, 1, 2, 3, 4, 5, 6, 7], 12, dev)
-for co, ci in ((32, 32), (64, 64), (128, 128), (256, 128), (512, 512)):
+for co, ci in ((32, 1), (32, 32), (64, 32), (64, 64), (128, 64), (128, 128), (128, 256)):     # the merged levels' layers
     k5 = torch.randn(co, ci, 5, 5, 5, device=dev); k3 = torch.randn(co, ci, 3, 3, 3, device=dev)
     k1 = torch.randn(co, ci, 1, 1, 1, device=dev); a3 = torch.randn(co, ci, 1, 1, 1, device=dev); a5 = torch.randn(co, ci, 1, 1, 1, device=dev)
     gw = torch.randn(5 * co, 12, device=dev); gb = torch.randn(5 * co, device=dev)
@@ -26,7 +26,7 @@ for co, ci in ((32, 32), (64, 64), (128, 128), (256, 128), (512, 512)):
     def fwd():
         return ops.gatrep_merge(k5, k3, k1, a3, a5, g, torch.bfloat16, want_wf=True, want_wd=True)
     flush = torch.empty(128 * 1024 * 1024, device=dev) if os.environ.get('GATREP_COLD') else None   # 512 MB: evicts L2 + MALL
-    for name, fn in (('fwd', fwd), ('bwd', bwd)):
+    for name, fn in ((('bwd', bwd),) if os.environ.get('GATREP_BWD_ONLY') else (('fwd', fwd), ('bwd', bwd))):
         for _ in range(5): fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
