@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define REPMODE_ABI_VERSION 5
+#define REPMODE_ABI_VERSION 6
 
 /* element types of activations / merged filters */
 #define REPMODE_F32 0  /* float in, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)          */
@@ -387,6 +387,20 @@ int repmode_crop_flip(const float* const* signal_vols, const float* const* targe
 int repmode_mse_loss(const float* out, const float* target, const int32_t* sample_task, int n, long v, int num_tasks,
                      float* dout, float* sums_ws, float* loss, float* loss_sample, float* task_mean, float* task_count,
                      void* stream);
+
+/* ---- sliding-window inference (fnet/fnet_model.py:149-223): the two ends of a batch of patches, SURVEY.md section 8f.3 ----
+ * patch_gather: :196-205 -- out[n][pd][ph][pw] = vol[starts[3n..3n+2] + (z, y, x)], the batch's crops of the device-resident
+ *   float volume [D][H][W] in one launch.  starts: HOST array [nb][3] (copied into the launch's arguments).
+ * patch_blend: :207-217 -- for n = 0 .. nb-1 in this order: pred_sum[patch n] += out[n] * gauss, weight_sum[patch n] += gauss
+ *   (float volumes [D][H][W]; out: [nb][pd][ph][pw] float32 or bf16 per `dtype`; gauss: float [pd][ph][pw],
+ *   fnet_model.py:225-247).  Patches of one batch may overlap: every voxel is owned by one thread that walks the patches in
+ *   batch order, so the additions happen in the reference's order (products and sums rounded separately), without atomics.
+ * nb <= REPMODE_PATCH_MAX per call; a patch that leaves the volume is an error. */
+#define REPMODE_PATCH_MAX 32
+int repmode_patch_gather(const float* vol, int D, int H, int W, const int* starts, int nb, int pd, int ph, int pw, float* out,
+                         void* stream);
+int repmode_patch_blend(const void* out, int dtype, const float* gauss, const int* starts, int nb, int pd, int ph, int pw,
+                        float* pred_sum, float* weight_sum, int D, int H, int W, void* stream);
 
 /* repmode_expert_frags for several blocks (both roles) in ONE launch; pointer arguments are HOST arrays of nblocks entries,
  * wd[i] may be NULL, or wf[i] when wd[i] is given.  nblocks <= REPMODE_GATREP_MULTI_MAX. */

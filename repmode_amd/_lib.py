@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('REPMODE_LIB') or os.path.join(_HERE, 'librepmode_hip.
 
 F32, BF16 = 0, 1
 DEFER = 1        # REPMODE_DEFER: queue the job for the next conv5 launch on the stream (include/repmode_hip.h)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c = ctypes
 _P = _c.c_void_p
@@ -75,6 +75,8 @@ _SIGNATURES = {
     'repmode_expert_frags': [_P, _P, _I, _I, _P, _P, _P],
     'repmode_crop_flip': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     'repmode_mse_loss': [_P, _P, _P, _I, _c.c_long, _I, _P, _P, _P, _P, _P, _P, _P],
+    'repmode_patch_gather': [_P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P],
+    'repmode_patch_blend': [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P],
     'repmode_expert_frags_multi': [_I, _P, _P, _P, _P, _P, _P, _P],
     'repmode_prof_enable': [_I],
     'repmode_prof_pause': [_I],

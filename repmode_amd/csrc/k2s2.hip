@@ -18,6 +18,8 @@
 // are bandwidth/latency bound; what they buy is the removal of the permute copies around a library GEMM.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 template <typename T>
@@ -163,6 +165,84 @@ __global__ __launch_bounds__(256, 2) void k2s2_kernel(K2Args a) {
   }
 }
 
+// Under-filled launches (the deep levels: a few hundred to a few thousand coarse voxels, hundreds of channels -- 16-64
+// workgroups of the kernel above, each one dependent chain of `reduction chunks` round trips to L2): the four waves of a
+// workgroup share ONE 32-voxel tile and split the taps (gather: two taps each, summed through LDS; scatter: one tap of
+// the z half each, nothing to sum), and a wave requests U reduction chunks' operands before it multiplies the first.
+template <typename T, bool SCATTER>
+__global__ __launch_bounds__(256, 2) void k2s2_split_kernel(K2Args a) {
+  constexpr int KV = KElem<T>::KV, KC = 2 * KV;
+  constexpr int U = 8;
+  __shared__ float red[SCATTER ? 1 : 4][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const long m = (long)blockIdx.x * 32 + l31;
+  const bool mvalid = m < a.M;
+  const long mc = mvalid ? m : a.M - 1;
+  const int rt = blockIdx.y;
+  const int nkc = a.CinP / KC, nrt = a.CoutP / 32;
+  const int Cin = a.Cin, Cout = a.Cout;
+  const bool vec = (Cin % KV) == 0;
+  const T* __restrict__ in = static_cast<const T*>(a.in);
+  const T* __restrict__ wt = static_cast<const T*>(a.w) + ((size_t)rt * nkc) * (32 * KC) + l31 * KC + khalf * KV;
+  const size_t tap_stride = (size_t)nrt * nkc * (32 * KC);
+  T* __restrict__ out = static_cast<T*>(a.out);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if constexpr (!SCATTER) {
+    const int p0 = 2 * wave;
+    const T* __restrict__ r0 = in + fine_row(mc, p0, a.d, a.h, a.wd) * Cin;
+    const T* __restrict__ r1 = in + fine_row(mc, p0 + 1, a.d, a.h, a.wd) * Cin;
+    const T* __restrict__ w0 = wt + (size_t)p0 * tap_stride;
+    const T* __restrict__ w1 = w0 + tap_stride;
+    for (int kc0 = 0; kc0 < nkc; kc0 += U) {
+      u32x4 b0[U], b1[U], a0[U], a1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int kc = min(kc0 + u, nkc - 1);
+        b0[u] = load_chunk<T>(r0, kc * KC + khalf * KV, Cin, vec);
+        b1[u] = load_chunk<T>(r1, kc * KC + khalf * KV, Cin, vec);
+        a0[u] = *reinterpret_cast<const u32x4*>(w0 + (size_t)kc * (32 * KC));
+        a1[u] = *reinterpret_cast<const u32x4*>(w1 + (size_t)kc * (32 * KC));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (kc0 + u < nkc) { KElem<T>::mma(a0[u], b0[u], acc); KElem<T>::mma(a1[u], b1[u], acc); }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    // wave q stores accumulator quad q (output channels rt 32 + 8 q + 4 khalf ...): the four partial sums in a fixed order
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = ((red[0][4 * wave + i][lane] + red[1][4 * wave + i][lane]) + red[2][4 * wave + i][lane]) + red[3][4 * wave + i][lane];
+    if (mvalid) store_quad<T>(out + (size_t)m * Cout, rt * 32 + 8 * wave + 4 * khalf, Cout, v[0], v[1], v[2], v[3]);
+  } else {
+    const int p = 4 * blockIdx.z + wave;
+    const T* __restrict__ r0 = in + (size_t)mc * Cin;
+    const T* __restrict__ w0 = wt + (size_t)p * tap_stride;
+    for (int kc0 = 0; kc0 < nkc; kc0 += U) {
+      u32x4 b0[U], a0[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int kc = min(kc0 + u, nkc - 1);
+        b0[u] = load_chunk<T>(r0, kc * KC + khalf * KV, Cin, vec);
+        a0[u] = *reinterpret_cast<const u32x4*>(w0 + (size_t)kc * (32 * KC));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (kc0 + u < nkc) KElem<T>::mma(a0[u], b0[u], acc);
+    }
+    if (mvalid) {
+      T* row = out + fine_row(m, p, a.d, a.h, a.wd) * Cout;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        store_quad<T>(row, rt * 32 + 8 * q + 4 * khalf, Cout, acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+  }
+}
+
 }  // namespace
 
 // in/out: channels-last, dtype.  scatter == 0: in is the FINE grid [N][2d][2h][2w][Cin], out the coarse grid
@@ -181,6 +261,20 @@ extern "C" int repmode_k2s2(const void* in, const void* w, void* out, int n, int
   a.CinP = repmode_padded_channels(cin, dtype, 1);
   a.CoutP = repmode_padded_channels(cout, dtype, 0);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  static const int split_below = []() { const char* e = getenv("REPMODE_K2S2_SPLIT_BELOW"); return e ? atoi(e) : 256; }();
+  if ((long)((a.M + 127) / 128) * (a.CoutP / 32) < split_below) {
+    // under-filled: 32-voxel workgroups whose waves split the taps (k2s2_split_kernel)
+    const dim3 grid((unsigned)((a.M + 31) / 32), (unsigned)(a.CoutP / 32), scatter ? 2u : 1u);
+    if (dtype == REPMODE_F32) {
+      if (scatter) hipLaunchKernelGGL((k2s2_split_kernel<float, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k2s2_split_kernel<float, false>), grid, dim3(256), 0, s, a);
+    } else {
+      if (scatter) hipLaunchKernelGGL((k2s2_split_kernel<bf16_t, true>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k2s2_split_kernel<bf16_t, false>), grid, dim3(256), 0, s, a);
+    }
+    RM_LAUNCH_CHECK("k2s2");
+    return REPMODE_OK;
+  }
   const dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)(a.CoutP / 32), scatter ? 2u : 1u);   // z: tap half (scatter)
   if (dtype == REPMODE_F32) {
     if (scatter) hipLaunchKernelGGL((k2s2_kernel<float, true>), grid, dim3(256), 0, s, a);

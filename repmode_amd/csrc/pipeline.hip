@@ -161,3 +161,110 @@ extern "C" int repmode_mse_loss(const float* out, const float* target, const int
   RM_LAUNCH_CHECK("mse_finish");
   return REPMODE_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Sliding-window inference (fnet/fnet_model.py:149-223): the two ends of a batch of patches.
+//   patch_gather  :196-205  the batch's crops of the (device-resident) volume, one launch (the reference slices and
+//                 stacks them one by one)
+//   patch_blend   :207-217  pred_sum[patch] += out * gaussian, weight_sum[patch] += gaussian for every patch of the
+//                 batch.  Patches of one batch overlap, so a thread owns a VOXEL of the batch's bounding box and walks the
+//                 patches in batch order: the float additions happen in the reference's order (one rounding per product
+//                 and per sum, no fused multiply-add), without atomics.
+// Patch origins travel in the kernel arguments (no device copy, no synchronisation).
+namespace {
+
+constexpr int PB_MAX = REPMODE_PATCH_MAX;
+
+struct PatchArgs {
+  int start[PB_MAX][3];
+  int nb, pd, ph, pw, D, H, W;
+  int lo[3], ext[3];        // bounding box of the batch (blend)
+};
+
+__global__ __launch_bounds__(256) void patch_gather_kernel(PatchArgs a, const float* __restrict__ vol, float* __restrict__ out) {
+  const int n = blockIdx.z, row = blockIdx.y;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= a.pw) return;
+  const int z = row / a.ph, y = row % a.ph;
+  const size_t src = ((size_t)(a.start[n][0] + z) * a.H + a.start[n][1] + y) * a.W + a.start[n][2] + x;
+  out[((size_t)n * a.pd * a.ph + row) * a.pw + x] = vol[src];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void patch_blend_kernel(PatchArgs a, const T* __restrict__ out, const float* __restrict__ gauss,
+                                                         float* __restrict__ pred_sum, float* __restrict__ weight_sum) {
+  const int row = blockIdx.y;
+  const int bx = blockIdx.x * 256 + threadIdx.x;
+  if (bx >= a.ext[2]) return;
+  const int z = a.lo[0] + row / a.ext[1], y = a.lo[1] + row % a.ext[1], x = a.lo[2] + bx;
+  const size_t at = ((size_t)z * a.H + y) * a.W + x;
+  float ps = 0.f, ws = 0.f;
+  bool hit = false;
+  for (int n = 0; n < a.nb; ++n) {
+    const int lz = z - a.start[n][0], ly = y - a.start[n][1], lx = x - a.start[n][2];
+    if ((unsigned)lz < (unsigned)a.pd && (unsigned)ly < (unsigned)a.ph && (unsigned)lx < (unsigned)a.pw) {
+      if (!hit) { ps = pred_sum[at]; ws = weight_sum[at]; hit = true; }
+      const size_t li = ((size_t)lz * a.ph + ly) * a.pw + lx;
+      const float g = gauss[li];
+      float o;
+      if constexpr (sizeof(T) == 2) o = bf16_to_f32(out[(size_t)n * a.pd * a.ph * a.pw + li]);
+      else o = out[(size_t)n * a.pd * a.ph * a.pw + li];
+      ps = __fadd_rn(ps, __fmul_rn(o, g));
+      ws = __fadd_rn(ws, g);
+    }
+  }
+  if (hit) { pred_sum[at] = ps; weight_sum[at] = ws; }
+}
+
+int fill_patch_args(PatchArgs& a, const int* starts, int nb, int pd, int ph, int pw, int D, int H, int W, const char* who) {
+  RM_REQUIRE(starts, "%s: null patch origins", who);
+  RM_REQUIRE(nb > 0 && nb <= PB_MAX, "%s: 1..%d patches per call, got %d", who, PB_MAX, nb);
+  RM_REQUIRE(pd > 0 && ph > 0 && pw > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape", who);
+  a.nb = nb; a.pd = pd; a.ph = ph; a.pw = pw; a.D = D; a.H = H; a.W = W;
+  const int pdim[3] = {pd, ph, pw}, vdim[3] = {D, H, W};
+  int hi[3] = {0, 0, 0};
+  for (int k = 0; k < 3; ++k) a.lo[k] = vdim[k];
+  for (int n = 0; n < nb; ++n)
+    for (int k = 0; k < 3; ++k) {
+      const int s = starts[3 * n + k];
+      RM_REQUIRE(s >= 0 && s + pdim[k] <= vdim[k], "%s: patch %d leaves the volume", who, n);
+      a.start[n][k] = s;
+      if (s < a.lo[k]) a.lo[k] = s;
+      if (s + pdim[k] > hi[k]) hi[k] = s + pdim[k];
+    }
+  for (int k = 0; k < 3; ++k) a.ext[k] = hi[k] - a.lo[k];
+  return REPMODE_OK;
+}
+
+}  // namespace
+
+// out[n][pd][ph][pw] = vol[start_n + (z, y, x)]; starts: HOST array [nb][3]
+extern "C" int repmode_patch_gather(const float* vol, int D, int H, int W, const int* starts, int nb, int pd, int ph, int pw,
+                                    float* out, void* stream) {
+  RM_REQUIRE(vol && out, "patch_gather: null pointer");
+  PatchArgs a{};
+  const int rc = fill_patch_args(a, starts, nb, pd, ph, pw, D, H, W, "patch_gather");
+  if (rc != REPMODE_OK) return rc;
+  hipLaunchKernelGGL(patch_gather_kernel, dim3(ceil_div(pw, 256), pd * ph, nb), dim3(256), 0, static_cast<hipStream_t>(stream), a, vol, out);
+  RM_LAUNCH_CHECK("patch_gather");
+  return REPMODE_OK;
+}
+
+// pred_sum[start_n + v] += out[n][v] * gauss[v], weight_sum[start_n + v] += gauss[v], n = 0 .. nb-1 in this order per voxel.
+// out: float32 or bf16 (dtype); starts: HOST array [nb][3]
+extern "C" int repmode_patch_blend(const void* out, int dtype, const float* gauss, const int* starts, int nb, int pd, int ph,
+                                   int pw, float* pred_sum, float* weight_sum, int D, int H, int W, void* stream) {
+  RM_REQUIRE(out && gauss && pred_sum && weight_sum, "patch_blend: null pointer");
+  RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "patch_blend: bad dtype %d", dtype);
+  PatchArgs a{};
+  const int rc = fill_patch_args(a, starts, nb, pd, ph, pw, D, H, W, "patch_blend");
+  if (rc != REPMODE_OK) return rc;
+  const dim3 grid(ceil_div(a.ext[2], 256), a.ext[0] * a.ext[1]);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == REPMODE_F32)
+    hipLaunchKernelGGL(patch_blend_kernel<float>, grid, dim3(256), 0, s, a, static_cast<const float*>(out), gauss, pred_sum, weight_sum);
+  else
+    hipLaunchKernelGGL(patch_blend_kernel<bf16_t>, grid, dim3(256), 0, s, a, static_cast<const bf16_t*>(out), gauss, pred_sum, weight_sum);
+  RM_LAUNCH_CHECK("patch_blend");
+  return REPMODE_OK;
+}

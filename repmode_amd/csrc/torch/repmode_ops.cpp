@@ -126,6 +126,11 @@ struct ZeroPool {
       plan = it->second;
       int64_t total = 0;
       for (int64_t v : plan) total += (v + ALIGN - 1) / ALIGN * ALIGN;
+      if (getenv("REPMODE_POOL_DEBUG")) {        // (developer aid: what the step's one memset covers)
+        fprintf(stderr, "[repmode] zero pool '%s': %zu buffers, %lld floats:", k.c_str(), plan.size(), (long long)total);
+        for (int64_t v : plan) fprintf(stderr, " %lld", (long long)v);
+        fprintf(stderr, "\n");
+      }
       buf = at::zeros({total}, like.options().dtype(at::kFloat));
     }
   }

@@ -220,9 +220,20 @@ class TaskPlan:
         self.n = len(host)
         self.slot_task_host = uniq
         self.task0 = uniq[0]
-        self.slot_task = torch.tensor(uniq, dtype=torch.int32).to(device, non_blocking=True)
-        self.sample_slot = torch.tensor(slots, dtype=torch.int32).to(device, non_blocking=True)
-        self.sample_task = torch.tensor(host, dtype=torch.int32).to(device, non_blocking=True)   # task id per sample
+        # the three index vectors travel as ONE copy out of pinned memory: a pageable source makes the copy synchronous --
+        # the host would wait for the previous step's kernels at the top of every step and lose its lead over the GPU.
+        # (Each vector starts on a 16-int boundary of the device buffer.)
+        pad = lambda v: v + [0] * (-len(v) % 16)
+        packed = torch.tensor(pad(uniq) + pad(slots) + host, dtype=torch.int32)
+        dev = torch.device(device)
+        if dev.type == 'cuda':
+            packed = packed.pin_memory()
+        buf = packed.to(dev, non_blocking=True)
+        o1 = len(pad(uniq))
+        o2 = o1 + len(pad(slots))
+        self.slot_task = buf[:len(uniq)]
+        self.sample_slot = buf[o1:o1 + len(slots)]
+        self.sample_task = buf[o2:o2 + len(host)]   # task id per sample
         self.bn_counted = False     # set by Net.forward once num_batches_tracked of every BN layer is advanced
 
 
@@ -659,3 +670,45 @@ def mode_conv3d(x_cl, k5, k3, k1, a3, a5, gate_w, gate_b, plan, out_f32=False, m
     """
     return torch_ops().mode_conv3d(x_cl, None, k5, k3, k1, a3, a5, gate_w, gate_b, *_plan_args(plan), out_f32,
                                    _MODE_CODE[mode])
+
+
+def patch_gather(volume, starts, patch_size):
+    """The crops ``volume[s : s + patch]`` of a device-resident float volume [D, H, W] for every origin in ``starts``,
+    stacked as [nb, 1, pd, ph, pw] -- one launch per 32 patches (fnet_model.py:196-205 slices and stacks one by one)."""
+    import ctypes
+    d, h, w = (int(v) for v in volume.shape[-3:])
+    vol = volume.reshape(d, h, w)
+    if vol.dtype != torch.float32 or not vol.is_contiguous():
+        vol = vol.float().contiguous()
+    pd, ph, pw = (int(v) for v in patch_size)
+    nb = len(starts)
+    out = torch.empty((nb, 1, pd, ph, pw), dtype=torch.float32, device=vol.device)
+    st = (ctypes.c_int * (3 * nb))(*[int(v) for s in starts for v in s])
+    for lo in range(0, nb, 32):             # REPMODE_PATCH_MAX per launch
+        hi = min(nb, lo + 32)
+        _lib.call('repmode_patch_gather', _ptr(vol), d, h, w, ctypes.byref(st, 3 * lo * 4), hi - lo, pd, ph, pw,
+                  _ptr(out[lo:hi]), _stream())
+    return out
+
+
+def patch_blend(out, gauss, starts, pred_sum, weight_sum):
+    """``pred_sum[patch] += out[n] * gauss; weight_sum[patch] += gauss`` for the patches of a batch in batch order
+    (fnet_model.py:207-217), in place, one launch per 32 patches.  out: [nb, 1, pd, ph, pw] float32 or bf16."""
+    import ctypes
+    d, h, w = (int(v) for v in pred_sum.shape[-3:])
+    pd, ph, pw = (int(v) for v in gauss.shape[-3:])
+    nb = len(starts)
+    if out.numel() != nb * pd * ph * pw:
+        raise ValueError('patch_blend: out %s does not hold %d patches of %s' % (tuple(out.shape), nb, (pd, ph, pw)))
+    for t in (pred_sum, weight_sum, gauss):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError('patch_blend: pred_sum, weight_sum and gauss must be contiguous float32 tensors')
+    if pred_sum.numel() != d * h * w or weight_sum.numel() != d * h * w:
+        raise ValueError('patch_blend: pred_sum / weight_sum must hold ONE volume (batch and channel dims of 1)')
+    out = out.contiguous()
+    code = dtype_code(out.dtype)
+    st = (ctypes.c_int * (3 * nb))(*[int(v) for s in starts for v in s])
+    for lo in range(0, nb, 32):
+        hi = min(nb, lo + 32)
+        _lib.call('repmode_patch_blend', _ptr(out[lo:hi]), code, _ptr(gauss), ctypes.byref(st, 3 * lo * 4), hi - lo, pd, ph, pw,
+                  _ptr(pred_sum), _ptr(weight_sum), d, h, w, _stream())

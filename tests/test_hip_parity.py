@@ -653,10 +653,12 @@ def test_bn_relu_channels_far_from_zero(shape):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('n,d,h,w,ci,co', [(2, 4, 4, 8, 32, 32), (1, 2, 3, 5, 6, 4), (2, 2, 2, 2, 64, 128), (1, 1, 1, 1, 2, 2)])
+@pytest.mark.parametrize('n,d,h,w,ci,co', [(2, 4, 4, 8, 32, 32), (1, 2, 3, 5, 6, 4), (2, 2, 2, 2, 64, 128), (1, 1, 1, 1, 2, 2),
+                                          (1, 32, 32, 32, 32, 32), (3, 4, 8, 8, 128, 128)])
 def test_down_up_k2s2(n, d, h, w, ci, co, dtype):
     """The stride-2 stages (gather / scatter GEMM kernels) against torch's Conv3d / ConvTranspose3d on CPU,
-    forward and backward.  d, h, w are the COARSE dims."""
+    forward and backward.  d, h, w are the COARSE dims.  The small cases run the under-filled launches' kernel (waves split
+    the taps), the 32^3 one the full-size kernel, the last one a level-2 layer of the network."""
     ops = _ops()
     gen = torch.Generator().manual_seed(ci * 3 + co)
     tol = 1e-4 if dtype == torch.float32 else 2e-2

@@ -152,3 +152,36 @@ def test_conv5_merged_experiment_vs_oracle(ci, co, shape, n):
     x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
     y = ops.conv5_merged(x_cl, w2, d[2], d[3], d[4], g, plan.sample_slot, co)
     assert rel_err(y.permute(0, 4, 1, 2, 3).cpu(), y_ref) < 2e-2
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_patch_gather_and_blend_match_the_indexing_expressions(dtype):
+    """repmode_patch_gather / repmode_patch_blend against the reference's own expressions (fnet_model.py:196-217: slice +
+    cat; ``pred_sum[patch] += out * gauss``, ``weight_sum[patch] += gauss`` patch by patch) on overlapping patches, LIFO
+    batches as predict() forms them, 40 patches in one call (two launches): bit-identical."""
+    ops = _ops()
+    from repmode_amd.model import get_gaussian, patch_grid
+    gen = torch.Generator().manual_seed(11)
+    img, patch = (20, 50, 70), (8, 16, 32)
+    vol = torch.randn(1, 1, *img, generator=gen).to(DEV)
+    gauss = torch.from_numpy(get_gaussian(patch)).to(DEV)
+    patches = patch_grid(img, patch)
+    assert len(patches) > 40
+    ps_k, ws_k = torch.zeros_like(vol), torch.zeros_like(vol)
+    ps_r, ws_r = torch.zeros_like(vol), torch.zeros_like(vol)
+    for bs in (3, 40, 5):
+        batch = [patches.pop() for _ in range(bs)]
+        starts = [s for s, _ in batch]
+        crops = ops.patch_gather(vol, starts, patch)
+        ref = torch.cat([vol[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] for s, e in batch], dim=0)
+        assert torch.equal(crops, ref)
+        out = torch.randn(bs, 1, *patch, generator=gen).to(DEV, dtype)
+        ops.patch_blend(out, gauss, starts, ps_k, ws_k)
+        for i, (s, e) in enumerate(batch):
+            ps_r[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] += out[i:i + 1] * gauss
+            ws_r[:, :, s[0]:e[0], s[1]:e[1], s[2]:e[2]] += gauss
+        assert torch.equal(ps_k, ps_r) and torch.equal(ws_k, ws_r)
+    # a patch that leaves the volume is refused
+    from repmode_amd import _lib
+    with pytest.raises(_lib.RepModeHipError):
+        ops.patch_gather(vol, [(15, 0, 0)], patch)
