@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define REPMODE_ABI_VERSION 6
+#define REPMODE_ABI_VERSION 7
 
 /* element types of activations / merged filters */
 #define REPMODE_F32 0  /* float in, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)          */
@@ -387,6 +387,12 @@ int repmode_crop_flip(const float* const* signal_vols, const float* const* targe
 int repmode_mse_loss(const float* out, const float* target, const int32_t* sample_task, int n, long v, int num_tasks,
                      float* dout, float* sums_ws, float* loss, float* loss_sample, float* task_mean, float* task_count,
                      void* stream);
+
+/* Developer / test switch of the convolution's pipelined form (csrc/conv5_igemm.hip, conv5_pipe_kernel; also REPMODE_CONV_PIPE):
+ * bit 0 = on (default), bit 1 = one channel sub-tile per wave everywhere, bit 2 = also on grids smaller than the chip.
+ * Results do not depend on it (same products, same summation order). */
+int repmode_set_conv_pipe(int mode);
+int repmode_get_conv_pipe(void);
 
 /* ---- sliding-window inference (fnet/fnet_model.py:149-223): the two ends of a batch of patches, SURVEY.md section 8f.3 ----
  * patch_gather: :196-205 -- out[n][pd][ph][pw] = vol[starts[3n..3n+2] + (z, y, x)], the batch's crops of the device-resident

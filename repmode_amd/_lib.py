@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('REPMODE_LIB') or os.path.join(_HERE, 'librepmode_hip.
 
 F32, BF16 = 0, 1
 DEFER = 1        # REPMODE_DEFER: queue the job for the next conv5 launch on the stream (include/repmode_hip.h)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _c = ctypes
 _P = _c.c_void_p
@@ -27,6 +27,8 @@ _SIGNATURES = {
     'repmode_device_arch': [_I, _c.c_char_p, _I],
     'repmode_set_deterministic': [_I],
     'repmode_get_deterministic': [],
+    'repmode_set_conv_pipe': [_I],
+    'repmode_get_conv_pipe': [],
     'repmode_padded_channels': [_I, _I, _I],
     'repmode_gate_softmax': [_P, _P, _P, _I, _I, _I, _P, _P],
     'repmode_gatrep_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],

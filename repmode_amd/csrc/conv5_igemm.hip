@@ -161,7 +161,7 @@ struct Cfg {
 #define RM_CONV_X16_WAVES 2     // (experiment: -DRM_CONV_X16_WAVES=3 asks for three waves per SIMD on the 4 x 4 x 16 tile)
 #endif
 template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false, bool ROWSTAT = false, bool MERGE = false>
-__global__ __launch_bounds__(C::NT, (C::BX == 16 && !MERGE) ? RM_CONV_X16_WAVES : 2) void conv5_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(C::NT, C::NT == 512 ? 4 : (C::BX == 16 && !MERGE) ? RM_CONV_X16_WAVES : 2) void conv5_igemm_kernel(ConvArgs a) {
   constexpr int KV = Elem<T>::KV;
   constexpr int KC = 2 * KV;
   constexpr int BZ = C::BZ, BY = C::BY, BX = C::BX, VW = C::VW, CW = C::CW;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(C::NT, (C::BX == 16 && !MERGE) ? RM_CONV_X16_WAVES 
 #ifdef RM_CONV_DMA
       constexpr int UNR = 1;     // (only channel counts that are no multiple of 8 (4) come here: one item at a time, few registers)
 #else
-      constexpr int UNR = (NITEMS + NT - 1) / NT >= 9 ? 9 : 4;   // loads in flight per thread per batch (latency-bound phase)
+      constexpr int UNR = NT == 512 ? 5 : (NITEMS + NT - 1) / NT >= 9 ? 9 : 4;   // loads in flight per thread per batch (latency-bound phase; 512 threads: 128 registers)
 #endif
       for (int it0 = 0; it0 < NITEMS; it0 += NT * UNR) {
         u32x4 v[UNR];
@@ -923,6 +923,337 @@ __global__ __launch_bounds__(C::NT, (C::BX == 16 && !MERGE) ? RM_CONV_X16_WAVES 
   RM_STAMP(60);
 }
 
+// =====================================================================================================================
+// conv5_pipe_kernel -- the wide levels' (x extent >= 32) element-typed bf16 convolution as ONE software pipeline per CU.
+//
+// The kernel above gives a CU two workgroups that each alternate "stage a 16-channel halo image" / "125 taps" / epilogue and
+// relies on their drifting out of phase; the PMC picture of its level-0 launches (profiles/r03_pmc_conv_level0.txt) is 53 %
+// MFMA-busy with a third of the wave cycles parked in s_waitcnt / barriers.  Here a CU runs ONE workgroup of four waves (one
+// per SIMD, the whole register file each) that never leaves the tap loop:
+//   * the halo image is double-buffered in LDS (2 x 73.7 KB); while the 125 taps of image `cur` run, the 18 sixteen-byte
+//     items per thread of the NEXT image (next channel chunk, or the first chunk of the workgroup's next brick) are requested
+//     two per tap row during rows 0..8 (buffer loads: positions outside the volume read as zero through the range check) and
+//     stored into the other buffer two per row during rows 14..22 -- one barrier per image, nothing waits for memory;
+//   * the 25 (dz, dy) rows are unrolled, so every LDS read is an immediate offset from one address register, every filter
+//     fragment one buffer load with a scalar offset; filter fragments run 1280 MFMA cycles ahead, across image boundaries;
+//   * a workgroup owns a contiguous range of (brick, channel tile) items (persistent grid: at most one workgroup per CU), so
+//     the epilogue's stores drain under the next brick's taps;
+//   * CW = 2 (layers with more than 32 output channels): a voxel fragment feeds two MFMAs -- 128 accumulator registers, which
+//     the two-workgroup form could not hold.
+// Out-of-volume taps are not skipped (the image holds zeros there); the launcher sends only volumes of several bricks here.
+template <int CW>
+__global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nitems) {
+  using C = Cfg<4, 4, 32, 4, 1, 4, CW>;
+  constexpr int KV = 8, KC = 16, VW = 4;
+  constexpr int BZ = C::BZ, BY = C::BY, BX = C::BX, BYH = C::BYH, BXH = C::BXH, VH = C::VH, PLS = C::PLS;
+  constexpr int BUF = 2 * PLS;                  // 16-byte slots of one halo image
+  constexpr int NIT = (2 * VH) / 256;           // halo items per thread
+  static_assert((2 * VH) % 256 == 0 && NIT == 18, "halo items: two per tap row over nine rows");
+  constexpr uint32_t OOB = 0x7fffffffu;         // beyond every descriptor's range: the load returns zeros
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* lds = reinterpret_cast<u32x4*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int khalf = lane >> 5, l31 = lane & 31;
+  if (a.tail.nblocks) {
+    if ((int)blockIdx.x < a.tail.nblocks) {
+      tail_run(a.tail, blockIdx.x, tid, reinterpret_cast<float*>(smem));
+      return;
+    }
+  }
+  const int conv_block = blockIdx.x - a.tail.nblocks, conv_blocks = gridDim.x - a.tail.nblocks;
+  const int L = xcd_remap(conv_block, conv_blocks);
+  const int per = nitems / conv_blocks, rem = nitems % conv_blocks;
+  int item = L * per + min(L, rem);
+  const int item_end = item + per + (L < rem ? 1 : 0);
+  if (item >= item_end) return;
+
+  const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, CinP = a.CinP, CoutP = a.CoutP;
+  const int Cin1 = a.Cin1, Cout1 = a.Cout1;
+  const int nkc = CinP / KC, nrt = CoutP / 32;
+  const uint32_t ts_bytes = (uint32_t)CoutP * (uint32_t)CinP * 2u;               // one tap of one slot
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, 0x7ffffffe, 0x00020000);
+  const int c1 = Cin1 > 0 ? Cin1 : Cin;                                           // channels of the first input tensor
+  const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.x), 0, (int)((size_t)a.N * D * H * W * c1 * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(Cin1 > 0 ? a.x2 : a.x), 0, (int)((size_t)a.N * D * H * W * (Cin1 > 0 ? Cin - Cin1 : c1) * 2), 0x00020000);
+
+  // ---- per-thread constants of the halo items: item u is halo voxel vh = 128 u + tid / 2, plane tid & 1
+  const int pl = tid & 1, vh0 = tid >> 1;
+  int hvox[NIT], hpc[NIT];
+#pragma unroll
+  for (int u = 0; u < NIT; ++u) {
+    const int vh = u * 128 + vh0;
+    const int xx = vh % BXH, t2 = vh / BXH;
+    const int yy = t2 % BYH, zz = t2 / BYH;
+    hvox[u] = (zz * H + yy) * W + xx;
+    hpc[u] = zz | (yy << 8) | (xx << 16);
+  }
+  const int lds_item = pl * PLS + vh0;                            // + 128 u
+  const int lane_w = (l31 * KC + khalf * KV) * 2;                 // this lane's 16 bytes of a filter fragment
+  const u32x4* lb0 = lds + khalf * PLS + (wave * BYH) * BXH + l31;   // this lane's voxel of sub-tile vs: + vs * BXH
+
+  // ---- the pipeline's unit: image (item, chunk)
+  struct Img { int n, z0, y0, x0, cot, chunk; uint32_t wbase[CW]; };
+  auto decode = [&](int it, int chunk) -> Img {
+    Img g;
+    int b = it;
+    g.cot = b % a.ncot; b /= a.ncot;
+    const int bx = b % a.nbx; b /= a.nbx;
+    const int by = b % a.nby; b /= a.nby;
+    const int bz = b % a.nbz;
+    g.n = b / a.nbz;
+    g.z0 = bz * BZ; g.y0 = by * BY; g.x0 = bx * BX;
+    g.chunk = chunk;
+    const int slot = a.sample_slot[g.n];
+#pragma unroll
+    for (int cs = 0; cs < CW; ++cs) {
+      const int rt = min(g.cot * CW + cs, nrt - 1);         // (a tile beyond the padded filter is clamped; never stored)
+      g.wbase[cs] = (uint32_t)slot * REPMODE_TAPS * ts_bytes + (uint32_t)((rt * nkc + chunk) * (32 * KC) * 2);
+    }
+    return g;
+  };
+  u32x4 hv[NIT];
+  auto halo_load = [&](const Img& g, int u) {
+    const int ci0 = g.chunk * KC;
+    const bool from2 = Cin1 > 0 && ci0 >= Cin1;
+    const int csrc = Cin1 > 0 ? (from2 ? Cin - Cin1 : Cin1) : Cin;
+    const int c = ci0 + pl * KV;
+    const int zz = hpc[u] & 0xff, yy = (hpc[u] >> 8) & 0xff, xx = hpc[u] >> 16;
+    const int gz = g.z0 - 2 + zz, gy = g.y0 - 2 + yy, gx = g.x0 - 2 + xx;
+    const bool ok = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin;
+    const int base_vox = ((g.n * D + g.z0 - 2) * H + g.y0 - 2) * W + g.x0 - 2;
+    const uint32_t off = (uint32_t)((base_vox + hvox[u]) * csrc + (c - (from2 ? Cin1 : 0))) * 2u;
+    hv[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(from2 ? rx2 : rx1, ok ? off : OOB, 0, 0));
+  };
+  auto wfrag = [&](const Img& g, int cs, int tap) -> u32x4 {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, lane_w, g.wbase[cs] + (uint32_t)tap * ts_bytes, 0));
+  };
+
+  f32x16 acc[CW][VW];
+#pragma unroll
+  for (int cs = 0; cs < CW; ++cs)
+#pragma unroll
+    for (int vs = 0; vs < VW; ++vs)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cs][vs][r] = 0.f;
+
+  // ---- prologue: the first image into buffer 0, the first two filter rows into registers
+  Img cur_g = decode(item, 0);
+  // filter rows in flight ahead of the one being multiplied: two (10 taps = 1280 MFMA cycles) with one channel sub-tile,
+  // one (5 taps of two sub-tiles: the same 1280 cycles) with two -- whose 128 accumulators leave no room for a third set
+  constexpr int RA = CW == 1 ? 2 : 1;
+  u32x4 a_cur[CW][5], a_n1[CW][5], a_n2[CW][5];
+#pragma unroll
+  for (int u = 0; u < NIT; ++u) halo_load(cur_g, u);
+#pragma unroll
+  for (int cs = 0; cs < CW; ++cs)
+#pragma unroll
+    for (int dx = 0; dx < 5; ++dx) {
+      a_cur[cs][dx] = wfrag(cur_g, cs, dx);
+      if constexpr (RA == 2) a_n1[cs][dx] = wfrag(cur_g, cs, 5 + dx);
+    }
+#pragma unroll
+  for (int u = 0; u < NIT; ++u) lds[lds_item + 128 * u] = hv[u];
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  int cur = 0;
+
+  for (;;) {
+    // the image after this one: next channel chunk of the brick, or the first chunk of the next item
+    const bool last_chunk = cur_g.chunk + 1 >= nkc;
+    const bool have_next = !last_chunk || item + 1 < item_end;
+    Img nxt_g = cur_g;
+    if (have_next) nxt_g = last_chunk ? decode(item + 1, 0) : decode(item, cur_g.chunk + 1);
+    const u32x4* lb = lb0 + cur * BUF;
+    u32x4* lw = lds + (cur ^ 1) * BUF + lds_item;
+    // Voxel fragments run TWO taps ahead in three rotating register sets (tap t uses set t % 3; everything below is
+    // unrolled, so the rotation is register naming, not moves), and each LDS read is issued in the shadow of one MFMA:
+    // M d M d M d M d -- a lone wave has ~5 issue slots per 32-cycle MFMA, and a read requested only one tap (128 cycles)
+    // ahead was not back in time.
+    auto tap_off = [&](int t) -> int { return (((t / 5) / 5) * BYH + ((t / 5) % 5)) * BXH + t % 5; };
+    u32x4 bq[3][VW];
+#pragma unroll
+    for (int vs = 0; vs < VW; ++vs) { bq[0][vs] = lb[vs * BXH + tap_off(0)]; bq[1][vs] = lb[vs * BXH + tap_off(1)]; }
+#pragma unroll
+    for (int r = 0; r < 25; ++r) {
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) {
+        const int t = r * 5 + dx;
+#pragma unroll
+        for (int vs = 0; vs < VW; ++vs) {
+#pragma unroll
+          for (int cs = 0; cs < CW; ++cs) Elem<bf16_t>::mma(a_cur[cs][dx], bq[t % 3][vs], acc[cs][vs]);
+          if (t + 2 < 125) bq[(t + 2) % 3][vs] = lb[vs * BXH + tap_off(t + 2)];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // this tap's filter fragment of the row RA ahead (the last RA rows: the next image's first rows)
+        if (r + RA < 25) {
+#pragma unroll
+          for (int cs = 0; cs < CW; ++cs) a_n2[cs][dx] = wfrag(cur_g, cs, (r + RA) * 5 + dx);
+        } else if (have_next) {
+#pragma unroll
+          for (int cs = 0; cs < CW; ++cs) a_n2[cs][dx] = wfrag(nxt_g, cs, (r + RA - 25) * 5 + dx);
+        }
+        // the next image: two items requested per row in rows 0..8, stored per row in rows 14..22
+        if (have_next && (dx == 1 || dx == 3)) {
+          const int k = dx >> 1;
+          if (r < 9) halo_load(nxt_g, 2 * r + k);
+          if (r >= 14 && r < 23) lw[128 * (2 * (r - 14) + k)] = hv[2 * (r - 14) + k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int cs = 0; cs < CW; ++cs)
+#pragma unroll
+        for (int dx = 0; dx < 5; ++dx) {
+          if constexpr (RA == 2) { a_cur[cs][dx] = a_n1[cs][dx]; a_n1[cs][dx] = a_n2[cs][dx]; }
+          else a_cur[cs][dx] = a_n2[cs][dx];
+        }
+    }
+    // every wave is done with image `cur` and has stored its part of the next one
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    if (last_chunk) {
+      // ---- epilogue of the brick (the stores drain under the next brick's taps).  32x32 C/D layout: column = lane & 31
+      // (voxel), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (output channels)
+      const int z0 = cur_g.z0, y0 = cur_g.y0, x0 = cur_g.x0, n_out = cur_g.n, cot = cur_g.cot;
+#pragma unroll
+      for (int vs = 0; vs < VW; ++vs) {
+        const int gz = z0 + wave, gy = y0 + vs, gx = x0 + l31;       // voxel m = (wave 4 + vs) 32 + l31 of the brick
+        const bool inside = gz < D && gy < H && gx < W;
+        const size_t vox = ((size_t)(n_out * D + gz) * H + gy) * W + gx;
+#pragma unroll
+        for (int cs = 0; cs < CW; ++cs) {
+          if (a.wide) {
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+              const int co16 = cot * C::COT + cs * 32 + 16 * qp;
+              if (co16 >= Cout) continue;
+              uint32_t pk[2][2];
+#pragma unroll
+              for (int g = 0; g < 2; ++g) {
+                const int q = 2 * qp + g;
+                float v0 = acc[cs][vs][4 * q + 0], v1 = acc[cs][vs][4 * q + 1];
+                float v2 = acc[cs][vs][4 * q + 2], v3 = acc[cs][vs][4 * q + 3];
+                if (a.bias) {
+                  const float* bp = a.bias + co16 + 8 * g + 4 * khalf;
+                  v0 += bp[0]; v1 += bp[1]; v2 += bp[2]; v3 += bp[3];
+                }
+                if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                pk[g][0] = pack_bf16x2(v0, v1);
+                pk[g][1] = pack_bf16x2(v2, v3);
+              }
+              const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+              const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+              if (!inside) continue;
+              const bool out2 = Cout1 > 0 && co16 >= Cout1;
+              const int Cout_ = Cout1 > 0 ? (out2 ? Cout - Cout1 : Cout1) : Cout;
+              const int co = (out2 ? co16 - Cout1 : co16) + 8 * khalf;
+              bf16_t* yp = static_cast<bf16_t*>(out2 ? a.y2 : a.y) + vox * Cout_ + co;
+              *reinterpret_cast<u32x4*>(yp) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int co_all = cot * C::COT + cs * 32 + 8 * q + 4 * khalf;
+              if (co_all >= Cout || !inside) continue;
+              const bool out2 = Cout1 > 0 && co_all >= Cout1;
+              const int Cout_ = Cout1 > 0 ? (out2 ? Cout - Cout1 : Cout1) : Cout;
+              const int co = out2 ? co_all - Cout1 : co_all;
+              float v0 = acc[cs][vs][4 * q + 0], v1 = acc[cs][vs][4 * q + 1];
+              float v2 = acc[cs][vs][4 * q + 2], v3 = acc[cs][vs][4 * q + 3];
+              if (a.bias) {
+                v0 += a.bias[co_all];
+                if (co_all + 1 < Cout) v1 += a.bias[co_all + 1];
+                if (co_all + 2 < Cout) v2 += a.bias[co_all + 2];
+                if (co_all + 3 < Cout) v3 += a.bias[co_all + 3];
+              }
+              if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+              const uint32_t p01 = pack_bf16x2(v0, v1), p23 = pack_bf16x2(v2, v3);
+              bf16_t* yp = static_cast<bf16_t*>(out2 ? a.y2 : a.y) + vox * Cout_ + co;
+              if ((Cout_ & 3) == 0) {
+                *reinterpret_cast<u32x2*>(yp) = u32x2{p01, p23};
+              } else {
+                yp[0] = (bf16_t)(p01 & 0xffffu);
+                if (co + 1 < Cout_) yp[1] = (bf16_t)(p01 >> 16);
+                if (co + 2 < Cout_) yp[2] = (bf16_t)(p23 & 0xffffu);
+                if (co + 3 < Cout_) yp[3] = (bf16_t)(p23 >> 16);
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int cs = 0; cs < CW; ++cs)
+#pragma unroll
+        for (int vs = 0; vs < VW; ++vs)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[cs][vs][r] = 0.f;
+      ++item;
+    }
+    if (!have_next) break;
+    cur_g = nxt_g;
+    cur ^= 1;
+  }
+}
+
+// eligibility + launch of the pipelined form (see the kernel's comment); returns -1 when the launch is not its kind.
+// REPMODE_CONV_PIPE / repmode_set_conv_pipe: bit 0 = on (default), bit 1 = one channel sub-tile per wave everywhere, bit 2 = also
+// on grids smaller than the chip (the parity tests' volumes).  Same box, interleaved, us per launch two-workgroup form /
+// pipelined: 32->32 (level 0) 227.6 / 216.7, 64->32 460.0 / 433.5, 64->64 (level 1) 116.4 / 98.1, 128->64 224.1 / 189.2
+// (one sub-tile per wave: 106.2, 206.8); conv5 launches of the train step 3945 -> 3702 us.  The step itself moves less
+// (11.82 -> 11.75 ms): with the convolutions drawing more power every other kernel of the step runs 2-6 % slower
+// (profiles/r03_pipe_ab.txt) -- the chip is power-limited over the step, not per kernel.
+static int g_pipe = []() { const char* e = getenv("REPMODE_CONV_PIPE"); return e ? atoi(e) : 1; }();
+
+int launch_pipe(ConvArgs a, hipStream_t stream) {
+  using C1 = Cfg<4, 4, 32, 4, 1, 4, 1>;
+  if (!g_pipe || a.W < 32 || a.D < 4 || a.H < 4 || a.dual || a.dxc || a.tap_lo != 0 || a.tap_hi != 4 || a.stats || a.out_f32 ||
+      (a.Cin & 7) != 0)
+    return -1;
+  // one descriptor spans each tensor: 32-bit byte offsets
+  const size_t vox = (size_t)a.N * a.D * a.H * a.W;
+  if (vox * (size_t)(a.Cin1 > 0 ? (a.Cin1 > a.Cin - a.Cin1 ? a.Cin1 : a.Cin - a.Cin1) : a.Cin) * 2 >= ((size_t)1 << 31)) return -1;
+  const int cw = (g_pipe & 2) ? 1 : (a.CoutP >= 64 ? 2 : 1);
+  a.nbz = ceil_div(a.D, C1::BZ);
+  a.nby = ceil_div(a.H, C1::BY);
+  a.nbx = ceil_div(a.W, C1::BX);
+  a.ncot = ceil_div(a.CoutP, 32 * cw);
+  a.ksplit = 1;
+  const long nitems = (long)a.N * a.nbz * a.nby * a.nbx * a.ncot;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    RM_HIP(hipGetDevice(&dev));
+    RM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus <= 0) cus = 256;
+  }
+  // filter offsets are 32-bit too (the number of slots is sample data: at most one per sample)
+  if ((size_t)a.N * REPMODE_TAPS * a.CoutP * a.CinP * 2 >= ((size_t)1 << 31)) return -1;
+  if (nitems < ((g_pipe & 4) ? 1 : cus) || nitems >= (1L << 30)) return -1;   // under-filled launches keep the two-workgroup form (bit 2: tests)
+  repmode_tail_take(stream, &a.tail);
+  const int nwg = (int)(nitems < cus ? nitems : cus);
+  const long grid = nwg + a.tail.nblocks;
+  constexpr int LDS_BYTES = 2 * C1::LDS_BYTES;
+  static_assert(LDS_BYTES >= TAIL_LDS_BYTES && LDS_BYTES <= 160 * 1024, "two halo images per workgroup");
+  static std::atomic<unsigned> attr_set{0};
+  int dev = 0;
+  RM_HIP(hipGetDevice(&dev));
+  if (!((attr_set.load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_pipe_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_pipe_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
+  }
+  const double alg = 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS;
+  repmode_prof_begin(REPMODE_PROF_CONV5, alg, stream);
+  if (cw == 2) hipLaunchKernelGGL(conv5_pipe_kernel<2>, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, a, (int)nitems);
+  else hipLaunchKernelGGL(conv5_pipe_kernel<1>, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, a, (int)nitems);
+  repmode_prof_end(stream);
+  RM_LAUNCH_CHECK("conv5_pipe");
+  return REPMODE_OK;
+}
+
 template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false, bool ROWSTAT = false, bool MERGE = false>
 int launch_cfg(ConvArgs a, hipStream_t stream) {
   a.nbz = ceil_div(a.D, C::BZ);
@@ -983,6 +1314,7 @@ using CfgX32 = Cfg<4, 4, 32, 4, 1, 4, 1>;      // 512 voxels x 32 channels   (le
 using CfgX16 = Cfg<4, 4, 16, 2, 2, 4, 1>;      // 256 voxels x 64 channels   (level 2)
 using CfgX8 = Cfg<4, 8, 8, 2, 2, 4, 1>;        // 256 voxels x 64 channels   (level 3)
 using CfgX4 = Cfg<2, 4, 4, 1, 4, 1, 1>;        // 32 voxels x 128 channels   (level 4)
+using CfgX32W8 = Cfg<4, 4, 32, 8, 1, 2, 1>;    // experiment: the levels 0-1 brick on 8 waves (two voxel sub-tiles each), 4 waves per SIMD
 
 // REPMODE_CONV_ROWSTAT=1: the row-stationary tap loop on the 4 x 4 x 32 tile (full 5x5x5 support only).  Built, measured,
 // OFF: same box, interleaved, us per launch tap-major / row-stationary: 32->32 237.2 / 256.1, 64->32 471.1 / 498.7,
@@ -996,10 +1328,17 @@ static const int g_wide = []() { const char* e = getenv("REPMODE_CONV_WIDE"); re
 // Experiment (REPMODE_CONV_X16_AT=<cout>): layers at least that wide in output channels take the 4 x 4 x 16 tile (256 voxels x 64
 // channels: two channel sub-tiles share a staged image) also when the volume is 32 or more voxels wide
 static const int g_x16_at = []() { const char* e = getenv("REPMODE_CONV_X16_AT"); return e ? atoi(e) : 0; }();
+// Experiment (REPMODE_CONV_W8=1): the 4 x 4 x 32 brick on 512 threads -- four waves per SIMD at <= 128 registers
+static const int g_w8 = []() { const char* e = getenv("REPMODE_CONV_W8"); return e ? atoi(e) : 0; }();
 
 template <typename T, bool SWAP, bool PAIR>
 int dispatch_tile(ConvArgs a, hipStream_t stream) {
+  if constexpr (sizeof(T) == 2 && !SWAP) {
+    const int rc = launch_pipe(a, stream);
+    if (rc != -1) return rc;
+  }
   if (a.W >= 32 && g_x16_at > 0 && a.Cout >= g_x16_at) return launch_cfg<T, CfgX16, SWAP, PAIR>(a, stream);
+  if (a.W >= 32 && g_w8) return launch_cfg<T, CfgX32W8, SWAP, PAIR>(a, stream);
   if (a.W >= 32) {
     if (g_rowstat && a.tap_lo == 0 && a.tap_hi == 4 && !a.dual) return launch_cfg<T, CfgX32, SWAP, PAIR, false, true>(a, stream);
     return launch_cfg<T, CfgX32, SWAP, PAIR>(a, stream);
@@ -1026,6 +1365,9 @@ int dispatch(ConvArgs a, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" int repmode_set_conv_pipe(int mode) { g_pipe = mode; return REPMODE_OK; }
+extern "C" int repmode_get_conv_pipe(void) { return g_pipe; }
 
 extern "C" int repmode_padded_channels(int channels, int dtype, int is_reduction_dim) {
   if (channels <= 0) return 0;

@@ -118,6 +118,17 @@ def get_deterministic():
     return bool(_lib.load().repmode_get_deterministic())
 
 
+def set_conv_pipe(mode):
+    """The convolution's pipelined one-wave-per-SIMD form on volumes 32 or more voxels wide (csrc/conv5_igemm.hip,
+    ``conv5_pipe_kernel``): bit 0 on (default 1), bit 1 one channel sub-tile per wave everywhere, bit 2 also on grids smaller
+    than the chip (tests).  0: the two-workgroup form everywhere.  Results do not depend on it."""
+    _lib.call('repmode_set_conv_pipe', int(mode))
+
+
+def get_conv_pipe():
+    return int(_lib.load().repmode_get_conv_pipe())
+
+
 def set_thin_kernels(on):
     """The one-channel first / last layers through their own kernels (csrc/thin_conv.hip; default) or round 2's fold of the x
     taps around the general kernel (REPMODE_THIN=0).  The operator library's switch (the ``thin_conv_*`` wrappers here
@@ -320,6 +331,19 @@ def conv5(x_cl, w, sample_slot, cout, out_f32=False, out=None, centre3=False, ac
     _lib.call('repmode_conv5_ex', _ptr(x_cl), _ptr(w), _ptr(sample_slot), _ptr(y), n, d, h, wd_, cin, cout, code,
               1 if out_dtype == torch.float32 else 0, (1 if centre3 else 0) | (2 if accumulate else 0) | (4 if dxc else 0), _stream())
     return y
+
+
+def conv5_pair(xa, xb, w, sample_slot, cout, cout1=0):
+    """``repmode_conv5_pair`` directly: input channels split over xa | xb (xb None: one tensor), output channels over two
+    tensors at ``cout1`` (0: one).  Element-typed output.  Returns (y, y2 or None)."""
+    n, d, h, wd_, ca = xa.shape
+    cb = xb.shape[-1] if xb is not None else 0
+    y = torch.empty((n, d, h, wd_, cout1 if cout1 else cout), dtype=xa.dtype, device=xa.device)
+    y2 = torch.empty((n, d, h, wd_, cout - cout1), dtype=xa.dtype, device=xa.device) if cout1 else None
+    _lib.call('repmode_conv5_pair', _ptr(xa), _ptr(xb) if xb is not None else None, ca if xb is not None else 0, _ptr(w),
+              _ptr(sample_slot), _ptr(y), _ptr(y2) if y2 is not None else None, cout1, n, d, h, wd_, ca + cb, cout,
+              dtype_code(xa.dtype), 0, 0, _stream())
+    return y, y2
 
 
 def conv5_deep_supported(x_cl):

@@ -185,3 +185,52 @@ def test_patch_gather_and_blend_match_the_indexing_expressions(dtype):
     from repmode_amd import _lib
     with pytest.raises(_lib.RepModeHipError):
         ops.patch_gather(vol, [(15, 0, 0)], patch)
+
+
+PIPE_CASES = [
+    # (N, D, H, W, Cin, Cout, Cin1, Cout1): volumes 32 or more voxels wide; ragged bricks, several channel chunks, one and two
+    # channel sub-tiles per wave, a two-tensor input (skip connection) and a two-tensor output (its data gradient)
+    (2, 6, 10, 40, 32, 32, 0, 0),
+    (3, 5, 9, 35, 48, 64, 0, 0),
+    (2, 8, 8, 64, 64, 96, 0, 0),
+    (2, 4, 12, 33, 64, 32, 32, 0),
+    (2, 7, 5, 32, 32, 64, 0, 32),
+    (9, 4, 4, 32, 16, 24, 0, 0),
+]
+
+
+@pytest.mark.parametrize('mode', [5, 7])
+@pytest.mark.parametrize('case', PIPE_CASES)
+def test_conv5_pipelined_form_vs_oracle_and_the_two_workgroup_form(case, mode):
+    """conv5_pipe_kernel (one workgroup per CU, double-buffered halo image, persistent item ranges; mode 5: two channel sub-tiles
+    per wave where the layer has them, 7: one) against the oracle and -- same products in the same order -- BIT-identical to
+    the two-workgroup kernel.  Small grids: several items per workgroup only where the grid exceeds the CU count, so the
+    batch-9 case and the train-step tests cover the persistent walk."""
+    ops = _ops()
+    from repmode_amd import _lib
+    n, d, h, w, cin, cout, cin1, cout1 = case
+    gen = torch.Generator().manual_seed(sum(case) + mode)
+    nslots = 3
+    slots = torch.tensor([i % nslots for i in range(n)], dtype=torch.int32)
+    x = torch.randn(n, cin, d, h, w, generator=gen).bfloat16().float()
+    wt = (torch.randn(nslots, cout, cin, 5, 5, 5, generator=gen) / np.sqrt(cin * 125)).bfloat16().float()
+    y_ref = orc.conv_per_sample(x, wt[slots.long()])
+    code = ops.dtype_code(torch.bfloat16)
+    wf = _layout_wf(wt, _lib.padded_channels(cout, code, False), _lib.padded_channels(cin, code, True), _kc(torch.bfloat16)).to(DEV, torch.bfloat16)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    outs = []
+    try:
+        for m in (mode, 0):
+            ops.set_conv_pipe(m)
+            if cin1 or cout1:
+                xa = x_cl[..., :cin1].contiguous() if cin1 else x_cl
+                xb = x_cl[..., cin1:].contiguous() if cin1 else None
+                ya, yb = ops.conv5_pair(xa, xb, wf, slots.to(DEV), cout, cout1)
+                y = torch.cat([ya, yb], dim=-1) if yb is not None else ya
+            else:
+                y = ops.conv5(x_cl, wf, slots.to(DEV), cout)
+            outs.append(y.float().cpu())
+    finally:
+        ops.set_conv_pipe(1)
+    assert rel_err(outs[0].permute(0, 4, 1, 2, 3), y_ref) < 6e-3          # (bf16 output)
+    assert torch.equal(outs[0], outs[1])
