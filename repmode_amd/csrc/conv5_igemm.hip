@@ -161,7 +161,7 @@ struct Cfg {
 #define RM_CONV_X16_WAVES 2     // (experiment: -DRM_CONV_X16_WAVES=3 asks for three waves per SIMD on the 4 x 4 x 16 tile)
 #endif
 template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false, bool ROWSTAT = false, bool MERGE = false>
-__global__ __launch_bounds__(C::NT, C::NT == 512 ? 4 : (C::BX == 16 && !MERGE) ? RM_CONV_X16_WAVES : 2) void conv5_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(C::NT, (C::BX == 16 && !MERGE) ? RM_CONV_X16_WAVES : 2) void conv5_igemm_kernel(ConvArgs a) {
   constexpr int KV = Elem<T>::KV;
   constexpr int KC = 2 * KV;
   constexpr int BZ = C::BZ, BY = C::BY, BX = C::BX, VW = C::VW, CW = C::CW;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(C::NT, C::NT == 512 ? 4 : (C::BX == 16 && !MERGE) ?
 #ifdef RM_CONV_DMA
       constexpr int UNR = 1;     // (only channel counts that are no multiple of 8 (4) come here: one item at a time, few registers)
 #else
-      constexpr int UNR = NT == 512 ? 5 : (NITEMS + NT - 1) / NT >= 9 ? 9 : 4;   // loads in flight per thread per batch (latency-bound phase; 512 threads: 128 registers)
+      constexpr int UNR = (NITEMS + NT - 1) / NT >= 9 ? 9 : 4;   // loads in flight per thread per batch (latency-bound phase)
 #endif
       for (int it0 = 0; it0 < NITEMS; it0 += NT * UNR) {
         u32x4 v[UNR];
@@ -1015,20 +1015,29 @@ __global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nite
     return g;
   };
   u32x4 hv[NIT];
-  auto halo_load = [&](const Img& g, int u) {
+  // the scalars of an image's halo requests, computed once per image (a descriptor select inside the tap loop is a branch)
+  struct Halo { __amdgpu_buffer_rsrc_t rs; int csrc, coff, base_vox, z0, y0, x0; bool on; };
+  auto halo_of = [&](const Img& g, bool on) -> Halo {
+    Halo q;
     const int ci0 = g.chunk * KC;
     const bool from2 = Cin1 > 0 && ci0 >= Cin1;
-    const int csrc = Cin1 > 0 ? (from2 ? Cin - Cin1 : Cin1) : Cin;
-    const int c = ci0 + pl * KV;
-    const int zz = hpc[u] & 0xff, yy = (hpc[u] >> 8) & 0xff, xx = hpc[u] >> 16;
-    const int gz = g.z0 - 2 + zz, gy = g.y0 - 2 + yy, gx = g.x0 - 2 + xx;
-    const bool ok = (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W && c < Cin;
-    const int base_vox = ((g.n * D + g.z0 - 2) * H + g.y0 - 2) * W + g.x0 - 2;
-    const uint32_t off = (uint32_t)((base_vox + hvox[u]) * csrc + (c - (from2 ? Cin1 : 0))) * 2u;
-    hv[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(from2 ? rx2 : rx1, ok ? off : OOB, 0, 0));
+    q.rs = from2 ? rx2 : rx1;
+    q.csrc = Cin1 > 0 ? (from2 ? Cin - Cin1 : Cin1) : Cin;
+    const int c = ci0 + pl * KV;                                   // (per-thread: the plane's first channel)
+    q.coff = c - (from2 ? Cin1 : 0);
+    q.on = on && c < Cin;
+    q.base_vox = ((g.n * D + g.z0 - 2) * H + g.y0 - 2) * W + g.x0 - 2;
+    q.z0 = g.z0 - 2; q.y0 = g.y0 - 2; q.x0 = g.x0 - 2;
+    return q;
   };
-  auto wfrag = [&](const Img& g, int cs, int tap) -> u32x4 {
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, lane_w, g.wbase[cs] + (uint32_t)tap * ts_bytes, 0));
+  auto halo_load = [&](const Halo& q, int u) {
+    const int zz = hpc[u] & 0xff, yy = (hpc[u] >> 8) & 0xff, xx = hpc[u] >> 16;
+    const bool ok = q.on && (unsigned)(q.z0 + zz) < (unsigned)D && (unsigned)(q.y0 + yy) < (unsigned)H && (unsigned)(q.x0 + xx) < (unsigned)W;
+    const uint32_t off = (uint32_t)((q.base_vox + hvox[u]) * q.csrc + q.coff) * 2u;
+    hv[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(q.rs, ok ? off : OOB, 0, 0));
+  };
+  auto wfrag = [&](const Img& g, int cs, int tap, int voff) -> u32x4 {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, voff, g.wbase[cs] + (uint32_t)tap * ts_bytes, 0));
   };
 
   f32x16 acc[CW][VW];
@@ -1045,14 +1054,17 @@ __global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nite
   // one (5 taps of two sub-tiles: the same 1280 cycles) with two -- whose 128 accumulators leave no room for a third set
   constexpr int RA = CW == 1 ? 2 : 1;
   u32x4 a_cur[CW][5], a_n1[CW][5], a_n2[CW][5];
+  {
+    const Halo q0 = halo_of(cur_g, true);
 #pragma unroll
-  for (int u = 0; u < NIT; ++u) halo_load(cur_g, u);
+    for (int u = 0; u < NIT; ++u) halo_load(q0, u);
+  }
 #pragma unroll
   for (int cs = 0; cs < CW; ++cs)
 #pragma unroll
     for (int dx = 0; dx < 5; ++dx) {
-      a_cur[cs][dx] = wfrag(cur_g, cs, dx);
-      if constexpr (RA == 2) a_n1[cs][dx] = wfrag(cur_g, cs, 5 + dx);
+      a_cur[cs][dx] = wfrag(cur_g, cs, dx, lane_w);
+      if constexpr (RA == 2) a_n1[cs][dx] = wfrag(cur_g, cs, 5 + dx, lane_w);
     }
 #pragma unroll
   for (int u = 0; u < NIT; ++u) lds[lds_item + 128 * u] = hv[u];
@@ -1065,6 +1077,8 @@ __global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nite
     const bool have_next = !last_chunk || item + 1 < item_end;
     Img nxt_g = cur_g;
     if (have_next) nxt_g = last_chunk ? decode(item + 1, 0) : decode(item, cur_g.chunk + 1);
+    const int lane_w_nxt = have_next ? lane_w : (int)OOB;
+    const Halo hq = halo_of(nxt_g, have_next);
     const u32x4* lb = lb0 + cur * BUF;
     u32x4* lw = lds + (cur ^ 1) * BUF + lds_item;
     // Voxel fragments run TWO taps ahead in three rotating register sets (tap t uses set t % 3; everything below is
@@ -1088,17 +1102,20 @@ __global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nite
           __builtin_amdgcn_sched_barrier(0);
         }
         // this tap's filter fragment of the row RA ahead (the last RA rows: the next image's first rows)
+        // (No branch in here: `have_next` false turns the next image's requests into out-of-range offsets -- zeros, no memory
+        // traffic -- and its stores into writes of a buffer nobody reads.  A uniform branch per row split the unrolled loop into
+        // blocks with full s_waitcnt at their seams: 660 instead of 217 us on level 0.)
         if (r + RA < 25) {
 #pragma unroll
-          for (int cs = 0; cs < CW; ++cs) a_n2[cs][dx] = wfrag(cur_g, cs, (r + RA) * 5 + dx);
-        } else if (have_next) {
+          for (int cs = 0; cs < CW; ++cs) a_n2[cs][dx] = wfrag(cur_g, cs, (r + RA) * 5 + dx, lane_w);
+        } else {
 #pragma unroll
-          for (int cs = 0; cs < CW; ++cs) a_n2[cs][dx] = wfrag(nxt_g, cs, (r + RA - 25) * 5 + dx);
+          for (int cs = 0; cs < CW; ++cs) a_n2[cs][dx] = wfrag(nxt_g, cs, (r + RA - 25) * 5 + dx, lane_w_nxt);
         }
         // the next image: two items requested per row in rows 0..8, stored per row in rows 14..22
-        if (have_next && (dx == 1 || dx == 3)) {
+        if (dx == 1 || dx == 3) {
           const int k = dx >> 1;
-          if (r < 9) halo_load(nxt_g, 2 * r + k);
+          if (r < 9) halo_load(hq, 2 * r + k);
           if (r >= 14 && r < 23) lw[128 * (2 * (r - 14) + k)] = hv[2 * (r - 14) + k];
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1314,7 +1331,6 @@ using CfgX32 = Cfg<4, 4, 32, 4, 1, 4, 1>;      // 512 voxels x 32 channels   (le
 using CfgX16 = Cfg<4, 4, 16, 2, 2, 4, 1>;      // 256 voxels x 64 channels   (level 2)
 using CfgX8 = Cfg<4, 8, 8, 2, 2, 4, 1>;        // 256 voxels x 64 channels   (level 3)
 using CfgX4 = Cfg<2, 4, 4, 1, 4, 1, 1>;        // 32 voxels x 128 channels   (level 4)
-using CfgX32W8 = Cfg<4, 4, 32, 8, 1, 2, 1>;    // experiment: the levels 0-1 brick on 8 waves (two voxel sub-tiles each), 4 waves per SIMD
 
 // REPMODE_CONV_ROWSTAT=1: the row-stationary tap loop on the 4 x 4 x 32 tile (full 5x5x5 support only).  Built, measured,
 // OFF: same box, interleaved, us per launch tap-major / row-stationary: 32->32 237.2 / 256.1, 64->32 471.1 / 498.7,
@@ -1328,8 +1344,8 @@ static const int g_wide = []() { const char* e = getenv("REPMODE_CONV_WIDE"); re
 // Experiment (REPMODE_CONV_X16_AT=<cout>): layers at least that wide in output channels take the 4 x 4 x 16 tile (256 voxels x 64
 // channels: two channel sub-tiles share a staged image) also when the volume is 32 or more voxels wide
 static const int g_x16_at = []() { const char* e = getenv("REPMODE_CONV_X16_AT"); return e ? atoi(e) : 0; }();
-// Experiment (REPMODE_CONV_W8=1): the 4 x 4 x 32 brick on 512 threads -- four waves per SIMD at <= 128 registers
-static const int g_w8 = []() { const char* e = getenv("REPMODE_CONV_W8"); return e ? atoi(e) : 0; }();
+// (Measured and removed: the 4 x 4 x 32 brick on 512 threads, four waves per SIMD at 128 registers -- 260 vs 222 us on level 0,
+// 130 vs 113 on level 1; profiles/r03_pipe_ab.txt.  More waves is not what the tap loop lacks.)
 
 template <typename T, bool SWAP, bool PAIR>
 int dispatch_tile(ConvArgs a, hipStream_t stream) {
@@ -1338,7 +1354,6 @@ int dispatch_tile(ConvArgs a, hipStream_t stream) {
     if (rc != -1) return rc;
   }
   if (a.W >= 32 && g_x16_at > 0 && a.Cout >= g_x16_at) return launch_cfg<T, CfgX16, SWAP, PAIR>(a, stream);
-  if (a.W >= 32 && g_w8) return launch_cfg<T, CfgX32W8, SWAP, PAIR>(a, stream);
   if (a.W >= 32) {
     if (g_rowstat && a.tap_lo == 0 && a.tap_hi == 4 && !a.dual) return launch_cfg<T, CfgX32, SWAP, PAIR, false, true>(a, stream);
     return launch_cfg<T, CfgX32, SWAP, PAIR>(a, stream);
