@@ -1025,9 +1025,19 @@ __global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nite
     q.csrc = Cin1 > 0 ? (from2 ? Cin - Cin1 : Cin1) : Cin;
     const int c = ci0 + pl * KV;                                   // (per-thread: the plane's first channel)
     q.coff = c - (from2 ? Cin1 : 0);
+#ifdef RM_PIPE_NOHALO
+    on = false;        // (timing experiment, -DRM_PIPE_NOHALO: no halo fetches after the first image -- WRONG RESULTS)
+#endif
     q.on = on && c < Cin;
+#ifdef RM_PIPE_SAMEHALO
+    // (timing experiment: every image is fetched from ONE interior brick of sample 0 -- real data, always L2-resident: what
+    // the kernel would run at if no halo fetch ever missed.  WRONG RESULTS)
+    q.base_vox = ((0 * D + 4 - 2) * H + 4 - 2) * W + 32 - 2;
+    q.z0 = 2; q.y0 = 2; q.x0 = 30;
+#else
     q.base_vox = ((g.n * D + g.z0 - 2) * H + g.y0 - 2) * W + g.x0 - 2;
     q.z0 = g.z0 - 2; q.y0 = g.y0 - 2; q.x0 = g.x0 - 2;
+#endif
     return q;
   };
   auto halo_load = [&](const Halo& q, int u) {
@@ -1070,14 +1080,22 @@ __global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nite
   for (int u = 0; u < NIT; ++u) lds[lds_item + 128 * u] = hv[u];
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   int cur = 0;
+#ifdef RM_CONV_TIMING
+  int st_ = 0;          // image counter of the shader-clock stamps (tools/conv_phase_timing.py): 4 per image, 16 images
+#endif
 
   for (;;) {
+    RM_STAMP(st_ * 4 + 0);
     // the image after this one: next channel chunk of the brick, or the first chunk of the next item
     const bool last_chunk = cur_g.chunk + 1 >= nkc;
     const bool have_next = !last_chunk || item + 1 < item_end;
     Img nxt_g = cur_g;
     if (have_next) nxt_g = last_chunk ? decode(item + 1, 0) : decode(item, cur_g.chunk + 1);
+#ifdef RM_PIPE_NOFILT
+    const int lane_w_nxt = (int)OOB;     // (timing experiment, -DRM_PIPE_NOFILT: filter fragments read as zeros -- WRONG RESULTS)
+#else
     const int lane_w_nxt = have_next ? lane_w : (int)OOB;
+#endif
     const Halo hq = halo_of(nxt_g, have_next);
     const u32x4* lb = lb0 + cur * BUF;
     u32x4* lw = lds + (cur ^ 1) * BUF + lds_item;
@@ -1107,7 +1125,11 @@ __global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nite
         // blocks with full s_waitcnt at their seams: 660 instead of 217 us on level 0.)
         if (r + RA < 25) {
 #pragma unroll
+#ifdef RM_PIPE_NOFILT
+          for (int cs = 0; cs < CW; ++cs) a_n2[cs][dx] = wfrag(cur_g, cs, (r + RA) * 5 + dx, (int)OOB);
+#else
           for (int cs = 0; cs < CW; ++cs) a_n2[cs][dx] = wfrag(cur_g, cs, (r + RA) * 5 + dx, lane_w);
+#endif
         } else {
 #pragma unroll
           for (int cs = 0; cs < CW; ++cs) a_n2[cs][dx] = wfrag(nxt_g, cs, (r + RA - 25) * 5 + dx, lane_w_nxt);
@@ -1120,6 +1142,7 @@ __global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nite
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (r == 12) RM_STAMP(st_ * 4 + 1);
 #pragma unroll
       for (int cs = 0; cs < CW; ++cs)
 #pragma unroll
@@ -1128,8 +1151,10 @@ __global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nite
           else a_cur[cs][dx] = a_n2[cs][dx];
         }
     }
+    RM_STAMP(st_ * 4 + 2);
     // every wave is done with image `cur` and has stored its part of the next one
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    RM_STAMP(st_ * 4 + 3);
 
     if (last_chunk) {
       // ---- epilogue of the brick (the stores drain under the next brick's taps).  32x32 C/D layout: column = lane & 31
@@ -1212,17 +1237,306 @@ __global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nite
     if (!have_next) break;
     cur_g = nxt_g;
     cur ^= 1;
+#ifdef RM_CONV_TIMING
+    ++st_;
+#endif
+  }
+}
+
+// =====================================================================================================================
+// conv5_ws_kernel -- conv5_pipe_kernel with the waves SPECIALISED: eight waves per workgroup, one MFMA wave and one loader
+// wave per SIMD.  The stamps of the pipelined kernel (tools/conv_phase_timing.py, timing build) show its tap rows 13..24 at
+// 94 % of the MFMA rate but rows 0..12 -- where each wave also requests the next halo image -- at 71 %, and level 1 losing
+// 23 % to halo fetches that miss L2 (a timing build that fetches every image from one resident brick: 96 -> 74 us): on gfx950
+// a wave's vector-memory operations retire IN ORDER, so every filter fragment requested behind a slow halo fetch waits for
+// it.  Here the MFMA waves' memory queue holds nothing but filter fragments (L2 hits) and the brick's output stores; the
+// loader waves (wave 4 + s on SIMD s, ~150 instructions per image) fetch the next image into the other LDS buffer and meet
+// the MFMA waves at the one barrier per image.  Two waves per SIMD: 256 registers each, which the MFMA waves can afford once
+// the halo staging registers (108) are gone -- filter fragments run 4 rows ahead (one channel sub-tile) / 1 row (two).
+template <int CW>
+__global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems) {
+  using C = Cfg<4, 4, 32, 4, 1, 4, CW>;
+  constexpr int KV = 8, KC = 16, VW = 4;
+  constexpr int BZ = C::BZ, BY = C::BY, BX = C::BX, BYH = C::BYH, BXH = C::BXH, VH = C::VH, PLS = C::PLS;
+  constexpr int BUF = 2 * PLS;                  // 16-byte slots of one halo image
+  constexpr int NIT = (2 * VH) / 256;           // halo items per loader thread
+  static_assert((2 * VH) % 256 == 0, "halo items: whole rounds of the 256 loader threads");
+  constexpr uint32_t OOB = 0x7fffffffu;         // beyond every descriptor's range: the load returns zeros
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4* lds = reinterpret_cast<u32x4*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int khalf = lane >> 5, l31 = lane & 31;
+  if (a.tail.nblocks) {
+    if ((int)blockIdx.x < a.tail.nblocks) {
+      if (tid < 256) tail_run(a.tail, blockIdx.x, tid, reinterpret_cast<float*>(smem));   // (the jobs are written for 256 threads)
+      return;
+    }
+  }
+  const int conv_block = blockIdx.x - a.tail.nblocks, conv_blocks = gridDim.x - a.tail.nblocks;
+  const int L = xcd_remap(conv_block, conv_blocks);
+  const int per = nitems / conv_blocks, rem = nitems % conv_blocks;
+  int item = L * per + min(L, rem);
+  const int item_end = item + per + (L < rem ? 1 : 0);
+  if (item >= item_end) return;
+
+  const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, CinP = a.CinP, CoutP = a.CoutP;
+  const int Cin1 = a.Cin1, Cout1 = a.Cout1;
+  const int nkc = CinP / KC, nrt = CoutP / 32;
+
+  // brick of an item (both roles walk the same sequence of images: items item .. item_end-1, chunks 0 .. nkc-1 of each)
+  struct Brick { int n, z0, y0, x0, cot; };
+  auto brick_of = [&](int it) -> Brick {
+    Brick g;
+    int b = it;
+    g.cot = b % a.ncot; b /= a.ncot;
+    const int bx = b % a.nbx; b /= a.nbx;
+    const int by = b % a.nby; b /= a.nby;
+    const int bz = b % a.nbz;
+    g.n = b / a.nbz;
+    g.z0 = bz * BZ; g.y0 = by * BY; g.x0 = bx * BX;
+    return g;
+  };
+
+  if (wave >= 4) {
+    // =============================== loader waves: the halo images =========================================
+    const int ht = tid - 256;
+    const int pl = ht & 1, vh0 = ht >> 1;
+    const int c1 = Cin1 > 0 ? Cin1 : Cin;                                           // channels of the first input tensor
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.x), 0, (int)((size_t)a.N * D * H * W * c1 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(Cin1 > 0 ? a.x2 : a.x), 0, (int)((size_t)a.N * D * H * W * (Cin1 > 0 ? Cin - Cin1 : c1) * 2), 0x00020000);
+    int hvox[NIT], hpc[NIT];                    // item u: halo voxel vh = 128 u + ht / 2, plane ht & 1
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int vh = u * 128 + vh0;
+      const int xx = vh % BXH, t2 = vh / BXH;
+      const int yy = t2 % BYH, zz = t2 / BYH;
+      hvox[u] = (zz * H + yy) * W + xx;
+      hpc[u] = zz | (yy << 8) | (xx << 16);
+    }
+    u32x4* lw0 = lds + pl * PLS + vh0;          // + 128 u, + BUF for the second buffer
+    auto fetch = [&](const Brick& g, int chunk, int buf) {
+      const int ci0 = chunk * KC;
+      const bool from2 = Cin1 > 0 && ci0 >= Cin1;
+      const __amdgpu_buffer_rsrc_t rs = from2 ? rx2 : rx1;
+      const int csrc = Cin1 > 0 ? (from2 ? Cin - Cin1 : Cin1) : Cin;
+      const int c = ci0 + pl * KV;
+      const int coff = c - (from2 ? Cin1 : 0);
+      const bool on = c < Cin;
+      const int base_vox = ((g.n * D + g.z0 - 2) * H + g.y0 - 2) * W + g.x0 - 2;
+      u32x4 hv[NIT];
+#pragma unroll
+      for (int u = 0; u < NIT; ++u) {
+        const int zz = hpc[u] & 0xff, yy = (hpc[u] >> 8) & 0xff, xx = hpc[u] >> 16;
+        const bool ok = on && (unsigned)(g.z0 - 2 + zz) < (unsigned)D && (unsigned)(g.y0 - 2 + yy) < (unsigned)H &&
+                        (unsigned)(g.x0 - 2 + xx) < (unsigned)W;
+        const uint32_t off = (uint32_t)((base_vox + hvox[u]) * csrc + coff) * 2u;
+        hv[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB, 0, 0));
+      }
+#pragma unroll
+      for (int u = 0; u < NIT; ++u) lw0[buf * BUF + 128 * u] = hv[u];
+    };
+    Brick g = brick_of(item);
+    int chunk = 0, cur = 0;
+    fetch(g, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (;;) {
+      const bool last_chunk = chunk + 1 >= nkc;
+      const bool have_next = !last_chunk || item + 1 < item_end;
+      if (have_next) {
+        if (last_chunk) { ++item; chunk = 0; g = brick_of(item); } else { ++chunk; }
+        fetch(g, chunk, cur ^ 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (!have_next) break;
+      cur ^= 1;
+    }
+    return;
+  }
+
+  // ================================= MFMA waves: the taps =================================================
+  const uint32_t ts_bytes = (uint32_t)CoutP * (uint32_t)CinP * 2u;               // one tap of one slot
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, 0x7ffffffe, 0x00020000);
+  const int lane_w = (l31 * KC + khalf * KV) * 2;                 // this lane's 16 bytes of a filter fragment
+  const u32x4* lb0 = lds + khalf * PLS + (wave * BYH) * BXH + l31;   // this lane's voxel of sub-tile vs: + vs * BXH
+  struct Img { Brick b; int chunk; uint32_t wbase[CW]; };
+  auto image_of = [&](const Brick& b, int chunk) -> Img {
+    Img g;
+    g.b = b; g.chunk = chunk;
+    const int slot = a.sample_slot[b.n];
+#pragma unroll
+    for (int cs = 0; cs < CW; ++cs) {
+      const int rt = min(b.cot * CW + cs, nrt - 1);         // (a tile beyond the padded filter is clamped; never stored)
+      g.wbase[cs] = (uint32_t)slot * REPMODE_TAPS * ts_bytes + (uint32_t)((rt * nkc + chunk) * (32 * KC) * 2);
+    }
+    return g;
+  };
+  auto wfrag = [&](const Img& g, int cs, int tap, int voff) -> u32x4 {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, voff, g.wbase[cs] + (uint32_t)tap * ts_bytes, 0));
+  };
+
+  f32x16 acc[CW][VW];
+#pragma unroll
+  for (int cs = 0; cs < CW; ++cs)
+#pragma unroll
+    for (int vs = 0; vs < VW; ++vs)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cs][vs][r] = 0.f;
+
+  // filter rows in flight ahead of the one being multiplied, voxel fragments (taps) in flight ahead
+  constexpr int RA = CW == 1 ? 4 : 1;
+  constexpr int TA = CW == 1 ? 2 : 1;
+  Img cur_g = image_of(brick_of(item), 0);
+  u32x4 aq[RA + 1][CW][5];
+#pragma unroll
+  for (int k = 0; k < RA; ++k)
+#pragma unroll
+    for (int cs = 0; cs < CW; ++cs)
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) aq[k][cs][dx] = wfrag(cur_g, cs, k * 5 + dx, lane_w);
+  asm volatile("s_barrier" ::: "memory");          // the loaders have stored the first image
+  int cur = 0;
+
+  for (;;) {
+    const bool last_chunk = cur_g.chunk + 1 >= nkc;
+    const bool have_next = !last_chunk || item + 1 < item_end;
+    Img nxt_g = cur_g;
+    if (have_next) nxt_g = last_chunk ? image_of(brick_of(item + 1), 0) : image_of(cur_g.b, cur_g.chunk + 1);
+    const int lane_w_nxt = have_next ? lane_w : (int)OOB;
+    const u32x4* lb = lb0 + cur * BUF;
+    auto tap_off = [&](int t) -> int { return (((t / 5) / 5) * BYH + ((t / 5) % 5)) * BXH + t % 5; };
+    u32x4 bq[TA + 1][VW];
+#pragma unroll
+    for (int k = 0; k < TA; ++k)
+#pragma unroll
+      for (int vs = 0; vs < VW; ++vs) bq[k][vs] = lb[vs * BXH + tap_off(k)];
+#pragma unroll
+    for (int r = 0; r < 25; ++r) {
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) {
+        const int t = r * 5 + dx;
+#pragma unroll
+        for (int vs = 0; vs < VW; ++vs) {
+#pragma unroll
+          for (int cs = 0; cs < CW; ++cs) Elem<bf16_t>::mma(aq[0][cs][dx], bq[t % (TA + 1)][vs], acc[cs][vs]);
+          if (t + TA < 125) bq[(t + TA) % (TA + 1)][vs] = lb[vs * BXH + tap_off(t + TA)];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // this tap's filter fragment of the row RA ahead (the last RA rows: the next image's first rows; no next image:
+        // out-of-range offsets, zeros without memory traffic -- no branch in the unrolled loop)
+        if (r + RA < 25) {
+#pragma unroll
+          for (int cs = 0; cs < CW; ++cs) aq[RA][cs][dx] = wfrag(cur_g, cs, (r + RA) * 5 + dx, lane_w);
+        } else {
+#pragma unroll
+          for (int cs = 0; cs < CW; ++cs) aq[RA][cs][dx] = wfrag(nxt_g, cs, (r + RA - 25) * 5 + dx, lane_w_nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int k = 0; k < RA; ++k)
+#pragma unroll
+        for (int cs = 0; cs < CW; ++cs)
+#pragma unroll
+          for (int dx = 0; dx < 5; ++dx) aq[k][cs][dx] = aq[k + 1][cs][dx];
+    }
+    // every MFMA wave is done with image `cur`, every loader wave has stored the next one
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    if (last_chunk) {
+      // ---- epilogue of the brick (the stores drain under the next brick's taps).  32x32 C/D layout: column = lane & 31
+      // (voxel), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (output channels)
+      const int z0 = cur_g.b.z0, y0 = cur_g.b.y0, x0 = cur_g.b.x0, n_out = cur_g.b.n, cot = cur_g.b.cot;
+#pragma unroll
+      for (int vs = 0; vs < VW; ++vs) {
+        const int gz = z0 + wave, gy = y0 + vs, gx = x0 + l31;       // voxel m = (wave 4 + vs) 32 + l31 of the brick
+        const bool inside = gz < D && gy < H && gx < W;
+        const size_t vox = ((size_t)(n_out * D + gz) * H + gy) * W + gx;
+#pragma unroll
+        for (int cs = 0; cs < CW; ++cs) {
+          if (a.wide) {
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+              const int co16 = cot * C::COT + cs * 32 + 16 * qp;
+              if (co16 >= Cout) continue;
+              uint32_t pk[2][2];
+#pragma unroll
+              for (int g = 0; g < 2; ++g) {
+                const int q = 2 * qp + g;
+                float v0 = acc[cs][vs][4 * q + 0], v1 = acc[cs][vs][4 * q + 1];
+                float v2 = acc[cs][vs][4 * q + 2], v3 = acc[cs][vs][4 * q + 3];
+                if (a.bias) {
+                  const float* bp = a.bias + co16 + 8 * g + 4 * khalf;
+                  v0 += bp[0]; v1 += bp[1]; v2 += bp[2]; v3 += bp[3];
+                }
+                if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                pk[g][0] = pack_bf16x2(v0, v1);
+                pk[g][1] = pack_bf16x2(v2, v3);
+              }
+              const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+              const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+              if (!inside) continue;
+              const bool out2 = Cout1 > 0 && co16 >= Cout1;
+              const int Cout_ = Cout1 > 0 ? (out2 ? Cout - Cout1 : Cout1) : Cout;
+              const int co = (out2 ? co16 - Cout1 : co16) + 8 * khalf;
+              bf16_t* yp = static_cast<bf16_t*>(out2 ? a.y2 : a.y) + vox * Cout_ + co;
+              *reinterpret_cast<u32x4*>(yp) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int co_all = cot * C::COT + cs * 32 + 8 * q + 4 * khalf;
+              if (co_all >= Cout || !inside) continue;
+              const bool out2 = Cout1 > 0 && co_all >= Cout1;
+              const int Cout_ = Cout1 > 0 ? (out2 ? Cout - Cout1 : Cout1) : Cout;
+              const int co = out2 ? co_all - Cout1 : co_all;
+              float v0 = acc[cs][vs][4 * q + 0], v1 = acc[cs][vs][4 * q + 1];
+              float v2 = acc[cs][vs][4 * q + 2], v3 = acc[cs][vs][4 * q + 3];
+              if (a.bias) {
+                v0 += a.bias[co_all];
+                if (co_all + 1 < Cout) v1 += a.bias[co_all + 1];
+                if (co_all + 2 < Cout) v2 += a.bias[co_all + 2];
+                if (co_all + 3 < Cout) v3 += a.bias[co_all + 3];
+              }
+              if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+              const uint32_t p01 = pack_bf16x2(v0, v1), p23 = pack_bf16x2(v2, v3);
+              bf16_t* yp = static_cast<bf16_t*>(out2 ? a.y2 : a.y) + vox * Cout_ + co;
+              if ((Cout_ & 3) == 0) {
+                *reinterpret_cast<u32x2*>(yp) = u32x2{p01, p23};
+              } else {
+                yp[0] = (bf16_t)(p01 & 0xffffu);
+                if (co + 1 < Cout_) yp[1] = (bf16_t)(p01 >> 16);
+                if (co + 2 < Cout_) yp[2] = (bf16_t)(p23 & 0xffffu);
+                if (co + 3 < Cout_) yp[3] = (bf16_t)(p23 >> 16);
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int cs = 0; cs < CW; ++cs)
+#pragma unroll
+        for (int vs = 0; vs < VW; ++vs)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[cs][vs][r] = 0.f;
+      ++item;
+    }
+    if (!have_next) break;
+    cur_g = nxt_g;
+    cur ^= 1;
   }
 }
 
 // eligibility + launch of the pipelined form (see the kernel's comment); returns -1 when the launch is not its kind.
-// REPMODE_CONV_PIPE / repmode_set_conv_pipe: bit 0 = on (default), bit 1 = one channel sub-tile per wave everywhere, bit 2 = also
-// on grids smaller than the chip (the parity tests' volumes).  Same box, interleaved, us per launch two-workgroup form /
+// REPMODE_CONV_PIPE / repmode_set_conv_pipe: bit 0 = on, bit 1 = one channel sub-tile per wave everywhere, bit 2 = also on grids
+// smaller than the chip (the parity tests' volumes), bit 3 = the wave-specialised kernel (conv5_ws_kernel); default 9.  Same box, interleaved, us per launch two-workgroup form /
 // pipelined: 32->32 (level 0) 227.6 / 216.7, 64->32 460.0 / 433.5, 64->64 (level 1) 116.4 / 98.1, 128->64 224.1 / 189.2
 // (one sub-tile per wave: 106.2, 206.8); conv5 launches of the train step 3945 -> 3702 us.  The step itself moves less
 // (11.82 -> 11.75 ms): with the convolutions drawing more power every other kernel of the step runs 2-6 % slower
 // (profiles/r03_pipe_ab.txt) -- the chip is power-limited over the step, not per kernel.
-static int g_pipe = []() { const char* e = getenv("REPMODE_CONV_PIPE"); return e ? atoi(e) : 1; }();
+static int g_pipe = []() { const char* e = getenv("REPMODE_CONV_PIPE"); return e ? atoi(e) : 9; }();
 
 int launch_pipe(ConvArgs a, hipStream_t stream) {
   using C1 = Cfg<4, 4, 32, 4, 1, 4, 1>;
@@ -1260,11 +1574,16 @@ int launch_pipe(ConvArgs a, hipStream_t stream) {
   if (!((attr_set.load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_pipe_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_pipe_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
   }
   const double alg = 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS;
   repmode_prof_begin(REPMODE_PROF_CONV5, alg, stream);
-  if (cw == 2) hipLaunchKernelGGL(conv5_pipe_kernel<2>, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, a, (int)nitems);
+  if (g_pipe & 8) {       // the wave-specialised form
+    if (cw == 2) hipLaunchKernelGGL(conv5_ws_kernel<2>, dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
+    else hipLaunchKernelGGL(conv5_ws_kernel<1>, dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
+  } else if (cw == 2) hipLaunchKernelGGL(conv5_pipe_kernel<2>, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, a, (int)nitems);
   else hipLaunchKernelGGL(conv5_pipe_kernel<1>, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, a, (int)nitems);
   repmode_prof_end(stream);
   RM_LAUNCH_CHECK("conv5_pipe");

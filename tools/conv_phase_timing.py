@@ -13,6 +13,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from repmode_amd import ops, _lib
+if os.environ.get('REPMODE_LIB'):          # the timing build of the library
+    _lib.LIB_PATH = os.environ['REPMODE_LIB']
 
 args = [int(a) for a in sys.argv[1:]]
 cin, cout, d, h, w = (args + [32, 32, 32, 64, 64][len(args):])[:5]
@@ -29,6 +31,20 @@ fn = lib.repmode_debug_conv_timing
 fn.argtypes = [ctypes.c_void_p]
 assert fn(buf) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(64, 64).astype(np.int64)
+if os.environ.get('REPMODE_CONV_PIPE', '1') != '0' and w >= 32:
+    # the pipelined kernel's stamps: per image (brick x channel chunk) start, after tap row 12, after row 24, after the barrier
+    for b in (0, 1, 8, 9, 33, 63):
+        row = t[b]
+        t0 = row[0]
+        out = []
+        for it in range(16):
+            s = row[it * 4:it * 4 + 4]
+            if s[3] == 0 or s[3] < t0:
+                break
+            nxt = row[it * 4 + 4] if it < 15 and row[it * 4 + 4] > s[3] else s[3]
+            out.append('img%d +%d: rows0-12 %d rows13-24 %d barrier %d tail %d' % (it, s[0] - t0, s[1] - s[0], s[2] - s[1], s[3] - s[2], nxt - s[3]))
+        print('wg %2d | ' % b + ' | '.join(out))
+    sys.exit(0)
 for b in (0, 1, 8, 9, 33, 63):
     row = t[b]
     t0 = row[0]
