@@ -1252,8 +1252,10 @@ __global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nite
 // it.  Here the MFMA waves' memory queue holds nothing but filter fragments (L2 hits) and the brick's output stores; the
 // loader waves (wave 4 + s on SIMD s, ~150 instructions per image) fetch the next image into the other LDS buffer and meet
 // the MFMA waves at the one barrier per image.  Two waves per SIMD: 256 registers each, which the MFMA waves can afford once
-// the halo staging registers (108) are gone -- filter fragments run 4 rows ahead (one channel sub-tile) / 1 row (two).
-template <int CW>
+// the halo staging registers (108) are gone -- filter fragments run 4 rows ahead (one channel sub-tile) / 2 rows (two).
+// PLAIN: the training path's epilogue (16-byte stores, no bias, no ReLU) as straight-line code -- the general one is a
+// chain of uniform branches per (sub-tile, quad pair) that cost 4.3 k cycles per brick (stamps), 11 % of a level-0 brick.
+template <int CW, bool PLAIN>
 __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems) {
   using C = Cfg<4, 4, 32, 4, 1, 4, CW>;
   constexpr int KV = 8, KC = 16, VW = 4;
@@ -1386,7 +1388,7 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
       for (int r = 0; r < 16; ++r) acc[cs][vs][r] = 0.f;
 
   // filter rows in flight ahead of the one being multiplied, voxel fragments (taps) in flight ahead
-  constexpr int RA = CW == 1 ? 4 : 1;
+  constexpr int RA = CW == 1 ? 4 : 2;
   constexpr int TA = CW == 1 ? 2 : 1;
   Img cur_g = image_of(brick_of(item), 0);
   u32x4 aq[RA + 1][CW][5];
@@ -1398,8 +1400,12 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
       for (int dx = 0; dx < 5; ++dx) aq[k][cs][dx] = wfrag(cur_g, cs, k * 5 + dx, lane_w);
   asm volatile("s_barrier" ::: "memory");          // the loaders have stored the first image
   int cur = 0;
+#ifdef RM_CONV_TIMING
+  int st_ = 0;
+#endif
 
   for (;;) {
+    RM_STAMP(st_ * 4 + 0);
     const bool last_chunk = cur_g.chunk + 1 >= nkc;
     const bool have_next = !last_chunk || item + 1 < item_end;
     Img nxt_g = cur_g;
@@ -1435,6 +1441,7 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (r == 12) RM_STAMP(st_ * 4 + 1);
 #pragma unroll
       for (int k = 0; k < RA; ++k)
 #pragma unroll
@@ -1442,8 +1449,10 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
 #pragma unroll
           for (int dx = 0; dx < 5; ++dx) aq[k][cs][dx] = aq[k + 1][cs][dx];
     }
+    RM_STAMP(st_ * 4 + 2);
     // every MFMA wave is done with image `cur`, every loader wave has stored the next one
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    RM_STAMP(st_ * 4 + 3);
 
     if (last_chunk) {
       // ---- epilogue of the brick (the stores drain under the next brick's taps).  32x32 C/D layout: column = lane & 31
@@ -1456,7 +1465,23 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
         const size_t vox = ((size_t)(n_out * D + gz) * H + gy) * W + gx;
 #pragma unroll
         for (int cs = 0; cs < CW; ++cs) {
-          if (a.wide) {
+          if constexpr (PLAIN) {
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+              const int co16 = cot * C::COT + cs * 32 + 16 * qp;
+              const uint32_t p00 = pack_bf16x2(acc[cs][vs][8 * qp + 0], acc[cs][vs][8 * qp + 1]);
+              const uint32_t p01 = pack_bf16x2(acc[cs][vs][8 * qp + 2], acc[cs][vs][8 * qp + 3]);
+              const uint32_t p10 = pack_bf16x2(acc[cs][vs][8 * qp + 4], acc[cs][vs][8 * qp + 5]);
+              const uint32_t p11 = pack_bf16x2(acc[cs][vs][8 * qp + 6], acc[cs][vs][8 * qp + 7]);
+              const auto r0 = __builtin_amdgcn_permlane32_swap(p00, p10, false, false);
+              const auto r1 = __builtin_amdgcn_permlane32_swap(p01, p11, false, false);
+              const bool out2 = Cout1 > 0 && co16 >= Cout1;
+              const int Cout_ = Cout1 > 0 ? (out2 ? Cout - Cout1 : Cout1) : Cout;
+              const int co = (out2 ? co16 - Cout1 : co16) + 8 * khalf;
+              bf16_t* yp = static_cast<bf16_t*>(out2 ? a.y2 : a.y) + vox * Cout_ + co;
+              if (inside && co16 < Cout) *reinterpret_cast<u32x4*>(yp) = u32x4{r0[0], r1[0], r0[1], r1[1]};
+            }
+          } else if (a.wide) {
 #pragma unroll
             for (int qp = 0; qp < 2; ++qp) {
               const int co16 = cot * C::COT + cs * 32 + 16 * qp;
@@ -1526,6 +1551,9 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
     if (!have_next) break;
     cur_g = nxt_g;
     cur ^= 1;
+#ifdef RM_CONV_TIMING
+    ++st_;
+#endif
   }
 }
 
@@ -1574,15 +1602,20 @@ int launch_pipe(ConvArgs a, hipStream_t stream) {
   if (!((attr_set.load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_pipe_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_pipe_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
   }
   const double alg = 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS;
   repmode_prof_begin(REPMODE_PROF_CONV5, alg, stream);
   if (g_pipe & 8) {       // the wave-specialised form
-    if (cw == 2) hipLaunchKernelGGL(conv5_ws_kernel<2>, dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
-    else hipLaunchKernelGGL(conv5_ws_kernel<1>, dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
+    const bool plain = a.wide && !a.bias && !a.relu;
+    if (cw == 2 && plain) hipLaunchKernelGGL((conv5_ws_kernel<2, true>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
+    else if (cw == 2) hipLaunchKernelGGL((conv5_ws_kernel<2, false>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
+    else if (plain) hipLaunchKernelGGL((conv5_ws_kernel<1, true>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
+    else hipLaunchKernelGGL((conv5_ws_kernel<1, false>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
   } else if (cw == 2) hipLaunchKernelGGL(conv5_pipe_kernel<2>, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, a, (int)nitems);
   else hipLaunchKernelGGL(conv5_pipe_kernel<1>, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, a, (int)nitems);
   repmode_prof_end(stream);
