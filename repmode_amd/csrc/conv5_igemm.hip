@@ -1299,6 +1299,19 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
     g.z0 = bz * BZ; g.y0 = by * BY; g.x0 = bx * BX;
     return g;
   };
+  // the item after g (item + 1) without the five divisions: carry through (cot, bx, by, bz, n)
+  auto brick_next = [&](Brick g) -> Brick {
+    if (++g.cot < a.ncot) return g;
+    g.cot = 0;
+    if ((g.x0 += BX) < a.nbx * BX) return g;
+    g.x0 = 0;
+    if ((g.y0 += BY) < a.nby * BY) return g;
+    g.y0 = 0;
+    if ((g.z0 += BZ) < a.nbz * BZ) return g;
+    g.z0 = 0;
+    ++g.n;
+    return g;
+  };
 
   if (wave >= 4) {
     // =============================== loader waves: the halo images =========================================
@@ -1348,7 +1361,7 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
       const bool last_chunk = chunk + 1 >= nkc;
       const bool have_next = !last_chunk || item + 1 < item_end;
       if (have_next) {
-        if (last_chunk) { ++item; chunk = 0; g = brick_of(item); } else { ++chunk; }
+        if (last_chunk) { ++item; chunk = 0; g = brick_next(g); } else { ++chunk; }
         fetch(g, chunk, cur ^ 1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1364,10 +1377,14 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
   const int lane_w = (l31 * KC + khalf * KV) * 2;                 // this lane's 16 bytes of a filter fragment
   const u32x4* lb0 = lds + khalf * PLS + (wave * BYH) * BXH + l31;   // this lane's voxel of sub-tile vs: + vs * BXH
   struct Img { Brick b; int chunk; uint32_t wbase[CW]; };
+  // the samples' slots: one vector load for the first 64 samples, then a lane read per image (a load per image sat at the
+  // head of the wave's in-order memory queue, in front of the image's filter fragments)
+  const int slot64 = a.sample_slot[min(lane, a.N - 1)];
   auto image_of = [&](const Brick& b, int chunk) -> Img {
     Img g;
     g.b = b; g.chunk = chunk;
-    const int slot = a.sample_slot[b.n];
+    const int n_u = __builtin_amdgcn_readfirstlane(b.n);
+    const int slot = n_u < 64 ? __builtin_amdgcn_readlane(slot64, n_u) : a.sample_slot[n_u];
 #pragma unroll
     for (int cs = 0; cs < CW; ++cs) {
       const int rt = min(b.cot * CW + cs, nrt - 1);         // (a tile beyond the padded filter is clamped; never stored)
@@ -1409,7 +1426,7 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
     const bool last_chunk = cur_g.chunk + 1 >= nkc;
     const bool have_next = !last_chunk || item + 1 < item_end;
     Img nxt_g = cur_g;
-    if (have_next) nxt_g = last_chunk ? image_of(brick_of(item + 1), 0) : image_of(cur_g.b, cur_g.chunk + 1);
+    if (have_next) nxt_g = last_chunk ? image_of(brick_next(cur_g.b), 0) : image_of(cur_g.b, cur_g.chunk + 1);
     const int lane_w_nxt = have_next ? lane_w : (int)OOB;
     const u32x4* lb = lb0 + cur * BUF;
     auto tap_off = [&](int t) -> int { return (((t / 5) / 5) * BYH + ((t / 5) % 5)) * BXH + t % 5; };
