@@ -16,6 +16,8 @@
 // with f32 atomics (split-K over voxel chunks and over the samples of a slot).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int TY = 4, TX = 16, TV = TY * TX;   // output voxels per tile
@@ -261,15 +263,24 @@ __device__ unsigned long long g_wgrad_timing[64 * 64];
 // before the MFMAs of the current one and only transposed into LDS after them.  Without it the phase timing
 // (tools/wgrad_phase_timing.py) showed ~7k cycles of serialized load->LDS staging next to ~5k cycles of MFMAs
 // per tile.  !VEC keeps the simple stage-then-compute loop with per-element loads.
-template <int TZ, int TY, int TX, bool VEC, bool DENSE = false>
-__global__ __launch_bounds__(256, DENSE ? 3 : 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
+// WS (with VEC): the waves are SPECIALISED as in conv5_ws_kernel -- eight waves, one MFMA wave and one loader wave per SIMD,
+// one workgroup per CU, the operand tiles double-buffered in LDS.  The stamps of the two-workgroup form
+// (profiles/r03_pmc_wgrad.txt) show its two workgroups in step: ~2.2 k cycles of fetch-wait + transposition, then ~6.5 k for
+// the 200 MFMAs of BOTH workgroups' waves on a SIMD -- 43 % MFMA-busy.  Here the loader waves fetch and transpose tile k + 1
+// into the other buffer while the MFMA waves multiply tile k; one barrier per tile.
+template <int TZ, int TY, int TX, bool VEC, bool DENSE = false, bool WS = false>
+__global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf16_kernel(WgradArgs a) {
   using G = WgTile<TZ, TY, TX>;
   constexpr int TV = G::TV, HY = G::HY, RG = G::RG, NGX = G::NGX, ROW_C = G::ROW_C, DYS = G::DYS;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
+  static_assert(!WS || (VEC && !DENSE), "wave specialisation: the software-pipelined form only");
+  constexpr int LDS_SET = G::LDS_OPERANDS;                   // one buffer: x tile + dy tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[WS ? (2 * LDS_SET > G::LDS ? 2 * LDS_SET : G::LDS) : G::LDS];
   unsigned char* xT = smem;
   unsigned char* dyT = smem + 32 * ROW_C;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = WS ? (int)(threadIdx.x & 255) : (int)threadIdx.x;       // index within the role (staging items, stamps)
+  const int lane = tid & 63, wave = tid >> 6;
+  const bool loader = WS && threadIdx.x >= 256;
   const int cq = wave & 1, ciq = wave >> 1;
   const int l15 = lane & 15, kg = lane >> 4;
   RM_WSTAMP(59);
@@ -321,17 +332,17 @@ __global__ __launch_bounds__(256, DENSE ? 3 : 2) void conv5_wgrad_bf16_kernel(Wg
   constexpr int NWROW = TY - GPR + 5;                // distinct halo rows (relative to the lane's) the taps of a plane touch
   const unsigned char* xlane = xT + (ciq * 16 + l15) * ROW_C + ((kg / NGX) * RG + kg % NGX) * 16;
   const unsigned char* alane = dyT + (cq * 16 + l15) * DYS + kg * 16;
-  auto mma_tile = [&]() {
+  auto mma_tile = [&](int boff) {
     // The B operands of step (ks, dyi) are the window of halo row yyb(ks) + dyi of plane zz(ks): steps with equal sums share
     // it (TX = 32: 40 steps, 12 windows).  So the loop runs over WINDOWS -- one ds_read_b128 + one ds_read_b64 and five
     // v_perm / alignbit each, requested one window ahead -- and every window feeds the MFMAs of all steps that use it.
     bf16x8 afr[G::KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks)
-      afr[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(alane + ks * 64));
+      afr[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(alane + boff + ks * 64));
     auto window = [&](int w, u32x4& lo, u32x2& hi) {
       const int zz = w / NWROW, rr = w % NWROW;
-      const unsigned char* xb = xlane + ((zz * HY + rr) * RG) * 16;
+      const unsigned char* xb = xlane + boff + ((zz * HY + rr) * RG) * 16;
       lo = *reinterpret_cast<const u32x4*>(G::SWZ ? xb + (l15 & 1) * 16 : xb);                 // words 0..3: elements 0..7
       hi = *reinterpret_cast<const u32x2*>(G::SWZ ? xb + 16 - (l15 & 1) * 16 : xb + 16);      // words 4, 5: elements 8..11
     };
@@ -385,8 +396,8 @@ __global__ __launch_bounds__(256, DENSE ? 3 : 2) void conv5_wgrad_bf16_kernel(Wg
       *reinterpret_cast<uint32_t*>(dst + k * stride) = bf16_elem(v0, k) | (bf16_elem(v1, k) << 16);
   };
   // the same into xT: channel rows cg*8 + k, halo row yr, x pair p
-  auto put_x_pair = [&](int cg, int yr, int p, const u32x4& v0, const u32x4& v1) {
-    unsigned char* base = xT + (cg * 8) * ROW_C;
+  auto put_x_pair = [&](int cg, int yr, int p, const u32x4& v0, const u32x4& v1, int boff) {
+    unsigned char* base = xT + boff + (cg * 8) * ROW_C;
     const int off0 = x_pair_off(yr, p, 0), off1 = x_pair_off(yr, p, 1);
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -453,7 +464,7 @@ __global__ __launch_bounds__(256, DENSE ? 3 : 2) void conv5_wgrad_bf16_kernel(Wg
                      rdy, (row_ok && gx + 1 < W) ? off + (uint32_t)Cout * 2 : OOB, 0, 0));
       }
     };
-    auto stage = [&]() {
+    auto stage = [&](int boff) {
       int tid_ = tid;
       asm volatile("" : "+v"(tid_));
 #pragma unroll
@@ -462,35 +473,64 @@ __global__ __launch_bounds__(256, DENSE ? 3 : 2) void conv5_wgrad_bf16_kernel(Wg
         const int p = it % NPAIR; int r = it / NPAIR;
         const int cg = r & 3; r >>= 2;
         const int hy = r % HY, zz = r / HY;
-        if (it < NIT_X) put_x_pair(cg, zz * HY + hy, p, px0[u], px1[u]);
+        if (it < NIT_X) put_x_pair(cg, zz * HY + hy, p, px0[u], px1[u], boff);
       }
 #pragma unroll
       for (int u = 0; u < NDY; ++u) {
         const int it = u * 256 + tid_;
         const int q = it % (TV / 2), cg = it / (TV / 2);
-        if (it < NIT_DY) put_pair(dyT + (cg * 8) * DYS + q * 4, DYS, pd0[u], pd1[u]);
+        if (it < NIT_DY) put_pair(dyT + boff + (cg * 8) * DYS + q * 4, DYS, pd0[u], pd1[u]);
       }
     };
     bool have = advance();
-    if (have) fetch();
 #ifdef RM_CONV_TIMING
     int tl_ = 0;
 #endif
+    if constexpr (WS) {
+      // both roles walk the same tile sequence; barrier k separates "tile k staged in buffer k & 1" from its MFMAs, and a
+      // buffer is staged again only after the barrier behind the MFMAs that read it
+      int boff = 0;
+      if (loader) {
+        if (have) fetch();
+        while (have) {
+          stage(boff);                                   // (waits for the tile's loads, transposes it into the buffer)
+          have = advance();
+          if (have) fetch();                             // in flight across the barrier
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          boff ^= LDS_SET;
+        }
+        return;
+      }
+      while (have) {
+        RM_WSTAMP(tl_ * 3 + 0);
+        asm volatile("s_barrier" ::: "memory");
+        RM_WSTAMP(tl_ * 3 + 1);
+        mma_tile(boff);
+        RM_WSTAMP(tl_ * 3 + 2);
+        have = advance();
+        boff ^= LDS_SET;
+#ifdef RM_CONV_TIMING
+        ++tl_;
+#endif
+      }
+    } else {
+    if (have) fetch();
     while (have) {
       RM_WSTAMP(tl_ * 3 + 0);
       __syncthreads();     // every wave is done with the previous tile in LDS
-      stage();
+      stage(0);
       __syncthreads();
       RM_WSTAMP(tl_ * 3 + 1);
       have = advance();
       if (have) fetch();   // in flight during the MFMAs below
       RM_WPRIO(1);
-      mma_tile();
+      mma_tile(0);
       RM_WPRIO(0);
       RM_WSTAMP(tl_ * 3 + 2);
 #ifdef RM_CONV_TIMING
       ++tl_;
 #endif
+    }
     }
   } else {
   const bool vec_x = (Cin & 7) == 0, vec_dy = (Cout & 7) == 0;
@@ -518,7 +558,7 @@ __global__ __launch_bounds__(256, DENSE ? 3 : 2) void conv5_wgrad_bf16_kernel(Wg
         if ((unsigned)gx < (unsigned)W) v0 = load8_bf16(rowp + (size_t)gx * Cin, c, Cin, vec_x);
         if ((unsigned)(gx + 1) < (unsigned)W) v1 = load8_bf16(rowp + (size_t)(gx + 1) * Cin, c, Cin, vec_x);
       }
-      put_x_pair(cg, zz * HY + hy, p, v0, v1);
+      put_x_pair(cg, zz * HY + hy, p, v0, v1, 0);
     }
     // ---- stage dy (transposed)
     for (int it = tid; it < NIT_DY; it += 256) {
@@ -536,7 +576,7 @@ __global__ __launch_bounds__(256, DENSE ? 3 : 2) void conv5_wgrad_bf16_kernel(Wg
       put_pair(dyT + (cg * 8) * DYS + m * 2, DYS, v0, v1);
     }
     __syncthreads();
-    mma_tile();
+    mma_tile(0);
   }
   }
   }
@@ -639,7 +679,27 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   // (64 -> 64) 148 -> 131, level 2 (64 -> 128) 96 -> 83.
   const bool vec = (a.Cin & 7) == 0 && (a.Cout & 7) == 0 && a.W >= WGRAD_PIPE_MINW &&
                    (size_t)a.D * a.H * a.W * (a.Cin > a.Cout ? a.Cin : a.Cout) * 2 < ((size_t)1 << 31);
-  static long resident2 = 0, resident3 = 0;   // per instantiation: the regular kernel / the three-per-CU form (8x16 tile only)
+  // The wave-specialised form (see the kernel's comment) where a workgroup gets a long tile loop: one workgroup per CU halves
+  // the workgroups in flight, and its un-overlapped prologue + epilogue (~40 k cycles = 11 of its tile steps) must be a small
+  // part of the loop.  Same box, interleaved, us per launch two-workgroup / specialised: level 0 32->32 240.4 / 221.2,
+  // 64->32 464.1 / 427.2 (86 and 171 tiles per workgroup); level 1 64->64 131.5 / 135.9, 128->64 252.3 / 270.8 (22 tiles).
+  // REPMODE_WGRAD_WS: 0 never, 1 (default) by the tile count, 2 always.
+  static const int ws_mode = []() { const char* e = getenv("REPMODE_WGRAD_WS"); return e ? atoi(e) : 1; }();
+  bool ws = false;
+  if (vec && TX >= 32 && ws_mode != 0 && !a.dy2) {
+    const long fixed1 = (long)a.nslots * a.ncot * a.ncit * a.ndz;
+    const long est_nc = fixed1 >= 256 ? 1 : 256 / fixed1;
+    const double per_wg = (double)a.ntiles * (n > a.nslots ? (double)n / a.nslots : 1.0) / (double)est_nc;
+    ws = ws_mode == 2 || per_wg >= 48.0;
+  }
+  static long resident2 = 0, resident3 = 0, resident_ws = 0;   // per instantiation: the regular kernel / the three-per-CU form (8x16 tile only) / WS
+  if (TX >= 32 && !resident_ws) {
+    int per_cu = 0, cus = 0, dev = 0;
+    RM_HIP(hipGetDevice(&dev));
+    RM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    RM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv5_wgrad_bf16_kernel<TZ, TY, TX, true, false, TX >= 32>, 512, 0));
+    resident_ws = (long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+  }
   if (!resident2) {
     int per_cu = 0, cus = 0, dev = 0;
     RM_HIP(hipGetDevice(&dev));
@@ -671,13 +731,13 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   // 128 -> 128) are one round of 768 instead of two of 512: 88 -> 77 us; 960 (12 slots) are two rounds either way:
   // 189 -> 235 us -- so both forms are priced, the dense one at 1.25 per round.
   bool dense = false;
-  if (TX == 16 && vec && resident3 > resident2) {
+  if (TX == 16 && vec && !ws && resident3 > resident2) {
     long c2, c3;
     double p2 = price(a.ndz, resident2, &c2), p3 = 1.25 * price(a.ndz, resident3, &c3);
     if (a.dy2) { p2 += price(a.ndz2, resident2, &c2); p3 += 1.25 * price(a.ndz2, resident3, &c3); }
     dense = p3 < p2;
   }
-  const long resident = dense ? resident3 : resident2;
+  const long resident = ws ? resident_ws : dense ? resident3 : resident2;
   auto plan = [&](int ndz, int layout, int* tiles_per_block, int* nchunks, int* direct) -> long {
     const long fixed = (long)a.nslots * a.ncot * a.ncit * ndz;
     long want_chunks = 1;
@@ -700,7 +760,9 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
   repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, s);
   // (levels with W < 16 hand a workgroup only a tile or two per sample: nothing to overlap, and the plain loop is ~15 % faster there)
-  if (vec && dense)
+  if (ws)
+    hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true, false, TX >= 32>), dim3((unsigned)grid), dim3(TX >= 32 ? 512 : 256), 0, s, a);
+  else if (vec && dense)
     hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true, TX == 16>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else if (vec)
     hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
