@@ -19,10 +19,12 @@ Workloads (BASELINE.json ``configs``):
   ``--batch B`` overrides the per-GPU batch for either.
 
 Also reported in the same line:
-  roofline      the conv5_igemm kernel (forward + data-gradient launches of levels 0-2, the dominant kernel): algorithmic
+  roofline      the MoDE convolution of conv5_igemm.hip (forward + data-gradient launches; the dominant kernel): since round 3
+                two symbols -- conv5_ws_kernel (levels 0-1, 14 launches, 3/4 of the FLOPs) and conv5_igemm_kernel (levels 2-4),
+                together and each under ``by_kernel``: algorithmic
                 FLOPs (the layer's merged 125-tap convolution, 2 * voxels * Cin * Cout * 125, once per layer and
                 direction) / HIP-event duration on the launch stream, against the dense bf16 MFMA peak;
-                ``all_conv_kernels``: the same over conv5_igemm + conv5_deep (levels 3-4) + the one-channel layers' kernels.  ``traffic``: HBM bytes per
+                ``all_conv_kernels``: the same + conv5_deep (levels 3-4) + the one-channel layers' kernels.  ``traffic``: HBM bytes per
                 launch from rocprofv3 PMC passes of THIS build (profiles/*_pmc_traffic.json carries the hash of
                 the kernel sources it was taken on), else null.
   fwd           forward only (BASELINE's ">= 40 % MFMA on fused GatRep+Conv3d forward"): voxels/s of the whole
@@ -55,7 +57,8 @@ NUM_TASKS = 12
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
 FWD_FLOP_PER_VOXEL = 2083520.0                    # whole forward; MoDE convs alone 2,072,000
 FWD_CONV_FLOP_PER_VOXEL = 2072000.0
-CONV_KINDS = ('conv5_igemm', 'conv5_deep', 'conv5_thin')     # the forward / data-gradient convolution kernels of the MoDE blocks
+CONV_KINDS = ('conv5_ws', 'conv5_igemm', 'conv5_deep', 'conv5_thin')     # the forward / data-gradient convolution kernels of the MoDE blocks
+MAIN_KINDS = ('conv5_ws', 'conv5_igemm')      # conv5_igemm.hip: the wide levels' wave-specialised kernel + the general one (levels 2-4)
 
 
 class Opts:
@@ -277,7 +280,7 @@ def main():
     torch.cuda.synchronize()
     train_prof = {}
     if not args.no_prof and rank == 0:
-        for kind in ('conv5_igemm', 'conv5_deep', 'conv5_thin', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd'):
+        for kind in ('conv5_ws', 'conv5_igemm', 'conv5_deep', 'conv5_thin', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd'):
             train_prof[kind] = _lib.prof_summary(kind)
         train_recs = _lib.prof_records() if args.dump_launches else None
     _lib.prof_enable(False)
@@ -374,12 +377,22 @@ def main():
                     continue          # kind not recorded (default: the dominant kernel only; --prof-all for all)
                 kinds[kind] = {'launches': n, 'ms_per_step': ms / max(profiled_steps, 1),
                                'rate': (work / (ms * 1e-3) / 1e12) if ms > 0 else None}   # TFLOP/s or TB/s
-            n, ms, flops = train_prof['conv5_igemm']
+            # the MoDE convolution of conv5_igemm.hip: conv5_ws_kernel (levels 0-1, since round 3) + conv5_igemm_kernel (levels 2-4)
+            n, ms, flops = (sum(v) for v in zip(*(train_prof[k] for k in MAIN_KINDS)))
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             peak = PEAK_TFLOPS[args.dtype]
-            traffic, traffic_file = pmc_traffic('conv5_igemm', b, args.dtype)
+            tr_parts = [(pmc_traffic(k, b, args.dtype), train_prof[k][0]) for k in MAIN_KINDS if train_prof[k][0]]
+            traffic_file = next((t[1] for t, _ in tr_parts if t[1]), None)
+            traffic = (sum(t[0] * c for t, c in tr_parts) / sum(c for _, c in tr_parts)) if tr_parts and all(t[0] for t, _ in tr_parts) else None
             alg_bytes, alg_n = conv5_igemm_algorithmic_bytes(b, len(set(task.tolist())))
-            out['roofline'] = {'kernel': 'conv5_igemm_kernel', 'bound': 'mfma', 'achieved': achieved, 'peak': peak,
+            by_kernel = {}
+            for k, sym in (('conv5_ws', 'conv5_ws_kernel'), ('conv5_igemm', 'conv5_igemm_kernel')):
+                kn, kms, kfl = train_prof[k]
+                if kn:
+                    by_kernel[sym] = {'launches': kn, 'avg_launch_ms': kms / kn, 'achieved': kfl / (kms * 1e-3) / 1e12,
+                                      'frac': kfl / (kms * 1e-3) / 1e12 / peak, 'traffic': pmc_traffic(k, b, args.dtype)[0]}
+            out['roofline'] = {'kernel': 'conv5_ws_kernel + conv5_igemm_kernel (conv5_igemm.hip: the MoDE convolution, forward and data gradient)',
+                               'by_kernel': by_kernel, 'bound': 'mfma', 'achieved': achieved, 'peak': peak,
                                'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_file,
                                'launches': n, 'avg_launch_ms': ms / max(n, 1),
                                'flops_per_launch': flops / max(n, 1),

@@ -426,7 +426,8 @@ int repmode_expert_frags_multi(int nblocks, const float* const* k5, const float*
 #define REPMODE_PROF_WGRAD_THIN 4 /* conv5_wgrad_thin */
 #define REPMODE_PROF_CONV5_DEEP 5 /* conv5_deep (per-expert formulation, deep levels) */
 #define REPMODE_PROF_CONV5_THIN 6 /* the one-channel first / last layers' own kernels */
-#define REPMODE_PROF_KINDS 7
+#define REPMODE_PROF_CONV5_WS 7   /* conv5_ws_kernel / conv5_pipe_kernel: the wide levels' pipelined convolution (conv5_igemm.hip) */
+#define REPMODE_PROF_KINDS 8
 int repmode_prof_enable(int on);
 /* Suspend (1) / resume (0) recording; the records so far are kept (sampling a subset of the steps). */
 int repmode_prof_pause(int paused);

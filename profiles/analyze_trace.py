@@ -32,12 +32,12 @@ def main():
         print('%-80s calls %5s  %8.3f ms/step  avg %8.1f us  %5.1f%%' % (
             short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6 / steps, float(r['AverageNs']) / 1e3,
             100 * float(r['TotalDurationNs']) / tot))
-    ig = [r for r in rows if 'conv5_igemm_kernel' in r['Name']]
+    ig = [r for r in rows if 'conv5_igemm_kernel' in r['Name'] or 'conv5_ws_kernel' in r['Name'] or 'conv5_pipe_kernel' in r['Name']]
     if ig:
         calls = sum(int(r['Calls']) for r in ig)
-        print('conv5_igemm_kernel, all %d instantiations: %d calls, %.1f us average  (compare bench.py roofline.avg_launch_ms)'
+        print('conv5_ws_kernel + conv5_igemm_kernel, all %d instantiations: %d calls, %.1f us average  (compare bench.py roofline.avg_launch_ms)'
               % (len(ig), calls, sum(float(r['TotalDurationNs']) for r in ig) / calls / 1e3))
-    for key in ('conv5_igemm', 'conv5_deep', 'thin_', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd', 'bn_', 'k2s2', 'expert_mix', 'box_sum'):
+    for key in ('conv5_ws', 'conv5_igemm', 'conv5_deep', 'thin_', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd', 'bn_', 'k2s2', 'expert_mix', 'box_sum'):
         ks = [r for r in tr if key in r['Kernel_Name']]
         if not ks:
             continue
@@ -48,6 +48,7 @@ def main():
 
 FAMILIES = [('conv5_deep level 3 (per-expert pair)', 'conv5_deep_kernel<DCfg<4, 8, 8'), ('conv5_deep level 4 (per-expert pair)', 'conv5_deep_kernel<DCfg<2, 4, 4'),
             ('thin layers (own kernels)', 'thin_in1_kernel'), ('thin layers (own kernels)', 'thin_out1_kernel'),
+            ('conv5_ws level 0-1 (wave-specialised)', 'conv5_ws_kernel'), ('conv5_pipe level 0-1', 'conv5_pipe_kernel'),
             ('conv5_igemm level 0-1', 'conv5_igemm_kernel<unsigned short, Cfg<4, 4, 32'),
             ('conv5_igemm level 2', 'conv5_igemm_kernel<unsigned short, Cfg<4, 4, 16'),
             ('conv5_igemm level 3', 'conv5_igemm_kernel<unsigned short, Cfg<4, 8, 8'),

@@ -1626,7 +1626,7 @@ int launch_pipe(ConvArgs a, hipStream_t stream) {
     attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
   }
   const double alg = 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS;
-  repmode_prof_begin(REPMODE_PROF_CONV5, alg, stream);
+  repmode_prof_begin(REPMODE_PROF_CONV5_WS, alg, stream);
   if (g_pipe & 8) {       // the wave-specialised form
     const bool plain = a.wide && !a.bias && !a.relu;
     if (cw == 2 && plain) hipLaunchKernelGGL((conv5_ws_kernel<2, true>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
