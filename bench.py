@@ -103,14 +103,19 @@ def conv5_igemm_algorithmic_bytes(batch, nslots):
               (2, 64, 128), (2, 128, 128), (2, 256, 128), (2, 128, 128)]
     pair = [(3, 128, 256), (3, 256, 256), (3, 512, 256), (3, 256, 256), (4, 256, 512), (4, 512, 512)]
     total, n = 0.0, 0
+    wide = [0.0, 0]                                              # levels 0-1: the launches of conv5_ws_kernel
     for l, ci, co in merged:
         osz = 2 if l < 2 else 4
         for a, b in ((ci, co), (co, ci)):                       # forward, data gradient
-            total += batch * v[l] * (a * 2 + b * osz) + nslots * 125 * ci * co * 2
+            t = batch * v[l] * (a * 2 + b * osz) + nslots * 125 * ci * co * 2
+            total += t
             n += 1
+            if l < 2:
+                wide[0] += t; wide[1] += 1
     for l, ci, co in pair:
         total += batch * v[l] * (ci * 2 + 2 * co * 4) + (125 + 27) * ci * co * 2
         n += 1
+    conv5_igemm_algorithmic_bytes.by_kernel = {'conv5_ws': (wide[0], wide[1]), 'conv5_igemm': (total - wide[0], n - wide[1])}
     return total, n
 
 
@@ -389,8 +394,12 @@ def main():
             for k, sym in (('conv5_ws', 'conv5_ws_kernel'), ('conv5_igemm', 'conv5_igemm_kernel')):
                 kn, kms, kfl = train_prof[k]
                 if kn:
+                    ab, an = conv5_igemm_algorithmic_bytes.by_kernel[k]
+                    ktr = pmc_traffic(k, b, args.dtype)[0]
                     by_kernel[sym] = {'launches': kn, 'avg_launch_ms': kms / kn, 'achieved': kfl / (kms * 1e-3) / 1e12,
-                                      'frac': kfl / (kms * 1e-3) / 1e12 / peak, 'traffic': pmc_traffic(k, b, args.dtype)[0]}
+                                      'frac': kfl / (kms * 1e-3) / 1e12 / peak, 'traffic': ktr,
+                                      'algorithmic_bytes_per_launch': ab / max(an, 1),
+                                      'traffic_over_algorithmic': (ktr / (ab / an)) if ktr and an else None}
             out['roofline'] = {'kernel': 'conv5_ws_kernel + conv5_igemm_kernel (conv5_igemm.hip: the MoDE convolution, forward and data gradient)',
                                'by_kernel': by_kernel, 'bound': 'mfma', 'achieved': achieved, 'peak': peak,
                                'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_file,

@@ -390,7 +390,7 @@ int repmode_mse_loss(const float* out, const float* target, const int32_t* sampl
 
 /* Developer / test switch of the convolution's pipelined form (csrc/conv5_igemm.hip, conv5_pipe_kernel; also REPMODE_CONV_PIPE):
  * bit 0 = on, bit 1 = one channel sub-tile per wave everywhere, bit 2 = also on grids smaller than the chip, bit 3 = the
- * wave-specialised kernel (MFMA waves + loader waves); default 9.
+ * wave-specialised kernel (MFMA waves + loader waves), bit 4 = its items along z first; default 25.
  * Results do not depend on it (same products, same summation order). */
 int repmode_set_conv_pipe(int mode);
 int repmode_get_conv_pipe(void);

@@ -119,6 +119,7 @@ struct ConvArgs {
   // 2 N samples (the two expert outputs), else both jobs ADD into sample v % N.
   int dual;
   int wide;            // element-typed bf16 output: 16-byte stores through v_permlane32_swap (see the epilogue)
+  int zfast;           // conv5_ws_kernel: a workgroup's items run along z first (channel tile, z, x, y, sample) instead of x first
   // MERGE kernels only: w = the experts' two un-merged slots (repmode_expert_frags), the 1x1 experts' parameters [Cout][Cin]
   // and the gate probabilities g[slot][5][Cout]
   const float* mk1;
@@ -1292,6 +1293,16 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
     Brick g;
     int b = it;
     g.cot = b % a.ncot; b /= a.ncot;
+    if (a.zfast) {
+      // z first: consecutive items of a workgroup share half of their halo images (a brick is 4 planes thick, its image 8),
+      // and all workgroups, in step, sit in one z slab of the batch -- the y neighbours' shared rows are in L2
+      const int bz = b % a.nbz; b /= a.nbz;
+      const int bx = b % a.nbx; b /= a.nbx;
+      const int by = b % a.nby;
+      g.n = b / a.nby;
+      g.z0 = bz * BZ; g.y0 = by * BY; g.x0 = bx * BX;
+      return g;
+    }
     const int bx = b % a.nbx; b /= a.nbx;
     const int by = b % a.nby; b /= a.nby;
     const int bz = b % a.nbz;
@@ -1299,10 +1310,20 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
     g.z0 = bz * BZ; g.y0 = by * BY; g.x0 = bx * BX;
     return g;
   };
-  // the item after g (item + 1) without the five divisions: carry through (cot, bx, by, bz, n)
+  // the item after g (item + 1) without the five divisions: carry through (cot, bx, by, bz, n) / (cot, bz, bx, by, n)
   auto brick_next = [&](Brick g) -> Brick {
     if (++g.cot < a.ncot) return g;
     g.cot = 0;
+    if (a.zfast) {
+      if ((g.z0 += BZ) < a.nbz * BZ) return g;
+      g.z0 = 0;
+      if ((g.x0 += BX) < a.nbx * BX) return g;
+      g.x0 = 0;
+      if ((g.y0 += BY) < a.nby * BY) return g;
+      g.y0 = 0;
+      ++g.n;
+      return g;
+    }
     if ((g.x0 += BX) < a.nbx * BX) return g;
     g.x0 = 0;
     if ((g.y0 += BY) < a.nby * BY) return g;
@@ -1576,12 +1597,13 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
 
 // eligibility + launch of the pipelined form (see the kernel's comment); returns -1 when the launch is not its kind.
 // REPMODE_CONV_PIPE / repmode_set_conv_pipe: bit 0 = on, bit 1 = one channel sub-tile per wave everywhere, bit 2 = also on grids
-// smaller than the chip (the parity tests' volumes), bit 3 = the wave-specialised kernel (conv5_ws_kernel); default 9.  Same box, interleaved, us per launch two-workgroup form /
+// smaller than the chip (the parity tests' volumes), bit 3 = the wave-specialised kernel (conv5_ws_kernel), bit 4 = its items
+// along z first (HBM reads per launch at batch 8: 87.4 -> 61.0 MB, 64->32 401.5 -> 396.6 us); default 25.  Same box, interleaved, us per launch two-workgroup form /
 // pipelined: 32->32 (level 0) 227.6 / 216.7, 64->32 460.0 / 433.5, 64->64 (level 1) 116.4 / 98.1, 128->64 224.1 / 189.2
 // (one sub-tile per wave: 106.2, 206.8); conv5 launches of the train step 3945 -> 3702 us.  The step itself moves less
 // (11.82 -> 11.75 ms): with the convolutions drawing more power every other kernel of the step runs 2-6 % slower
 // (profiles/r03_pipe_ab.txt) -- the chip is power-limited over the step, not per kernel.
-static int g_pipe = []() { const char* e = getenv("REPMODE_CONV_PIPE"); return e ? atoi(e) : 9; }();
+static int g_pipe = []() { const char* e = getenv("REPMODE_CONV_PIPE"); return e ? atoi(e) : 25; }();
 
 int launch_pipe(ConvArgs a, hipStream_t stream) {
   using C1 = Cfg<4, 4, 32, 4, 1, 4, 1>;
@@ -1597,6 +1619,7 @@ int launch_pipe(ConvArgs a, hipStream_t stream) {
   a.nbx = ceil_div(a.W, C1::BX);
   a.ncot = ceil_div(a.CoutP, 32 * cw);
   a.ksplit = 1;
+  a.zfast = (g_pipe & 16) ? 1 : 0;
   const long nitems = (long)a.N * a.nbz * a.nby * a.nbx * a.ncot;
   static int cus = 0;
   if (!cus) {
