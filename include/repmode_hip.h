@@ -390,8 +390,9 @@ int repmode_mse_loss(const float* out, const float* target, const int32_t* sampl
 
 /* Developer / test switch of the convolution's pipelined form (csrc/conv5_igemm.hip, conv5_pipe_kernel; also REPMODE_CONV_PIPE):
  * bit 0 = on, bit 1 = one channel sub-tile per wave everywhere, bit 2 = also on grids smaller than the chip, bit 3 = the
- * wave-specialised kernel (MFMA waves + loader waves), bit 4 = its items along z first; default 25.
- * Results do not depend on it (same products, same summation order). */
+ * wave-specialised kernel (MFMA waves + loader waves),  bit 4 = its items along z first, bit 5 = row-stationary tap
+ * order on the 32-channel layers (another float summation order of the 125 taps); default 57.
+ * Results do not depend on bits 0-4 (same products, same summation order); bit 5 reorders the float sums of a chunk's taps. */
 int repmode_set_conv_pipe(int mode);
 int repmode_get_conv_pipe(void);
 

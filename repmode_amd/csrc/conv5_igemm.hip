@@ -1256,8 +1256,12 @@ __global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nite
 // the halo staging registers (108) are gone -- filter fragments run 4 rows ahead (one channel sub-tile) / 2 rows (two).
 // PLAIN: the training path's epilogue (16-byte stores, no bias, no ReLU) as straight-line code -- the general one is a
 // chain of uniform branches per (sub-tile, quad pair) that cost 4.3 k cycles per brick (stamps), 11 % of a level-0 brick.
-template <int CW, bool PLAIN>
+// RS (CW = 1 only): row-stationary tap order -- for a fixed (dz, dx) the voxel fragment of halo row y' = vs + dy serves every
+// (sub-tile vs, dy) pair that lands on it: 8 LDS reads + 5 filter fragments feed 20 MFMAs (0.4 reads per MFMA instead of 1).
+// The summation order of the 125 taps differs from the tap-major kernels (float rounding: not bit-identical to them).
+template <int CW, bool PLAIN, bool RS = false>
 __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems) {
+  static_assert(!RS || CW == 1, "row-stationary order: one channel sub-tile per wave");
   using C = Cfg<4, 4, 32, 4, 1, 4, CW>;
   constexpr int KV = 8, KC = 16, VW = 4;
   constexpr int BZ = C::BZ, BY = C::BY, BX = C::BX, BYH = C::BYH, BXH = C::BXH, VH = C::VH, PLS = C::PLS;
@@ -1426,7 +1430,7 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
       for (int r = 0; r < 16; ++r) acc[cs][vs][r] = 0.f;
 
   // filter rows in flight ahead of the one being multiplied, voxel fragments (taps) in flight ahead
-  constexpr int RA = CW == 1 ? 4 : 2;
+  constexpr int RA = RS ? 3 : CW == 1 ? 4 : 2;     // filter rows (RS: (dz, dx) groups) ahead
   constexpr int TA = CW == 1 ? 2 : 1;
   Img cur_g = image_of(brick_of(item), 0);
   u32x4 aq[RA + 1][CW][5];
@@ -1435,7 +1439,7 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
 #pragma unroll
     for (int cs = 0; cs < CW; ++cs)
 #pragma unroll
-      for (int dx = 0; dx < 5; ++dx) aq[k][cs][dx] = wfrag(cur_g, cs, k * 5 + dx, lane_w);
+      for (int dx = 0; dx < 5; ++dx) aq[k][cs][dx] = wfrag(cur_g, cs, RS ? ((k / 5) * 5 + dx) * 5 + k % 5 : k * 5 + dx, lane_w);
   asm volatile("s_barrier" ::: "memory");          // the loaders have stored the first image
   int cur = 0;
 #ifdef RM_CONV_TIMING
@@ -1450,6 +1454,35 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
     if (have_next) nxt_g = last_chunk ? image_of(brick_next(cur_g.b), 0) : image_of(cur_g.b, cur_g.chunk + 1);
     const int lane_w_nxt = have_next ? lane_w : (int)OOB;
     const u32x4* lb = lb0 + cur * BUF;
+    if constexpr (RS) {
+      // group q = (dz, dx): halo rows y' = 0..7 of plane wave + dz at x shift dx; filter fragments of taps (dz, dy = 0..4, dx)
+      auto grp_off = [&](int q, int yy) -> int { return ((q / 5) * BYH + yy) * BXH + q % 5; };
+      auto grp_tap = [&](int q, int dy) -> int { return ((q / 5) * 5 + dy) * 5 + q % 5; };
+      u32x4 bg[2][8];
+#pragma unroll
+      for (int yy = 0; yy < 8; ++yy) bg[0][yy] = lb[grp_off(0, yy)];
+#pragma unroll
+      for (int q = 0; q < 25; ++q) {
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy) {
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs) {
+            Elem<bf16_t>::mma(aq[0][0][dy], bg[q & 1][vs + dy], acc[0][vs]);
+            // the next group's eight voxel fragments in the shadows of this group's first eight MFMAs
+            if (q + 1 < 25 && dy * VW + vs < 8) bg[(q + 1) & 1][dy * VW + vs] = lb[grp_off(q + 1, dy * VW + vs)];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (q + RA < 25) aq[RA][0][dy] = wfrag(cur_g, 0, grp_tap(q + RA, dy), lane_w);
+          else aq[RA][0][dy] = wfrag(nxt_g, 0, grp_tap(q + RA - 25, dy), lane_w_nxt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (q == 12) RM_STAMP(st_ * 4 + 1);
+#pragma unroll
+        for (int k = 0; k < RA; ++k)
+#pragma unroll
+          for (int dy = 0; dy < 5; ++dy) aq[k][0][dy] = aq[k + 1][0][dy];
+      }
+    } else {
     auto tap_off = [&](int t) -> int { return (((t / 5) / 5) * BYH + ((t / 5) % 5)) * BXH + t % 5; };
     u32x4 bq[TA + 1][VW];
 #pragma unroll
@@ -1486,6 +1519,7 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
         for (int cs = 0; cs < CW; ++cs)
 #pragma unroll
           for (int dx = 0; dx < 5; ++dx) aq[k][cs][dx] = aq[k + 1][cs][dx];
+    }
     }
     RM_STAMP(st_ * 4 + 2);
     // every MFMA wave is done with image `cur`, every loader wave has stored the next one
@@ -1598,12 +1632,14 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
 // eligibility + launch of the pipelined form (see the kernel's comment); returns -1 when the launch is not its kind.
 // REPMODE_CONV_PIPE / repmode_set_conv_pipe: bit 0 = on, bit 1 = one channel sub-tile per wave everywhere, bit 2 = also on grids
 // smaller than the chip (the parity tests' volumes), bit 3 = the wave-specialised kernel (conv5_ws_kernel), bit 4 = its items
-// along z first (HBM reads per launch at batch 8: 87.4 -> 61.0 MB, 64->32 401.5 -> 396.6 us); default 25.  Same box, interleaved, us per launch two-workgroup form /
+// along z first (HBM reads per launch at batch 8: 87.4 -> 61.0 MB, 64->32 401.5 -> 396.6 us), bit 5 = row-stationary tap
+// order on the 32-channel layers (8 LDS reads per 20 MFMAs: level 0 200.5 -> 189.4 us, 64->32 403.1 -> 381.1; the kernel is
+// power-limited and an LDS read costs energy); default 57.  Same box, interleaved, us per launch two-workgroup form /
 // pipelined: 32->32 (level 0) 227.6 / 216.7, 64->32 460.0 / 433.5, 64->64 (level 1) 116.4 / 98.1, 128->64 224.1 / 189.2
 // (one sub-tile per wave: 106.2, 206.8); conv5 launches of the train step 3945 -> 3702 us.  The step itself moves less
 // (11.82 -> 11.75 ms): with the convolutions drawing more power every other kernel of the step runs 2-6 % slower
 // (profiles/r03_pipe_ab.txt) -- the chip is power-limited over the step, not per kernel.
-static int g_pipe = []() { const char* e = getenv("REPMODE_CONV_PIPE"); return e ? atoi(e) : 25; }();
+static int g_pipe = []() { const char* e = getenv("REPMODE_CONV_PIPE"); return e ? atoi(e) : 57; }();
 
 int launch_pipe(ConvArgs a, hipStream_t stream) {
   using C1 = Cfg<4, 4, 32, 4, 1, 4, 1>;
@@ -1643,6 +1679,8 @@ int launch_pipe(ConvArgs a, hipStream_t stream) {
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_pipe_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_pipe_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
@@ -1654,7 +1692,9 @@ int launch_pipe(ConvArgs a, hipStream_t stream) {
     const bool plain = a.wide && !a.bias && !a.relu;
     if (cw == 2 && plain) hipLaunchKernelGGL((conv5_ws_kernel<2, true>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
     else if (cw == 2) hipLaunchKernelGGL((conv5_ws_kernel<2, false>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
+    else if (plain && (g_pipe & 32)) hipLaunchKernelGGL((conv5_ws_kernel<1, true, true>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
     else if (plain) hipLaunchKernelGGL((conv5_ws_kernel<1, true>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
+    else if (g_pipe & 32) hipLaunchKernelGGL((conv5_ws_kernel<1, false, true>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
     else hipLaunchKernelGGL((conv5_ws_kernel<1, false>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
   } else if (cw == 2) hipLaunchKernelGGL(conv5_pipe_kernel<2>, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, a, (int)nitems);
   else hipLaunchKernelGGL(conv5_pipe_kernel<1>, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, a, (int)nitems);

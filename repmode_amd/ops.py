@@ -121,8 +121,9 @@ def get_deterministic():
 def set_conv_pipe(mode):
     """The convolution's pipelined one-wave-per-SIMD form on volumes 32 or more voxels wide (csrc/conv5_igemm.hip,
     ``conv5_pipe_kernel`` / ``conv5_ws_kernel``): bit 0 on, bit 1 one channel sub-tile per wave everywhere, bit 2 also on grids
-    smaller than the chip (tests), bit 3 the wave-specialised kernel, bit 4 its items along z first; default 25.  0: the two-workgroup form everywhere.
-    Results do not depend on it."""
+    smaller than the chip (tests), bit 3 the wave-specialised kernel, bit 4 its items along z first, bit 5 row-stationary tap order on 32-channel layers;
+    default 57.  0: the two-workgroup form everywhere.
+    Results do not depend on bits 0-4; bit 5 changes the float summation order of the taps."""
     _lib.call('repmode_set_conv_pipe', int(mode))
 
 

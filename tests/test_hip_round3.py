@@ -199,7 +199,7 @@ PIPE_CASES = [
 ]
 
 
-@pytest.mark.parametrize('mode', [5, 7, 13, 15, 29])
+@pytest.mark.parametrize('mode', [5, 7, 13, 15, 29, 61])
 @pytest.mark.parametrize('case', PIPE_CASES)
 def test_conv5_pipelined_form_vs_oracle_and_the_two_workgroup_form(case, mode):
     """conv5_pipe_kernel (one workgroup per CU, double-buffered halo image, persistent item ranges; mode 5: two channel sub-tiles
@@ -231,6 +231,9 @@ def test_conv5_pipelined_form_vs_oracle_and_the_two_workgroup_form(case, mode):
                 y = ops.conv5(x_cl, wf, slots.to(DEV), cout)
             outs.append(y.float().cpu())
     finally:
-        ops.set_conv_pipe(25)
+        ops.set_conv_pipe(57)
     assert rel_err(outs[0].permute(0, 4, 1, 2, 3), y_ref) < 6e-3          # (bf16 output)
-    assert torch.equal(outs[0], outs[1])
+    if mode & 32:       # row-stationary tap order (32-channel layers): another summation order of the 125 taps
+        assert rel_err(outs[0], outs[1]) < 8e-3
+    else:
+        assert torch.equal(outs[0], outs[1])
