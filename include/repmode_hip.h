@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define REPMODE_ABI_VERSION 7
+#define REPMODE_ABI_VERSION 8
 
 /* element types of activations / merged filters */
 #define REPMODE_F32 0  /* float in, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)          */
@@ -395,6 +395,11 @@ int repmode_mse_loss(const float* out, const float* target, const int32_t* sampl
  * Results do not depend on bits 0-4 (same products, same summation order); bit 5 reorders the float sums of a chunk's taps. */
 int repmode_set_conv_pipe(int mode);
 int repmode_get_conv_pipe(void);
+/* The same kind of switch for the bf16 filter gradient's wave-specialised form (csrc/conv5_wgrad.hip; also REPMODE_WGRAD_WS):
+ * 0 never, 1 where a workgroup has a long tile loop (default), 2 wherever the tile allows.  Results: the same sums; how the voxel
+ * range is split over workgroups (float atomics) follows the form. */
+int repmode_set_wgrad_ws(int mode);
+int repmode_get_wgrad_ws(void);
 
 /* ---- sliding-window inference (fnet/fnet_model.py:149-223): the two ends of a batch of patches, SURVEY.md section 8f.3 ----
  * patch_gather: :196-205 -- out[n][pd][ph][pw] = vol[starts[3n..3n+2] + (z, y, x)], the batch's crops of the device-resident

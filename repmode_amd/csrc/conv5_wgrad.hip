@@ -19,6 +19,9 @@
 #include <cstdlib>
 
 namespace {
+// REPMODE_WGRAD_WS / repmode_set_wgrad_ws: the wave-specialised form of the bf16 filter gradient -- 0 never, 1 where a workgroup
+// has a long tile loop (default), 2 wherever the tile allows
+int g_wgrad_ws = []() { const char* e = getenv("REPMODE_WGRAD_WS"); return e ? atoi(e) : 1; }();
 
 constexpr int TY = 4, TX = 16, TV = TY * TX;   // output voxels per tile
 constexpr int HY = TY + 4, HX = TX + 4, HV = HY * HX;
@@ -684,7 +687,7 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   // part of the loop.  Same box, interleaved, us per launch two-workgroup / specialised: level 0 32->32 240.4 / 221.2,
   // 64->32 464.1 / 427.2 (86 and 171 tiles per workgroup); level 1 64->64 131.5 / 135.9, 128->64 252.3 / 270.8 (22 tiles).
   // REPMODE_WGRAD_WS: 0 never, 1 (default) by the tile count, 2 always.
-  static const int ws_mode = []() { const char* e = getenv("REPMODE_WGRAD_WS"); return e ? atoi(e) : 1; }();
+  const int ws_mode = g_wgrad_ws;
   bool ws = false;
   if (vec && TX >= 32 && ws_mode != 0 && !a.dy2) {
     const long fixed1 = (long)a.nslots * a.ncot * a.ncit * a.ndz;
@@ -772,6 +775,9 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int repmode_set_wgrad_ws(int mode) { g_wgrad_ws = mode; return REPMODE_OK; }
+extern "C" int repmode_get_wgrad_ws(void) { return g_wgrad_ws; }
 
 extern "C" int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32_t* sample_slot, int nslots,
                                       float* dw, int n, int d, int h, int wdim, int cin, int cout, int dtype,

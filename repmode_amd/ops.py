@@ -131,6 +131,16 @@ def get_conv_pipe():
     return int(_lib.load().repmode_get_conv_pipe())
 
 
+def set_wgrad_ws(mode):
+    """The bf16 filter gradient's wave-specialised form (csrc/conv5_wgrad.hip): 0 never, 1 where a workgroup has a long tile
+    loop (default), 2 wherever the tile allows."""
+    _lib.call('repmode_set_wgrad_ws', int(mode))
+
+
+def get_wgrad_ws():
+    return int(_lib.load().repmode_get_wgrad_ws())
+
+
 def set_thin_kernels(on):
     """The one-channel first / last layers through their own kernels (csrc/thin_conv.hip; default) or round 2's fold of the x
     taps around the general kernel (REPMODE_THIN=0).  The operator library's switch (the ``thin_conv_*`` wrappers here

@@ -217,3 +217,32 @@ def test_deterministic_mode_is_bitwise_reproducible(dtype):
         assert (u == v) if isinstance(u, float) else torch.equal(u, v)
     # against the default mode: the losses (two steps) within 1 %
     assert abs(a[0] - c[0]) < 1e-2 * abs(c[0]) and abs(a[3] - c[3]) < 1e-2 * abs(c[3])
+
+
+@pytest.mark.timeout(900)
+def test_batch24_train_iters_bf16_against_the_float32_path():
+    """BASELINE configs[2] under test: ``Model.do_train_iter`` at batch 24 of 1x32x64x64, all 12
+    tasks, mult_chan 32 -- the per-expert levels with 12 slots, the filter gradient's grid plans, the wave-specialised kernels
+    at three times the headline batch.  Three bf16 steps against three float32 steps of the same kernels' parity mode from the
+    same seeded state and data (the float32 path is what the goldens pin to the reference): losses within 2 %."""
+    from repmode_amd.model import Model
+    gen = torch.Generator().manual_seed(24)
+    xs = [torch.randn(24, 1, 32, 64, 64, generator=gen) for _ in range(3)]
+    ts = [torch.randn(24, 1, 32, 64, 64, generator=gen) for _ in range(3)]
+    tasks = torch.arange(24) % 12
+    losses = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        torch.manual_seed(0)
+        m = Model(Opts(), nn_module='RepMode', lr=1e-3, gpu_ids=0, mult_chan=32, dtype=dtype)
+        out = []
+        for x, t in zip(xs, ts):
+            y, per_sample = m.do_train_iter(x.to(DEV), t.to(DEV), tasks)
+            assert y.shape == x.shape and torch.isfinite(y).all() and per_sample.shape == (24,)
+            out.append(float(m.last_loss))
+        losses[dtype] = out
+        del m
+        torch.cuda.empty_cache()
+    record('batch24_train_iters', f32=losses[torch.float32], bf16=losses[torch.bfloat16])
+    for a, b in zip(losses[torch.bfloat16], losses[torch.float32]):
+        assert abs(a - b) < 2e-2 * abs(b), losses
+    assert losses[torch.bfloat16][2] < losses[torch.bfloat16][0]          # (Adam at 1e-3 on random targets: the loss falls)

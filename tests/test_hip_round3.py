@@ -196,6 +196,9 @@ PIPE_CASES = [
     (2, 4, 12, 33, 64, 32, 32, 0),
     (2, 7, 5, 32, 32, 64, 0, 32),
     (9, 4, 4, 32, 16, 24, 0, 0),
+    (70, 4, 4, 32, 16, 32, 0, 0),       # more than 64 samples: slots beyond the lane-read register
+    (2, 4, 8, 32, 24, 32, 0, 0),        # a half-empty last channel chunk (24 = 16 + 8)
+    (2, 4, 8, 32, 32, 48, 0, 0),        # two channel sub-tiles per wave, the second one half used
 ]
 
 
@@ -237,3 +240,40 @@ def test_conv5_pipelined_form_vs_oracle_and_the_two_workgroup_form(case, mode):
         assert rel_err(outs[0], outs[1]) < 8e-3
     else:
         assert torch.equal(outs[0], outs[1])
+
+
+WGRAD_WS_CASES = [
+    # (N, D, H, W, Cin, Cout): volumes 32 or more voxels wide (the 1 x 8 x 32 tile), ragged in every direction
+    (2, 6, 10, 40, 32, 32),
+    (3, 5, 9, 35, 16, 48),
+    (2, 4, 16, 64, 64, 32),
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_WS_CASES)
+def test_conv5_wgrad_wave_specialised_vs_oracle(case):
+    """The filter gradient's wave-specialised form (loader waves fetch and transpose tile k + 1 while MFMA waves multiply tile
+    k; forced with mode 2 -- by default only long tile loops take it) against the oracle, and against the two-workgroup form
+    (same products; the voxel range is split differently over workgroups: float atomics order)."""
+    ops = _ops()
+    n, d, h, w, cin, cout = case
+    gen = torch.Generator().manual_seed(sum(case) + 3)
+    tasks = [5, 9, 5][:n]
+    plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+    x = torch.randn(n, cin, d, h, w, generator=gen).bfloat16().float()
+    dy = torch.randn(n, cout, d, h, w, generator=gen).bfloat16().float()
+    wt = torch.zeros(plan.nslots, cout, cin, 5, 5, 5, requires_grad=True)
+    slots = torch.tensor([plan.slot_task_host.index(t) for t in tasks])
+    (orc.conv_per_sample(x, wt[slots]) * dy).sum().backward()
+    dw_ref = wt.grad.reshape(plan.nslots, cout, cin, 125).permute(0, 3, 1, 2)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    got = []
+    try:
+        for mode in (2, 0):
+            ops.set_wgrad_ws(mode)
+            got.append(ops.conv5_wgrad(x_cl, dy_cl, plan, cout).cpu())
+    finally:
+        ops.set_wgrad_ws(1)
+    assert rel_err(got[0], dw_ref) < TOL_BF16_ACC
+    assert rel_err(got[0], got[1]) < 1e-5
