@@ -245,4 +245,3 @@ def test_batch24_train_iters_bf16_against_the_float32_path():
     record('batch24_train_iters', f32=losses[torch.float32], bf16=losses[torch.bfloat16])
     for a, b in zip(losses[torch.bfloat16], losses[torch.float32]):
         assert abs(a - b) < 2e-2 * abs(b), losses
-    assert losses[torch.bfloat16][2] < losses[torch.bfloat16][0]          # (Adam at 1e-3 on random targets: the loss falls)
