@@ -12,7 +12,7 @@
 //   one operand is 16 bytes (8 bf16 / 4 f32 of consecutive input channels), so both element
 //   types share every byte offset below.
 //
-// Data movement:
+// Data movement (all kernels of this file):
 //   * activations are NDHWC; a workgroup owns a BZ x BY x BX brick of output voxels of one sample
 //     and, per chunk of KC input channels, stages the (BZ+4)(BY+4)(BX+4) halo brick once into LDS
 //     (zero filled outside the volume) and reuses it for all 125 taps.
@@ -20,9 +20,18 @@
 //     voxel-linear.  Lane l of a wave reads voxel (l & 31) of plane (l >> 5): 32 consecutive
 //     16-byte slots -> conflict-free ds_read_b128, and a tap shift is a constant byte offset.
 //   * filter fragments come straight from global/L2 (fragment-major layout: each 32 x KC tile is
-//     1 KiB contiguous = one fully coalesced wave load), prefetched one (dz,dy) row = 5 taps ahead.
-//   * epilogue: the 32x32 accumulator tile holds 4 consecutive output channels per lane per
-//     register quad -> 8-byte (bf16) / 16-byte (f32) channel-contiguous stores.
+//     1 KiB contiguous = one fully coalesced wave load).
+//
+// Three kernels:
+//   conv5_igemm_kernel  the general one: every dtype, tile, epilogue (float output with split-K atomics, bias + ReLU,
+//                       BatchNorm statistics, pair / dual-expert launches); two workgroups per CU that alternate
+//                       "stage an image" / "125 taps" / epilogue.  Since round 3 it runs levels 2-4 and the eval /
+//                       float32 paths.  (Its ROWSTAT / MERGE instantiations and the RM_CONV_* macros are measured
+//                       experiments)
+//   conv5_ws_kernel     round 3, the wide levels (x extent >= 32, bf16, element-typed output: 3/4 of the network's conv
+//                       FLOPs): one workgroup per CU as a software pipeline of four MFMA waves and four loader waves over
+//                       a double-buffered image -- see the comment above it.
+//   conv5_pipe_kernel   the same pipeline without loader waves (the step before; kept for A/B and its timing builds).
 #include "common.h"
 #include "tail_jobs.h"
 
@@ -1430,7 +1439,7 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
       for (int r = 0; r < 16; ++r) acc[cs][vs][r] = 0.f;
 
   // filter rows in flight ahead of the one being multiplied, voxel fragments (taps) in flight ahead
-  constexpr int RA = RS ? 3 : CW == 1 ? 4 : 2;     // filter rows (RS: (dz, dx) groups) ahead
+  constexpr int RA = RS ? 3 : CW == 1 ? 4 : PLAIN ? 2 : 1;     // filter rows (RS: (dz, dx) groups) ahead; the eval epilogue needs the registers
   constexpr int TA = CW == 1 ? 2 : 1;
   Img cur_g = image_of(brick_of(item), 0);
   u32x4 aq[RA + 1][CW][5];

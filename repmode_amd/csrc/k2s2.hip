@@ -16,6 +16,8 @@
 // 32 voxels x KC input channels read straight from HBM/L2 (every input element is used exactly once per
 // output-channel tile, so there is nothing to stage in LDS).  0.55 % of the network's FLOPs: these kernels
 // are bandwidth/latency bound; what they buy is the removal of the permute copies around a library GEMM.
+// k2s2_kernel: 128 coarse voxels per workgroup (the wide levels); k2s2_split_kernel: the under-filled deep levels (the waves
+// of a workgroup split the taps of one 32-voxel tile).  Filter gradients: k2s2_wgrad_kernel (bf16), k2s2_wgrad_f32_kernel.
 #include "common.h"
 
 #include <cstdlib>
