@@ -11,6 +11,8 @@
 // Backward is the autograd of the same lines: expert gradients, gate-probability gradients
 // (reduced over ci and taps), then the softmax Jacobian and the gate Linear's weight/bias grads.
 #include "common.h"
+
+#include <cstdlib>
 #include "tail_jobs.h"
 
 namespace {
@@ -221,22 +223,31 @@ __device__ __forceinline__ void gatrep_fwd_body(
   // tile group may split the taps between them (blockIdx.z = grp * tsplit + part): small layers would
   // otherwise run as a handful of long, latency-bound single-wave loops.
   constexpr int MAXT = (TAPS + TQ - 1) / TQ;
-  int tapj[MAXT];
-  bool c3j[MAXT];
+  // Round 3: the slot loop below is branch-free and its stores are buffer stores -- ONE 32-bit byte offset per tap (invalid
+  // taps: an out-of-range offset, the store is dropped by the range check) and the slot's offset in an SGPR.  Before, every
+  // (slot, tap) body carried two branches and a 64-bit multiply-add for its address: 6.5 k instructions per wave, a third of
+  // them address arithmetic and exec-mask juggling.  Same products in the same order (a masked term is added as an exact
+  // + 0, or selected away), so the merged values are bit-identical.
+  bool c3j[MAXT], ctrj[MAXT];
+  int voff[MAXT];
   float v5a[MAXT], v5b[MAXT], v3a[MAXT], v3b[MAXT];
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     const int phase = tq + TQ * j;                 // tap phase index; phases are dealt round-robin to the parts
     const int tap = phase;
     const bool mine = tap < TAPS && (j % tsplit) == part;
-    tapj[j] = mine ? tap : -1;
     int t3 = 0;
     c3j[j] = mine && in_centre3(tap, t3);
+    ctrj[j] = mine && tap == 62;
     v5a[j] = mine ? s5[pr * TAPS + tap] : 0.f;
     v5b[j] = mine ? s5[(pr + 1) * TAPS + tap] : 0.f;
     v3a[j] = c3j[j] ? s3[pr * 27 + t3] : 0.f;
     v3b[j] = c3j[j] ? s3[(pr + 1) * 27 + t3] : 0.f;
+    const int tap_out = WRITE_WD ? TAPS - 1 - tap : tap;
+    voff[j] = mine ? (int)(((size_t)tap_out * tap_stride + tile_off) * sizeof(T)) : 0x7fffffff;
   }
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      wout, 0, (int)((size_t)nslots * slot_stride * sizeof(T)), 0x00020000);       // (< 2 GiB: checked by the launchers)
   const float e2a = s1[pr], e2b = s1[pr + 1], e3a = sa3[pr], e3b = sa3[pr + 1], e4a = sa5[pr], e4b = sa5[pr + 1];
   for (int s0 = 0; s0 < nslots; s0 += 16) {
     const int ns = min(16, nslots - s0);
@@ -248,24 +259,28 @@ __device__ __forceinline__ void gatrep_fwd_body(
     for (int sl = 0; sl < ns; ++sl) {
       const float ga0 = sg[sl][0][colA], ga1 = sg[sl][1][colA], ga2 = sg[sl][2][colA], ga3 = sg[sl][3][colA], ga4 = sg[sl][4][colA];
       const float gb0 = sg[sl][0][colB], gb1 = sg[sl][1][colB], gb2 = sg[sl][2][colB], gb3 = sg[sl][3][colB], gb4 = sg[sl][4][colB];
-      T* wslot = wout + (size_t)(s0 + sl) * slot_stride + tile_off;
+      const int soff = (int)((size_t)(s0 + sl) * slot_stride * sizeof(T));
       // same association order as RepMode.py:184-188: ((((g0 k5 + g1 k3) + g2 k1) + g3 a3) + g4 a5)
       const float ca3 = ga3 * e3a, cb3 = gb3 * e3b, ca4 = ga4 * e4a, cb4 = gb4 * e4b;
 #pragma unroll
       for (int j = 0; j < MAXT; ++j) {
-        if (tapj[j] < 0) continue;
         float ra = ga0 * v5a[j], rb = gb0 * v5b[j];
-        if (c3j[j]) {
-          ra += ga1 * v3a[j];
-          rb += gb1 * v3b[j];
-          if (tapj[j] == 62) { ra += ga2 * e2a; rb += gb2 * e2b; }
-          ra += ca3;
-          rb += cb3;
-        }
+        ra += ga1 * v3a[j];                          // (outside the centre cube v3 = 0: an exact + 0)
+        rb += gb1 * v3b[j];
+        const float ra2 = ra + ga2 * e2a, rb2 = rb + gb2 * e2b;
+        ra = ctrj[j] ? ra2 : ra;
+        rb = ctrj[j] ? rb2 : rb;
+        const float ra3 = ra + ca3, rb3 = rb + cb3;
+        ra = c3j[j] ? ra3 : ra;
+        rb = c3j[j] ? rb3 : rb;
         ra += ca4;
         rb += cb4;
-        const int tap_out = WRITE_WD ? TAPS - 1 - tapj[j] : tapj[j];
-        store_pair<T>(wslot + (size_t)tap_out * tap_stride, ra, rb);
+        if constexpr (sizeof(T) == 2) {
+          __builtin_amdgcn_raw_buffer_store_b32(pack_bf16x2(ra, rb), rs, voff[j], soff, 0);
+        } else {
+          const f32x2 v = {ra, rb};
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff[j], soff, 0);
+        }
       }
     }
   }
@@ -566,6 +581,8 @@ static int gatrep_fwd_t(const float* k5, const float* k3, const float* k1, const
     nwd = (long)nkc_d * nrt_d * 8 * ts_d;
   }
   RM_REQUIRE(nwf + nwd < (1L << 31), "gatrep_fwd: grid too large");
+  RM_REQUIRE((double)nslots * TAPS * repmode_padded_channels(co, dtype, 0) * repmode_padded_channels(ci, dtype, 0) * sizeof(T) < 2.0e9,
+             "gatrep_fwd: the merged filters of all slots must stay below 2 GB (32-bit store offsets)");
   hipLaunchKernelGGL((gatrep_fwd_kernel<T>), dim3((unsigned)(nwf + nwd)), dim3(256), 0, s, k5, k3, k1, a3, a5, gs, nslots, co,
                      ci, (int)nwf, nrt_f, nkc_f, ts_f, static_cast<T*>(wf), nrt_d, nkc_d, ts_d, static_cast<T*>(wd));
   RM_LAUNCH_CHECK("gatrep_fwd");
@@ -618,6 +635,7 @@ struct GatrepMultiArgs {
   int first[GM_MAX + 1];          // first workgroup of each block (prefix sums)
   int nblocks, nslots, num_tasks;
   const int32_t* slot_task;
+  int order;          // 1: a tile's eight row groups on one XCD, dispatched together (see the kernel)
 };
 
 template <typename T>
@@ -627,17 +645,35 @@ __global__ __launch_bounds__(256) void gatrep_fwd_multi_kernel(GatrepMultiArgs<T
   while (i + 1 < a.nblocks && (int)blockIdx.x >= a.first[i + 1]) ++i;       // (uniform; at most GM_MAX - 1 steps)
   int b = blockIdx.x - a.first[i];
   const GateSrc gs{nullptr, a.gate_w[i], a.gate_b[i], a.slot_task, a.num_tasks, a.g_out[i]};
+  // Which (reduction chunk, row tile, tap part, group of 4 rows) a workgroup takes.  The eight groups of one 1 KiB fragment
+  // tile each write a 128-byte piece of it per (slot, tap); with the group as the SLOWEST index (round 2) those pieces came
+  // from workgroups thousands of launch slots apart, on different XCDs -- isolated 128-byte writes at a 1 KiB pitch.  Now
+  // (REPMODE_GATREP_ORDER, default 1): workgroups b, b + 8, ... b + 56 of a block of 64 -- same XCD (b mod 8), dispatched
+  // together -- are the eight groups of one tile, so a tile's pieces meet in one L2 within microseconds.
+  auto decode = [&](int bb, int nkc, int nrt, int ts, int& kc, int& rt, int& zidx) {
+    const int ntile = nkc * nrt * ts;
+    if (a.order && (ntile & 7) == 0) {
+      const int x = bb & 7, q = bb >> 3;
+      const int grp = q & 7, t = (q >> 3) * 8 + x;
+      kc = t % nkc;
+      rt = (t / nkc) % nrt;
+      zidx = grp * ts + t / (nkc * nrt);
+    } else {
+      kc = bb % nkc; bb /= nkc;
+      rt = bb % nrt;
+      zidx = bb / nrt;
+    }
+  };
+  int kc, rt, zidx;
   if (b < a.nwf[i]) {
-    const int kc = b % a.nkc_f[i]; b /= a.nkc_f[i];
-    const int rt = b % a.nrt_f[i];
+    decode(b, a.nkc_f[i], a.nrt_f[i], a.ts_f[i], kc, rt, zidx);
     gatrep_fwd_body<T, false>(L, a.k5[i], a.k3[i], a.k1[i], a.a3[i], a.a5[i], gs, a.nslots, a.co[i], a.ci[i], a.nrt_f[i], a.nkc_f[i],
-                              a.ts_f[i], a.wf[i], kc, rt, b / a.nrt_f[i]);
+                              a.ts_f[i], a.wf[i], kc, rt, zidx);
   } else {
     b -= a.nwf[i];
-    const int kc = b % a.nkc_d[i]; b /= a.nkc_d[i];
-    const int rt = b % a.nrt_d[i];
+    decode(b, a.nkc_d[i], a.nrt_d[i], a.ts_d[i], kc, rt, zidx);
     gatrep_fwd_body<T, true>(L, a.k5[i], a.k3[i], a.k1[i], a.a3[i], a.a5[i], gs, a.nslots, a.co[i], a.ci[i], a.nrt_d[i], a.nkc_d[i],
-                             a.ts_d[i], a.wd[i], kc, rt, b / a.nrt_d[i]);
+                             a.ts_d[i], a.wd[i], kc, rt, zidx);
   }
 }
 
@@ -649,12 +685,16 @@ int gatrep_fwd_multi_t(int nblocks, const float* const* k5, const float* const* 
   constexpr int KC = FragGeom<T>::KC;
   GatrepMultiArgs<T> a{};
   a.nblocks = nblocks; a.nslots = nslots; a.num_tasks = num_tasks; a.slot_task = slot_task;
+  static const int order = []() { const char* e = getenv("REPMODE_GATREP_ORDER"); return e ? atoi(e) : 1; }();
+  a.order = order;
   long total = 0;
   double bytes = 0;
   for (int i = 0; i < nblocks; ++i) {
     RM_REQUIRE(k5[i] && k3[i] && k1[i] && a3[i] && a5[i] && gate_w[i] && gate_b[i] && (wf[i] || wd[i]) && (g_out[i] || !wf[i]),
                "gatrep_fwd_multi: null pointer (block %d)", i);
     RM_REQUIRE(co[i] > 0 && ci[i] > 0, "gatrep_fwd_multi: bad shape (block %d)", i);
+    RM_REQUIRE((double)nslots * TAPS * repmode_padded_channels(co[i], dtype, 0) * repmode_padded_channels(ci[i], dtype, 0) * sizeof(T) < 2.0e9,
+               "gatrep_fwd_multi: the merged filters of all slots must stay below 2 GB (32-bit store offsets; block %d)", i);
     a.k5[i] = k5[i]; a.k3[i] = k3[i]; a.k1[i] = k1[i]; a.a3[i] = a3[i]; a.a5[i] = a5[i];
     a.gate_w[i] = gate_w[i]; a.gate_b[i] = gate_b[i]; a.g_out[i] = g_out[i];
     a.wf[i] = static_cast<T*>(wf[i]); a.wd[i] = static_cast<T*>(wd[i]);
@@ -785,19 +825,37 @@ struct XfMultiArgs {
   int co[XM_MAX], ci[XM_MAX], nrt_f[XM_MAX], nkc_f[XM_MAX], nrt_d[XM_MAX], nkc_d[XM_MAX], nwf[XM_MAX];
   int first[XM_MAX + 1];
   int nblocks;
+  int order;
 };
 __global__ __launch_bounds__(256) void expert_frags_multi_kernel(XfMultiArgs a) {
   __shared__ XfLds L;
   int i = 0;
   while (i + 1 < a.nblocks && (int)blockIdx.x >= a.first[i + 1]) ++i;
   int b = blockIdx.x - a.first[i];
+  // (as in gatrep_fwd_multi_kernel: the four row quarters of one 1 KiB tile -- 256-byte pieces per tap -- on one XCD, dispatched
+  // together: workgroups b, b + 8, b + 16, b + 24 of a block of 32)
+  auto decode = [&](int bb, int nkc, int nrt, int& kc, int& rt, int& q) {
+    const int ntile = nkc * nrt;
+    if (a.order && (ntile & 7) == 0) {
+      const int x = bb & 7, w = bb >> 3;
+      q = w & 3;
+      const int t = (w >> 2) * 8 + x;
+      kc = t % nkc;
+      rt = t / nkc;
+    } else {
+      kc = bb % nkc; bb /= nkc;
+      rt = bb % nrt;
+      q = bb / nrt;
+    }
+  };
+  int kc, rt, q;
   if (b < a.nwf[i]) {
-    const int kc = b % a.nkc_f[i]; b /= a.nkc_f[i];
-    expert_frags_body<false>(L, a.k5[i], a.k3[i], a.co[i], a.ci[i], a.nrt_f[i], a.nkc_f[i], a.wf[i], kc, b % a.nrt_f[i], b / a.nrt_f[i]);
+    decode(b, a.nkc_f[i], a.nrt_f[i], kc, rt, q);
+    expert_frags_body<false>(L, a.k5[i], a.k3[i], a.co[i], a.ci[i], a.nrt_f[i], a.nkc_f[i], a.wf[i], kc, rt, q);
   } else {
     b -= a.nwf[i];
-    const int kc = b % a.nkc_d[i]; b /= a.nkc_d[i];
-    expert_frags_body<true>(L, a.k5[i], a.k3[i], a.co[i], a.ci[i], a.nrt_d[i], a.nkc_d[i], a.wd[i], kc, b % a.nrt_d[i], b / a.nrt_d[i]);
+    decode(b, a.nkc_d[i], a.nrt_d[i], kc, rt, q);
+    expert_frags_body<true>(L, a.k5[i], a.k3[i], a.co[i], a.ci[i], a.nrt_d[i], a.nkc_d[i], a.wd[i], kc, rt, q);
   }
 }
 }  // namespace
@@ -808,6 +866,8 @@ extern "C" int repmode_expert_frags_multi(int nblocks, const float* const* k5, c
   RM_REQUIRE(nblocks > 0 && nblocks <= XM_MAX, "expert_frags_multi: 1..%d blocks per call, got %d", XM_MAX, nblocks);
   XfMultiArgs a{};
   a.nblocks = nblocks;
+  static const int order = []() { const char* e = getenv("REPMODE_GATREP_ORDER"); return e ? atoi(e) : 1; }();
+  a.order = order;
   long total = 0;
   double bytes = 0;
   for (int i = 0; i < nblocks; ++i) {
