@@ -169,6 +169,11 @@ __device__ __forceinline__ void gatrep_fwd_body(
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int NIT = PAIRS / 4;
     float va[NIT], vb[NIT], vc[NIT];
+    // (round 3: buffer loads with 32-bit offsets -- a dead pair or a lane beyond the row reads through an out-of-range offset,
+    // i.e. zero; the predicated 64-bit-address form was ~60 instructions per iteration and made the launch issue-bound)
+    const __amdgpu_buffer_rsrc_t r5 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(k5), 0, co_n * ci_n * TAPS * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(k3), 0, co_n * ci_n * 27 * 4, 0x00020000);
+    constexpr int OOB = 0x7fffffff;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int pm = wave + 4 * it;
@@ -177,10 +182,10 @@ __device__ __forceinline__ void gatrep_fwd_body(
       const int row = rt * 32 + grp * 4 + rr, red = kc * KC + kk;
       const int co = WRITE_WD ? red : row, ci = WRITE_WD ? row : red;
       const bool live = co < co_n && ci < ci_n;
-      const size_t oi = live ? (size_t)co * ci_n + ci : 0;
-      va[it] = live ? k5[oi * TAPS + lane] : 0.f;
-      vb[it] = (live && lane + 64 < TAPS) ? k5[oi * TAPS + lane + 64] : 0.f;
-      vc[it] = (live && lane < 27) ? k3[oi * 27 + lane] : 0.f;
+      const int oi = co * ci_n + ci;
+      va[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r5, live ? (oi * TAPS + lane) * 4 : OOB, 0, 0));
+      vb[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r5, (live && lane + 64 < TAPS) ? (oi * TAPS + lane + 64) * 4 : OOB, 0, 0));
+      vc[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r3, (live && lane < 27) ? (oi * 27 + lane) * 4 : OOB, 0, 0));
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
