@@ -229,3 +229,23 @@ def test_wgrad_lds_layout_is_conflict_free_in_the_bank_model():
         assert ('conv5_wgrad_bf16_kernel<%d, %d, %d' % t) in src or ('launch_wgrad_bf16<%d, %d, %d>' % t) in src, t
         assert chk.wgrad_x(*t) == 0 and chk.wgrad_dy(*t) == 0, t
         assert chk.round1_x(*t) == 4 * 5 * t[0] * t[1] * t[2] // 32        # one extra cycle per lane group and read
+
+
+def test_task_plan_index_vectors_share_one_buffer():
+    """ops.TaskPlan packs slot_task | sample_slot | sample_task into ONE int32 buffer (one pinned host-to-device copy per step on a
+    GPU): each vector starts on a 16-int boundary of it and holds what the separate tensors held."""
+    import torch
+    from repmode_amd import ops
+    tasks = [7, 3, 7, 11, 0, 3, 3, 9, 7]
+    plan = ops.TaskPlan(torch.tensor(tasks), 12, 'cpu', training=True)
+    uniq = sorted(set(tasks))
+    assert plan.nslots == len(uniq) and plan.slot_task_host == uniq
+    assert plan.slot_task.tolist() == uniq
+    assert plan.sample_slot.tolist() == [uniq.index(t) for t in tasks]
+    assert plan.sample_task.tolist() == tasks
+    for v in (plan.slot_task, plan.sample_slot, plan.sample_task):
+        assert v.dtype == torch.int32 and v.is_contiguous() and v.storage_offset() % 16 == 0
+    assert plan.slot_task.untyped_storage().data_ptr() == plan.sample_task.untyped_storage().data_ptr()
+    # eval mode: one slot (the first sample's task), RepMode.py:209-210
+    ev = ops.TaskPlan(torch.tensor(tasks), 12, 'cpu', training=False)
+    assert ev.nslots == 1 and ev.slot_task.tolist() == [7] and ev.sample_slot.tolist() == [0] * len(tasks)
