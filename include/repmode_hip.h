@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define REPMODE_ABI_VERSION 8
+#define REPMODE_ABI_VERSION 9
 
 /* element types of activations / merged filters */
 #define REPMODE_F32 0  /* float in, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)          */
@@ -391,10 +391,17 @@ int repmode_mse_loss(const float* out, const float* target, const int32_t* sampl
 /* Developer / test switch of the convolution's pipelined form (csrc/conv5_igemm.hip, conv5_pipe_kernel; also REPMODE_CONV_PIPE):
  * bit 0 = on, bit 1 = one channel sub-tile per wave everywhere, bit 2 = also on grids smaller than the chip, bit 3 = the
  * wave-specialised kernel (MFMA waves + loader waves),  bit 4 = its items along z first, bit 5 = row-stationary tap
- * order on the 32-channel layers (another float summation order of the 125 taps); default 57.
- * Results do not depend on bits 0-4 (same products, same summation order); bit 5 reorders the float sums of a chunk's taps. */
+ * order on the 32-channel layers (another float summation order of the 125 taps), bit 6 = (round 4) the wave-specialised
+ * kernel's 16-voxel-brick form on volumes 16..31 voxels wide (level 2 of the network at the 32x64x64 patch); default 121.
+ * Results do not depend on bits 0-4 and 6 (same products, same summation order); bit 5 reorders the float sums of a chunk's taps. */
 int repmode_set_conv_pipe(int mode);
 int repmode_get_conv_pipe(void);
+/* 1 when a 5x5x5 convolution of this shape (RepMode.py:204-208 or its data gradient: pass the channel counts of the direction)
+ * should write its element-typed bf16 output: the whole channel reduction runs inside one workgroup on a grid that fills the
+ * chip (volumes >= 32 voxels wide; 16-wide ones with enough bricks for the 16-voxel form above).  0: ask for the float
+ * output -- the reduction is then split over workgroups with float atomics (the deep levels).  A pure function of the shape,
+ * the device's CU count and the switch above; the operator library asks it per layer and direction. */
+int repmode_conv5_elem_out(int n, int d, int h, int w, int cin, int cout, int dtype);
 /* The same kind of switch for the bf16 filter gradient's wave-specialised form (csrc/conv5_wgrad.hip; also REPMODE_WGRAD_WS):
  * 0 never, 1 where a workgroup has a long tile loop (default), 2 wherever the tile allows.  Results: the same sums; how the voxel
  * range is split over workgroups (float atomics) follows the form. */

@@ -75,6 +75,115 @@ def conv_per_sample(x, w):
     return y.view(n, co, *x.shape[2:])
 
 
+# --------------------------------------------------------------------------- #
+# bfloat16 emulation (round 4; VERDICT round 3 "missing 4"): the same restatement with values rounded to bfloat16 exactly
+# where the HIP path's throughput mode rounds them, computed on the CPU in float32 between those points -- an independent
+# bf16 implementation of RepMode.py:194-214 for the network-level gradient tests.  Rounding points:
+#   * a block's input (``to_cl(x, bf16)``) and the data gradient it returns (bf16 tensor);
+#   * the merged filter, once per task, after the float32 merge (fragment-major bf16 ``wf`` / ``wd``); in the per-expert
+#     formulation of the deep levels the 5^3 / 3^3 experts themselves, the three 1x1 experts and their inputs
+#     [x | box3(x) | box5(x)] (gemm3 rounds its operands while staging), and the gate-scaled output gradients;
+#   * the convolution's output where the kernels write the element type (``elem_out``), float where they keep float;
+#   * the gradient entering a merged block's backward (``grads[0].to(bf16)``);
+#   * BatchNorm + ReLU's output, and its data gradient where its input is a bf16 tensor; statistics / sums in float32;
+#   * the stride-2 stages: rounded filter, bf16 output, bf16 gradients.
+# Straight-through: the filter gradient is float32 from bf16 operands (conv5_wgrad), GatRep backward float32.
+# --------------------------------------------------------------------------- #
+def _q(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundSTE(torch.autograd.Function):
+    """forward: round to bf16 (kept in float32 storage); backward: the gradient passes unchanged."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _q(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _GradRound(torch.autograd.Function):
+    """forward: identity; backward: the gradient is rounded to bf16 (a bf16 gradient tensor in the HIP path)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _q(g)
+
+
+def round_ste(x):
+    return _RoundSTE.apply(x)
+
+
+def grad_round(x):
+    return _GradRound.apply(x) if x.requires_grad else x
+
+
+class Emulation:
+    """Policy of the bf16 emulation: which convolutions write a bf16 tensor (``elem_out(n, d, h, w, cin, cout) -> bool``: the
+    tests pass the kernel library's own answer, ``repmode_conv5_elem_out``; default: volumes >= 32 voxels wide, or >= 16
+    with at least 128 (brick, 32-channel) items -- the library's rule on a 256-CU part) and which blocks take the per-expert
+    formulation (training, more than two distinct tasks, volumes at most 8 voxels wide: repmode_ops.cpp ``use_unmerged``)."""
+
+    def __init__(self, elem_out=None, unmerged_max_w=8):
+        self._elem_out = elem_out
+        self.unmerged_max_w = unmerged_max_w
+
+    def elem_out(self, n, d, h, w, cin, cout):
+        if self._elem_out is not None:
+            return bool(self._elem_out(n, d, h, w, cin, cout))
+        if w >= 32:
+            return True
+        if w < 16 or d < 4 or h < 4 or cin % 8:
+            return False
+        return n * -(-d // 4) * -(-h // 4) * -(-w // 16) * -(-cout // 32) >= 128
+
+    def unmerged(self, training, tasks, w):
+        return bool(training) and len(set(int(t) for t in tasks)) > 2 and w <= self.unmerged_max_w
+
+
+def mode_conv_pre_bn_bf16(x, k5, k3, k1, a3, a5, gate_w, gate_b, tasks, emu, training=True, final=False, fold=None):
+    """``mode_conv_pre_bn`` with the HIP path's bf16 rounding points (see the section comment).  Returns (y, y_is_bf16).
+    ``fold = (scale, bias)``: an eval-mode BatchNorm folded into the block (scale into the gate probabilities before the merge
+    is rounded, bias + ReLU after the convolution; repmode_ops.cpp op_mode_block)."""
+    n, ci, d, h, w = x.shape
+    co = k5.shape[0]
+    x = grad_round(round_ste(x))
+    g = gate_probs(gate_w, gate_b, tasks, co)
+    if emu.unmerged(training, tasks, w):
+        # y[n] = sum_e g[n, e, :] * conv(x[n], K_e)  (ModeConvUnmerged): float output, float incoming gradient
+        # zero-padded box means (box.hip) as depthwise convolutions with a constant kernel (RepMode.py:161-163, 176-180)
+        box3 = F.conv3d(x, x.new_full((ci, 1, 3, 3, 3), 1.0 / 27.0), padding=1, groups=ci)
+        box5 = F.conv3d(x, x.new_full((ci, 1, 5, 5, 5), 1.0 / 125.0), padding=2, groups=ci)
+        ps = [F.conv3d(x, round_ste(k5), padding=2), F.conv3d(x, round_ste(k3), padding=1),
+              F.conv3d(x, round_ste(k1)), F.conv3d(round_ste(box3), round_ste(a3)), F.conv3d(round_ste(box5), round_ste(a5))]
+        y = sum(g[:, e, :, None, None, None] * grad_round(p) for e, p in enumerate(ps))
+        return y, False
+    if fold is not None:
+        g = g * fold[0].view(1, 1, -1)
+    wq = round_ste(merge_filters(expert_bank(k5, k3, k1, a3, a5), g))
+    y = conv_per_sample(x, wq) if training else F.conv3d(x, wq[0], padding=2)
+    y = grad_round(y)
+    if fold is not None:
+        y = torch.relu(y + fold[1].view(1, -1, 1, 1, 1))
+    bf16_out = (not final) and emu.elem_out(n, d, h, w, ci, co)
+    return (round_ste(y) if bf16_out else y), bf16_out
+
+
+def bn_relu_bf16(bn, y, y_is_bf16):
+    """BatchNorm3d + ReLU (RepMode.py:146-149, 212) as bnrelu.hip runs it in the throughput mode: float32 statistics of
+    the stored tensor, bf16 output; its data gradient has the input tensor's type."""
+    if y_is_bf16:
+        y = grad_round(y)
+    return round_ste(torch.relu(bn(y)))
+
+
 def mode_conv_pre_bn(x, k5, k3, k1, a3, a5, gate_w, gate_b, tasks, training=True):
     """The MoDE block up to (not including) ``subsequent_layer``  (RepMode.py:194-210)."""
     co = k5.shape[0]
@@ -135,10 +244,25 @@ class MoDEConv(torch.nn.Module):
         else:
             self.subsequent_layer = torch.nn.Identity()
         self.gate = torch.nn.Linear(num_tasks, num_experts * out_chan, bias=True)
+        self.emu = None          # an Emulation: the block runs with the HIP path's bf16 rounding points (Net(emulate=...))
 
     def forward(self, x, tasks):
         ps = (self.expert_conv5x5_conv, self.expert_conv3x3_conv, self.expert_conv1x1_conv,
               self.expert_avg3x3_conv, self.expert_avg5x5_conv, self.gate.weight, self.gate.bias)
+        if self.emu is not None:
+            final = self.conv_type != 'normal'
+            fold = None
+            if not final and not self.training and not torch.is_grad_enabled() and \
+                    self.emu.elem_out(x.shape[0], *x.shape[2:], x.shape[1], self.out_chan):
+                bn = self.subsequent_layer[0]                  # eval, no autograd: BatchNorm folded (op_mode_block)
+                scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+                fold = (scale, bn.bias - bn.running_mean * scale)
+            y, is_bf16 = mode_conv_pre_bn_bf16(x, *ps, tasks, self.emu, self.training, final, fold)
+            if final:
+                return y
+            if fold is not None:
+                return round_ste(y)
+            return bn_relu_bf16(self.subsequent_layer[0], y, is_bf16)
         if REFERENCE_STYLE and self.training:
             y = mode_conv_reference_style(x, *ps, tasks)
         else:
@@ -166,14 +290,31 @@ def _up(ci, co):                                              # RepMode.py:97-10
                                torch.nn.BatchNorm3d(co), torch.nn.ReLU(inplace=True))
 
 
+def _stage2_bf16(stage, x):
+    """A stride-2 stage (Conv3d / ConvTranspose3d k2 s2 + BatchNorm3d + ReLU) with the HIP path's rounding points
+    (k2s2.hip: bf16 operands, bf16 output; Down2 / Up2 backward: bf16 gradients)."""
+    conv, bn = stage[0], stage[1]
+    x = grad_round(x)
+    wq = round_ste(conv.weight)
+    if isinstance(conv, torch.nn.ConvTranspose3d):
+        y = F.conv_transpose3d(x, wq, stride=2)
+    else:
+        y = F.conv3d(x, wq, stride=2)
+    return bn_relu_bf16(bn, round_ste(grad_round(y)), True)
+
+
 class MoDEEncoderBlock(torch.nn.Module):                      # RepMode.py:74-89
     def __init__(self, num_experts, num_tasks, in_chan, out_chan):
         super().__init__()
         self.conv_more = MoDESubNet2Conv(num_experts, num_tasks, in_chan, out_chan)
         self.conv_down = _down(out_chan)
+        self.emu = None
 
     def forward(self, x, t):
         skip = self.conv_more(x, t)
+        if self.emu is not None:
+            skip = grad_round(skip)          # (two consumers: autograd adds their bf16 gradients in bf16)
+            return _stage2_bf16(self.conv_down, skip), skip
         return self.conv_down(skip), skip
 
 
@@ -182,15 +323,19 @@ class MoDEDecoderBlock(torch.nn.Module):                      # RepMode.py:92-10
         super().__init__()
         self.convt = _up(in_chan, out_chan)
         self.conv_less = MoDESubNet2Conv(num_experts, num_tasks, in_chan, out_chan)
+        self.emu = None
 
     def forward(self, x, skip, t):
-        return self.conv_less(torch.cat((skip, self.convt(x)), 1), t)
+        up = _stage2_bf16(self.convt, x) if self.emu is not None else self.convt(x)
+        return self.conv_less(torch.cat((skip, up), 1), t)
 
 
 class Net(torch.nn.Module):
     """RepMode.py:8-71.  ``forward(x[N,1,D,H,W], tasks int64[N])``."""
 
-    def __init__(self, opts, mult_chan=32, in_channels=1, out_channels=1):
+    def __init__(self, opts, mult_chan=32, in_channels=1, out_channels=1, emulate=None, elem_out=None):
+        """``emulate=torch.bfloat16``: every block runs with the HIP path's bf16 rounding points (``Emulation``; ``elem_out``:
+        the kernel library's per-convolution answer where the tests have it)."""
         super().__init__()
         self.opts = opts
         self.num_tasks = len(opts.adopted_datasets)
@@ -205,6 +350,14 @@ class Net(torch.nn.Module):
         self.decoder_block2 = MoDEDecoderBlock(e, t, m * 4, m * 2)
         self.decoder_block1 = MoDEDecoderBlock(e, t, m * 2, m)
         self.conv_out = MoDEConv(e, t, mult_chan, out_channels, conv_type='final')
+        if emulate is not None:
+            assert emulate == torch.bfloat16, 'the emulation restates the bf16 throughput mode'
+            self.set_emulation(Emulation(elem_out))
+
+    def set_emulation(self, emu):
+        for m in self.modules():
+            if isinstance(m, (MoDEConv, MoDEEncoderBlock, MoDEDecoderBlock)):
+                m.emu = emu
 
     def forward(self, x, t):
         t = t.long()

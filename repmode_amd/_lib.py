@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('REPMODE_LIB') or os.path.join(_HERE, 'librepmode_hip.
 
 F32, BF16 = 0, 1
 DEFER = 1        # REPMODE_DEFER: queue the job for the next conv5 launch on the stream (include/repmode_hip.h)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _c = ctypes
 _P = _c.c_void_p
@@ -29,6 +29,7 @@ _SIGNATURES = {
     'repmode_get_deterministic': [],
     'repmode_set_conv_pipe': [_I],
     'repmode_get_conv_pipe': [],
+    'repmode_conv5_elem_out': [_I] * 7,
     'repmode_set_wgrad_ws': [_I],
     'repmode_get_wgrad_ws': [],
     'repmode_padded_channels': [_I, _I, _I],

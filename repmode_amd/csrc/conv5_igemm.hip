@@ -93,6 +93,13 @@ __device__ unsigned long long g_conv_timing[64 * 64];
 #define RM_PRIO(p) do {} while (0)
 #endif
 
+// conv5_ws_kernel on 16-voxel bricks, one channel sub-tile per wave: filter rows / voxel-fragment taps in flight ahead
+#ifndef RM_WS16_RA
+#define RM_WS16_RA 6
+#endif
+#ifndef RM_WS16_TA
+#define RM_WS16_TA 3
+#endif
 #ifndef CONV_SPLIT_TARGET
 #define CONV_SPLIT_TARGET 512
 #endif
@@ -1268,11 +1275,19 @@ __global__ __launch_bounds__(256, 1) void conv5_pipe_kernel(ConvArgs a, int nite
 // RS (CW = 1 only): row-stationary tap order -- for a fixed (dz, dx) the voxel fragment of halo row y' = vs + dy serves every
 // (sub-tile vs, dy) pair that lands on it: 8 LDS reads + 5 filter fragments feed 20 MFMAs (0.4 reads per MFMA instead of 1).
 // The summation order of the 125 taps differs from the tap-major kernels (float rounding: not bit-identical to them).
-template <int CW, bool PLAIN, bool RS = false>
+// BXT = 16 (round 4): the same pipeline on a 4 x 4 x 16 brick for volumes 16 voxels wide (level 2 of the network at the
+// 32 x 64 x 64 patch) -- a wave's sub-tile is two x rows of 16 voxels (lane l: row l >> 4, x = l & 15), two sub-tiles per wave,
+// 41 KB per halo image.  At batch 8 level 2 has 2048 output tiles of 32 x 32 -- two per MFMA wave of the chip -- so an item is
+// (brick, 32 channels) with the whole channel reduction inside: 256 items, no split reduction, bf16 output (round 3 ran these
+// layers through the two-workgroup kernel with the reduction split four ways over float atomics: 2.56 x the algorithmic traffic).
+template <int CW, bool PLAIN, bool RS = false, int BXT = 32>
 __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems) {
-  static_assert(!RS || CW == 1, "row-stationary order: one channel sub-tile per wave");
-  using C = Cfg<4, 4, 32, 4, 1, 4, CW>;
-  constexpr int KV = 8, KC = 16, VW = 4;
+  static_assert(!RS || (CW == 1 && BXT == 32), "row-stationary order: one channel sub-tile per wave, 32-voxel rows");
+  static_assert(BXT == 32 || BXT == 16, "brick width");
+  constexpr int VW = BXT == 32 ? 4 : 2;            // voxel sub-tiles per MFMA wave
+  constexpr int SUBROWS = 32 / BXT;                // x rows per sub-tile
+  using C = Cfg<4, 4, BXT, 4, 1, VW, CW>;
+  constexpr int KV = 8, KC = 16;
   constexpr int BZ = C::BZ, BY = C::BY, BX = C::BX, BYH = C::BYH, BXH = C::BXH, VH = C::VH, PLS = C::PLS;
   constexpr int BUF = 2 * PLS;                  // 16-byte slots of one halo image
   constexpr int NIT = (2 * VH) / 256;           // halo items per loader thread
@@ -1409,7 +1424,8 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
   const uint32_t ts_bytes = (uint32_t)CoutP * (uint32_t)CinP * 2u;               // one tap of one slot
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, 0x7ffffffe, 0x00020000);
   const int lane_w = (l31 * KC + khalf * KV) * 2;                 // this lane's 16 bytes of a filter fragment
-  const u32x4* lb0 = lds + khalf * PLS + (wave * BYH) * BXH + l31;   // this lane's voxel of sub-tile vs: + vs * BXH
+  // this lane's voxel of sub-tile vs: + vs * SUBROWS * BXH
+  const u32x4* lb0 = lds + khalf * PLS + (wave * BYH + (BXT == 32 ? 0 : (l31 >> 4))) * BXH + (BXT == 32 ? l31 : (l31 & 15));
   struct Img { Brick b; int chunk; uint32_t wbase[CW]; };
   // the samples' slots: one vector load for the first 64 samples, then a lane read per image (a load per image sat at the
   // head of the wave's in-order memory queue, in front of the image's filter fragments)
@@ -1439,8 +1455,10 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
       for (int r = 0; r < 16; ++r) acc[cs][vs][r] = 0.f;
 
   // filter rows in flight ahead of the one being multiplied, voxel fragments (taps) in flight ahead
-  constexpr int RA = RS ? 3 : CW == 1 ? 4 : PLAIN ? 2 : 1;     // filter rows (RS: (dz, dx) groups) ahead; the eval epilogue needs the registers
-  constexpr int TA = CW == 1 ? 2 : 1;
+  // (16-voxel bricks: a tap is VW * CW = 2 or 4 MFMAs, half of the wide brick's -- the same distance in cycles is twice the rows)
+  constexpr int RA = BXT == 16 ? (CW == 1 ? RM_WS16_RA : 2)
+                               : RS ? 3 : CW == 1 ? 4 : PLAIN ? 2 : 1;     // filter rows (RS: (dz, dx) groups) ahead; the eval epilogue needs the registers
+  constexpr int TA = BXT == 16 ? (CW == 1 ? RM_WS16_TA : 2) : CW == 1 ? 2 : 1;
   Img cur_g = image_of(brick_of(item), 0);
   u32x4 aq[RA + 1][CW][5];
 #pragma unroll
@@ -1497,7 +1515,7 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
 #pragma unroll
     for (int k = 0; k < TA; ++k)
 #pragma unroll
-      for (int vs = 0; vs < VW; ++vs) bq[k][vs] = lb[vs * BXH + tap_off(k)];
+      for (int vs = 0; vs < VW; ++vs) bq[k][vs] = lb[vs * SUBROWS * BXH + tap_off(k)];
 #pragma unroll
     for (int r = 0; r < 25; ++r) {
 #pragma unroll
@@ -1507,7 +1525,7 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
         for (int vs = 0; vs < VW; ++vs) {
 #pragma unroll
           for (int cs = 0; cs < CW; ++cs) Elem<bf16_t>::mma(aq[0][cs][dx], bq[t % (TA + 1)][vs], acc[cs][vs]);
-          if (t + TA < 125) bq[(t + TA) % (TA + 1)][vs] = lb[vs * BXH + tap_off(t + TA)];
+          if (t + TA < 125) bq[(t + TA) % (TA + 1)][vs] = lb[vs * SUBROWS * BXH + tap_off(t + TA)];
           __builtin_amdgcn_sched_barrier(0);
         }
         // this tap's filter fragment of the row RA ahead (the last RA rows: the next image's first rows; no next image:
@@ -1541,7 +1559,8 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
       const int z0 = cur_g.b.z0, y0 = cur_g.b.y0, x0 = cur_g.b.x0, n_out = cur_g.b.n, cot = cur_g.b.cot;
 #pragma unroll
       for (int vs = 0; vs < VW; ++vs) {
-        const int gz = z0 + wave, gy = y0 + vs, gx = x0 + l31;       // voxel m = (wave 4 + vs) 32 + l31 of the brick
+        // voxel m = (wave VW + vs) 32 + l31 of the brick
+        const int gz = z0 + wave, gy = y0 + vs * SUBROWS + (BXT == 32 ? 0 : (l31 >> 4)), gx = x0 + (BXT == 32 ? l31 : (l31 & 15));
         const bool inside = gz < D && gy < H && gx < W;
         const size_t vox = ((size_t)(n_out * D + gz) * H + gy) * W + gx;
 #pragma unroll
@@ -1648,36 +1667,57 @@ __global__ __launch_bounds__(512, 2) void conv5_ws_kernel(ConvArgs a, int nitems
 // (one sub-tile per wave: 106.2, 206.8); conv5 launches of the train step 3945 -> 3702 us.  The step itself moves less
 // (11.82 -> 11.75 ms): with the convolutions drawing more power every other kernel of the step runs 2-6 % slower
 // (profiles/r03_pipe_ab.txt) -- the chip is power-limited over the step, not per kernel.
-static int g_pipe = []() { const char* e = getenv("REPMODE_CONV_PIPE"); return e ? atoi(e) : 57; }();
+static int g_pipe = []() { const char* e = getenv("REPMODE_CONV_PIPE"); return e ? atoi(e) : 121; }();
 
-int launch_pipe(ConvArgs a, hipStream_t stream) {
-  using C1 = Cfg<4, 4, 32, 4, 1, 4, 1>;
-  if (!g_pipe || a.W < 32 || a.D < 4 || a.H < 4 || a.dual || a.dxc || a.tap_lo != 0 || a.tap_hi != 4 || a.stats || a.out_f32 ||
-      (a.Cin & 7) != 0)
-    return -1;
-  // one descriptor spans each tensor: 32-bit byte offsets
-  const size_t vox = (size_t)a.N * a.D * a.H * a.W;
-  if (vox * (size_t)(a.Cin1 > 0 ? (a.Cin1 > a.Cin - a.Cin1 ? a.Cin1 : a.Cin - a.Cin1) : a.Cin) * 2 >= ((size_t)1 << 31)) return -1;
-  const int cw = (g_pipe & 2) ? 1 : (a.CoutP >= 64 ? 2 : 1);
-  a.nbz = ceil_div(a.D, C1::BZ);
-  a.nby = ceil_div(a.H, C1::BY);
-  a.nbx = ceil_div(a.W, C1::BX);
-  a.ncot = ceil_div(a.CoutP, 32 * cw);
-  a.ksplit = 1;
-  a.zfast = (g_pipe & 16) ? 1 : 0;
-  const long nitems = (long)a.N * a.nbz * a.nby * a.nbx * a.ncot;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    RM_HIP(hipGetDevice(&dev));
-    RM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (cus <= 0) cus = 256;
+int device_cus() {
+  // per device (advisor round 3: a function-static count belonged to whichever device called first)
+  static std::atomic<int> cus_of[32];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int c = cus_of[dev & 31].load(std::memory_order_relaxed);
+  if (c <= 0) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    cus_of[dev & 31].store(c, std::memory_order_relaxed);
   }
-  // filter offsets are 32-bit too (the number of slots is sample data: at most one per sample)
-  if ((size_t)a.N * REPMODE_TAPS * a.CoutP * a.CinP * 2 >= ((size_t)1 << 31)) return -1;
-  if (nitems < ((g_pipe & 4) ? 1 : cus) || nitems >= (1L << 30)) return -1;   // under-filled launches keep the two-workgroup form (bit 2: tests)
+  return c;
+}
+
+// The shape side of the pipelined form's eligibility (what does not depend on the call's epilogue / tap flags): the brick
+// width (32, or 16 on volumes 16..31 voxels wide: bit 6), channel sub-tiles per wave, item count.  false: not its kind.
+struct PipePlan { int bx, cw, nbz, nby, nbx, ncot; long nitems; };
+bool pipe_plan(int N, int D, int H, int W, int Cin, int CoutP, PipePlan* p) {
+  if (!g_pipe || W < 16 || D < 4 || H < 4 || (Cin & 7) != 0) return false;
+  const bool x16 = W < 32;
+  if (x16 && (g_pipe & (8 | 64)) != (8 | 64)) return false;            // (16-voxel bricks: the wave-specialised kernel only)
+  const int cus = device_cus();
+  p->bx = x16 ? 16 : 32;
+  p->nbz = ceil_div(D, 4);
+  p->nby = ceil_div(H, 4);
+  p->nbx = ceil_div(W, p->bx);
+  const long bricks = (long)N * p->nbz * p->nby * p->nbx;
+  int cw = (g_pipe & 2) ? 1 : (CoutP >= 64 ? 2 : 1);
+  if (x16 && cw == 2) {
+    // 16-voxel bricks: an item of two channel sub-tiles is twice as long; take it only where the shorter grid does not cost
+    // rounds (batch 8 of level 2: 128 two-tile items would leave half of the chip idle, 256 one-tile items fill it).
+    // Priced in one-tile item units: ceil(items / CUs) per workgroup, a two-tile item at 1.7 (it reads LDS half as often).
+    const long i1 = bricks * ceil_div(CoutP, 32), i2 = bricks * ceil_div(CoutP, 64);
+    const double t1 = (double)((i1 + cus - 1) / cus), t2 = 1.7 * (double)((i2 + cus - 1) / cus);
+    if (t1 <= t2) cw = 1;
+  }
+  p->cw = cw;
+  p->ncot = ceil_div(CoutP, 32 * cw);
+  p->nitems = bricks * p->ncot;
+  // under-filled launches keep the two-workgroup form (bit 2: the parity tests' small volumes); a 16-voxel launch from half a chip
+  const long need = (g_pipe & 4) ? 1 : (x16 ? cus / 2 : cus);
+  return p->nitems >= need && p->nitems < (1L << 30);
+}
+
+template <int BXT>
+int launch_pipe_bx(ConvArgs a, const PipePlan& pl, hipStream_t stream) {
+  using C1 = Cfg<4, 4, BXT, 4, 1, BXT == 32 ? 4 : 2, 1>;
+  const int cus = device_cus();
   repmode_tail_take(stream, &a.tail);
-  const int nwg = (int)(nitems < cus ? nitems : cus);
+  const int nwg = (int)(pl.nitems < cus ? pl.nitems : cus);
   const long grid = nwg + a.tail.nblocks;
   constexpr int LDS_BYTES = 2 * C1::LDS_BYTES;
   static_assert(LDS_BYTES >= TAIL_LDS_BYTES && LDS_BYTES <= 160 * 1024, "two halo images per workgroup");
@@ -1685,31 +1725,54 @@ int launch_pipe(ConvArgs a, hipStream_t stream) {
   int dev = 0;
   RM_HIP(hipGetDevice(&dev));
   if (!((attr_set.load(std::memory_order_acquire) >> (dev & 31)) & 1u)) {
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_pipe_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_pipe_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    if constexpr (BXT == 32) {
+      RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_pipe_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+      RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_pipe_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+      RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+      RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    }
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, true, false, BXT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<1, false, false, BXT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<2, true, false, BXT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv5_ws_kernel<2, false, false, BXT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
   }
+  const int cw = pl.cw;
+  const int nitems = (int)pl.nitems;
   const double alg = 2.0 * a.N * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS;
   repmode_prof_begin(REPMODE_PROF_CONV5_WS, alg, stream);
-  if (g_pipe & 8) {       // the wave-specialised form
+  const dim3 g((unsigned)grid);
+  if ((g_pipe & 8) || BXT == 16) {       // the wave-specialised form
     const bool plain = a.wide && !a.bias && !a.relu;
-    if (cw == 2 && plain) hipLaunchKernelGGL((conv5_ws_kernel<2, true>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
-    else if (cw == 2) hipLaunchKernelGGL((conv5_ws_kernel<2, false>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
-    else if (plain && (g_pipe & 32)) hipLaunchKernelGGL((conv5_ws_kernel<1, true, true>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
-    else if (plain) hipLaunchKernelGGL((conv5_ws_kernel<1, true>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
-    else if (g_pipe & 32) hipLaunchKernelGGL((conv5_ws_kernel<1, false, true>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
-    else hipLaunchKernelGGL((conv5_ws_kernel<1, false>), dim3((unsigned)grid), dim3(512), LDS_BYTES, stream, a, (int)nitems);
-  } else if (cw == 2) hipLaunchKernelGGL(conv5_pipe_kernel<2>, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, a, (int)nitems);
-  else hipLaunchKernelGGL(conv5_pipe_kernel<1>, dim3((unsigned)grid), dim3(256), LDS_BYTES, stream, a, (int)nitems);
+    const bool rs = BXT == 32 && (g_pipe & 32);
+    if (cw == 2 && plain) hipLaunchKernelGGL((conv5_ws_kernel<2, true, false, BXT>), g, dim3(512), LDS_BYTES, stream, a, nitems);
+    else if (cw == 2) hipLaunchKernelGGL((conv5_ws_kernel<2, false, false, BXT>), g, dim3(512), LDS_BYTES, stream, a, nitems);
+    else if (plain && rs) { if constexpr (BXT == 32) hipLaunchKernelGGL((conv5_ws_kernel<1, true, true>), g, dim3(512), LDS_BYTES, stream, a, nitems); }
+    else if (plain) hipLaunchKernelGGL((conv5_ws_kernel<1, true, false, BXT>), g, dim3(512), LDS_BYTES, stream, a, nitems);
+    else if (rs) { if constexpr (BXT == 32) hipLaunchKernelGGL((conv5_ws_kernel<1, false, true>), g, dim3(512), LDS_BYTES, stream, a, nitems); }
+    else hipLaunchKernelGGL((conv5_ws_kernel<1, false, false, BXT>), g, dim3(512), LDS_BYTES, stream, a, nitems);
+  } else if constexpr (BXT == 32) {
+    if (cw == 2) hipLaunchKernelGGL(conv5_pipe_kernel<2>, g, dim3(256), LDS_BYTES, stream, a, nitems);
+    else hipLaunchKernelGGL(conv5_pipe_kernel<1>, g, dim3(256), LDS_BYTES, stream, a, nitems);
+  }
   repmode_prof_end(stream);
   RM_LAUNCH_CHECK("conv5_pipe");
   return REPMODE_OK;
+}
+
+int launch_pipe(ConvArgs a, hipStream_t stream) {
+  if (a.dual || a.dxc || a.tap_lo != 0 || a.tap_hi != 4 || a.stats || a.out_f32) return -1;
+  PipePlan pl;
+  if (!pipe_plan(a.N, a.D, a.H, a.W, a.Cin, a.CoutP, &pl)) return -1;
+  // one descriptor spans each tensor: 32-bit byte offsets
+  const size_t vox = (size_t)a.N * a.D * a.H * a.W;
+  if (vox * (size_t)(a.Cin1 > 0 ? (a.Cin1 > a.Cin - a.Cin1 ? a.Cin1 : a.Cin - a.Cin1) : a.Cin) * 2 >= ((size_t)1 << 31)) return -1;
+  // filter offsets are 32-bit too (the number of slots is sample data: at most one per sample)
+  if ((size_t)a.N * REPMODE_TAPS * a.CoutP * a.CinP * 2 >= ((size_t)1 << 31)) return -1;
+  a.nbz = pl.nbz; a.nby = pl.nby; a.nbx = pl.nbx; a.ncot = pl.ncot;
+  a.ksplit = 1;
+  a.zfast = (g_pipe & 16) ? 1 : 0;
+  return pl.bx == 32 ? launch_pipe_bx<32>(a, pl, stream) : launch_pipe_bx<16>(a, pl, stream);
 }
 
 template <typename T, typename C, bool SWAP, bool PAIR, bool DXC = false, bool ROWSTAT = false, bool MERGE = false>
@@ -1824,6 +1887,17 @@ int dispatch(ConvArgs a, hipStream_t stream) {
 
 extern "C" int repmode_set_conv_pipe(int mode) { g_pipe = mode; return REPMODE_OK; }
 extern "C" int repmode_get_conv_pipe(void) { return g_pipe; }
+
+// 1: a 5x5x5 convolution of this shape writes its element-typed (bf16) output with the whole channel reduction inside one
+// workgroup at a grid that fills the chip -- volumes 32 or more voxels wide, and (round 4) 16-wide volumes with enough bricks
+// for the wave-specialised kernel's 16-voxel form; 0: the caller should ask for the float output, whose reduction is split over
+// workgroups (float atomics) until the grid fills the chip.  The operator library asks per layer and direction.
+extern "C" int repmode_conv5_elem_out(int n, int d, int h, int wdim, int cin, int cout, int dtype) {
+  if (dtype != REPMODE_BF16 || n <= 0 || d <= 0 || h <= 0 || wdim <= 0 || cin <= 0 || cout <= 0) return 0;
+  if (wdim >= 32) return 1;
+  PipePlan pl;
+  return pipe_plan(n, d, h, wdim, cin, round_up(cout, 32), &pl) ? 1 : 0;
+}
 
 extern "C" int repmode_padded_channels(int channels, int dtype, int is_reduction_dim) {
   if (channels <= 0) return 0;

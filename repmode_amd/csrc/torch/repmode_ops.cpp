@@ -399,6 +399,12 @@ struct Epi {
 // BatchNorm forward that follows it
 thread_local int tl_stats_half = -1;
 
+// Does a convolution of this shape write its element-typed output (whole reduction in one workgroup), or the float one whose
+// reduction is split over workgroups?  The kernel library decides (repmode_conv5_elem_out): per layer and direction.
+inline bool elem_out(int64_t n, int64_t d, int64_t h, int64_t w, int64_t cin, int64_t cout, at::ScalarType dt) {
+  return dt == at::kBFloat16 && repmode_conv5_elem_out((int)n, (int)d, (int)h, (int)w, (int)cin, (int)cout, REPMODE_BF16) != 0;
+}
+
 // y[n] = x[n] (*) w[sample_slot[n]], 5^3 'same' cross-correlation, NDHWC -- RepMode.py:204-210
 // dual (per-expert formulation): 0 = off; else the 5x5x5 and the 3x3x3 expert's convolutions in ONE launch (see
 // repmode_conv5_ex): DUAL_OUT2 = x holds n samples, the output 2 n (the two expert outputs); DUAL_IN2 = x holds 2 n samples
@@ -739,7 +745,7 @@ struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
     Tensor dx;
     if (need_dx) {
       // deep levels (small volumes) split the channel reduction over workgroups -> float output
-      const bool f32 = x_cl.size(3) < 32;
+      const bool f32 = !elem_out(x_cl.size(0), x_cl.size(1), x_cl.size(2), x_cl.size(3), co, ci, dt);
       if (dt == at::kBFloat16 && co == 1 && ci != 1) dx = thin_conv_in1(dy, wd, plan.sample_slot, ci, f32);   // last layer: dy has one channel
       else if (dt == at::kBFloat16 && ci == 1 && co != 1) dx = thin_conv_out1(dy, wd, plan.sample_slot);
       else dx = conv5(dy, wd, plan.sample_slot, ci, f32);
@@ -830,7 +836,7 @@ struct ModeConvPair : public torch::autograd::Function<ModeConvPair> {
     fork.to_main();
     Tensor dxa, dxb;
     if (wd.defined()) {
-      const bool f32 = w_ < 32 || dt == at::kFloat;   // deep levels: split reduction -> float output
+      const bool f32 = dt == at::kFloat || !elem_out(n, d, h, w_, co, ci, dt);   // deep levels: split reduction -> float output
       int flags = 0;
       if (f32 && dt == at::kBFloat16) {
         auto ta = g_pool.take({n, d, h, w_, ca}, xa);
@@ -1329,6 +1335,12 @@ Tensor op_mode_block(const Tensor& x, const OptTensor& x2, const Tensor& k5, con
   require_hip(x, "input");
   TORCH_CHECK(x.dim() == 5, "MoDE block: input must be [N, C, D, H, W], got ", x.sizes());
   const at::ScalarType dt = code_dtype(dtype);
+  {
+    // float output also where the convolution splits its channel reduction over workgroups (small volumes: the deep levels)
+    DeviceGuard guard(x.device());
+    const int64_t cin = x.size(1) + (x2.has_value() ? x2->size(1) : 0);
+    if (dt == at::kBFloat16 && !elem_out(x.size(0), x.size(2), x.size(3), x.size(4), cin, k5.size(0), dt)) out_f32 = true;
+  }
   Plan plan = make_plan(slot_task, sample_slot, sample_task, nslots, num_tasks, training, task0);
   OptTensor x2_cl;
   if (x2.has_value()) x2_cl = to_cl(*x2, dt);

@@ -87,9 +87,9 @@ class MoDEConv(torch.nn.Module):
         'normal' block -- BatchNorm3d + ReLU (RepMode.py:194-214)."""
         plan = t if isinstance(t, ops.TaskPlan) else ops.TaskPlan(t, self.num_tasks, x.device, self.training)
         dtype = _resolve_dtype(x, self.compute_dtype)
-        # float output where a later stage reduces it in f32 anyway: the final layer, and the deep
-        # levels whose reduction is split over workgroups (f32 atomics)
-        out_f32 = self.conv_type == 'final' or x.shape[-1] < 32
+        # float output where a later stage reduces it in f32 anyway: the final layer (the operator adds the deep levels,
+        # whose reduction is split over workgroups with f32 atomics: repmode_conv5_elem_out)
+        out_f32 = self.conv_type == 'final'
         if self.conv_type == 'normal':
             bn = ops.bn_args(self.subsequent_layer[0], x.device, count=not getattr(t, 'bn_counted', False))
         else:

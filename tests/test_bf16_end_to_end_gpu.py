@@ -72,6 +72,73 @@ def test_bf16_train_iter_losses_and_gradients():
     assert cos > 0.7 and abs(ratio - 1.0) < 0.05, (cos, ratio)        # the whole 123.9 M-element gradient (measured 0.764, 1.006)
 
 
+def _lib_elem_out():
+    """The kernel library's own answer to 'does this convolution write a bf16 tensor' -- the emulating oracle's policy."""
+    from repmode_amd import _lib
+    lib = _lib.load()
+    return lambda n, d, h, w, cin, cout: lib.repmode_conv5_elem_out(n, d, h, w, cin, cout, _lib.BF16) != 0
+
+
+# per-tensor bound of the HIP bf16 gradient against the bf16-EMULATING oracle (oracle.Net(emulate=torch.bfloat16): float32
+# CPU arithmetic between the rounding points the HIP path has) in relative 2-norm.  Measured on three boxes (round 4,
+# gpurun_out/test_measurements.jsonl 'bf16_emulated_grads'): see EMU_BOUND's comment below.
+EMU_BOUND = 5e-2
+EMU_CASES = {
+    # G4b's batch (two distinct tasks: every block merged) and a four-sample batch with three distinct tasks (levels 3-4 take
+    # the per-expert formulation: bf16 experts, gemm3's rounded operands, gate-scaled output gradients)
+    'merged': dict(tasks=[3, 7, 3], shape=(16, 64, 64)),
+    'per_expert': dict(tasks=[1, 5, 7, 1], shape=(16, 64, 64)),
+}
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize('case', sorted(EMU_CASES))
+def test_bf16_gradients_against_the_bf16_emulating_oracle(case):
+    """Network-level bf16 parity PINNED (missing 4 / weak 1): one bf16 forward + backward of the mult_chan-32
+    network through the HIP path against ``orc.Net(emulate=torch.bfloat16)`` -- the CPU oracle rounding to bf16 exactly where
+    the kernels do (block inputs, merged filters / per-expert operands, element-typed conv outputs, BatchNorm outputs, bf16
+    gradient tensors) and float32 in between -- from the same seeded state: the loss, the output, and EVERY parameter gradient
+    in relative 2-norm.  Two implementations that round at the same places flip the same ReLU masks, so the comparison is tight
+    where the float32 oracle only allowed a cosine (kept below as the second, loose line).  A systematic 10 % error in one
+    deep layer's gradient (what a wrong constant in gatrep_bwd would produce) is 2 x the bound: asserted on the checker."""
+    from repmode_amd.nn_modules.RepMode import Net
+    cfg = EMU_CASES[case]
+    tasks = torch.tensor(cfg['tasks'])
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(len(cfg['tasks']), 1, *cfg['shape'], generator=gen)
+    tgt = torch.randn(len(cfg['tasks']), 1, *cfg['shape'], generator=gen)
+    torch.manual_seed(0)
+    net = Net(Opts(), mult_chan=32, dtype=torch.bfloat16)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    net.to(DEV).train()
+    y = net(x.to(DEV), tasks)
+    loss = torch.nn.functional.mse_loss(y.float(), tgt.to(DEV))
+    loss.backward()
+    got = {k: p.grad.detach().float().cpu() for k, p in net.named_parameters()}
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    emu = orc.Net(Opts(), mult_chan=32, emulate=torch.bfloat16, elem_out=_lib_elem_out())
+    emu.load_state_dict(state)
+    emu.train()
+    ye = emu(x, tasks)
+    loss_e = torch.nn.functional.mse_loss(ye, tgt)
+    loss_e.backward()
+    want = {k: p.grad.detach() for k, p in emu.named_parameters()}
+    errs = {k: _rel2(got[k], want[k]) for k in got}
+    worst = max(errs, key=errs.get)
+    out_err = _rel2(y.float(), ye)
+    whole = _rel2(torch.cat([got[k].reshape(-1) for k in got]), torch.cat([want[k].reshape(-1) for k in got]))
+    record('bf16_emulated_grads', case=case, loss=float(loss), loss_emu=float(loss_e), out=out_err, whole=whole, worst=errs[worst],
+           worst_name=worst, by_tensor={k: round(v, 5) for k, v in errs.items()})
+    assert abs(float(loss) - float(loss_e)) < 2e-3 * abs(float(loss_e)), (float(loss), float(loss_e))
+    assert out_err < 1e-2, out_err
+    assert errs[worst] < EMU_BOUND, (worst, errs[worst], whole)
+    assert whole < EMU_BOUND / 2, whole
+    # the checker would see a systematic error: 10 % on one deep layer's expert gradient
+    k = 'bottle_block.conv1.expert_conv5x5_conv'
+    assert _rel2(1.1 * got[k], want[k]) > EMU_BOUND
+    assert _rel2(got[k] + 0.1 * got[k].abs(), want[k]) > EMU_BOUND
+
+
 def test_net_golden_bf16_gradients():
     """G3 (reference Net, mult_chan 2) in bf16: output in 2-norm and the whole parameter gradient by direction and norm against
     the reference's float32 ones.  2 ... 32 channels a layer and 4 voxels on the deepest level: one bf16 rounding moves a whole

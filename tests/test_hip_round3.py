@@ -222,6 +222,7 @@ def test_conv5_pipelined_form_vs_oracle_and_the_two_workgroup_form(case, mode):
     wf = _layout_wf(wt, _lib.padded_channels(cout, code, False), _lib.padded_channels(cin, code, True), _kc(torch.bfloat16)).to(DEV, torch.bfloat16)
     x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
     outs = []
+    default = ops.get_conv_pipe()
     try:
         for m in (mode, 0):
             ops.set_conv_pipe(m)
@@ -234,12 +235,64 @@ def test_conv5_pipelined_form_vs_oracle_and_the_two_workgroup_form(case, mode):
                 y = ops.conv5(x_cl, wf, slots.to(DEV), cout)
             outs.append(y.float().cpu())
     finally:
-        ops.set_conv_pipe(57)
+        ops.set_conv_pipe(default)
     assert rel_err(outs[0].permute(0, 4, 1, 2, 3), y_ref) < 6e-3          # (bf16 output)
     if mode & 32:       # row-stationary tap order (32-channel layers): another summation order of the 125 taps
         assert rel_err(outs[0], outs[1]) < 8e-3
     else:
         assert torch.equal(outs[0], outs[1])
+
+
+PIPE16_CASES = [
+    # (N, D, H, W, Cin, Cout, Cin1, Cout1): volumes 16..31 voxels wide (round 4: the 4 x 4 x 16 brick of conv5_ws_kernel -- level 2
+    # of the network at the 32x64x64 patch); ragged bricks in every direction, one and several channel chunks, a skip
+    # connection's two-tensor input and its data gradient's two-tensor output, more items than workgroups
+    (2, 8, 16, 16, 64, 128, 0, 0),      # the network's level-2 shape (enc3.conv1)
+    (3, 5, 9, 20, 48, 64, 0, 0),
+    (2, 6, 10, 24, 32, 32, 0, 0),
+    (2, 4, 12, 17, 64, 32, 32, 0),
+    (2, 7, 5, 16, 32, 64, 0, 32),
+    (2, 4, 8, 31, 24, 48, 0, 0),        # a half-empty last channel chunk; the second channel sub-tile half used
+    (40, 4, 8, 16, 16, 64, 0, 0),       # 320 (one sub-tile) / 160 items: persistent item ranges
+]
+
+
+@pytest.mark.parametrize('mode', [77, 79, 93])
+@pytest.mark.parametrize('case', PIPE16_CASES)
+def test_conv5_wave_specialised_16_voxel_bricks_vs_oracle_and_the_two_workgroup_form(case, mode):
+    """conv5_ws_kernel's 16-voxel-brick form (bit 6 of the switch; 77: by price one or two channel sub-tiles per wave, 79: one,
+    93: items along z first) against the oracle and BIT-identical to the two-workgroup kernel's unsplit bf16-output launch
+    (same products in the same order: chunk by chunk, tap by tap)."""
+    ops = _ops()
+    from repmode_amd import _lib
+    n, d, h, w, cin, cout, cin1, cout1 = case
+    gen = torch.Generator().manual_seed(sum(case) + mode)
+    nslots = 3
+    slots = torch.tensor([i % nslots for i in range(n)], dtype=torch.int32)
+    x = torch.randn(n, cin, d, h, w, generator=gen).bfloat16().float()
+    wt = (torch.randn(nslots, cout, cin, 5, 5, 5, generator=gen) / np.sqrt(cin * 125)).bfloat16().float()
+    y_ref = orc.conv_per_sample(x, wt[slots.long()])
+    code = ops.dtype_code(torch.bfloat16)
+    wf = _layout_wf(wt, _lib.padded_channels(cout, code, False), _lib.padded_channels(cin, code, True), _kc(torch.bfloat16)).to(DEV, torch.bfloat16)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    outs = []
+    default = ops.get_conv_pipe()
+    try:
+        for m in (mode, 0):
+            ops.set_conv_pipe(m)
+            assert _lib.load().repmode_conv5_elem_out(n, d, h, w, cin, cout, code) == (1 if m else 0)
+            if cin1 or cout1:
+                xa = x_cl[..., :cin1].contiguous() if cin1 else x_cl
+                xb = x_cl[..., cin1:].contiguous() if cin1 else None
+                ya, yb = ops.conv5_pair(xa, xb, wf, slots.to(DEV), cout, cout1)
+                y = torch.cat([ya, yb], dim=-1) if yb is not None else ya
+            else:
+                y = ops.conv5(x_cl, wf, slots.to(DEV), cout)
+            outs.append(y.float().cpu())
+    finally:
+        ops.set_conv_pipe(default)
+    assert rel_err(outs[0].permute(0, 4, 1, 2, 3), y_ref) < 6e-3          # (bf16 output)
+    assert torch.equal(outs[0], outs[1])
 
 
 WGRAD_WS_CASES = [
