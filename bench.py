@@ -19,9 +19,10 @@ Workloads (BASELINE.json ``configs``):
   ``--batch B`` overrides the per-GPU batch for either.
 
 Also reported in the same line:
-  roofline      the MoDE convolution of conv5_igemm.hip (forward + data-gradient launches; the dominant kernel): since round 3
-                two symbols -- conv5_ws_kernel (levels 0-1, 14 launches, 3/4 of the FLOPs) and conv5_igemm_kernel (levels 2-4),
-                together and each under ``by_kernel``: algorithmic
+  roofline      the MoDE convolution of conv5_igemm.hip (forward + data-gradient launches; the dominant kernel): two symbols --
+                conv5_ws_kernel (levels 0-2 since round 4: 22 launches, 93 % of the conv FLOPs) and conv5_igemm_kernel (the
+                per-expert levels' forward pair), together and each under ``by_kernel``; beside them (round 4) the filter
+                gradient conv5_wgrad_bf16_kernel, the step's largest kernel family, with its own algorithmic bytes: algorithmic
                 FLOPs (the layer's merged 125-tap convolution, 2 * voxels * Cin * Cout * 125, once per layer and
                 direction) / HIP-event duration on the launch stream, against the dense bf16 MFMA peak;
                 ``all_conv_kernels``: the same + conv5_deep (levels 3-4) + the one-channel layers' kernels.  ``traffic``: HBM bytes per
@@ -58,7 +59,7 @@ PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # dense MFMA peaks, MI355X_MIC
 FWD_FLOP_PER_VOXEL = 2083520.0                    # whole forward; MoDE convs alone 2,072,000
 FWD_CONV_FLOP_PER_VOXEL = 2072000.0
 CONV_KINDS = ('conv5_ws', 'conv5_igemm', 'conv5_deep', 'conv5_thin')     # the forward / data-gradient convolution kernels of the MoDE blocks
-MAIN_KINDS = ('conv5_ws', 'conv5_igemm')      # conv5_igemm.hip: the wide levels' wave-specialised kernel + the general one (levels 2-4)
+MAIN_KINDS = ('conv5_ws', 'conv5_igemm')      # conv5_igemm.hip: the wave-specialised kernel (levels 0-2) + the general one (the per-expert levels' pair)
 
 
 class Opts:
@@ -93,30 +94,51 @@ def pmc_traffic(kind, batch, dtype):
 
 
 def conv5_igemm_algorithmic_bytes(batch, nslots):
-    """Algorithmic HBM bytes per train step of the launches that go through conv5_igemm_kernel at the default policy, and their
-    count: every tensor once -- bf16 input, output (bf16 on levels 0-1, float where the reduction is split: levels
-    2-4) and the filter (one per slot: 125 taps x Cin x Cout bf16; the per-expert pair of levels 3-4: 125 + 27 taps, shared by
-    the batch).  Levels 0-2: forward + data gradient of every merged block but the two one-channel layers (own kernels);
-    levels 3-4: the forward pair (their data gradient runs in conv5_deep)."""
-    v = [PATCH[0] * PATCH[1] * PATCH[2] // 8 ** l for l in range(5)]
+    """Algorithmic HBM bytes per train step of the forward / data-gradient launches of conv5_igemm.hip at the default policy,
+    and their count: every tensor once -- bf16 input, output (bf16 where the kernel library writes the element
+    type -- `repmode_conv5_elem_out`: levels 0-1, and since round 4 level 2 at this batch --, float where the reduction is split
+    over workgroups) and the filter (one per slot: 125 taps x Cin x Cout bf16; the per-expert pair of levels 3-4: 125 + 27
+    taps, shared by the batch).  Merged levels: forward + data gradient of every merged block but the two one-channel layers
+    (own kernels); levels 3-4: the forward pair (their data gradient runs in conv5_deep)."""
+    from repmode_amd import _lib
+    lib = _lib.load()
+    dims = [(PATCH[0] >> l, PATCH[1] >> l, PATCH[2] >> l) for l in range(5)]
+    v = [d * h * w for d, h, w in dims]
     merged = [(0, 32, 32), (0, 64, 32), (0, 32, 32), (1, 32, 64), (1, 64, 64), (1, 128, 64), (1, 64, 64),
               (2, 64, 128), (2, 128, 128), (2, 256, 128), (2, 128, 128)]
     pair = [(3, 128, 256), (3, 256, 256), (3, 512, 256), (3, 256, 256), (4, 256, 512), (4, 512, 512)]
     total, n = 0.0, 0
-    wide = [0.0, 0]                                              # levels 0-1: the launches of conv5_ws_kernel
+    wide = [0.0, 0]                                              # the launches of conv5_ws_kernel (element-typed output)
     for l, ci, co in merged:
-        osz = 2 if l < 2 else 4
         for a, b in ((ci, co), (co, ci)):                       # forward, data gradient
-            t = batch * v[l] * (a * 2 + b * osz) + nslots * 125 * ci * co * 2
+            elem = lib.repmode_conv5_elem_out(batch, *dims[l], a, b, _lib.BF16) != 0
+            t = batch * v[l] * (a * 2 + b * (2 if elem else 4)) + nslots * 125 * ci * co * 2
             total += t
             n += 1
-            if l < 2:
+            if elem:
                 wide[0] += t; wide[1] += 1
     for l, ci, co in pair:
         total += batch * v[l] * (ci * 2 + 2 * co * 4) + (125 + 27) * ci * co * 2
         n += 1
     conv5_igemm_algorithmic_bytes.by_kernel = {'conv5_ws': (wide[0], wide[1]), 'conv5_igemm': (total - wide[0], n - wide[1])}
     return total, n
+
+
+def conv5_wgrad_algorithmic_bytes(batch, nslots):
+    """Algorithmic HBM bytes per train step of the filter-gradient launches (conv5_wgrad_bf16_kernel; autograd of
+    RepMode.py:207): both operands once -- the layer's bf16 input and bf16 output gradient -- and the float32 filter gradient
+    once per slot (merged levels 0-2: 125 taps x Cin x Cout per distinct task; the per-expert pair of levels 3-4: 125 + 27 taps,
+    shared by the batch, two gate-scaled output gradients).  The two one-channel layers have their own kernel and kind."""
+    v = [PATCH[0] * PATCH[1] * PATCH[2] // 8 ** l for l in range(5)]
+    merged = [(0, 32, 32), (0, 64, 32), (0, 32, 32), (1, 32, 64), (1, 64, 64), (1, 128, 64), (1, 64, 64),
+              (2, 64, 128), (2, 128, 128), (2, 256, 128), (2, 128, 128)]
+    pair = [(3, 128, 256), (3, 256, 256), (3, 512, 256), (3, 256, 256), (4, 256, 512), (4, 512, 512)]
+    total = 0.0
+    for l, ci, co in merged:
+        total += batch * v[l] * (ci + co) * 2 + nslots * 125 * ci * co * 4
+    for l, ci, co in pair:
+        total += batch * v[l] * (ci + 2 * co) * 2 + (125 + 27) * ci * co * 4
+    return total
 
 
 def cpu_baseline():
@@ -391,7 +413,12 @@ def main():
             traffic = (sum(t[0] * c for t, c in tr_parts) / sum(c for _, c in tr_parts)) if tr_parts and all(t[0] for t, _ in tr_parts) else None
             alg_bytes, alg_n = conv5_igemm_algorithmic_bytes(b, len(set(task.tolist())))
             by_kernel = {}
-            for k, sym in (('conv5_ws', 'conv5_ws_kernel'), ('conv5_igemm', 'conv5_igemm_kernel')):
+            # (round 4) the filter gradient -- the step's largest kernel family -- beside them: its launches per profiled step
+            # carry the whole step's algorithmic bytes (a skip connection's layer is two launches over one filter gradient)
+            wg_n = train_prof['conv5_wgrad'][0]
+            conv5_igemm_algorithmic_bytes.by_kernel['conv5_wgrad'] = (
+                conv5_wgrad_algorithmic_bytes(b, len(set(task.tolist()))) * max(profiled_steps, 1), wg_n)
+            for k, sym in (('conv5_ws', 'conv5_ws_kernel'), ('conv5_igemm', 'conv5_igemm_kernel'), ('conv5_wgrad', 'conv5_wgrad_bf16_kernel')):
                 kn, kms, kfl = train_prof[k]
                 if kn:
                     ab, an = conv5_igemm_algorithmic_bytes.by_kernel[k]

@@ -75,6 +75,10 @@ int repmode_padded_channels(int channels, int dtype, int is_reduction_dim);
  * g[s][e][o] = softmax_e(gate_w[e*Co+o][slot_task[s]] + gate_b[e*Co+o])      (float [S][5][Co]) */
 int repmode_gate_softmax(const float* gate_w, const float* gate_b, const int32_t* slot_task,
                          int nslots, int num_tasks, int co, float* g, void* stream);
+/* The same for several blocks in one launch (the per-expert blocks of a forward pass, one "slot" per sample): gate_w[i] /
+ * gate_b[i] / co[i] / g[i] per block, one slot_task vector for all.  nblocks <= REPMODE_GATREP_MULTI_MAX (defined below). */
+int repmode_gate_softmax_multi(int nblocks, const float* const* gate_w, const float* const* gate_b, const int* co,
+                               const int32_t* slot_task, int nslots, int num_tasks, float* const* g, void* stream);
 
 /* ---- GatRep forward: RepMode.py:165-169 (trans_kernel), :173-180, :182-190 (routing) ----
  * W_s = g0*K5 + g1*pad(K3) + g2*pad(K1) + g3*pad(A3/27) + g4*A5/125, per output channel,
@@ -388,6 +392,25 @@ int repmode_mse_loss(const float* out, const float* target, const int32_t* sampl
                      float* dout, float* sums_ws, float* loss, float* loss_sample, float* task_mean, float* task_count,
                      void* stream);
 
+/* ---- the optimizer pass (fnet/fnet_model.py:55 `torch.optim.Adam(net.parameters(), lr)`, :112 `optimizer.step()`) ----
+ * torch.optim.Adam's update with its defaults' structure (no weight decay, no amsgrad), float32, in place:
+ *     m <- m + (1 - beta1)(g - m);  v <- v beta2 + (1 - beta2) g g;
+ *     p <- p - lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)           (step = 1 on the first call)
+ * the two bias corrections evaluated on the host in double precision, as torch's single-tensor path does.
+ * adam_multi: ntensors <= REPMODE_ADAM_MULTI_MAX float tensors of numel[i] elements (parameter, gradient, exp_avg,
+ *   exp_avg_sq) in one launch.
+ * adam_expert_frags: the same update for the 5x5x5 (p5 ...: [co][ci][125]) and 3x3x3 (p3 ...: [co][ci][27]) experts of
+ *   nblocks <= REPMODE_GATREP_MULTI_MAX MoDE blocks, and the UPDATED experts written once more as the convolution kernels'
+ *   fragment-major bf16 operands, exactly what repmode_expert_frags(k5, k3, co, ci, wf, wd) lays out (wf[i] / wd[i] as there;
+ *   either may be NULL) -- the per-expert formulation's forward pass then needs no layout launch. */
+#define REPMODE_ADAM_MULTI_MAX 40
+int repmode_adam_multi(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v, const long* numel,
+                       double lr, double beta1, double beta2, double eps, long step, void* stream);
+int repmode_adam_expert_frags(int nblocks, float* const* p5, const float* const* g5, float* const* m5, float* const* v5,
+                              float* const* p3, const float* const* g3, float* const* m3, float* const* v3, const int* co,
+                              const int* ci, void* const* wf, void* const* wd, double lr, double beta1, double beta2, double eps,
+                              long step, void* stream);
+
 /* Developer / test switch of the convolution's pipelined form (csrc/conv5_igemm.hip, conv5_pipe_kernel; also REPMODE_CONV_PIPE):
  * bit 0 = on, bit 1 = one channel sub-tile per wave everywhere, bit 2 = also on grids smaller than the chip, bit 3 = the
  * wave-specialised kernel (MFMA waves + loader waves),  bit 4 = its items along z first, bit 5 = row-stationary tap
@@ -428,8 +451,9 @@ int repmode_expert_frags_multi(int nblocks, const float* const* k5, const float*
                                void* const* wf, void* const* wd, void* stream);
 
 /* ---- measurement: per-launch HIP-event timing of the library's kernels on their own stream.
- * repmode_prof_enable(1) clears the records and starts recording every kind, (2) records the convolution kernels only
- * (conv5_igemm, conv5_deep, the thin layers'; least perturbation of the timed region), (0) stops.  repmode_prof_summary()
+ * repmode_prof_enable(1) clears the records and starts recording every kind, (2) records the MFMA kernels of the MoDE
+ * convolution only (conv5_igemm / conv5_ws, conv5_deep, the thin layers', and -- round 4 -- the filter gradient conv5_wgrad;
+ * least perturbation of the timed region), (0) stops.  repmode_prof_summary()
  * synchronises the recorded events and returns, for one kernel kind, the number of launches, the
  * summed duration (ms) and the summed algorithmic work (FLOPs for the conv kernels, bytes for GatRep). */
 #define REPMODE_PROF_CONV5 0    /* conv5_igemm (forward and data-gradient launches) */

@@ -30,10 +30,13 @@ _SIGNATURES = {
     'repmode_set_conv_pipe': [_I],
     'repmode_get_conv_pipe': [],
     'repmode_conv5_elem_out': [_I] * 7,
+    'repmode_adam_multi': [_I, _P, _P, _P, _P, _P, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_long, _P],
+    'repmode_adam_expert_frags': [_I] + [_P] * 12 + [_c.c_double] * 4 + [_c.c_long, _P],
     'repmode_set_wgrad_ws': [_I],
     'repmode_get_wgrad_ws': [],
     'repmode_padded_channels': [_I, _I, _I],
     'repmode_gate_softmax': [_P, _P, _P, _I, _I, _I, _P, _P],
+    'repmode_gate_softmax_multi': [_I, _P, _P, _P, _P, _I, _I, _P, _P],
     'repmode_gatrep_fwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     'repmode_gatrep_fwd_multi': [_I] + [_P] * 10 + [_I, _I, _I] + [_P] * 4,
     'repmode_gatrep_fwd_gate': [_P] * 8 + [_I] * 5 + [_P] * 4,
@@ -148,6 +151,12 @@ def load_torch_ops():
             'repmode_amd has no CPU or eager fallback.' % TORCH_LIB_PATH)
     torch.ops.load_library(TORCH_LIB_PATH)
     _torch_ops_loaded = True
+    from .optim import install_foreign_step_hook      # (the store of expert operands kept across steps: see optim.py)
+    install_foreign_step_hook()
+
+
+def torch_ops_loaded():
+    return _torch_ops_loaded
 
 
 _FUNCS = {}     # name -> bound foreign function (the hot path makes ~500 calls per train step)
@@ -178,7 +187,7 @@ PROF_KINDS = {'conv5_igemm': 0, 'conv5_wgrad': 1, 'gatrep_fwd': 2, 'gatrep_bwd':
 
 
 def prof_enable(on):
-    """False/0: off; True/1: every kernel kind; 2: the forward / data-gradient convolution kernels only."""
+    """False/0: off; True/1: every kernel kind; 2: the MoDE convolution's MFMA kernels only (forward / data gradient / filter gradient)."""
     call('repmode_prof_enable', int(on))
 
 

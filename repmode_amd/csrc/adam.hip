@@ -1,0 +1,323 @@
+// adam.hip -- the optimizer pass of the train step as this build's own kernels (round 4).
+//
+// The reference's harness steps `torch.optim.Adam(net.parameters(), lr)` (fnet/fnet_model.py:55, :112): betas (0.9, 0.999),
+// eps 1e-8, no weight decay, no amsgrad.  Per element, in float32, with the step's bias corrections computed on the host in
+// double precision exactly as torch's single-tensor path does (torch/optim/adam.py `_single_tensor_adam`):
+//     m <- m + (1 - beta1) (g - m)                       exp_avg.lerp_(grad, 1 - beta1)
+//     v <- v beta2 + (1 - beta2) g g                     exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+//     p <- p - (lr / (1 - beta1^t)) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+//
+// Two kernels:
+//   adam_multi_kernel        any list of float tensors (<= ADAM_MAX per launch, the pointers travel in the launch arguments):
+//                            a workgroup owns a 4096-element chunk of one tensor -- one read of p, g, m, v, one write of p, m, v.
+//   adam_frags_kernel        the 5x5x5 and 3x3x3 experts of the blocks that run the per-expert formulation (the deep levels:
+//                            84 % of the parameters).  The same update, and the UPDATED values leave the kernel a second time
+//                            as the convolution kernels' fragment-major bf16 operands (both roles: rows = co for the forward
+//                            conv, rows = ci with flipped taps for the data gradient) -- what repmode_expert_frags_multi
+//                            re-derives from the parameters at the start of every forward pass (round 3: 238 us per step, a
+//                            second read of 420 MB that this pass has in registers anyway).  A workgroup owns a 16 x 16
+//                            (co, ci) tile with all 125 + 27 taps: the parameter layout [co][ci][taps] makes its 16 rows 8 KB
+//                            contiguous runs; the updated values are staged as bf16 in LDS ([tap][co][ci], 78 KB) and written
+//                            out as 512-byte pieces of the 1 KiB fragment tiles.
+#include "common.h"
+
+#include <cmath>
+
+namespace {
+
+__host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ __forceinline__ int rup(int a, int b) { return cdiv(a, b) * b; }
+
+constexpr int ADAM_MAX = REPMODE_ADAM_MULTI_MAX;                   // tensors per adam_multi launch (launch arguments <= 4 KB)
+constexpr int ADAM_CHUNK = 4096;               // elements per workgroup: 256 threads x 4 x float4
+
+struct AdamHyper {
+  float w1;          // 1 - beta1
+  float beta2;
+  float w2;          // 1 - beta2
+  float bc2_sqrt;    // sqrt(1 - beta2^t)
+  float eps;
+  float neg_step;    // -(lr / (1 - beta1^t))
+};
+
+__device__ __forceinline__ void adam_elem(const AdamHyper& h, float& p, float g, float& m, float& v) {
+  m = m + h.w1 * (g - m);
+  v = v * h.beta2 + h.w2 * g * g;
+  const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
+  p = p + h.neg_step * (m / denom);
+}
+
+struct AdamMultiArgs {
+  float* p[ADAM_MAX];
+  const float* g[ADAM_MAX];
+  float* m[ADAM_MAX];
+  float* v[ADAM_MAX];
+  long numel[ADAM_MAX];
+  int first[ADAM_MAX + 1];       // first workgroup of tensor i
+  int nt;
+  AdamHyper h;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamMultiArgs a) {
+  int i = 0;
+  while (i + 1 < a.nt && (int)blockIdx.x >= a.first[i + 1]) ++i;
+  const long base = (long)((int)blockIdx.x - a.first[i]) * ADAM_CHUNK;
+  const long n = a.numel[i];
+  float* __restrict__ p = a.p[i];
+  const float* __restrict__ g = a.g[i];
+  float* __restrict__ m = a.m[i];
+  float* __restrict__ v = a.v[i];
+  const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  if (vec && base + ADAM_CHUNK <= n) {
+    f32x4 P[4], G[4], M[4], V[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long o = base + (long)(u * 256 + threadIdx.x) * 4;
+      P[u] = *reinterpret_cast<const f32x4*>(p + o);
+      G[u] = *reinterpret_cast<const f32x4*>(g + o);
+      M[u] = *reinterpret_cast<const f32x4*>(m + o);
+      V[u] = *reinterpret_cast<const f32x4*>(v + o);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long o = base + (long)(u * 256 + threadIdx.x) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float pp = P[u][k], mm = M[u][k], vv = V[u][k];
+        adam_elem(a.h, pp, G[u][k], mm, vv);
+        P[u][k] = pp; M[u][k] = mm; V[u][k] = vv;
+      }
+      *reinterpret_cast<f32x4*>(p + o) = P[u];
+      *reinterpret_cast<f32x4*>(m + o) = M[u];
+      *reinterpret_cast<f32x4*>(v + o) = V[u];
+    }
+    return;
+  }
+  const long end = base + ADAM_CHUNK < n ? base + ADAM_CHUNK : n;
+  for (long o = base + threadIdx.x; o < end; o += 256) {
+    float pp = p[o], mm = m[o], vv = v[o];
+    adam_elem(a.h, pp, g[o], mm, vv);
+    p[o] = pp; m[o] = mm; v[o] = vv;
+  }
+}
+
+// ---- the per-expert blocks' 5x5x5 / 3x3x3 experts: update + fragment-major bf16 operands
+constexpr int AF_MAX = REPMODE_GATREP_MULTI_MAX;
+constexpr int AF_T = 16;                                 // the workgroup's tile: AF_T output x AF_T input channels
+constexpr int AF_TAPS5 = REPMODE_TAPS, AF_TAPS3 = 27;
+
+struct AdamFragArgs {
+  float* p5[AF_MAX]; const float* g5[AF_MAX]; float* m5[AF_MAX]; float* v5[AF_MAX];
+  float* p3[AF_MAX]; const float* g3[AF_MAX]; float* m3[AF_MAX]; float* v3[AF_MAX];
+  bf16_t* wf[AF_MAX]; bf16_t* wd[AF_MAX];
+  int co[AF_MAX], ci[AF_MAX];
+  int first[AF_MAX + 1];
+  int nblocks;
+  AdamHyper h;
+};
+
+// One parameter tensor's part of the tile: rows co0 .. co0+15, input channels ci0 .. ci0+15, TAPS taps each.  A row is
+// ncols * TAPS contiguous floats (16-byte aligned when ci is a multiple of 4: taps * 16 * 4 bytes per ci tile, and every row
+// starts a multiple of ci * taps floats in).  Updated in place; the new value goes to lds[tap][row][col] as bf16.
+template <int TAPS>
+__device__ __forceinline__ void adam_tile_rows(const AdamHyper& h, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, int co_n, int ci_n, int co0, int ci0, bf16_t* lds) {
+  const int nrows = max(0, min(AF_T, co_n - co0)), ncols = max(0, min(AF_T, ci_n - ci0));
+  const int run = ncols * TAPS;                                  // floats of a row inside the tile
+  const bool vec = (((long)ci_n * TAPS) & 3) == 0 && ((ci0 * TAPS) & 3) == 0 && (run & 3) == 0 &&
+                   (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  // zero what the tile does not cover (ragged channel counts): the fragment tiles' padding must be zero
+  if (nrows < AF_T || ncols < AF_T) {
+    for (int i = threadIdx.x; i < TAPS * AF_T * AF_T; i += 256) {
+      const int r = (i / AF_T) % AF_T, c = i % AF_T;
+      if (r >= nrows || c >= ncols) lds[i] = 0;
+    }
+  }
+  if (vec) {
+    const int nvec = run / 4;                                    // float4 items per row (TAPS = 125: 500, 27: 108)
+    constexpr int RPI = 2;                                       // rows in flight per iteration
+    for (int r0 = 0; r0 < nrows; r0 += RPI) {
+      for (int it0 = 0; it0 < nvec; it0 += 256) {
+        f32x4 P[RPI], G[RPI], M[RPI], V[RPI];
+        const int it = it0 + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < RPI; ++u) {
+          const long o = ((long)(co0 + r0 + u) * ci_n + ci0) * TAPS + (long)it * 4;
+          if (it < nvec && r0 + u < nrows) {
+            P[u] = *reinterpret_cast<const f32x4*>(p + o);
+            G[u] = *reinterpret_cast<const f32x4*>(g + o);
+            M[u] = *reinterpret_cast<const f32x4*>(m + o);
+            V[u] = *reinterpret_cast<const f32x4*>(v + o);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < RPI; ++u) {
+          if (it < nvec && r0 + u < nrows) {
+            const long o = ((long)(co0 + r0 + u) * ci_n + ci0) * TAPS + (long)it * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              float pp = P[u][k], mm = M[u][k], vv = V[u][k];
+              adam_elem(h, pp, G[u][k], mm, vv);
+              P[u][k] = pp; M[u][k] = mm; V[u][k] = vv;
+            }
+            *reinterpret_cast<f32x4*>(p + o) = P[u];
+            *reinterpret_cast<f32x4*>(m + o) = M[u];
+            *reinterpret_cast<f32x4*>(v + o) = V[u];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int e = it * 4 + k, c = e / TAPS, t = e - c * TAPS;
+              lds[(t * AF_T + r0 + u) * AF_T + c] = f32_to_bf16(P[u][k]);
+            }
+          }
+        }
+      }
+    }
+  } else {
+    for (int r = 0; r < nrows; ++r) {
+      for (int e = threadIdx.x; e < run; e += 256) {
+        const long o = ((long)(co0 + r) * ci_n + ci0) * TAPS + e;
+        float pp = p[o], mm = m[o], vv = v[o];
+        adam_elem(h, pp, g[o], mm, vv);
+        p[o] = pp; m[o] = mm; v[o] = vv;
+        const int c = e / TAPS, t = e - c * TAPS;
+        lds[(t * AF_T + r) * AF_T + c] = f32_to_bf16(pp);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_frags_kernel(AdamFragArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* s5 = reinterpret_cast<bf16_t*>(smem);                   // [125][16 co][16 ci]
+  bf16_t* s3 = s5 + AF_TAPS5 * AF_T * AF_T;                       // [27][16 co][16 ci]
+  int i = 0;
+  while (i + 1 < a.nblocks && (int)blockIdx.x >= a.first[i + 1]) ++i;
+  const int b = blockIdx.x - a.first[i];
+  const int co_n = a.co[i], ci_n = a.ci[i];
+  // tiles over the PADDED extents (32-row tiles of either role): a tile beyond the data only writes the operands' zero padding
+  const int nit = rup(ci_n, 32) / AF_T;
+  // workgroup -> tile: the ci tile fastest (a row of the parameter tensor is walked by consecutive workgroups)
+  const int it_ = b % nit, ct_ = b / nit;
+  const int co0 = ct_ * AF_T, ci0 = it_ * AF_T;
+  adam_tile_rows<AF_TAPS5>(a.h, a.p5[i], a.g5[i], a.m5[i], a.v5[i], co_n, ci_n, co0, ci0, s5);
+  adam_tile_rows<AF_TAPS3>(a.h, a.p3[i], a.g3[i], a.m3[i], a.v3[i], co_n, ci_n, co0, ci0, s3);
+  __syncthreads();
+
+  // ---- the fragment-major operands (layouts: include/repmode_hip.h, repmode_expert_frags).  Forward role: rows = co,
+  // reduction = ci: tile (rt = co0 / 32, kc = ci0 / 16) of [slot][tap][CoP/32][CiP/16][32][16], this workgroup's 16 rows are
+  // 512 contiguous bytes of it.  128 threads move one tap's piece as dwords; the two halves of the workgroup take two taps.
+  const int half = threadIdx.x >> 7, t128 = threadIdx.x & 127;
+  if (a.wf[i] && ci0 < rup(ci_n, 16)) {          // (the forward role pads its reduction, ci, to 16 only)
+    const int coP = rup(co_n, 32), ciP = rup(ci_n, 16);
+    const size_t tap_stride = (size_t)coP * ciP;                   // elements per tap of one slot
+    const size_t tile = ((size_t)(co0 / 32) * (ciP / 16) + ci0 / 16) * (32 * 16) + (size_t)(co0 % 32) * 16;
+    uint32_t* out = reinterpret_cast<uint32_t*>(a.wf[i] + tile);
+    const uint32_t* s5w = reinterpret_cast<const uint32_t*>(s5);
+    const uint32_t* s3w = reinterpret_cast<const uint32_t*>(s3);
+    for (int tap = half; tap < AF_TAPS5; tap += 2) {
+      out[(size_t)tap * tap_stride / 2 + t128] = s5w[tap * (AF_T * AF_T / 2) + t128];
+      const int dz = tap / 25, dy = (tap / 5) % 5, dx = tap % 5;
+      if (dz >= 1 && dz <= 3 && dy >= 1 && dy <= 3) {               // slot 1: the rows a centred-3x3x3 convolution reads
+        const bool in = dx >= 1 && dx <= 3;
+        const int t3 = ((dz - 1) * 3 + (dy - 1)) * 3 + (dx - 1);
+        out[((size_t)AF_TAPS5 + tap) * tap_stride / 2 + t128] = in ? s3w[t3 * (AF_T * AF_T / 2) + t128] : 0u;
+      }
+    }
+  }
+  // Data-gradient role: rows = ci, reduction = co, taps flipped: tile (rt = ci0 / 32, kc = co0 / 16) of
+  // [slot][124 - tap][CiP/32][CoP/16][32][16]; element (row = ci, k = co) comes from lds[tap][co][ci]: a transposed read.
+  if (a.wd[i] && co0 < rup(co_n, 16)) {
+    const int ciP = rup(ci_n, 32), coP = rup(co_n, 16);
+    const size_t tap_stride = (size_t)ciP * coP;
+    const size_t tile = ((size_t)(ci0 / 32) * (coP / 16) + co0 / 16) * (32 * 16) + (size_t)(ci0 % 32) * 16;
+    uint32_t* out = reinterpret_cast<uint32_t*>(a.wd[i] + tile);
+    const int row = t128 >> 3, kp = t128 & 7;                       // this thread's dword: row ci = row, co pair (2 kp, 2 kp + 1)
+    for (int tap = half; tap < AF_TAPS5; tap += 2) {
+      const bf16_t* s = s5 + tap * (AF_T * AF_T);
+      const uint32_t w = (uint32_t)s[(2 * kp) * AF_T + row] | ((uint32_t)s[(2 * kp + 1) * AF_T + row] << 16);
+      const int tap_out = AF_TAPS5 - 1 - tap;
+      out[(size_t)tap_out * tap_stride / 2 + t128] = w;
+      const int dz = tap / 25, dy = (tap / 5) % 5, dx = tap % 5;
+      if (dz >= 1 && dz <= 3 && dy >= 1 && dy <= 3) {
+        const bool in = dx >= 1 && dx <= 3;
+        const int t3 = ((dz - 1) * 3 + (dy - 1)) * 3 + (dx - 1);
+        const bf16_t* q = s3 + t3 * (AF_T * AF_T);
+        const uint32_t w3 = in ? ((uint32_t)q[(2 * kp) * AF_T + row] | ((uint32_t)q[(2 * kp + 1) * AF_T + row] << 16)) : 0u;
+        out[((size_t)AF_TAPS5 + tap_out) * tap_stride / 2 + t128] = w3;
+      }
+    }
+  }
+}
+
+constexpr int AF_LDS_BYTES = (AF_TAPS5 + AF_TAPS3) * AF_T * AF_T * 2;
+
+int fill_hyper(AdamHyper* h, double lr, double beta1, double beta2, double eps, long step) {
+  RM_REQUIRE(step >= 1, "adam: step count starts at 1 (got %ld)", step);
+  RM_REQUIRE(lr >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0, "adam: bad hyper-parameters");
+  const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+  h->w1 = (float)(1.0 - beta1);
+  h->beta2 = (float)beta2;
+  h->w2 = (float)(1.0 - beta2);
+  h->bc2_sqrt = (float)std::sqrt(bc2);
+  h->eps = (float)eps;
+  h->neg_step = (float)(-(lr / bc1));
+  return REPMODE_OK;
+}
+
+}  // namespace
+
+extern "C" int repmode_adam_multi(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                  const long* numel, double lr, double beta1, double beta2, double eps, long step, void* stream) {
+  RM_REQUIRE(p && g && m && v && numel, "adam_multi: null pointer");
+  RM_REQUIRE(ntensors > 0 && ntensors <= ADAM_MAX, "adam_multi: 1..%d tensors per call, got %d", ADAM_MAX, ntensors);
+  AdamMultiArgs a{};
+  if (int rc = fill_hyper(&a.h, lr, beta1, beta2, eps, step)) return rc;
+  a.nt = ntensors;
+  long total = 0;
+  for (int i = 0; i < ntensors; ++i) {
+    RM_REQUIRE(p[i] && g[i] && m[i] && v[i] && numel[i] > 0, "adam_multi: bad tensor %d", i);
+    RM_REQUIRE((((uintptr_t)p[i] | (uintptr_t)g[i] | (uintptr_t)m[i] | (uintptr_t)v[i]) & 3) == 0, "adam_multi: tensor %d is not float-aligned", i);
+    a.p[i] = p[i]; a.g[i] = g[i]; a.m[i] = m[i]; a.v[i] = v[i]; a.numel[i] = numel[i];
+    a.first[i] = (int)total;
+    total += (numel[i] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+  }
+  a.first[ntensors] = (int)total;
+  RM_REQUIRE(total < (1L << 31), "adam_multi: grid too large");
+  hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  RM_LAUNCH_CHECK("adam_multi");
+  return REPMODE_OK;
+}
+
+extern "C" int repmode_adam_expert_frags(int nblocks, float* const* p5, const float* const* g5, float* const* m5, float* const* v5,
+                                         float* const* p3, const float* const* g3, float* const* m3, float* const* v3, const int* co,
+                                         const int* ci, void* const* wf, void* const* wd, double lr, double beta1, double beta2,
+                                         double eps, long step, void* stream) {
+  RM_REQUIRE(p5 && g5 && m5 && v5 && p3 && g3 && m3 && v3 && co && ci && wf && wd, "adam_expert_frags: null pointer");
+  RM_REQUIRE(nblocks > 0 && nblocks <= AF_MAX, "adam_expert_frags: 1..%d blocks per call, got %d", AF_MAX, nblocks);
+  AdamFragArgs a{};
+  if (int rc = fill_hyper(&a.h, lr, beta1, beta2, eps, step)) return rc;
+  a.nblocks = nblocks;
+  long total = 0;
+  for (int i = 0; i < nblocks; ++i) {
+    RM_REQUIRE(p5[i] && g5[i] && m5[i] && v5[i] && p3[i] && g3[i] && m3[i] && v3[i] && co[i] > 0 && ci[i] > 0, "adam_expert_frags: bad block %d", i);
+    RM_REQUIRE((((uintptr_t)wf[i] | (uintptr_t)wd[i]) & 15) == 0, "adam_expert_frags: operand buffers must be 16-byte aligned");
+    a.p5[i] = p5[i]; a.g5[i] = g5[i]; a.m5[i] = m5[i]; a.v5[i] = v5[i];
+    a.p3[i] = p3[i]; a.g3[i] = g3[i]; a.m3[i] = m3[i]; a.v3[i] = v3[i];
+    a.wf[i] = static_cast<bf16_t*>(wf[i]); a.wd[i] = static_cast<bf16_t*>(wd[i]);
+    a.co[i] = co[i]; a.ci[i] = ci[i];
+    a.first[i] = (int)total;
+    total += (long)(rup(co[i], 32) / AF_T) * (rup(ci[i], 32) / AF_T);
+  }
+  a.first[nblocks] = (int)total;
+  RM_REQUIRE(total < (1L << 31), "adam_expert_frags: grid too large");
+  static bool attr_done[32] = {};
+  int dev = 0;
+  RM_HIP(hipGetDevice(&dev));
+  if (!attr_done[dev & 31]) {
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&adam_frags_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, AF_LDS_BYTES));
+    attr_done[dev & 31] = true;
+  }
+  hipLaunchKernelGGL(adam_frags_kernel, dim3((unsigned)total), dim3(256), AF_LDS_BYTES, static_cast<hipStream_t>(stream), a);
+  RM_LAUNCH_CHECK("adam_expert_frags");
+  return REPMODE_OK;
+}

@@ -695,25 +695,28 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
     const double per_wg = (double)a.ntiles * (n > a.nslots ? (double)n / a.nslots : 1.0) / (double)est_nc;
     ws = ws_mode == 2 || per_wg >= 48.0;
   }
-  static long resident2 = 0, resident3 = 0, resident_ws = 0;   // per instantiation: the regular kernel / the three-per-CU form (8x16 tile only) / WS
-  if (TX >= 32 && !resident_ws) {
-    int per_cu = 0, cus = 0, dev = 0;
-    RM_HIP(hipGetDevice(&dev));
+  // workgroups resident at once, per instantiation AND per device (advisor round 3: function statics belonged to whichever
+  // device called first): the regular kernel / the three-per-CU form (8x16 tile only) / the wave-specialised form
+  static long res_tab[32][3] = {};
+  int dev = 0;
+  RM_HIP(hipGetDevice(&dev));
+  long* res = res_tab[dev & 31];
+  if (!res[0]) {
+    int per_cu = 0, cus = 0;
     RM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    RM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv5_wgrad_bf16_kernel<TZ, TY, TX, true, false, TX >= 32>, 512, 0));
-    resident_ws = (long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
-  }
-  if (!resident2) {
-    int per_cu = 0, cus = 0, dev = 0;
-    RM_HIP(hipGetDevice(&dev));
-    RM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus <= 0) cus = 256;
+    if (TX >= 32) {
+      RM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv5_wgrad_bf16_kernel<TZ, TY, TX, true, false, TX >= 32>, 512, 0));
+      res[2] = (long)(per_cu > 0 ? per_cu : 1) * cus;
+    }
     if (TX == 16) {
       RM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv5_wgrad_bf16_kernel<TZ, TY, TX, true, TX == 16>, 256, 0));
-      resident3 = (long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+      res[1] = (long)(per_cu > 0 ? per_cu : 1) * cus;
     }
     RM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv5_wgrad_bf16_kernel<TZ, TY, TX, true>, 256, 0));
-    resident2 = (long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 256);
+    res[0] = (long)(per_cu > 0 ? per_cu : 1) * cus;
   }
+  const long resident2 = res[0], resident3 = res[1], resident_ws = res[2];
   const double ov = TX >= 32 ? 3.5 : 6.0;
   const double tiles = (double)a.ntiles * (n > a.nslots ? (double)n / a.nslots : 1.0);
   // best chunk count of a job of `ndz` planes on `resident` slots; returns its price

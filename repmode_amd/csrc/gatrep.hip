@@ -41,6 +41,38 @@ __global__ void gate_softmax_kernel(const float* __restrict__ gate_w, const floa
   for (int e = 0; e < E; ++e) g[((size_t)s * E + e) * co + o] = logit[e] * inv;
 }
 
+// several blocks' gates from one launch (the per-expert blocks of a forward pass: one "slot" per sample; round 3 launched one
+// 6 us kernel per block)
+constexpr int GSM_MAX = REPMODE_GATREP_MULTI_MAX;
+struct GateMultiArgs {
+  const float* gate_w[GSM_MAX]; const float* gate_b[GSM_MAX]; float* g[GSM_MAX];
+  int co[GSM_MAX], first[GSM_MAX + 1];
+  int nblocks, nslots, num_tasks;
+};
+__global__ __launch_bounds__(256) void gate_softmax_multi_kernel(GateMultiArgs a, const int32_t* __restrict__ slot_task) {
+  int i = 0;
+  while (i + 1 < a.nblocks && (int)blockIdx.x >= a.first[i + 1]) ++i;
+  const int idx = ((int)blockIdx.x - a.first[i]) * 256 + threadIdx.x;
+  const int co = a.co[i];
+  if (idx >= a.nslots * co) return;
+  const float* __restrict__ gate_w = a.gate_w[i];
+  const float* __restrict__ gate_b = a.gate_b[i];
+  const int s = idx / co, o = idx % co;
+  const int task = slot_task[s];
+  float logit[E], mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    logit[e] = gate_w[(size_t)(e * co + o) * a.num_tasks + task] + gate_b[e * co + o];
+    mx = fmaxf(mx, logit[e]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) { logit[e] = expf(logit[e] - mx); sum += logit[e]; }
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int e = 0; e < E; ++e) a.g[i][((size_t)s * E + e) * co + o] = logit[e] * inv;
+}
+
 template <typename T>
 __device__ __forceinline__ T from_f32(float v);
 template <>
@@ -562,6 +594,31 @@ extern "C" int repmode_gate_softmax(const float* gate_w, const float* gate_b, co
                      static_cast<hipStream_t>(stream), gate_w, gate_b, slot_task, nslots, num_tasks, co, g);
   repmode_prof_end(static_cast<hipStream_t>(stream));
   RM_LAUNCH_CHECK("gate_softmax");
+  return REPMODE_OK;
+}
+
+extern "C" int repmode_gate_softmax_multi(int nblocks, const float* const* gate_w, const float* const* gate_b, const int* co,
+                                          const int32_t* slot_task, int nslots, int num_tasks, float* const* g, void* stream) {
+  RM_REQUIRE(gate_w && gate_b && co && slot_task && g, "gate_softmax_multi: null pointer");
+  RM_REQUIRE(nblocks > 0 && nblocks <= GSM_MAX, "gate_softmax_multi: 1..%d blocks per call, got %d", GSM_MAX, nblocks);
+  RM_REQUIRE(nslots > 0 && num_tasks > 0, "gate_softmax_multi: bad shape");
+  GateMultiArgs a{};
+  a.nblocks = nblocks; a.nslots = nslots; a.num_tasks = num_tasks;
+  long total = 0;
+  double bytes = 0;
+  for (int i = 0; i < nblocks; ++i) {
+    RM_REQUIRE(gate_w[i] && gate_b[i] && g[i] && co[i] > 0, "gate_softmax_multi: bad block %d", i);
+    a.gate_w[i] = gate_w[i]; a.gate_b[i] = gate_b[i]; a.g[i] = g[i]; a.co[i] = co[i];
+    a.first[i] = (int)total;
+    total += ceil_div(nslots * co[i], 256);
+    bytes += (double)nslots * co[i] * 4.0 * (2 * E + E);
+  }
+  a.first[nblocks] = (int)total;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  repmode_prof_begin(REPMODE_PROF_GATREP_FWD, bytes, s);
+  hipLaunchKernelGGL(gate_softmax_multi_kernel, dim3((unsigned)total), dim3(256), 0, s, a, slot_task);
+  repmode_prof_end(s);
+  RM_LAUNCH_CHECK("gate_softmax_multi");
   return REPMODE_OK;
 }
 

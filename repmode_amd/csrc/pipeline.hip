@@ -182,8 +182,10 @@ struct PatchArgs {
 };
 
 __global__ __launch_bounds__(256) void patch_gather_kernel(PatchArgs a, const float* __restrict__ vol, float* __restrict__ out) {
-  const int n = blockIdx.z, row = blockIdx.y;
-  const int x = blockIdx.x * 256 + threadIdx.x;
+  // (rows folded into grid.x: grid.y / grid.z are limited to 65535, a patch has pd * ph rows -- advisor round 3)
+  const int nxb = (a.pw + 255) / 256;
+  const int n = blockIdx.y, row = blockIdx.x / nxb;
+  const int x = (blockIdx.x % nxb) * 256 + threadIdx.x;
   if (x >= a.pw) return;
   const int z = row / a.ph, y = row % a.ph;
   const size_t src = ((size_t)(a.start[n][0] + z) * a.H + a.start[n][1] + y) * a.W + a.start[n][2] + x;
@@ -193,8 +195,11 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(PatchArgs a, const fl
 template <typename T>
 __global__ __launch_bounds__(256) void patch_blend_kernel(PatchArgs a, const T* __restrict__ out, const float* __restrict__ gauss,
                                                          float* __restrict__ pred_sum, float* __restrict__ weight_sum) {
-  const int row = blockIdx.y;
-  const int bx = blockIdx.x * 256 + threadIdx.x;
+  // (the bounding box's rows folded into grid.x: a LIFO batch that crosses a z-slab boundary has (pd + stride) * H rows, more
+  // than grid.y's 65535 on volumes taller than ~1365 voxels -- advisor round 3)
+  const int nxb = (a.ext[2] + 255) / 256;
+  const int row = blockIdx.x / nxb;
+  const int bx = (blockIdx.x % nxb) * 256 + threadIdx.x;
   if (bx >= a.ext[2]) return;
   const int z = a.lo[0] + row / a.ext[1], y = a.lo[1] + row % a.ext[1], x = a.lo[2] + bx;
   const size_t at = ((size_t)z * a.H + y) * a.W + x;
@@ -245,7 +250,8 @@ extern "C" int repmode_patch_gather(const float* vol, int D, int H, int W, const
   PatchArgs a{};
   const int rc = fill_patch_args(a, starts, nb, pd, ph, pw, D, H, W, "patch_gather");
   if (rc != REPMODE_OK) return rc;
-  hipLaunchKernelGGL(patch_gather_kernel, dim3(ceil_div(pw, 256), pd * ph, nb), dim3(256), 0, static_cast<hipStream_t>(stream), a, vol, out);
+  RM_REQUIRE((long)ceil_div(pw, 256) * pd * ph < (1L << 31), "patch_gather: patch too large");
+  hipLaunchKernelGGL(patch_gather_kernel, dim3((unsigned)(ceil_div(pw, 256) * pd * ph), nb), dim3(256), 0, static_cast<hipStream_t>(stream), a, vol, out);
   RM_LAUNCH_CHECK("patch_gather");
   return REPMODE_OK;
 }
@@ -259,7 +265,8 @@ extern "C" int repmode_patch_blend(const void* out, int dtype, const float* gaus
   PatchArgs a{};
   const int rc = fill_patch_args(a, starts, nb, pd, ph, pw, D, H, W, "patch_blend");
   if (rc != REPMODE_OK) return rc;
-  const dim3 grid(ceil_div(a.ext[2], 256), a.ext[0] * a.ext[1]);
+  RM_REQUIRE((long)ceil_div(a.ext[2], 256) * a.ext[0] * a.ext[1] < (1L << 31), "patch_blend: bounding box too large");
+  const dim3 grid((unsigned)(ceil_div(a.ext[2], 256) * a.ext[0] * a.ext[1]));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == REPMODE_F32)
     hipLaunchKernelGGL(patch_blend_kernel<float>, grid, dim3(256), 0, s, a, static_cast<const float*>(out), gauss, pred_sum, weight_sum);

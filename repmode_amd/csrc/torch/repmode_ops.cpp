@@ -739,7 +739,10 @@ struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
     Fork fork(need_dx && (whole || g_overlap), x_cl);
     fork.to_side();
     if (whole) dw = conv5_wgrad(x_cl, dy, plan.sample_slot, plan.nslots, co);
-    const bool defer = g_tail && need_dx && !(whole || g_overlap);      // (one stream: the data-gradient conv below hosts the job)
+    // (one stream: the data-gradient conv below hosts the job -- unless it is one of the one-channel layers' own kernels,
+    // which host nothing: the job is then launched on its own at once instead of queued and flushed)
+    const bool thin_dx = g_thin && dt == at::kBFloat16 && ((ci == 1) != (co == 1));
+    const bool defer = g_tail && need_dx && !(whole || g_overlap) && !thin_dx;
     std::vector<Tensor> pg = filter_and_expert_grads(dw, k5, k3, k1, a3, a5, g, plan, defer);
     fork.to_main();
     Tensor dx;
@@ -749,7 +752,7 @@ struct ModeConvMerged : public torch::autograd::Function<ModeConvMerged> {
       if (dt == at::kBFloat16 && co == 1 && ci != 1) dx = thin_conv_in1(dy, wd, plan.sample_slot, ci, f32);   // last layer: dy has one channel
       else if (dt == at::kBFloat16 && ci == 1 && co != 1) dx = thin_conv_out1(dy, wd, plan.sample_slot);
       else dx = conv5(dy, wd, plan.sample_slot, ci, f32);
-      if (defer) RM_CALL(repmode_tail_flush, stream_handle());      // (nothing left unless the conv above was not reached)
+      if (defer) RM_CALL(repmode_tail_flush, stream_handle());      // (nothing left unless the conv above took a path that hosts no jobs)
       if (dx.scalar_type() != dt) dx = dx.to(dt);
     }
     fork.join();
@@ -1179,7 +1182,13 @@ Tensor mse_sums_ws(const Tensor& like) {
   const std::string key = std::to_string(like.device().index()) + ":" + std::to_string((uintptr_t)stream_handle());
   std::lock_guard<std::mutex> lock(mu);
   auto it = ws.find(key);
-  if (it == ws.end()) it = ws.emplace(key, at::zeros({1024}, like.options().dtype(at::kFloat))).first;
+  if (it == ws.end()) {
+    // (advisor round 3) one 4 KB accumulator per stream a loss ever ran on would otherwise live for the process: the map is
+    // bounded -- a stream's accumulator is all zero between calls, so forgetting it costs one allocation on its next use.
+    // A graph capture should find its stream's entry already made: Model runs its warm-up steps on the capture stream.
+    if (ws.size() >= 16) ws.clear();
+    it = ws.emplace(key, at::zeros({1024}, like.options().dtype(at::kFloat))).first;
+  }
   return it->second;
 }
 
@@ -1190,9 +1199,14 @@ struct MseLoss : public torch::autograd::Function<MseLoss> {
     Tensor task_mean = at::empty({num_tasks}, out.options()), task_count = at::empty({num_tasks}, out.options());
     Tensor dout = want_grad ? at::empty_like(out) : Tensor();
     Tensor ws = mse_sums_ws(out);
-    RM_CALL(repmode_mse_loss, out.data_ptr<float>(), target.data_ptr<float>(), sample_task.data_ptr<int32_t>(), (int)n, (long)v,
-            (int)num_tasks, want_grad ? dout.data_ptr<float>() : nullptr, ws.data_ptr<float>(), loss.data_ptr<float>(),
-            loss_sample.data_ptr<float>(), task_mean.data_ptr<float>(), task_count.data_ptr<float>(), stream_handle());
+    try {
+      RM_CALL(repmode_mse_loss, out.data_ptr<float>(), target.data_ptr<float>(), sample_task.data_ptr<int32_t>(), (int)n, (long)v,
+              (int)num_tasks, want_grad ? dout.data_ptr<float>() : nullptr, ws.data_ptr<float>(), loss.data_ptr<float>(),
+              loss_sample.data_ptr<float>(), task_mean.data_ptr<float>(), task_count.data_ptr<float>(), stream_handle());
+    } catch (...) {
+      ws.zero_();        // (a launch that failed between "accumulate" and "finish" must not poison the stream's later losses)
+      throw;
+    }
     ctx->save_for_backward({dout});
     ctx->mark_non_differentiable({loss_sample, task_mean, task_count});
     return {loss, loss_sample, task_mean, task_count};
@@ -1413,6 +1427,130 @@ Tensor op_stage2_bn_relu(const Tensor& x, const Tensor& weight, const Tensor& bn
   return from_cl(bn_relu_cl(y, bn_w, bn_b, bn_rm, bn_rv, bn_batch_stats, bn_momentum, bn_eps, code_dtype(out_dtype)));
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The per-expert blocks' experts in the conv kernels' layout, kept ACROSS steps (round 4).  They depend on the parameters
+// only, so the optimizer pass that has just written the parameters emits them as well (op adam_step ->
+// repmode_adam_expert_frags) and the next forward pass finds them ready: no layout launch, no second read of the experts.
+// An entry is valid for one version of its two parameters (autograd's version counters: any in-place write from outside --
+// load_state_dict, another optimizer -- makes it stale and prepare_filters lays the experts out again into the same buffers);
+// weak references tell a dead parameter from a new one at the same address.
+struct FragEntry {
+  c10::weak_intrusive_ptr<c10::TensorImpl> w5, w3;
+  Tensor wf, wd;
+  int64_t co = 0, ci = 0;
+  uint32_t ver5 = 0, ver3 = 0;
+  bool wf_valid = false, wd_valid = false;
+  bool used = false;             // a forward pass since the last optimizer step took it
+  FragEntry(const Tensor& k5, const Tensor& k3)
+      : w5(c10::intrusive_ptr<c10::TensorImpl>::reclaim_copy(k5.unsafeGetTensorImpl())),
+        w3(c10::intrusive_ptr<c10::TensorImpl>::reclaim_copy(k3.unsafeGetTensorImpl())) {}
+  bool same_params(const Tensor& k5, const Tensor& k3) const {
+    return !w5.expired() && !w3.expired() && w5._unsafe_get_target() == k5.unsafeGetTensorImpl() &&
+           w3._unsafe_get_target() == k3.unsafeGetTensorImpl();
+  }
+  bool current(const Tensor& k5, const Tensor& k3) const { return same_params(k5, k3) && ver5 == k5._version() && ver3 == k3._version(); }
+};
+std::mutex g_frag_mu;
+std::unordered_map<void*, FragEntry> g_frag_store;
+bool g_frag_keep = []() {          // (REPMODE_FRAG_STORE=0: lay the experts out at every forward pass, as round 3 did)
+  const char* e = std::getenv("REPMODE_FRAG_STORE");
+  return e ? std::atoi(e) != 0 : true;
+}();
+
+void op_clear_frag_store() {
+  std::lock_guard<std::mutex> lock(g_frag_mu);
+  g_frag_store.clear();
+}
+int64_t op_frag_store_size() {
+  std::lock_guard<std::mutex> lock(g_frag_mu);
+  return (int64_t)g_frag_store.size();
+}
+
+// torch.optim.Adam's step (fnet_model.py:55, 112) over the whole parameter list through the build's own kernels
+// (csrc/adam.hip): the 5x5x5 / 3x3x3 experts of the blocks whose last forward pass ran the per-expert formulation go
+// through repmode_adam_expert_frags (update + the conv operands of the next forward pass), everything else through
+// repmode_adam_multi.  `step`: the 1-based count of this update (all tensors of a call share it).
+void op_adam_step(const std::vector<Tensor>& params, const std::vector<Tensor>& grads, const std::vector<Tensor>& exp_avgs,
+                  const std::vector<Tensor>& exp_avg_sqs, double lr, double beta1, double beta2, double eps, int64_t step) {
+  const size_t n = params.size();
+  TORCH_CHECK(grads.size() == n && exp_avgs.size() == n && exp_avg_sqs.size() == n, "adam_step: list lengths differ");
+  if (n == 0) return;
+  require_hip(params[0], "parameters");
+  DeviceGuard guard(params[0].device());
+  std::unordered_map<const void*, size_t> index;
+  for (size_t i = 0; i < n; ++i) {
+    for (const Tensor* t : {&params[i], &grads[i], &exp_avgs[i], &exp_avg_sqs[i]})
+      TORCH_CHECK(t->scalar_type() == at::kFloat && t->is_contiguous() && t->device() == params[0].device() && t->numel() == params[i].numel(),
+                  "adam_step: parameter ", i, ": float32 contiguous tensors of one shape on one device (parameter, gradient, exp_avg, exp_avg_sq)");
+    index[params[i].data_ptr()] = i;
+  }
+  std::vector<char> done(n, 0);
+  // ---- the per-expert blocks
+  struct Blk { size_t i5, i3; FragEntry* fe; };
+  std::vector<Blk> blks;
+  {
+    std::lock_guard<std::mutex> lock(g_frag_mu);
+    for (auto& kv : g_frag_store) {
+      FragEntry& fe = kv.second;
+      if (!fe.used) continue;
+      auto it5 = index.find(kv.first);
+      if (it5 == index.end()) continue;
+      const Tensor& k5 = params[it5->second];
+      if (fe.w3.expired()) continue;
+      auto it3 = index.find(fe.w3._unsafe_get_target()->data());
+      if (it3 == index.end() || !fe.same_params(k5, params[it3->second])) continue;
+      blks.push_back({it5->second, it3->second, &fe});
+    }
+    for (size_t b0 = 0; b0 < blks.size(); b0 += REPMODE_GATREP_MULTI_MAX) {
+      const int cnt = (int)std::min<size_t>(REPMODE_GATREP_MULTI_MAX, blks.size() - b0);
+      std::vector<float*> p5, m5, v5, p3, m3, v3;
+      std::vector<const float*> g5, g3;
+      std::vector<int> co, ci;
+      std::vector<void*> wf, wd;
+      for (int j = 0; j < cnt; ++j) {
+        const Blk& b = blks[b0 + j];
+        p5.push_back(params[b.i5].data_ptr<float>()); g5.push_back(grads[b.i5].data_ptr<float>());
+        m5.push_back(exp_avgs[b.i5].data_ptr<float>()); v5.push_back(exp_avg_sqs[b.i5].data_ptr<float>());
+        p3.push_back(params[b.i3].data_ptr<float>()); g3.push_back(grads[b.i3].data_ptr<float>());
+        m3.push_back(exp_avgs[b.i3].data_ptr<float>()); v3.push_back(exp_avg_sqs[b.i3].data_ptr<float>());
+        co.push_back((int)b.fe->co); ci.push_back((int)b.fe->ci);
+        wf.push_back(b.fe->wf.defined() ? b.fe->wf.data_ptr() : nullptr);
+        wd.push_back(b.fe->wd.defined() ? b.fe->wd.data_ptr() : nullptr);
+        done[b.i5] = done[b.i3] = 1;
+      }
+      RM_CALL(repmode_adam_expert_frags, cnt, p5.data(), g5.data(), m5.data(), v5.data(), p3.data(), g3.data(), m3.data(), v3.data(),
+              co.data(), ci.data(), wf.data(), wd.data(), lr, beta1, beta2, eps, (long)step, stream_handle());
+    }
+    // ---- every other tensor
+    std::vector<float*> p, m, v;
+    std::vector<const float*> g;
+    std::vector<long> numel;
+    auto flush = [&]() {
+      if (p.empty()) return;
+      RM_CALL(repmode_adam_multi, (int)p.size(), p.data(), g.data(), m.data(), v.data(), numel.data(), lr, beta1, beta2, eps, (long)step,
+              stream_handle());
+      p.clear(); g.clear(); m.clear(); v.clear(); numel.clear();
+    };
+    for (size_t i = 0; i < n; ++i) {
+      if (done[i] || params[i].numel() == 0) continue;
+      p.push_back(params[i].data_ptr<float>()); g.push_back(grads[i].data_ptr<float>());
+      m.push_back(exp_avgs[i].data_ptr<float>()); v.push_back(exp_avg_sqs[i].data_ptr<float>());
+      numel.push_back((long)params[i].numel());
+      if (p.size() == REPMODE_ADAM_MULTI_MAX) flush();
+    }
+    flush();
+    // the parameters changed in place: autograd's version counters say so, and the operands emitted above belong to the new version
+    for (size_t i = 0; i < n; ++i) params[i].unsafeGetTensorImpl()->bump_version();
+    for (const Blk& b : blks) {
+      b.fe->ver5 = params[b.i5]._version();
+      b.fe->ver3 = params[b.i3]._version();
+      b.fe->wf_valid = b.fe->wf.defined();
+      b.fe->wd_valid = b.fe->wd.defined();
+      b.fe->used = false;
+    }
+  }
+}
+
 // All blocks' forward filters on the `prep` stream, ahead of the forward pass (see PrepEntry).  w_in[i]: the x extent of
 // block i's input (selects the formulation exactly as mode_conv3d does), need_dx[i]: the block's input needs a gradient.
 void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>& k3, const std::vector<Tensor>& k1,
@@ -1451,6 +1589,9 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
       std::vector<int> xco, xci;
       std::vector<PrepEntry> xe;
       std::vector<void*> xk;
+      std::vector<const float*> ggw, ggb;       // the per-expert blocks' gates (per SAMPLE), all from one launch
+      std::vector<float*> ggo;
+      std::vector<int> gco;
       for (size_t i = 0; i < nb && dt == at::kBFloat16; ++i) {
         if (!(plan.training && plan.nslots > 2 && w_in[i] <= g_unmerged_max_w)) continue;
         Tensor K5 = k5[i].contiguous(), K3 = k3[i].contiguous();
@@ -1460,17 +1601,66 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
         e.dt = dt;
         e.unmerged = true;
         e.rows = plan.n;
-        e.wf = at::empty({2, TAPS, padded(co, code, false), padded(ci, code, true)}, K5.options().dtype(dt));
-        if (need_dx[i]) e.wd = at::empty({2, TAPS, padded(ci, code, false), padded(co, code, true)}, K5.options().dtype(dt));
-        x5.push_back(K5.data_ptr<float>()); x3.push_back(K3.data_ptr<float>());
-        xwf.push_back(e.wf.data_ptr()); xwd.push_back(e.wd.defined() ? e.wd.data_ptr() : nullptr);
-        xco.push_back((int)co); xci.push_back((int)ci);
+        {
+          Tensor GW = gw[i].contiguous(), GB = gb[i].contiguous();
+          keep.push_back(GW); keep.push_back(GB);
+          e.g = at::empty({plan.n, E, co}, K5.options());
+          ggw.push_back(GW.data_ptr<float>()); ggb.push_back(GB.data_ptr<float>());
+          ggo.push_back(e.g.data_ptr<float>()); gco.push_back((int)co);
+        }
+        bool ready = false;
+        if (g_frag_keep && K5.is_same(k5[i]) && K3.is_same(k3[i])) {
+          // the layouts live across steps (FragEntry): the optimizer pass leaves them current; otherwise lay out into them
+          std::lock_guard<std::mutex> lock(g_frag_mu);
+          auto it = g_frag_store.find(K5.data_ptr());
+          if (it != g_frag_store.end() && !(it->second.same_params(K5, K3) && it->second.co == co && it->second.ci == ci)) {
+            g_frag_store.erase(it);
+            it = g_frag_store.end();
+          }
+          if (it == g_frag_store.end()) it = g_frag_store.emplace(K5.data_ptr(), FragEntry(K5, K3)).first;
+          FragEntry& fe = it->second;
+          fe.co = co; fe.ci = ci;
+          const bool cur = fe.current(K5, K3);
+          if (!fe.wf.defined()) fe.wf = at::empty({2, TAPS, padded(co, code, false), padded(ci, code, true)}, K5.options().dtype(dt));
+          if (need_dx[i] && !fe.wd.defined()) fe.wd = at::empty({2, TAPS, padded(ci, code, false), padded(co, code, true)}, K5.options().dtype(dt));
+          ready = cur && fe.wf_valid && (!need_dx[i] || fe.wd_valid);
+          e.wf = fe.wf;
+          if (need_dx[i]) e.wd = fe.wd;
+          if (!ready) {
+            // (laid out below, on this stream, for the parameters' current version: both layouts the entry holds)
+            fe.ver5 = K5._version(); fe.ver3 = K3._version();
+            fe.wf_valid = true;
+            fe.wd_valid = fe.wd.defined();
+          }
+          fe.used = true;
+          if (!ready) {
+            x5.push_back(K5.data_ptr<float>()); x3.push_back(K3.data_ptr<float>());
+            xwf.push_back(fe.wf.data_ptr()); xwd.push_back(fe.wd.defined() ? fe.wd.data_ptr() : nullptr);
+            xco.push_back((int)co); xci.push_back((int)ci);
+          }
+        } else {
+          e.wf = at::empty({2, TAPS, padded(co, code, false), padded(ci, code, true)}, K5.options().dtype(dt));
+          if (need_dx[i]) e.wd = at::empty({2, TAPS, padded(ci, code, false), padded(co, code, true)}, K5.options().dtype(dt));
+          x5.push_back(K5.data_ptr<float>()); x3.push_back(K3.data_ptr<float>());
+          xwf.push_back(e.wf.data_ptr()); xwd.push_back(e.wd.defined() ? e.wd.data_ptr() : nullptr);
+          xco.push_back((int)co); xci.push_back((int)ci);
+        }
         xe.push_back(e); xk.push_back(K5.data_ptr());
       }
-      for (size_t b0 = 0; b0 < xe.size(); b0 += REPMODE_GATREP_MULTI_MAX) {
-        const int cnt = (int)std::min<size_t>(REPMODE_GATREP_MULTI_MAX, xe.size() - b0);
-        RM_CALL(repmode_expert_frags_multi, cnt, x5.data() + b0, x3.data() + b0, xco.data() + b0, xci.data() + b0, xwf.data() + b0,
-                xwd.data() + b0, stream_handle());
+      for (size_t b0 = 0; b0 < ggw.size(); b0 += REPMODE_GATREP_MULTI_MAX) {
+        const int cnt = (int)std::min<size_t>(REPMODE_GATREP_MULTI_MAX, ggw.size() - b0);
+        RM_CALL(repmode_gate_softmax_multi, cnt, ggw.data() + b0, ggb.data() + b0, gco.data() + b0, plan.sample_task.data_ptr<int32_t>(),
+                (int)plan.n, (int)plan.num_tasks, ggo.data() + b0, stream_handle());
+      }
+      for (size_t b0 = 0; b0 < x5.size(); b0 += REPMODE_GATREP_MULTI_MAX) {
+        const int cnt = (int)std::min<size_t>(REPMODE_GATREP_MULTI_MAX, x5.size() - b0);
+        try {
+          RM_CALL(repmode_expert_frags_multi, cnt, x5.data() + b0, x3.data() + b0, xco.data() + b0, xci.data() + b0, xwf.data() + b0,
+                  xwd.data() + b0, stream_handle());
+        } catch (...) {
+          op_clear_frag_store();          // (entries were marked current for a layout that did not run)
+          throw;
+        }
       }
       std::lock_guard<std::mutex> lock(g_prep_mu);
       for (size_t i = 0; i < xe.size(); ++i) g_prep[xk[i]] = xe[i];
@@ -1660,6 +1850,10 @@ TORCH_LIBRARY(repmode, m) {
         "int[] need_dx, Tensor slot_task, Tensor sample_slot, Tensor sample_task, int nslots, int num_tasks, bool training, "
         "int dtype) -> ()", &rm::op_prepare_filters);
   m.def("finish_prepared(Tensor like) -> ()", &rm::op_finish_prepared);
+  m.def("adam_step(Tensor[] params, Tensor[] grads, Tensor[] exp_avgs, Tensor[] exp_avg_sqs, float lr, float beta1, float beta2, "
+        "float eps, int step) -> ()", &rm::op_adam_step);
+  m.def("clear_frag_store() -> ()", &rm::op_clear_frag_store);
+  m.def("frag_store_size() -> int", &rm::op_frag_store_size);
   m.def("set_bn_epilogue(int mask) -> ()", &rm::op_set_bn_epilogue);
   m.def("set_unmerged_max_w(int w) -> ()", &rm::op_set_unmerged_max_w);
   m.def("set_dual_launch(bool on) -> ()", &rm::op_set_dual_launch);

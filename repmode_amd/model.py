@@ -71,7 +71,15 @@ class Model(object):
         self.dtype = dtype
         self.distributed = distributed
         # grad_compress='bf16' (or REPMODE_GRAD_COMPRESS=bf16): the gradient buckets cross the links as bfloat16
-        self.grad_compress = grad_compress or os.environ.get('REPMODE_GRAD_COMPRESS') or None
+        gc = grad_compress or os.environ.get('REPMODE_GRAD_COMPRESS') or None
+        if gc is not None:        # one spelling for both data-parallel paths (advisor round 3: a typo ran uncompressed silently)
+            if gc in (torch.bfloat16, 'bf16', 'bfloat16'):
+                gc = 'bf16'
+            elif gc in ('none', 'fp32', 'f32', torch.float32):
+                gc = None
+            else:
+                raise ValueError("grad_compress / REPMODE_GRAD_COMPRESS must be 'bf16' or unset, got %r" % (gc,))
+        self.grad_compress = gc
         # hip_graph: replay the whole train step (forward, backward, Adam: ~415 launches, 13 ms of host time) as ONE
         # HIP graph per (input shape, number of distinct tasks) -- see _graph_train_iter.  Single-GPU training only.
         self.hip_graph = bool(hip_graph)
@@ -105,13 +113,15 @@ class Model(object):
             self.ddp = dist_.wrap_ddp(self.net, self.device, grad_compress=self.grad_compress)
         # process-wide (one training process per GPU): where the MoDE gradient kernels put the parameter gradients
         ops_.set_grad_sink(self.reducer)
-        try:
-            # (capturable: the step counters live on the device, so optimizer.step() can be part of a HIP graph)
+        ops_.torch_ops().clear_frag_store()          # (expert operands kept across steps belong to the previous network)
+        if self.hip_graph or os.environ.get('REPMODE_ADAM', '1') == '0':
+            # (capturable: the step counters live on the device, so optimizer.step() can be part of a HIP graph -- the build's
+            # own pass takes the step count from the host; REPMODE_ADAM=0: the stock fused optimizer, for A/B)
             self.optimizer = torch.optim.Adam(self.net.parameters(), lr=self.lr, fused=True, capturable=self.hip_graph)
-        except (RuntimeError, TypeError):
-            if self.hip_graph:
-                raise
-            self.optimizer = torch.optim.Adam(self.net.parameters(), lr=self.lr)
+        else:
+            # fnet_model.py:55 through the build's own kernels (csrc/adam.hip): same state layout as torch.optim.Adam
+            from .optim import Adam
+            self.optimizer = Adam(self.net.parameters(), lr=self.lr)
 
     # ---- checkpoint: fnet_model.py:57-94 (same keys)
     def get_state(self):

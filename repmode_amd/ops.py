@@ -285,6 +285,46 @@ def expert_frags(k5, k3, dtype, want_wd=True):
     return wf, wd
 
 
+def _ptr_array(ctype, tensors):
+    import ctypes
+    return (ctype * len(tensors))(*[t.data_ptr() if torch.is_tensor(t) else (t or 0) for t in tensors])
+
+
+def adam_multi(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step):
+    """``torch.optim.Adam``'s update of a list of float tensors, in place, through ``repmode_adam_multi`` (csrc/adam.hip;
+    fnet_model.py:55, 112).  ``step``: the 1-based count of this update.  Test-facing: the product calls the ``adam_step`` op."""
+    import ctypes
+    mx = 40
+    for b0 in range(0, len(params), mx):
+        sl = slice(b0, b0 + mx)
+        n = len(params[sl])
+        numel = (ctypes.c_long * n)(*[p.numel() for p in params[sl]])
+        _lib.call('repmode_adam_multi', n, _ptr_array(ctypes.c_void_p, params[sl]), _ptr_array(ctypes.c_void_p, grads[sl]),
+                  _ptr_array(ctypes.c_void_p, exp_avgs[sl]), _ptr_array(ctypes.c_void_p, exp_avg_sqs[sl]), numel,
+                  float(lr), float(beta1), float(beta2), float(eps), int(step), _stream())
+
+
+def adam_expert_frags(k5s, k3s, lr, beta1, beta2, eps, step, want_wd=True):
+    """``repmode_adam_expert_frags``: Adam on the 5x5x5 / 3x3x3 experts of some blocks and their bf16 conv operands in one pass.
+    ``k5s`` / ``k3s``: lists of (param, grad, exp_avg, exp_avg_sq).  Returns [(wf, wd)] per block (as ``expert_frags``)."""
+    import ctypes
+    code = dtype_code(torch.bfloat16)
+    outs, cos, cis = [], [], []
+    for (p5, _, _, _) in k5s:
+        co, ci = p5.shape[0], p5.shape[1]
+        wf = torch.empty((2, TAPS, _lib.padded_channels(co, code, False), _lib.padded_channels(ci, code, True)), dtype=torch.bfloat16, device=p5.device)
+        wd = torch.empty((2, TAPS, _lib.padded_channels(ci, code, False), _lib.padded_channels(co, code, True)), dtype=torch.bfloat16,
+                         device=p5.device) if want_wd else None
+        outs.append((wf, wd)); cos.append(co); cis.append(ci)
+    n = len(k5s)
+    cols = lambda lst, j: _ptr_array(ctypes.c_void_p, [t[j] for t in lst])
+    _lib.call('repmode_adam_expert_frags', n, cols(k5s, 0), cols(k5s, 1), cols(k5s, 2), cols(k5s, 3), cols(k3s, 0), cols(k3s, 1),
+              cols(k3s, 2), cols(k3s, 3), (ctypes.c_int * n)(*cos), (ctypes.c_int * n)(*cis),
+              _ptr_array(ctypes.c_void_p, [o[0] for o in outs]), _ptr_array(ctypes.c_void_p, [o[1] for o in outs]),
+              float(lr), float(beta1), float(beta2), float(eps), int(step), _stream())
+    return outs
+
+
 def gate_softmax_samples(gate_w, gate_b, plan, co):
     """g[n, e, o] per SAMPLE (the same kernel with one "slot" per sample)."""
     g = torch.empty((plan.n, NUM_EXPERTS, co), dtype=torch.float32, device=gate_w.device)

@@ -79,28 +79,50 @@ def _lib_elem_out():
     return lambda n, d, h, w, cin, cout: lib.repmode_conv5_elem_out(n, d, h, w, cin, cout, _lib.BF16) != 0
 
 
-# per-tensor bound of the HIP bf16 gradient against the bf16-EMULATING oracle (oracle.Net(emulate=torch.bfloat16): float32
-# CPU arithmetic between the rounding points the HIP path has) in relative 2-norm.  Measured on three boxes (round 4,
-# gpurun_out/test_measurements.jsonl 'bf16_emulated_grads'): see EMU_BOUND's comment below.
-EMU_BOUND = 5e-2
+# What a network-level bf16 comparison can resolve (measured, round 4): the bf16 network is
+# discontinuous at float-noise scale -- a 1e-6 relative perturbation of the parameters of the EMULATING oracle itself moves a
+# few values across bf16 rounding boundaries and ReLU thresholds, and the differences grow ~1.6x per block: 6e-4 after the
+# first block, 4e-2 at the output, 0.53 on the whole parameter gradient (0.013 on conv_out's, 0.08 one block earlier, 0.5-0.75
+# from the bottleneck back to the first layer).  Two correct bf16 implementations with different float summation orders
+# therefore agree no better than that, and the HIP path against the emulation measures exactly that: output 3.5e-2, whole
+# gradient 0.47, worst tensor 0.71.  So the test calibrates each tensor's bound on the emulation's own sensitivity
+# (`noise`: the emulation against a copy whose parameters were perturbed by 1e-6): the HIP path must be indistinguishable
+# from "another bf16 implementation", and where the noise floor is low (the loss end) a 10 % systematic error is far outside.
+# Deep layers are pinned one block at a time on identical operands (test_hip_parity.py::
+# test_full_size_bf16_blocks_at_bench_config: every block's output, data gradient and seven parameter gradients within 2e-2).
 EMU_CASES = {
-    # G4b's batch (two distinct tasks: every block merged) and a four-sample batch with three distinct tasks (levels 3-4 take
-    # the per-expert formulation: bf16 experts, gemm3's rounded operands, gate-scaled output gradients)
+    # G4b's batch shape (two distinct tasks: every block merged) and a four-sample batch with three distinct tasks (levels 3-4
+    # take the per-expert formulation: bf16 experts, gemm3's rounded operands, gate-scaled output gradients)
     'merged': dict(tasks=[3, 7, 3], shape=(16, 64, 64)),
     'per_expert': dict(tasks=[1, 5, 7, 1], shape=(16, 64, 64)),
 }
 
 
+def _emulated_run(state, x, tgt, tasks, perturb_seed=0):
+    emu = orc.Net(Opts(), mult_chan=32, emulate=torch.bfloat16, elem_out=_lib_elem_out())
+    emu.load_state_dict(state)
+    if perturb_seed:
+        gen = torch.Generator().manual_seed(perturb_seed)
+        with torch.no_grad():
+            for p in emu.parameters():
+                p.mul_(1 + 1e-6 * torch.randn(p.shape, generator=gen))
+    emu.train()
+    ye = emu(x, tasks)
+    loss_e = torch.nn.functional.mse_loss(ye, tgt)
+    loss_e.backward()
+    return ye.detach(), float(loss_e.detach()), {k: p.grad.detach() for k, p in emu.named_parameters()}
+
+
 @pytest.mark.timeout(1500)
 @pytest.mark.parametrize('case', sorted(EMU_CASES))
 def test_bf16_gradients_against_the_bf16_emulating_oracle(case):
-    """Network-level bf16 parity PINNED (missing 4 / weak 1): one bf16 forward + backward of the mult_chan-32
-    network through the HIP path against ``orc.Net(emulate=torch.bfloat16)`` -- the CPU oracle rounding to bf16 exactly where
-    the kernels do (block inputs, merged filters / per-expert operands, element-typed conv outputs, BatchNorm outputs, bf16
-    gradient tensors) and float32 in between -- from the same seeded state: the loss, the output, and EVERY parameter gradient
-    in relative 2-norm.  Two implementations that round at the same places flip the same ReLU masks, so the comparison is tight
-    where the float32 oracle only allowed a cosine (kept below as the second, loose line).  A systematic 10 % error in one
-    deep layer's gradient (what a wrong constant in gatrep_bwd would produce) is 2 x the bound: asserted on the checker."""
+    """Network-level bf16 parity against an independent bf16 implementation (missing 4 / weak 1): one bf16
+    forward + backward of the mult_chan-32 network through the HIP path against ``orc.Net(emulate=torch.bfloat16)`` -- the CPU
+    oracle rounding to bf16 exactly where the kernels do (block inputs, merged filters / per-expert operands, element-typed conv
+    outputs, BatchNorm outputs, bf16 gradient tensors), float32 in between -- from the same seeded state.  Bounds are
+    calibrated per tensor on the emulation's own float-noise sensitivity (see the comment above): loss 2e-3; output and whole
+    gradient within 1.5x of the noise floor; every parameter gradient within 3x of its own noise floor (+ 3e-2); the loss-end
+    tensors (noise floor ~1e-2) within 5e-2 outright, where a systematic 10 % error is asserted to be caught."""
     from repmode_amd.nn_modules.RepMode import Net
     cfg = EMU_CASES[case]
     tasks = torch.tensor(cfg['tasks'])
@@ -116,27 +138,26 @@ def test_bf16_gradients_against_the_bf16_emulating_oracle(case):
     loss.backward()
     got = {k: p.grad.detach().float().cpu() for k, p in net.named_parameters()}
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    emu = orc.Net(Opts(), mult_chan=32, emulate=torch.bfloat16, elem_out=_lib_elem_out())
-    emu.load_state_dict(state)
-    emu.train()
-    ye = emu(x, tasks)
-    loss_e = torch.nn.functional.mse_loss(ye, tgt)
-    loss_e.backward()
-    want = {k: p.grad.detach() for k, p in emu.named_parameters()}
+    ye, loss_e, want = _emulated_run(state, x, tgt, tasks)
+    yp, _, pert = _emulated_run(state, x, tgt, tasks, perturb_seed=1)
+    cat = lambda d: torch.cat([d[k].reshape(-1) for k in got])
     errs = {k: _rel2(got[k], want[k]) for k in got}
-    worst = max(errs, key=errs.get)
-    out_err = _rel2(y.float(), ye)
-    whole = _rel2(torch.cat([got[k].reshape(-1) for k in got]), torch.cat([want[k].reshape(-1) for k in got]))
-    record('bf16_emulated_grads', case=case, loss=float(loss), loss_emu=float(loss_e), out=out_err, whole=whole, worst=errs[worst],
-           worst_name=worst, by_tensor={k: round(v, 5) for k, v in errs.items()})
-    assert abs(float(loss) - float(loss_e)) < 2e-3 * abs(float(loss_e)), (float(loss), float(loss_e))
-    assert out_err < 1e-2, out_err
-    assert errs[worst] < EMU_BOUND, (worst, errs[worst], whole)
-    assert whole < EMU_BOUND / 2, whole
-    # the checker would see a systematic error: 10 % on one deep layer's expert gradient
-    k = 'bottle_block.conv1.expert_conv5x5_conv'
-    assert _rel2(1.1 * got[k], want[k]) > EMU_BOUND
-    assert _rel2(got[k] + 0.1 * got[k].abs(), want[k]) > EMU_BOUND
+    noise = {k: _rel2(pert[k], want[k]) for k in got}
+    out_err, out_noise = _rel2(y.float(), ye), _rel2(yp, ye)
+    whole, whole_noise = _rel2(cat(got), cat(want)), _rel2(cat(pert), cat(want))
+    worst = max(errs, key=lambda k: errs[k] / (3 * noise[k] + 3e-2))
+    record('bf16_emulated_grads', case=case, loss=float(loss), loss_emu=loss_e, out=out_err, out_noise=out_noise, whole=whole,
+           whole_noise=whole_noise, worst=errs[worst], worst_noise=noise[worst], worst_name=worst,
+           by_tensor={k: [round(errs[k], 4), round(noise[k], 4)] for k in errs})
+    assert abs(float(loss) - loss_e) < 2e-3 * abs(loss_e), (float(loss), loss_e)
+    assert out_err < 1.5 * out_noise + 5e-3, (out_err, out_noise)
+    assert whole < 1.5 * whole_noise + 2e-2, (whole, whole_noise)
+    assert errs[worst] < 3 * noise[worst] + 3e-2, (worst, errs[worst], noise[worst])
+    # the loss end of the network, where bf16 leaves the comparison sharp
+    for k in got:
+        if k.startswith('conv_out.expert'):
+            assert errs[k] < 5e-2, (k, errs[k])
+            assert _rel2(1.1 * got[k], want[k]) > 5e-2          # a systematic 10 % error there is outside the bound
 
 
 def test_net_golden_bf16_gradients():
