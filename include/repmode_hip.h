@@ -426,7 +426,9 @@ int repmode_get_conv_pipe(void);
  * the device's CU count and the switch above; the operator library asks it per layer and direction. */
 int repmode_conv5_elem_out(int n, int d, int h, int w, int cin, int cout, int dtype);
 /* The same kind of switch for the bf16 filter gradient's wave-specialised form (csrc/conv5_wgrad.hip; also REPMODE_WGRAD_WS):
- * 0 never, 1 where a workgroup has a long tile loop (default), 2 wherever the tile allows.  Results: the same sums; how the voxel
+ * 0 never, 1 where a workgroup has a long tile loop, 2 wherever the tile allows, 3 (default since round 4) as 1 + the stream-K
+ * form -- persistent workgroups that each take an equal range of the launch's tile-step sequence -- on volumes >= 32 voxels
+ * wide with at most 64 samples (slot layout, one job; never in deterministic mode).  Results: the same sums; how the voxel
  * range is split over workgroups (float atomics) follows the form. */
 int repmode_set_wgrad_ws(int mode);
 int repmode_get_wgrad_ws(void);

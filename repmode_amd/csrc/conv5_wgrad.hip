@@ -20,8 +20,8 @@
 
 namespace {
 // REPMODE_WGRAD_WS / repmode_set_wgrad_ws: the wave-specialised form of the bf16 filter gradient -- 0 never, 1 where a workgroup
-// has a long tile loop (default), 2 wherever the tile allows
-int g_wgrad_ws = []() { const char* e = getenv("REPMODE_WGRAD_WS"); return e ? atoi(e) : 1; }();
+// has a long tile loop, 2 wherever the tile allows, 3 (default, round 4) as 1 + the stream-K form where it is eligible
+int g_wgrad_ws = []() { const char* e = getenv("REPMODE_WGRAD_WS"); return e ? atoi(e) : 3; }();
 
 constexpr int TY = 4, TX = 16, TV = TY * TX;   // output voxels per tile
 constexpr int HY = TY + 4, HX = TX + 4, HV = HY * HX;
@@ -45,6 +45,10 @@ struct WgradArgs {
   // Second job of a dual launch (repmode_conv5_wgrad_dual, bf16 kernels): workgroups [grid0, gridDim) compute another
   // output gradient's filter gradient over the same input -- the 3x3x3 expert's beside the 5x5x5 expert's in the
   // per-expert formulation.  grid0 == 0: single job.
+  // Stream-K form of the wave-specialised kernel (round 4): > 0 = the launch's total number of tile steps; the grid is a set of
+  // persistent workgroups that each take an equal range of the global step sequence (see the kernel).  0: one (unit, chunk) per
+  // workgroup as planned by nchunks / tiles_per_block.
+  long sk_total;
   int grid0;
   const void* dy2;
   float* dw2;
@@ -301,12 +305,13 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
   }
   // the five dz workgroups of one voxel chunk read the same dy / x tiles: adjacent logical ids, and
   // xcd_remap keeps adjacent ids on one XCD, so they share those tiles through one L2
+  // (not const: the stream-K form walks several units per workgroup)
   int bid = xcd_remap(bid_raw, grid_n);
-  const int dz = a.dz_lo + bid % a.ndz; bid /= a.ndz;
-  const int chunk = bid % a.nchunks; bid /= a.nchunks;
-  const int cit = bid % a.ncit;      bid /= a.ncit;
-  const int cot = bid % a.ncot;
-  const int slot = bid / a.ncot;
+  int dz = a.dz_lo + bid % a.ndz; bid /= a.ndz;
+  const int chunk = bid % max(a.nchunks, 1); bid /= max(a.nchunks, 1);
+  int cit = bid % a.ncit;      bid /= a.ncit;
+  int cot = bid % a.ncot;
+  int slot = bid / a.ncot;
   const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
 
   f32x4 acc[25];
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
   // which samples belong to this workgroup's slot: one vector load + ballot for the first 64 samples instead of a
   // chain of dependent scalar loads (cold after the kernel boundary: ~2 us each before the first tile is fetched)
   const unsigned long long mine64 =
-      a.nslots == 1 ? ~0ull : __ballot(lane < a.N && a.sample_slot[min(lane, a.N - 1)] == slot);   // one slot: every sample
+      (a.nslots == 1 || (WS && a.sk_total > 0)) ? ~0ull : __ballot(lane < a.N && a.sample_slot[min(lane, a.N - 1)] == slot);   // one slot: every sample
   auto in_slot = [&](int n) -> bool {
     return n < 64 ? ((mine64 >> n) & 1ull) != 0 : (a.nslots == 1 || a.sample_slot[n] == slot);
   };
@@ -485,11 +490,125 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
         if (it < NIT_DY) put_pair(dyT + boff + (cg * 8) * DYS + q * 4, DYS, pd0[u], pd1[u]);
       }
     };
-    bool have = advance();
+    bool have = (WS && a.sk_total > 0) ? false : advance();      // (stream-K walks its own sequence)
 #ifdef RM_CONV_TIMING
     int tl_ = 0;
 #endif
     if constexpr (WS) {
+      if (a.sk_total > 0) {
+        // ---- stream-K (round 4): a launch is ONE sequence of tile steps -- units (slot, co tile, ci tile, dz plane) in the
+        // order of the regular grid, inside a unit the samples of its slot, inside a sample the tiles whose input plane
+        // exists for this dz -- and every workgroup (at most one per CU, all resident) takes an equal range of it.  A range
+        // crosses unit boundaries: the MFMA waves flush the 25 accumulator tiles at the end of a unit (plain stores when the
+        // whole unit ran here, float atomics onto the cleared dw when it is shared with a neighbour) and go on with the next
+        // tile, which the loader waves have staged meanwhile -- the 6 k cycles of prologue and 25-30 k cycles of atomics
+        // epilogue that every (unit, chunk) workgroup of the regular grid pays (a third of a level-1 workgroup's
+        // time) are paid once per workgroup / overlapped, and no round of the grid is partly empty.
+        static_assert(TZ == 1, "stream-K: one z plane per tile");
+        const int tpp = a.nty * a.ntx;                       // tiles of one z plane
+        const int G2 = a.ncot * a.ncit;
+        auto zlo = [&](int dzz) -> int { return max(0, 2 - dzz); };            // planes z with 0 <= z + dz - 2 < D
+        auto zhi = [&](int dzz) -> int { return max(zlo(dzz), min(D, D + 2 - dzz)); };
+        int VT = 0;
+        for (int i = 0; i < a.ndz; ++i) VT += (zhi(a.dz_lo + i) - zlo(a.dz_lo + i)) * tpp;
+        const int slot64 = a.sample_slot[min(lane, a.N - 1)];                 // (the host sends at most 64 samples here)
+        auto mask_of = [&](int sl) -> unsigned long long { return __ballot(lane < a.N && slot64 == sl); };
+        auto kth = [&](unsigned long long m, int kk) -> int {
+          for (int i = 0; i < kk; ++i) m &= m - 1;
+          return __ffsll((long long)m) - 1;
+        };
+        const long wg = xcd_remap(blockIdx.x, gridDim.x);    // neighbouring ranges (same operands' tiles) on one XCD
+        const long g0 = a.sk_total * wg / gridDim.x, g1 = a.sk_total * (wg + 1) / gridDim.x;
+        const int steps = (int)(g1 - g0);
+        if (steps <= 0) return;
+        // decode the first step
+        unsigned long long mask;
+        int cnt, dzi = 0, t_lo = 0, t_hi = 0, k = 0;
+        long rem = g0;
+        slot = 0;
+        for (;;) {
+          mask = mask_of(slot); cnt = __popcll(mask);
+          const long span = (long)cnt * VT * G2;
+          if (rem < span) break;
+          rem -= span; ++slot;
+        }
+        {
+          const long per = (long)cnt * VT;
+          const int grp = (int)(rem / per);
+          rem -= (long)grp * per;
+          cot = grp / a.ncit; cit = grp % a.ncit;
+        }
+        for (;;) {
+          dz = a.dz_lo + dzi; t_lo = zlo(dz) * tpp; t_hi = zhi(dz) * tpp;
+          const long span = (long)cnt * (t_hi - t_lo);
+          if (rem < span) break;
+          rem -= span; ++dzi;
+        }
+        k = (int)(rem / (t_hi - t_lo));
+        tile = t_lo + (int)(rem % (t_hi - t_lo));
+        n = kth(mask, k);
+        bool head = k == 0 && tile == t_lo;                 // the current unit started in this workgroup, at its first step
+        auto last_of_unit = [&]() -> bool { return tile + 1 >= t_hi && k + 1 >= cnt; };
+        auto next = [&]() {                                 // the following step of the sequence (never called behind the last)
+          if (++tile < t_hi) return;
+          if (++k < cnt) { n = kth(mask, k); tile = t_lo; return; }
+          k = 0;
+          do {
+            if (++dzi == a.ndz) {
+              dzi = 0;
+              if (++cit == a.ncit) {
+                cit = 0;
+                if (++cot == a.ncot) { cot = 0; ++slot; mask = mask_of(slot); cnt = __popcll(mask); }
+              }
+            }
+            dz = a.dz_lo + dzi; t_lo = zlo(dz) * tpp; t_hi = zhi(dz) * tpp;
+          } while (t_hi <= t_lo);
+          tile = t_lo;
+          n = kth(mask, 0);
+        };
+        int boff = 0;
+        if (loader) {
+          fetch();
+          for (int i = 0; i < steps; ++i) {
+            stage(boff);
+            if (i + 1 < steps) { next(); fetch(); }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            boff ^= LDS_SET;
+          }
+          return;
+        }
+        for (int i = 0; i < steps; ++i) {
+          asm volatile("s_barrier" ::: "memory");
+          mma_tile(boff);
+          boff ^= LDS_SET;
+          const bool last = last_of_unit();
+          if (last || i + 1 == steps) {
+            // 16x16 C/D layout: column (ci) = lane & 15, row (co) = (lane >> 4) * 4 + r
+            const bool atomic = !(head && last);
+            const int ci = cit * 32 + ciq * 16 + l15;
+            if (ci < Cin) {
+#pragma unroll
+              for (int t = 0; t < 25; ++t) {
+                const int tap = dz * 25 + t;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int co = cot * 32 + cq * 16 + kg * 4 + r;
+                  if (co < Cout) {
+                    float* p = a.dw + (((size_t)slot * REPMODE_TAPS + tap) * Cout + co) * a.CinTot + a.ci_off + ci;
+                    if (atomic) unsafeAtomicAdd(p, acc[t][r]);
+                    else *p = acc[t][r];
+                  }
+                }
+              }
+            }
+#pragma unroll
+            for (int t = 0; t < 25; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            head = true;
+          }
+          if (i + 1 < steps) next();
+        }
+        return;
+      }
       // both roles walk the same tile sequence; barrier k separates "tile k staged in buffer k & 1" from its MFMAs, and a
       // buffer is staged again only after the barrier behind the MFMAs that read it
       int boff = 0;
@@ -717,6 +836,29 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
     res[0] = (long)(per_cu > 0 ? per_cu : 1) * cus;
   }
   const long resident2 = res[0], resident3 = res[1], resident_ws = res[2];
+  // Stream-K form (see the kernel): merged-formulation launches (slot layout, one job) on volumes >= 32 voxels wide, at most 64
+  // samples (one ballot tells a wave its slot's samples).  REPMODE_WGRAD_WS / repmode_set_wgrad_ws = 3 (default): where
+  // eligible; 0-2 keep the regular grid (1: wave-specialised by tile count, 2: always).
+  if (TX >= 32 && TZ == 1 && ws_mode == 3 && vec && !a.dy2 && a.layout == 0 && n <= 64 && a.sample_slot && !repmode_deterministic()) {
+    long vt = 0;
+    for (int i = 0; i < a.ndz; ++i) {
+      const int dzz = a.dz_lo + i, lo = 2 - dzz > 0 ? 2 - dzz : 0, hi = a.D + 2 - dzz < a.D ? a.D + 2 - dzz : a.D;
+      if (hi > lo) vt += (long)(hi - lo) * a.nty * a.ntx;
+    }
+    const long total = (long)n * vt * a.ncot * a.ncit;
+    // at most one workgroup per CU (all resident: nobody waits for a slot), and no workgroup shorter than ~8 tile steps
+    long g = resident_ws < total / 8 ? resident_ws : total / 8;
+    if (g < 1) g = 1;
+    if (total > 0 && total < (1L << 40)) {
+      a.sk_total = total;
+      a.nchunks = 1; a.tiles_per_block = a.ntiles; a.direct = 0;
+      if (!a.prezeroed) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * REPMODE_TAPS * a.Cout * a.CinTot * sizeof(float), s));
+      repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, s);
+      if constexpr (TX >= 32 && TZ == 1)
+        hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true, false, true>), dim3((unsigned)g), dim3(512), 0, s, a);
+      return REPMODE_OK;
+    }
+  }
   const double ov = TX >= 32 ? 3.5 : 6.0;
   const double tiles = (double)a.ntiles * (n > a.nslots ? (double)n / a.nslots : 1.0);
   // best chunk count of a job of `ndz` planes on `resident` slots; returns its price

@@ -133,7 +133,8 @@ def get_conv_pipe():
 
 def set_wgrad_ws(mode):
     """The bf16 filter gradient's wave-specialised form (csrc/conv5_wgrad.hip): 0 never, 1 where a workgroup has a long tile
-    loop (default), 2 wherever the tile allows."""
+    loop, 2 wherever the tile allows, 3 (default) as 1 plus the stream-K form (persistent workgroups over the launch's
+    tile-step sequence) on the merged levels' launches that are eligible for it."""
     _lib.call('repmode_set_wgrad_ws', int(mode))
 
 

@@ -322,11 +322,53 @@ def test_conv5_wgrad_wave_specialised_vs_oracle(case):
     x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
     dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
     got = []
+    default = ops.get_wgrad_ws()
     try:
         for mode in (2, 0):
             ops.set_wgrad_ws(mode)
             got.append(ops.conv5_wgrad(x_cl, dy_cl, plan, cout).cpu())
     finally:
-        ops.set_wgrad_ws(1)
+        ops.set_wgrad_ws(default)
     assert rel_err(got[0], dw_ref) < TOL_BF16_ACC
     assert rel_err(got[0], got[1]) < 1e-4        # (float atomics in another order: ~1e-6 measured)
+
+
+WGRAD_SK_CASES = [
+    # (N, D, H, W, Cin, Cout, tasks): the stream-K form (round 4) -- ragged volumes, several (co, ci) tiles, slots with one,
+    # two and three samples, volumes so thin that the outer dz planes have no input plane at all (D = 2), one workgroup and many
+    (2, 6, 10, 40, 32, 32, [5, 9]),
+    (3, 5, 9, 35, 16, 48, [5, 9, 5]),
+    (2, 4, 16, 64, 64, 32, [1, 1]),
+    (6, 2, 8, 32, 40, 72, [3, 3, 7, 3, 0, 7]),
+    (1, 1, 4, 33, 8, 8, [2]),
+    (9, 8, 16, 32, 64, 64, [4, 4, 4, 8, 8, 1, 1, 1, 1]),
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_SK_CASES)
+def test_conv5_wgrad_stream_k_vs_oracle(case):
+    """The filter gradient's stream-K form (mode 3, the default where eligible: persistent wave-specialised workgroups that each
+    take an equal range of the launch's tile-step sequence, flushing the accumulators at unit boundaries) against the oracle and
+    against the regular grid (mode 0): same products, another split of the voxel sums over workgroups (float atomics)."""
+    ops = _ops()
+    n, d, h, w, cin, cout, tasks = case
+    gen = torch.Generator().manual_seed(sum(case[:6]) + 5)
+    plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+    x = torch.randn(n, cin, d, h, w, generator=gen).bfloat16().float()
+    dy = torch.randn(n, cout, d, h, w, generator=gen).bfloat16().float()
+    wt = torch.zeros(plan.nslots, cout, cin, 5, 5, 5, requires_grad=True)
+    slots = torch.tensor([plan.slot_task_host.index(t) for t in tasks])
+    (orc.conv_per_sample(x, wt[slots]) * dy).sum().backward()
+    dw_ref = wt.grad.reshape(plan.nslots, cout, cin, 125).permute(0, 3, 1, 2)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    got = []
+    default = ops.get_wgrad_ws()
+    try:
+        for mode in (3, 0):
+            ops.set_wgrad_ws(mode)
+            got.append(ops.conv5_wgrad(x_cl, dy_cl, plan, cout).cpu())
+    finally:
+        ops.set_wgrad_ws(default)
+    assert rel_err(got[0], dw_ref) < TOL_BF16_ACC
+    assert rel_err(got[0], got[1]) < 1e-4
