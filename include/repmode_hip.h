@@ -63,6 +63,12 @@ int repmode_abi_version(void);
  * between steps, not while launches of the library are being issued from another thread. */
 int repmode_set_deterministic(int on);
 int repmode_get_deterministic(void);
+/* Data-parallel training: the persistent grids of the convolution (conv5_ws_kernel) and of the stream-K filter gradient launch
+ * at most one workgroup per CU that holds it for the whole launch; `n` > 0 makes them launch on n CUs fewer, so that a
+ * communication kernel issued beside them (RCCL's all-reduce of a gradient bucket) finds free CUs at once instead of queueing
+ * behind the launch.  Also REPMODE_RESERVE_CUS; default 0.  Results do not depend on it. */
+int repmode_set_reserve_cus(int n);
+int repmode_get_reserve_cus(void);
 const char* repmode_last_error(void);
 /* name of device `dev`'s gcnArchName into buf; REPMODE_ENODEV when there is none */
 int repmode_device_arch(int dev, char* buf, int buflen);

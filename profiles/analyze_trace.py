@@ -48,6 +48,7 @@ def main():
 
 FAMILIES = [('conv5_deep level 3 (per-expert pair)', 'conv5_deep_kernel<DCfg<4, 8, 8'), ('conv5_deep level 4 (per-expert pair)', 'conv5_deep_kernel<DCfg<2, 4, 4'),
             ('thin layers (own kernels)', 'thin_in1_kernel'), ('thin layers (own kernels)', 'thin_out1_kernel'),
+            ('conv5_ws level 2 (16-voxel bricks)', ('conv5_ws_kernel', ', 16>')),
             ('conv5_ws level 0-1 (wave-specialised)', 'conv5_ws_kernel'), ('conv5_pipe level 0-1', 'conv5_pipe_kernel'),
             ('conv5_igemm level 0-1', 'conv5_igemm_kernel<unsigned short, Cfg<4, 4, 32'),
             ('conv5_igemm level 2', 'conv5_igemm_kernel<unsigned short, Cfg<4, 4, 16'),
@@ -57,7 +58,7 @@ FAMILIES = [('conv5_deep level 3 (per-expert pair)', 'conv5_deep_kernel<DCfg<4, 
             ('conv5_wgrad level 3', 'conv5_wgrad_bf16_kernel<2, 8, 8'), ('conv5_wgrad level 4', 'conv5_wgrad_bf16_kernel<2, 4, 8'),
             ('conv5_wgrad_thin', 'wgrad_thin'), ('gatrep_fwd', 'gatrep_fwd'), ('gatrep_bwd', 'gatrep_bwd'),
             ('expert_frags', 'expert_frags'), ('gate softmax / backward', 'gate_'), ('BatchNorm+ReLU', 'bn_'),
-            ('k2s2 (stride-2 stages)', 'k2'), ('Adam (fused)', 'FusedAdam'), ('box_sum', 'box_sum'),
+            ('k2s2 (stride-2 stages)', 'k2'), ('Adam (torch fused)', 'FusedAdam'), ('Adam + expert operands (adam.hip)', 'adam_'), ('box_sum', 'box_sum'),
             ('expert_mix', 'expert_mix'), ('tap_transpose', 'tap_transpose'), ('thin-layer helpers', 'shift5'),
             ('thin-layer helpers', 'thin_pack'), ('1x1 experts (gemm3)', 'gemm3'), ('box_sum', 'box_expand'),
             ('loss (fused MSE)', 'mse_'), ('crop + flip', 'crop_flip'), ('rocBLAS', 'Cijk'), ('cat', 'CatArray'),
@@ -94,7 +95,7 @@ def families(tr):
             idle += max(0, int(b['Start_Timestamp']) - int(a['End_Timestamp'])) / 1e3
         for r in step:
             name = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
-            fam = next((f for f, pat in FAMILIES if pat in name), 'other')
+            fam = next((f for f, pat in FAMILIES if (all(q in name for q in pat) if isinstance(pat, tuple) else pat in name)), 'other')
             t[fam] = t.get(fam, 0.0) + (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
             c[fam] = c.get(fam, 0) + 1
     tot = sum(t.values()) / n

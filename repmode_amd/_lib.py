@@ -27,6 +27,8 @@ _SIGNATURES = {
     'repmode_device_arch': [_I, _c.c_char_p, _I],
     'repmode_set_deterministic': [_I],
     'repmode_get_deterministic': [],
+    'repmode_set_reserve_cus': [_I],
+    'repmode_get_reserve_cus': [],
     'repmode_set_conv_pipe': [_I],
     'repmode_get_conv_pipe': [],
     'repmode_conv5_elem_out': [_I] * 7,

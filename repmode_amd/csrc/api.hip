@@ -30,6 +30,14 @@ int repmode_det_cap(int site) {
 extern "C" int repmode_set_deterministic(int on) { g_deterministic = on ? 1 : 0; return REPMODE_OK; }
 extern "C" int repmode_get_deterministic(void) { return g_deterministic; }
 
+// CUs the persistent grids (conv5_ws_kernel, the stream-K filter gradient: at most one workgroup per CU) leave free -- room for
+// a communication kernel beside them (data-parallel training: RCCL's all-reduce kernels otherwise queue behind a launch whose
+// workgroups hold every CU for its whole duration).  REPMODE_RESERVE_CUS / repmode_set_reserve_cus; 0 by default.
+static int g_reserve_cus = []() { const char* e = std::getenv("REPMODE_RESERVE_CUS"); return e ? std::atoi(e) : 0; }();
+int repmode_reserve_cus() { return g_reserve_cus; }
+extern "C" int repmode_set_reserve_cus(int n) { g_reserve_cus = n > 0 ? n : 0; return REPMODE_OK; }
+extern "C" int repmode_get_reserve_cus(void) { return g_reserve_cus; }
+
 extern "C" int repmode_abi_version(void) { return REPMODE_ABI_VERSION; }
 extern "C" const char* repmode_last_error(void) { return g_err; }
 

@@ -101,6 +101,8 @@ bool repmode_deterministic();
 // 16 expert_mix, 32 BatchNorm, 64 filter gradient
 enum { RM_DET_CONV = 1, RM_DET_GEMM3 = 2, RM_DET_K2S2 = 4, RM_DET_MSE = 8, RM_DET_MIX = 16, RM_DET_BN = 32, RM_DET_WGRAD = 64 };
 int repmode_det_cap(int site);
+// CUs the persistent grids leave free (api.hip: REPMODE_RESERVE_CUS / repmode_set_reserve_cus)
+int repmode_reserve_cus();
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

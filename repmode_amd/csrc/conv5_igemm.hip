@@ -1679,7 +1679,8 @@ int device_cus() {
     if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
     cus_of[dev & 31].store(c, std::memory_order_relaxed);
   }
-  return c;
+  const int r = repmode_reserve_cus();           // (CUs left free for a communication kernel beside the persistent grid)
+  return c - r > 8 ? c - r : (c > 8 ? 8 : c);
 }
 
 // The shape side of the pipelined form's eligibility (what does not depend on the call's epilogue / tap flags): the brick

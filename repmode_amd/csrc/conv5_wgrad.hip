@@ -16,6 +16,7 @@
 // with f32 atomics (split-K over voxel chunks and over the samples of a slot).
 #include "common.h"
 
+#include <cmath>
 #include <cstdlib>
 
 namespace {
@@ -824,8 +825,8 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
     int per_cu = 0, cus = 0;
     RM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (cus <= 0) cus = 256;
-    if (TX >= 32) {
-      RM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv5_wgrad_bf16_kernel<TZ, TY, TX, true, false, TX >= 32>, 512, 0));
+    if constexpr (TX >= 16 && TZ == 1) {          // (the wave-specialised instantiation: one workgroup per CU)
+      RM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv5_wgrad_bf16_kernel<TZ, TY, TX, true, false, true>, 512, 0));
       res[2] = (long)(per_cu > 0 ? per_cu : 1) * cus;
     }
     if (TX == 16) {
@@ -839,22 +840,31 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   // Stream-K form (see the kernel): merged-formulation launches (slot layout, one job) on volumes >= 32 voxels wide, at most 64
   // samples (one ballot tells a wave its slot's samples).  REPMODE_WGRAD_WS / repmode_set_wgrad_ws = 3 (default): where
   // eligible; 0-2 keep the regular grid (1: wave-specialised by tile count, 2: always).
-  if (TX >= 32 && TZ == 1 && ws_mode == 3 && vec && !a.dy2 && a.layout == 0 && n <= 64 && a.sample_slot && !repmode_deterministic()) {
+  if (TX >= 16 && TZ == 1 && ws_mode == 3 && vec && !a.dy2 && a.layout == 0 && n <= 64 && a.sample_slot && !repmode_deterministic() &&
+      resident_ws > 0) {
     long vt = 0;
     for (int i = 0; i < a.ndz; ++i) {
       const int dzz = a.dz_lo + i, lo = 2 - dzz > 0 ? 2 - dzz : 0, hi = a.D + 2 - dzz < a.D ? a.D + 2 - dzz : a.D;
       if (hi > lo) vt += (long)(hi - lo) * a.nty * a.ntx;
     }
     const long total = (long)n * vt * a.ncot * a.ncit;
-    // at most one workgroup per CU (all resident: nobody waits for a slot), and no workgroup shorter than ~8 tile steps
-    long g = resident_ws < total / 8 ? resident_ws : total / 8;
+    // Workgroups: at most one per CU (all resident: nobody waits for a slot), none shorter than ~8 tile steps, and no more
+    // than the float atomics can follow: a workgroup shares at most the first and the last unit of its range with a
+    // neighbour -- two flushes of 25 x 32 x 32 floats through memory-side atomics that run at ~1.2 TB/s
+    // (profiles/r03_atomics.txt): 0.17 us of the chip's atomic throughput per workgroup, against total / g tile steps of
+    // KSTEPS x 25 MFMAs (16 cycles each, ~1.6 GHz under load) each.
+    const double t_step = (double)(TZ * TY * TX / 32) * 25.0 * 16.0 / 1600.0, t_atomic = 2.0 * 25.0 * 32.0 * 32.0 * 4.0 / 1.23e6;
+    long g = (long)std::sqrt((double)total * t_step / t_atomic);
+    const long room = resident_ws - repmode_reserve_cus() > 8 ? resident_ws - repmode_reserve_cus() : 8;   // (CUs left to a communication kernel)
+    if (g > room) g = room;
+    if (g > total / 8) g = total / 8;
     if (g < 1) g = 1;
     if (total > 0 && total < (1L << 40)) {
       a.sk_total = total;
       a.nchunks = 1; a.tiles_per_block = a.ntiles; a.direct = 0;
       if (!a.prezeroed) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * REPMODE_TAPS * a.Cout * a.CinTot * sizeof(float), s));
       repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, s);
-      if constexpr (TX >= 32 && TZ == 1)
+      if constexpr (TX >= 16 && TZ == 1)
         hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true, false, true>), dim3((unsigned)g), dim3(512), 0, s, a);
       return REPMODE_OK;
     }
@@ -909,7 +919,7 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, s);
   // (levels with W < 16 hand a workgroup only a tile or two per sample: nothing to overlap, and the plain loop is ~15 % faster there)
   if (ws)
-    hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true, false, TX >= 32>), dim3((unsigned)grid), dim3(TX >= 32 ? 512 : 256), 0, s, a);
+    hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true, false, TX >= 32>), dim3((unsigned)grid), dim3(TX >= 32 ? 512 : 256), 0, s, a);      // (ws is only ever set for TX >= 32)
   else if (vec && dense)
     hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true, TX == 16>), dim3((unsigned)grid), dim3(256), 0, s, a);
   else if (vec)

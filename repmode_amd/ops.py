@@ -118,6 +118,16 @@ def get_deterministic():
     return bool(_lib.load().repmode_get_deterministic())
 
 
+def set_reserve_cus(n):
+    """CUs the persistent grids (conv5_ws_kernel, the stream-K filter gradient) leave free for a communication kernel beside
+    them (``repmode_set_reserve_cus``; also REPMODE_RESERVE_CUS).  Results do not depend on it."""
+    _lib.call('repmode_set_reserve_cus', int(n))
+
+
+def get_reserve_cus():
+    return int(_lib.load().repmode_get_reserve_cus())
+
+
 def set_conv_pipe(mode):
     """The convolution's pipelined one-wave-per-SIMD form on volumes 32 or more voxels wide (csrc/conv5_igemm.hip,
     ``conv5_pipe_kernel`` / ``conv5_ws_kernel``): bit 0 on, bit 1 one channel sub-tile per wave everywhere, bit 2 also on grids

@@ -342,6 +342,10 @@ WGRAD_SK_CASES = [
     (6, 2, 8, 32, 40, 72, [3, 3, 7, 3, 0, 7]),
     (1, 1, 4, 33, 8, 8, [2]),
     (9, 8, 16, 32, 64, 64, [4, 4, 4, 8, 8, 1, 1, 1, 1]),
+    # volumes 16..31 voxels wide (the 1 x 8 x 16 tile: level 2 of the network)
+    (8, 8, 16, 16, 64, 128, [0, 1, 2, 3, 4, 5, 6, 7]),
+    (2, 6, 10, 20, 32, 32, [5, 9]),
+    (3, 5, 9, 17, 16, 48, [5, 9, 5]),
 ]
 
 
