@@ -110,6 +110,7 @@ struct ConvArgs {
   void* y;
   int N, D, H, W, Cin, Cout, CinP, CoutP;
   int nbz, nby, nbx, ncot, ksplit;
+  int ksplit2;         // dual-expert launch (round 4): the 3x3x3 job's own split factor (0: one factor for both jobs, round 3's grid)
   int out_f32;  // 0: store as T; 1: float output (SWAP kernels; atomicAdd when ksplit > 1)
   int tap_lo, tap_hi;  // dz and dy are restricted to [tap_lo, tap_hi] (0..4: full filter; 1..3: a 3x3 support)
   int accum;           // float output only: add to y (atomics, y is not cleared) instead of overwriting it
@@ -203,12 +204,21 @@ __global__ __launch_bounds__(C::NT, (C::BX == 16 && !MERGE) ? RM_CONV_X16_WAVES 
   }
   const int conv_block = blockIdx.x - a.tail.nblocks, conv_blocks = gridDim.x - a.tail.nblocks;
   int bid = xcd_remap(conv_block, conv_blocks);
-  const int kz = bid % a.ksplit;  bid /= a.ksplit;
+  // Dual-expert launch with per-job split factors (round 4): the 5x5x5 job is 125 taps, the centred 3x3x3 job 45 -- with one
+  // factor for both, the 3x3x3 job's workgroups finish in a third of the launch and their CUs idle.  Here a (brick, channel
+  // tile) owns ksplit + ksplit2 consecutive workgroups: the first ksplit split the 5x5x5 job's channel chunks, the others
+  // the 3x3x3 job's (neighbours: they stage the same halo bricks, one XCD's L2 serves both).
+  const bool two_ks = a.dual && a.ksplit2 > 0;
+  const int per_unit = two_ks ? a.ksplit + a.ksplit2 : a.ksplit;
+  const int j = bid % per_unit;  bid /= per_unit;
+  const bool second_ks = two_ks && j >= a.ksplit;
+  const int ksplit = second_ks ? a.ksplit2 : a.ksplit;
+  const int kz = second_ks ? j - a.ksplit : j;
   const int cot = bid % a.ncot;   bid /= a.ncot;
   const int bx = bid % a.nbx;     bid /= a.nbx;
   const int by = bid % a.nby;     bid /= a.nby;
   const int bz = bid % a.nbz;
-  const int nv = bid / a.nbz;                            // (virtual) sample of this workgroup
+  const int nv = two_ks ? bid / a.nbz + (second_ks ? a.N : 0) : bid / a.nbz;     // (virtual) sample of this workgroup
   const bool second = a.dual && nv >= a.N;               // dual launch: the 3x3x3 expert's job
   const int n = (a.dual && !(a.dual & 2)) ? (second ? nv - a.N : nv) : nv;      // input sample
   const int n_out = (a.dual && !(a.dual & 4)) ? (second ? nv - a.N : nv) : nv;  // output sample
@@ -258,8 +268,8 @@ __global__ __launch_bounds__(C::NT, (C::BX == 16 && !MERGE) ? RM_CONV_X16_WAVES 
       for (int r = 0; r < 16; ++r) acc[cs][vs][r] = 0.f;
 
   const int nchunks = CinP / KC;
-  const int c_begin = (int)((long)kz * nchunks / a.ksplit);
-  const int c_end = (int)((long)(kz + 1) * nchunks / a.ksplit);
+  const int c_begin = (int)((long)kz * nchunks / ksplit);
+  const int c_end = (int)((long)(kz + 1) * nchunks / ksplit);
   const bool vec_ok = (Cin % KV) == 0;
 
 #ifdef RM_CONV_DMA
@@ -774,7 +784,7 @@ __global__ __launch_bounds__(C::NT, (C::BX == 16 && !MERGE) ? RM_CONV_X16_WAVES 
           const int cw = Cout1 > 0 ? (out2 ? Cout - Cout1 : Cout1) : Cout;
           float* yp = static_cast<float*>(out2 ? a.y2 : a.y) + (((size_t)(n_out * D + gz) * H + gy) * W + gx) * cw +
                       (out2 ? co - Cout1 : co);
-          if (a.ksplit > 1 || a.accum || (a.dual && !(a.dual & 4))) {
+          if (ksplit > 1 || a.accum || (a.dual && !(a.dual & 4))) {
             unsafeAtomicAdd(yp, acc[cs][vs][r]);
           } else {
             float v = acc[cs][vs][r];
@@ -1798,9 +1808,28 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
   }
   RM_REQUIRE(!a.stats || !SWAP, "conv5: output statistics need the element-typed output path (bf16 input, not out_f32)");
   a.ksplit = ks;
+  a.ksplit2 = 0;
+  long nblocks = base * ks;
+  // dual-expert launch: per-job split factors (see the kernel) -- the 5x5x5 job twice as finely split as the 3x3x3 job where
+  // it still leaves a workgroup a whole chunk and the grid stays within two workgroups per CU.  Built, measured, OFF
+  // (REPMODE_DUAL_KS=1 to try; same box, interleaved, us per forward launch one factor / per-job factors,
+  // profiles/r04_dual_ks.txt): level 3 128->256 42.2 / 43.9, 256->256 60.8 / 59.9, 512->256 111.3 / 104.7; level 4 256->512
+  // 28.0 / 39.6, 512->512 47.5 / 82.5; train step 10.24 / 10.28 ms.  The 5x5x5 job's extra slices pay a halo staging and a
+  // tile of float atomics each; on level 4 (one 32-voxel brick per sample) that is most of a workgroup's time.
+  static const int dual_ks = []() { const char* e = getenv("REPMODE_DUAL_KS"); return e ? atoi(e) : 0; }();
+  if (a.dual && dual_ks && SWAP && !repmode_deterministic()) {
+    const long per_job = base / 2;                        // (brick, channel tile) units of one job
+    int k3 = ks, k5 = ks;
+    if (2 * ks <= nchunks && per_job * 3 * ks <= 2 * device_cus()) k5 = 2 * ks;                 // finer 5x5x5 job, same 3x3x3 job
+    else if (ks >= 2) k3 = ks / 2;                                                              // coarser 3x3x3 job
+    if (k5 != k3) {
+      a.ksplit = k5; a.ksplit2 = k3;
+      nblocks = per_job * (k5 + k3);
+    }
+  }
   // small jobs deferred to this launch (tail_jobs.h) become its first workgroups
   repmode_tail_take(stream, &a.tail);
-  const long grid = base * ks + a.tail.nblocks;
+  const long grid = nblocks + a.tail.nblocks;
   RM_REQUIRE(grid > 0 && grid < (1L << 31), "conv5: grid %ld out of range", grid);
   constexpr int LDS_BYTES = C::LDS_BYTES > TAIL_LDS_BYTES ? C::LDS_BYTES : TAIL_LDS_BYTES;   // (level 4's tile is smaller than a job's)
   const int lds_bytes = a.tail.nblocks ? LDS_BYTES : C::LDS_BYTES;
@@ -1813,7 +1842,7 @@ int launch_cfg(ConvArgs a, hipStream_t stream) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
   }
-  if ((ks > 1 || (a.dual && !(a.dual & 4))) && !a.accum) {
+  if ((ks > 1 || a.ksplit > 1 || (a.dual && !(a.dual & 4))) && !a.accum) {
     const size_t vox = (size_t)((a.dual & 4) ? 2 * a.N : a.N) * a.D * a.H * a.W;
     RM_HIP(hipMemsetAsync(a.y, 0, vox * (a.Cout1 > 0 ? a.Cout1 : a.Cout) * sizeof(float), stream));
     if (a.Cout1 > 0) RM_HIP(hipMemsetAsync(a.y2, 0, vox * (a.Cout - a.Cout1) * sizeof(float), stream));

@@ -416,7 +416,9 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
   if constexpr (VEC) {
     constexpr int NX = (NIT_X + 255) / 256, NDY = (NIT_DY + 255) / 256;
     constexpr uint32_t OOB = 0x80000000u;
-    u32x4 px0[NX], px1[NX], pd0[NDY], pd1[NDY];
+    // a tile's fetched operands on their way to LDS (the stream-K loader waves keep TWO tiles in flight: sets a and b)
+    struct TileRegs { u32x4 x0[NX], x1[NX], d0[NDY], d1[NDY]; };
+    TileRegs ra, rb;
 
     // work sequence: (sample of this slot, tile of this chunk), skipping tiles whose input planes for this dz are
     // all padding.  Everything here is wave-uniform (scalar loads of sample_slot).
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
         if (!(z0 + TZ - 1 + dz - 2 < 0 || z0 + dz - 2 >= D)) return true;
       }
     };
-    auto fetch = [&]() {
+    auto fetch_to = [&](TileRegs& tr) {
       const int txi = tile % a.ntx, t2 = tile / a.ntx;
       const int tyi = t2 % a.nty, tzi = t2 / a.nty;
       const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
@@ -453,9 +455,9 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
         const int c = cit * 32 + cg * 8;
         const bool row_ok = it < NIT_X && (unsigned)zin < (unsigned)D && (unsigned)gy < (unsigned)H && c < Cin;
         const uint32_t off = (uint32_t)((((zin * H + gy) * W + gx) * Cin + c) * 2);
-        px0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+        tr.x0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                      rx, (row_ok && (unsigned)gx < (unsigned)W) ? off : OOB, 0, 0));
-        px1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+        tr.x1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                      rx, (row_ok && (unsigned)(gx + 1) < (unsigned)W) ? off + (uint32_t)Cin * 2 : OOB, 0, 0));
       }
 #pragma unroll
@@ -468,12 +470,12 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
         const int c = cot * 32 + cg * 8;
         const bool row_ok = it < NIT_DY && gz < D && gy < H && c < Cout;
         const uint32_t off = (uint32_t)((((gz * H + gy) * W + gx) * Cout + c) * 2);
-        pd0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (row_ok && gx < W) ? off : OOB, 0, 0));
-        pd1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+        tr.d0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (row_ok && gx < W) ? off : OOB, 0, 0));
+        tr.d1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                      rdy, (row_ok && gx + 1 < W) ? off + (uint32_t)Cout * 2 : OOB, 0, 0));
       }
     };
-    auto stage = [&](int boff) {
+    auto stage_from = [&](TileRegs& tr, int boff) {
       int tid_ = tid;
       asm volatile("" : "+v"(tid_));
 #pragma unroll
@@ -482,15 +484,17 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
         const int p = it % NPAIR; int r = it / NPAIR;
         const int cg = r & 3; r >>= 2;
         const int hy = r % HY, zz = r / HY;
-        if (it < NIT_X) put_x_pair(cg, zz * HY + hy, p, px0[u], px1[u], boff);
+        if (it < NIT_X) put_x_pair(cg, zz * HY + hy, p, tr.x0[u], tr.x1[u], boff);
       }
 #pragma unroll
       for (int u = 0; u < NDY; ++u) {
         const int it = u * 256 + tid_;
         const int q = it % (TV / 2), cg = it / (TV / 2);
-        if (it < NIT_DY) put_pair(dyT + boff + (cg * 8) * DYS + q * 4, DYS, pd0[u], pd1[u]);
+        if (it < NIT_DY) put_pair(dyT + boff + (cg * 8) * DYS + q * 4, DYS, tr.d0[u], tr.d1[u]);
       }
     };
+    auto fetch = [&]() { fetch_to(ra); };
+    auto stage = [&](int boff) { stage_from(ra, boff); };
     bool have = (WS && a.sk_total > 0) ? false : advance();      // (stream-K walks its own sequence)
 #ifdef RM_CONV_TIMING
     int tl_ = 0;
@@ -569,12 +573,22 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
         };
         int boff = 0;
         if (loader) {
-          fetch();
-          for (int i = 0; i < steps; ++i) {
-            stage(boff);
-            if (i + 1 < steps) { next(); fetch(); }
+          // two tiles in flight (register sets a / b): a tile step is 1.6 k (16-voxel tile) .. 3.2 k MFMA cycles, a fetch from
+          // HBM / Infinity Cache 2-3 k -- with one tile ahead the level-2 launches ran at the loaders' pace (round 4: 90 us
+          // stream-K against 83 us regular on 128 -> 128)
+          fetch_to(ra);
+          if (steps > 1) { next(); fetch_to(rb); }
+          for (int i = 0; i < steps; i += 2) {
+            stage_from(ra, boff);
+            if (i + 2 < steps) { next(); fetch_to(ra); }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             boff ^= LDS_SET;
+            if (i + 1 < steps) {
+              stage_from(rb, boff);
+              if (i + 3 < steps) { next(); fetch_to(rb); }
+              asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+              boff ^= LDS_SET;
+            }
           }
           return;
         }
@@ -840,8 +854,15 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   // Stream-K form (see the kernel): merged-formulation launches (slot layout, one job) on volumes >= 32 voxels wide, at most 64
   // samples (one ballot tells a wave its slot's samples).  REPMODE_WGRAD_WS / repmode_set_wgrad_ws = 3 (default): where
   // eligible; 0-2 keep the regular grid (1: wave-specialised by tile count, 2: always).
-  if (TX >= 16 && TZ == 1 && ws_mode == 3 && vec && !a.dy2 && a.layout == 0 && n <= 64 && a.sample_slot && !repmode_deterministic() &&
-      resident_ws > 0) {
+  // The 16-voxel tile (level 2): a tile step is 100 MFMAs = 1.6 k cycles, about what four loader waves need to fetch AND
+  // transpose a tile (~150 VALU operations + 23 ds_write_b32 per thread), so stream-K runs at the loaders' pace there:
+  // same box, us per launch regular / stream-K (profiles/r04_wgrad_sk.txt): 64 -> 128 (320 units) 79.7 / 64.9, but 128 -> 128
+  // (640 units: the regular grid is one full round of the three-per-CU form) 79.6 / 85-91.  REPMODE_WGRAD_SK16: 0 never,
+  // 1 (default) below 512 units, 2 always.
+  static const int sk16 = []() { const char* e = getenv("REPMODE_WGRAD_SK16"); return e ? atoi(e) : 1; }();
+  const long sk_units = (long)a.nslots * a.ncot * a.ncit * a.ndz;
+  if (TX >= 16 && (TX >= 32 || sk16 == 2 || (sk16 == 1 && sk_units < 512)) && TZ == 1 && ws_mode == 3 && vec && !a.dy2 && a.layout == 0 && n <= 64 && a.sample_slot &&
+      !repmode_deterministic() && resident_ws > 0) {
     long vt = 0;
     for (int i = 0; i < a.ndz; ++i) {
       const int dzz = a.dz_lo + i, lo = 2 - dzz > 0 ? 2 - dzz : 0, hi = a.D + 2 - dzz < a.D ? a.D + 2 - dzz : a.D;
