@@ -1461,6 +1461,13 @@ void op_clear_frag_store() {
   std::lock_guard<std::mutex> lock(g_frag_mu);
   g_frag_store.clear();
 }
+// (a model whose train step is replayed as a HIP graph switches the store off: a replay updates the parameters with no
+// version counter and no optimizer hook to say so)
+void op_set_frag_store(bool on) {
+  std::lock_guard<std::mutex> lock(g_frag_mu);
+  g_frag_keep = on;
+  if (!on) g_frag_store.clear();
+}
 int64_t op_frag_store_size() {
   std::lock_guard<std::mutex> lock(g_frag_mu);
   return (int64_t)g_frag_store.size();
@@ -1589,6 +1596,10 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
       std::vector<int> xco, xci;
       std::vector<PrepEntry> xe;
       std::vector<void*> xk;
+      // (under stream capture the operands are the graph's own tensors: what a replay writes cannot be tracked by versions)
+      hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(c10::hip::getCurrentHIPStream(k5[0].device().index()).stream(), &cap_status);
+      const bool capturing = cap_status != hipStreamCaptureStatusNone;
       std::vector<const float*> ggw, ggb;       // the per-expert blocks' gates (per SAMPLE), all from one launch
       std::vector<float*> ggo;
       std::vector<int> gco;
@@ -1609,7 +1620,7 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
           ggo.push_back(e.g.data_ptr<float>()); gco.push_back((int)co);
         }
         bool ready = false;
-        if (g_frag_keep && K5.is_same(k5[i]) && K3.is_same(k3[i])) {
+        if (g_frag_keep && !capturing && K5.is_same(k5[i]) && K3.is_same(k3[i])) {
           // the layouts live across steps (FragEntry): the optimizer pass leaves them current; otherwise lay out into them
           std::lock_guard<std::mutex> lock(g_frag_mu);
           auto it = g_frag_store.find(K5.data_ptr());
@@ -1853,6 +1864,7 @@ TORCH_LIBRARY(repmode, m) {
   m.def("adam_step(Tensor[] params, Tensor[] grads, Tensor[] exp_avgs, Tensor[] exp_avg_sqs, float lr, float beta1, float beta2, "
         "float eps, int step) -> ()", &rm::op_adam_step);
   m.def("clear_frag_store() -> ()", &rm::op_clear_frag_store);
+  m.def("set_frag_store(bool on) -> ()", &rm::op_set_frag_store);
   m.def("frag_store_size() -> int", &rm::op_frag_store_size);
   m.def("set_bn_epilogue(int mask) -> ()", &rm::op_set_bn_epilogue);
   m.def("set_unmerged_max_w(int w) -> ()", &rm::op_set_unmerged_max_w);

@@ -249,3 +249,44 @@ def test_task_plan_index_vectors_share_one_buffer():
     # eval mode: one slot (the first sample's task), RepMode.py:209-210
     ev = ops.TaskPlan(torch.tensor(tasks), 12, 'cpu', training=False)
     assert ev.nslots == 1 and ev.slot_task.tolist() == [7] and ev.sample_slot.tolist() == [0] * len(tasks)
+
+
+def test_adam_bookkeeping_and_state_dict_interchange(monkeypatch):
+    """repmode_amd.optim.Adam on the host side (the kernels are the GPU tests'): it IS a torch.optim.Adam -- same state keys,
+    `step` counters as host scalars, parameters grouped by the number of updates they have seen, state dicts loadable by the
+    stock optimizer and back (counters a fused optimizer kept on the device come to the host: no device read per step)."""
+    import torch
+    from repmode_amd import ops, optim
+    calls = []
+
+    class FakeOps:
+        def adam_step(self, p, g, m, v, lr, b1, b2, eps, t):
+            calls.append((len(p), t, lr, b1, b2, eps))
+
+    monkeypatch.setattr(ops, 'torch_ops', lambda: FakeOps())
+    ps = [torch.nn.Parameter(torch.randn(3)) for _ in range(4)]
+    opt = optim.Adam(ps, lr=2e-3)
+    assert isinstance(opt, torch.optim.Adam)
+    for p in ps:
+        p.grad = torch.randn(3)
+    opt.step(); opt.step()
+    ps[0].grad = None
+    opt.step()
+    for p in ps:
+        p.grad = torch.randn(3)
+    opt.step()
+    assert [(c[0], c[1]) for c in calls] == [(4, 1), (4, 2), (3, 3), (1, 3), (3, 4)]
+    assert calls[0][2:] == (2e-3, 0.9, 0.999, 1e-8)
+    sd = opt.state_dict()
+    assert sorted(sd['state'][0]) == ['exp_avg', 'exp_avg_sq', 'step'] and float(sd['state'][0]['step']) == 3.0
+    assert not sd['state'][1]['step'].is_cuda and sd['param_groups'][0]['fused'] is False
+    stock = torch.optim.Adam(ps, lr=2e-3)
+    stock.load_state_dict(sd)
+    assert float(stock.state_dict()['state'][1]['step']) == 4.0
+    back = optim.Adam(ps, lr=2e-3)
+    back.load_state_dict(stock.state_dict())
+    assert float(back.state_dict()['state'][0]['step']) == 3.0
+    with pytest.raises(RuntimeError):
+        bad = optim.Adam(ps, lr=1e-3)
+        bad.param_groups[0]['weight_decay'] = 0.1
+        bad.step()

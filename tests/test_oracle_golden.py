@@ -217,3 +217,42 @@ def test_full_size_train_iter_scalars_match_reference():
         log = orc.loss_log(per.numpy(), tasks.tolist(), Opts.adopted_datasets, 0)   # (count_iter is the caller's; left at 0)
         assert sorted(log) == keys
         assert np.allclose([log[k] for k in keys], g['log_values'][s], rtol=1e-4)
+
+
+def test_bf16_emulation_rounds_where_it_says_and_keeps_gradients_flowing():
+    """The oracle's bf16-emulating mode (the checker of the network-level bf16 GPU tests): its two primitives, its default
+    policy, and the whole network on the reference's G3 golden -- bf16 rounding moves the float32 result by a few percent
+    (mult_chan 2: one rounding moves a whole BatchNorm statistic), never more, and every parameter still gets a gradient."""
+    x = torch.tensor([1.0 + 2 ** -9, 3.0, -1e-3], requires_grad=True)
+    q = orc.round_ste(x)
+    assert torch.equal(q.detach(), x.detach().bfloat16().float()) and q.detach()[0] != x.detach()[0]
+    (q * torch.tensor([1.0 + 2 ** -9, 1.0, 1.0])).sum().backward()
+    assert torch.equal(x.grad, torch.tensor([1.0 + 2 ** -9, 1.0, 1.0]))          # straight through: unrounded
+    y = torch.tensor([2.0], requires_grad=True)
+    (orc.grad_round(y) * (1.0 + 2 ** -9)).sum().backward()
+    assert float(y.grad) == float(torch.tensor(1.0 + 2 ** -9).bfloat16())       # the gradient is what gets rounded
+    emu = orc.Emulation()
+    assert emu.elem_out(8, 32, 64, 64, 32, 32) and emu.elem_out(8, 8, 16, 16, 128, 128)
+    assert not emu.elem_out(2, 8, 16, 16, 128, 128) and not emu.elem_out(8, 4, 8, 8, 256, 256)
+    assert emu.unmerged(True, [1, 5, 7, 1], 8) and not emu.unmerged(True, [1, 5, 1], 8) and not emu.unmerged(True, [1, 5, 7], 16)
+    assert not emu.unmerged(False, [1, 5, 7], 8)
+    seen = []
+    emu2 = orc.Emulation(elem_out=lambda *a: seen.append(a) or False)
+    assert emu2.elem_out(8, 32, 64, 64, 32, 32) is False and seen == [(8, 32, 64, 64, 32, 32)]
+    g = load_golden('g3_net_mc2.npz')
+    state = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('p.')}
+    tasks = torch.from_numpy(g['tasks'])
+    xs, tgt = torch.from_numpy(g['x']), torch.from_numpy(g['target'])
+    net = orc.Net(Opts(), mult_chan=int(g['mult_chan']), emulate=torch.bfloat16)
+    net.load_state_dict(state)
+    net.train()
+    y = net(xs, tasks)
+    torch.nn.functional.mse_loss(y, tgt).backward()
+    ref = torch.from_numpy(g['y'])
+    assert 1e-4 < float((y.detach() - ref).norm() / ref.norm()) < 0.2
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+    # eval mode without autograd: the folded-BatchNorm form of the blocks that write bf16
+    net.eval()
+    with torch.no_grad():
+        ye = net(xs[:1].expand(2, -1, -1, -1, -1), tasks[:1].expand(2))
+    assert bool(torch.isfinite(ye).all())
