@@ -114,10 +114,10 @@ class Model(object):
         # process-wide (one training process per GPU): where the MoDE gradient kernels put the parameter gradients
         ops_.set_grad_sink(self.reducer)
         ops_.torch_ops().clear_frag_store()          # (expert operands kept across steps belong to the previous network)
-        if self.hip_graph:
-            # a graph replay updates the parameters with no version counter and no optimizer hook to say so: this process
-            # lays the per-expert blocks' operands out at every forward pass, as the captured step does
-            ops_.torch_ops().set_frag_store(False)
+        # process-wide, like the gradient sink (one training process per GPU): a graph replay updates the parameters with no
+        # version counter and no optimizer hook to say so -- a model that replays its step lays the per-expert blocks'
+        # operands out at every forward pass, as the captured step does
+        ops_.torch_ops().set_frag_store(not self.hip_graph and os.environ.get('REPMODE_FRAG_STORE', '1') != '0')
         if self.hip_graph or os.environ.get('REPMODE_ADAM', '1') == '0':
             # (capturable: the step counters live on the device, so optimizer.step() can be part of a HIP graph -- the build's
             # own pass takes the step count from the host; REPMODE_ADAM=0: the stock fused optimizer, for A/B)
