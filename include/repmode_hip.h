@@ -213,6 +213,10 @@ int repmode_conv5_wgrad_ex(const void* x, const void* dy, const int32_t* sample_
 int repmode_conv5_wgrad_part(const void* x, const void* dy, const int32_t* sample_slot, int nslots, float* dw, int n,
                              int d, int h, int wdim, int cin, int cin_total, int ci_off, int cout, int dtype,
                              int centre3, void* stream);
+/* Planning query of the three entry points above (bf16, slot layout): *direct = 1 when the call with these arguments writes
+ * every element of its dw range with plain stores -- dw then needs no clearing (pass mode bit 3 and any memory) --, 0 when it
+ * adds partial sums with float atomics onto a dw that must be all zero.  Same planner, switches and device as the launch. */
+int repmode_conv5_wgrad_plan(int nslots, int n, int d, int h, int w, int cin, int cout, int dtype, int centre3, int* direct);
 
 /* Two filter gradients over the same input x in ONE launch (bf16; all samples in one slot): dw_a from dy_a with mode_a,
  * dw_b from dy_b with mode_b (modes as repmode_conv5_wgrad_ex: 0 / 1 tap-major all taps / planes dz 1..3, 2 / 3 the experts'

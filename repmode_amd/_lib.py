@@ -54,6 +54,7 @@ _SIGNATURES = {
     'repmode_conv5_wgrad': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad_ex': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad_part': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'repmode_conv5_wgrad_plan': [_I] * 9 + [_P],
     'repmode_conv5_wgrad_dual': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_wgrad_thin': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     'repmode_shift5': [_P, _I, _P, _c.c_long, _I, _P],

@@ -50,6 +50,8 @@ struct WgradArgs {
   // persistent workgroups that each take an equal range of the global step sequence (see the kernel).  0: one (unit, chunk) per
   // workgroup as planned by nchunks / tiles_per_block.
   long sk_total;
+  int* plan_out;        // host only: not NULL = plan the launch, report whether every element of dw will be written by plain
+                        // stores (1) or the output must be all zero on entry (0), and do not launch (repmode_conv5_wgrad_plan)
   int grid0;
   const void* dy2;
   float* dw2;
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
               }
             }
             dz = a.dz_lo + dzi; t_lo = zlo(dz) * tpp; t_hi = zhi(dz) * tpp;
-          } while (t_hi <= t_lo);
+          } while (t_hi <= t_lo || cnt == 0);            // (a dz without input planes, a slot without samples: no steps)
           tile = t_lo;
           n = kth(mask, 0);
         };
@@ -881,6 +883,7 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
     if (g > total / 8) g = total / 8;
     if (g < 1) g = 1;
     if (total > 0 && total < (1L << 40)) {
+      if (a.plan_out) { *a.plan_out = 0; return REPMODE_OK; }     // (shared units are added with float atomics)
       a.sk_total = total;
       a.nchunks = 1; a.tiles_per_block = a.ntiles; a.direct = 0;
       if (!a.prezeroed) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * REPMODE_TAPS * a.Cout * a.CinTot * sizeof(float), s));
@@ -929,6 +932,7 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
     return fixed * *nchunks;
   };
   long grid = plan(a.ndz, a.layout, &a.tiles_per_block, &a.nchunks, &a.direct);
+  if (a.plan_out) { *a.plan_out = a.direct && !a.dy2; return REPMODE_OK; }
   if (!a.direct && !a.prezeroed) RM_HIP(hipMemsetAsync(a.dw, 0, (size_t)a.nslots * (a.layout == 2 ? 27 : REPMODE_TAPS) * a.Cout * a.CinTot * sizeof(float), s));
   if (a.dy2) {                       // dual launch: the second job is planned the same way, its workgroups follow the first's
     a.grid0 = (int)grid;
@@ -1035,6 +1039,37 @@ extern "C" int repmode_conv5_wgrad_part(const void* x, const void* dy, const int
   repmode_prof_end(s);
   RM_LAUNCH_CHECK("conv5_wgrad");
   return REPMODE_OK;
+}
+
+// Does repmode_conv5_wgrad[_ex / _part] with these arguments write EVERY element of its dw range by plain stores (*direct = 1:
+// dw needs no clearing -- the caller may hand over uninitialised memory, and pass mode bit 3 to say "no memset"), or does it
+// add partial sums with float atomics onto a dw that must be all zero (*direct = 0)?  The same planning code as the launch
+// (same switches, same device), without launching.  The operator library asks before it takes the buffer out of the step's
+// pooled memset: at batch 8 that keeps 260 MB of level-2 filter gradients out of it.
+extern "C" int repmode_conv5_wgrad_plan(int nslots, int n, int d, int h, int wdim, int cin, int cout, int dtype, int centre3, int* direct) {
+  RM_REQUIRE(direct, "conv5_wgrad_plan: null pointer");
+  RM_REQUIRE(n > 0 && nslots > 0 && d > 0 && h > 0 && wdim > 0 && cin > 0 && cout > 0, "conv5_wgrad_plan: bad shape");
+  *direct = 0;
+  centre3 &= 7;
+  static const int enabled = []() { const char* e = getenv("REPMODE_WGRAD_PLAN"); return e ? atoi(e) : 1; }();   // (0: always a cleared buffer, for A/B)
+  if (!enabled || dtype != REPMODE_BF16 || centre3 > 1) return REPMODE_OK;          // (float32 parity path / expert layouts: keep the cleared buffer)
+  static const int32_t dummy_slot = 0;
+  WgradArgs a{};
+  a.sample_slot = &dummy_slot;            // (only tested for NULL by the planner)
+  a.N = n; a.D = d; a.H = h; a.W = wdim; a.Cin = cin; a.Cout = cout;
+  a.CinTot = cin; a.ci_off = 0;
+  a.ncot = ceil_div(cout, 32);
+  a.ncit = ceil_div(cin, 32);
+  a.nslots = nslots;
+  a.dz_lo = centre3 == 1 ? 1 : 0;
+  a.ndz = centre3 == 1 ? 3 : 5;
+  a.layout = 0;
+  a.plan_out = direct;
+  if (wdim >= 32 && h >= 8) return launch_wgrad_bf16<1, 8, 32>(a, n, nullptr);
+  if (wdim >= 32) return launch_wgrad_bf16<1, 4, 32>(a, n, nullptr);
+  if (wdim >= 16) return launch_wgrad_bf16<1, 8, 16>(a, n, nullptr);
+  if (wdim >= 8) return launch_wgrad_bf16<2, 8, 8>(a, n, nullptr);
+  return launch_wgrad_bf16<2, 4, 8>(a, n, nullptr);
 }
 
 // Two filter gradients over the SAME input in one launch (bf16, every sample in one slot): the per-expert formulation's

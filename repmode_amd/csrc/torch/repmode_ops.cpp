@@ -502,10 +502,21 @@ Tensor thin_conv_out1(const Tensor& x_cl, const Tensor& w, const Tensor& sample_
 // dw[s, tap, o, i] (float32) summed over the samples of each slot
 Tensor conv5_wgrad(const Tensor& x_cl, const Tensor& dy_cl, const Tensor& sample_slot, int64_t nslots, int64_t cout, bool centre3 = false) {
   const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), wd_ = x_cl.size(3), cin = x_cl.size(4);
+  const bool thin = x_cl.scalar_type() == at::kBFloat16 && ((cin == 1) != (cout == 1)) && !centre3;
+  // a launch that writes every element with plain stores needs no cleared buffer: it stays out of the step's pooled memset
+  int direct = 0;
+  if (!thin && x_cl.scalar_type() == at::kBFloat16)
+    RM_CALL(repmode_conv5_wgrad_plan, (int)nslots, (int)n, (int)d, (int)h, (int)wd_, (int)cin, (int)cout, REPMODE_BF16, centre3 ? 1 : 0, &direct);
+  if (direct) {
+    Tensor dw = at::empty({nslots, TAPS, cout, cin}, x_cl.options().dtype(at::kFloat));
+    RM_CALL(repmode_conv5_wgrad_ex, x_cl.data_ptr(), dy_cl.data_ptr(), sample_slot.data_ptr<int32_t>(), (int)nslots, dw.data_ptr<float>(),
+            (int)n, (int)d, (int)h, (int)wd_, (int)cin, (int)cout, REPMODE_BF16, (centre3 ? 1 : 0) | 8, stream_handle());
+    return dw;
+  }
   auto tk = g_pool.take({nslots, TAPS, cout, cin}, x_cl);
   Tensor dw = tk.first;
   const bool pre = tk.second;
-  if (x_cl.scalar_type() == at::kBFloat16 && ((cin == 1) != (cout == 1)) && !centre3) {
+  if (thin) {
     // thin layer: taps stand in for the missing channel dimension (conv5_wgrad_thin)
     const bool first = cin == 1;
     const Tensor& a_t = first ? dy_cl : x_cl;
@@ -819,10 +830,19 @@ struct ModeConvPair : public torch::autograd::Function<ModeConvPair> {
     const bool whole = wd.defined() && forks(xa);
     Tensor dw;
     auto filter_grad = [&]() {
-      // the two channel ranges of one (cleared) buffer
-      auto tk = g_pool.take({plan.nslots, TAPS, co, ci}, xa);
-      dw = tk.first;
-      if (!tk.second) dw.zero_();
+      // the two channel ranges of one buffer: cleared (pooled memset), unless both launches write their range with plain stores
+      int da = 0, db = 0;
+      if (dt == at::kBFloat16) {
+        RM_CALL(repmode_conv5_wgrad_plan, (int)plan.nslots, (int)n, (int)d, (int)h, (int)w_, (int)ca, (int)co, REPMODE_BF16, 0, &da);
+        RM_CALL(repmode_conv5_wgrad_plan, (int)plan.nslots, (int)n, (int)d, (int)h, (int)w_, (int)cb, (int)co, REPMODE_BF16, 0, &db);
+      }
+      if (da && db) {
+        dw = at::empty({plan.nslots, TAPS, co, ci}, xa.options().dtype(at::kFloat));
+      } else {
+        auto tk = g_pool.take({plan.nslots, TAPS, co, ci}, xa);
+        dw = tk.first;
+        if (!tk.second) dw.zero_();
+      }
       const Tensor* parts[2] = {&xa, &xb};
       const int64_t offs[2] = {0, ca};
       for (int i = 0; i < 2; ++i)
