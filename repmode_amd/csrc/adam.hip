@@ -102,6 +102,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMultiArgs a) {
 }
 
 // ---- the per-expert blocks' 5x5x5 / 3x3x3 experts: update + fragment-major bf16 operands
+#ifndef RM_ADAM_RPI
+#define RM_ADAM_RPI 2
+#endif
 constexpr int AF_MAX = REPMODE_GATREP_MULTI_MAX;
 constexpr int AF_T = 16;                                 // the workgroup's tile: AF_T output x AF_T input channels
 constexpr int AF_TAPS5 = REPMODE_TAPS, AF_TAPS3 = 27;
@@ -119,7 +122,7 @@ struct AdamFragArgs {
 // One parameter tensor's part of the tile: rows co0 .. co0+15, input channels ci0 .. ci0+15, TAPS taps each.  A row is
 // ncols * TAPS contiguous floats (16-byte aligned when ci is a multiple of 4: taps * 16 * 4 bytes per ci tile, and every row
 // starts a multiple of ci * taps floats in).  Updated in place; the new value goes to lds[tap][row][col] as bf16.
-template <int TAPS>
+template <int TAPS, int NT>
 __device__ __forceinline__ void adam_tile_rows(const AdamHyper& h, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, int co_n, int ci_n, int co0, int ci0, bf16_t* lds) {
   const int nrows = max(0, min(AF_T, co_n - co0)), ncols = max(0, min(AF_T, ci_n - ci0));
@@ -128,16 +131,16 @@ __device__ __forceinline__ void adam_tile_rows(const AdamHyper& h, float* __rest
                    (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
   // zero what the tile does not cover (ragged channel counts): the fragment tiles' padding must be zero
   if (nrows < AF_T || ncols < AF_T) {
-    for (int i = threadIdx.x; i < TAPS * AF_T * AF_T; i += 256) {
+    for (int i = threadIdx.x; i < TAPS * AF_T * AF_T; i += NT) {
       const int r = (i / AF_T) % AF_T, c = i % AF_T;
       if (r >= nrows || c >= ncols) lds[i] = 0;
     }
   }
   if (vec) {
     const int nvec = run / 4;                                    // float4 items per row (TAPS = 125: 500, 27: 108)
-    constexpr int RPI = 2;                                       // rows in flight per iteration
+    constexpr int RPI = RM_ADAM_RPI;                             // rows in flight per iteration
     for (int r0 = 0; r0 < nrows; r0 += RPI) {
-      for (int it0 = 0; it0 < nvec; it0 += 256) {
+      for (int it0 = 0; it0 < nvec; it0 += NT) {
         f32x4 P[RPI], G[RPI], M[RPI], V[RPI];
         const int it = it0 + threadIdx.x;
 #pragma unroll
@@ -174,7 +177,7 @@ __device__ __forceinline__ void adam_tile_rows(const AdamHyper& h, float* __rest
     }
   } else {
     for (int r = 0; r < nrows; ++r) {
-      for (int e = threadIdx.x; e < run; e += 256) {
+      for (int e = threadIdx.x; e < run; e += NT) {
         const long o = ((long)(co0 + r) * ci_n + ci0) * TAPS + e;
         float pp = p[o], mm = m[o], vv = v[o];
         adam_elem(h, pp, g[o], mm, vv);
@@ -186,7 +189,13 @@ __device__ __forceinline__ void adam_tile_rows(const AdamHyper& h, float* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void adam_frags_kernel(AdamFragArgs a) {
+// NT threads per workgroup: two workgroups share a CU's LDS (78 KB each) and a workgroup alternates "load + update + stage" /
+// barrier / "write the operands", so the thread count sets how much of one phase hides under the other (same box,
+// tools/adam_microbench.py, the six per-expert blocks of the network, 104.6 M elements: 256 threads 701 us = 4.85 TB/s,
+// 512 threads 660 us = 5.15 TB/s, 1024 threads (one workgroup per CU by registers) 745 us; rows in flight per iteration
+// 1 / 2 / 4: no difference.  The plain kernel, short workgroups at full occupancy, streams at 6.5 TB/s.)
+template <int NT>
+__global__ __launch_bounds__(NT) void adam_frags_kernel(AdamFragArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* s5 = reinterpret_cast<bf16_t*>(smem);                   // [125][16 co][16 ci]
   bf16_t* s3 = s5 + AF_TAPS5 * AF_T * AF_T;                       // [27][16 co][16 ci]
@@ -199,13 +208,14 @@ __global__ __launch_bounds__(256) void adam_frags_kernel(AdamFragArgs a) {
   // workgroup -> tile: the ci tile fastest (a row of the parameter tensor is walked by consecutive workgroups)
   const int it_ = b % nit, ct_ = b / nit;
   const int co0 = ct_ * AF_T, ci0 = it_ * AF_T;
-  adam_tile_rows<AF_TAPS5>(a.h, a.p5[i], a.g5[i], a.m5[i], a.v5[i], co_n, ci_n, co0, ci0, s5);
-  adam_tile_rows<AF_TAPS3>(a.h, a.p3[i], a.g3[i], a.m3[i], a.v3[i], co_n, ci_n, co0, ci0, s3);
+  adam_tile_rows<AF_TAPS5, NT>(a.h, a.p5[i], a.g5[i], a.m5[i], a.v5[i], co_n, ci_n, co0, ci0, s5);
+  adam_tile_rows<AF_TAPS3, NT>(a.h, a.p3[i], a.g3[i], a.m3[i], a.v3[i], co_n, ci_n, co0, ci0, s3);
   __syncthreads();
 
   // ---- the fragment-major operands (layouts: include/repmode_hip.h, repmode_expert_frags).  Forward role: rows = co,
   // reduction = ci: tile (rt = co0 / 32, kc = ci0 / 16) of [slot][tap][CoP/32][CiP/16][32][16], this workgroup's 16 rows are
   // 512 contiguous bytes of it.  128 threads move one tap's piece as dwords; the two halves of the workgroup take two taps.
+  constexpr int NG = NT / 128;                                   // taps in flight: 128 threads move one tap's piece
   const int half = threadIdx.x >> 7, t128 = threadIdx.x & 127;
   if (a.wf[i] && ci0 < rup(ci_n, 16)) {          // (the forward role pads its reduction, ci, to 16 only)
     const int coP = rup(co_n, 32), ciP = rup(ci_n, 16);
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256) void adam_frags_kernel(AdamFragArgs a) {
     uint32_t* out = reinterpret_cast<uint32_t*>(a.wf[i] + tile);
     const uint32_t* s5w = reinterpret_cast<const uint32_t*>(s5);
     const uint32_t* s3w = reinterpret_cast<const uint32_t*>(s3);
-    for (int tap = half; tap < AF_TAPS5; tap += 2) {
+    for (int tap = half; tap < AF_TAPS5; tap += NG) {
       out[(size_t)tap * tap_stride / 2 + t128] = s5w[tap * (AF_T * AF_T / 2) + t128];
       const int dz = tap / 25, dy = (tap / 5) % 5, dx = tap % 5;
       if (dz >= 1 && dz <= 3 && dy >= 1 && dy <= 3) {               // slot 1: the rows a centred-3x3x3 convolution reads
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(256) void adam_frags_kernel(AdamFragArgs a) {
     const size_t tile = ((size_t)(ci0 / 32) * (coP / 16) + co0 / 16) * (32 * 16) + (size_t)(ci0 % 32) * 16;
     uint32_t* out = reinterpret_cast<uint32_t*>(a.wd[i] + tile);
     const int row = t128 >> 3, kp = t128 & 7;                       // this thread's dword: row ci = row, co pair (2 kp, 2 kp + 1)
-    for (int tap = half; tap < AF_TAPS5; tap += 2) {
+    for (int tap = half; tap < AF_TAPS5; tap += NG) {
       const bf16_t* s = s5 + tap * (AF_T * AF_T);
       const uint32_t w = (uint32_t)s[(2 * kp) * AF_T + row] | ((uint32_t)s[(2 * kp + 1) * AF_T + row] << 16);
       const int tap_out = AF_TAPS5 - 1 - tap;
@@ -249,6 +259,9 @@ __global__ __launch_bounds__(256) void adam_frags_kernel(AdamFragArgs a) {
   }
 }
 
+#ifndef AF_THREADS
+#define AF_THREADS 512
+#endif
 constexpr int AF_LDS_BYTES = (AF_TAPS5 + AF_TAPS3) * AF_T * AF_T * 2;
 
 int fill_hyper(AdamHyper* h, double lr, double beta1, double beta2, double eps, long step) {
@@ -314,10 +327,10 @@ extern "C" int repmode_adam_expert_frags(int nblocks, float* const* p5, const fl
   int dev = 0;
   RM_HIP(hipGetDevice(&dev));
   if (!attr_done[dev & 31]) {
-    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&adam_frags_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, AF_LDS_BYTES));
+    RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&adam_frags_kernel<AF_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, AF_LDS_BYTES));
     attr_done[dev & 31] = true;
   }
-  hipLaunchKernelGGL(adam_frags_kernel, dim3((unsigned)total), dim3(256), AF_LDS_BYTES, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(adam_frags_kernel<AF_THREADS>, dim3((unsigned)total), dim3(AF_THREADS), AF_LDS_BYTES, static_cast<hipStream_t>(stream), a);
   RM_LAUNCH_CHECK("adam_expert_frags");
   return REPMODE_OK;
 }

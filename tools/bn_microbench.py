@@ -10,7 +10,8 @@ from repmode_amd import ops, _lib
 if os.environ.get('REPMODE_LIB'):
     _lib.LIB_PATH = os.environ['REPMODE_LIB']
 dev = 'cuda:0'
-for (c, d, h, w, in_dt) in [(32, 32, 64, 64, torch.bfloat16), (64, 16, 32, 32, torch.float32), (128, 8, 16, 16, torch.float32),
+# (round 4: levels 0-2 hand BatchNorm a bf16 tensor, the per-expert levels 3-4 a float one)
+for (c, d, h, w, in_dt) in [(32, 32, 64, 64, torch.bfloat16), (64, 16, 32, 32, torch.bfloat16), (128, 8, 16, 16, torch.bfloat16),
                             (256, 4, 8, 8, torch.float32), (512, 2, 4, 4, torch.float32)]:
     x = torch.randn(8, d, h, w, c, device=dev).to(in_dt)
     bn = torch.nn.BatchNorm3d(c).to(dev)
