@@ -143,9 +143,9 @@ def conv5_wgrad_algorithmic_bytes(batch, nslots):
 
 def cpu_baseline():
     """Oracle train step (forward + backward + Adam, fp32) on the host cores: batch 2 of the headline patches (two
-    different tasks), up to 32 host threads (see below), >= 3 timed steps (8-15 s) of each organisation after a small warm-up -- the reference's
+    different tasks), up to 32 host threads (see below), >= 3 timed steps (~17 s on the GPU box) of each organisation after a small warm-up -- the reference's
     own (one merged filter + one batch-1 conv per sample in a Python loop, RepMode.py:182-190, 204-208) and the
-    vectorised restatement (gather + one contraction + one grouped conv).  Bounded: ~2 x 8-15 s on a 32+ core host."""
+    vectorised restatement (gather + one contraction + one grouped conv).  Bounded: ~2 x 17 s on a 32+ core host (40 s cap each)."""
     from oracle import repmode_oracle as orc
     # the oracle's PyTorch-CPU ops stop scaling well before a big host's hardware-thread count and then regress badly
     # (all 256+ threads of the GPU box: a batch-2 step did not finish in 5 minutes; 32 threads: ~7 s) -- 32 is the
