@@ -17,7 +17,7 @@
 //                            re-derives from the parameters at the start of every forward pass (round 3: 238 us per step, a
 //                            second read of 420 MB that this pass has in registers anyway).  A workgroup owns a 16 x 16
 //                            (co, ci) tile with all 125 + 27 taps: the parameter layout [co][ci][taps] makes its 16 rows 8 KB
-//                            contiguous runs; the updated values are staged as bf16 in LDS ([tap][co][ci], 78 KB) and written
+//                            contiguous runs; the updated values are staged as bf16 in LDS (parameter order, 78 KB; transposed on the way out) and written
 //                            out as 512-byte pieces of the 1 KiB fragment tiles.
 #include "common.h"
 
@@ -102,6 +102,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMultiArgs a) {
 }
 
 // ---- the per-expert blocks' 5x5x5 / 3x3x3 experts: update + fragment-major bf16 operands
+#ifndef RM_ADAM_TIMING
+#define RM_ADAM_TIMING 0
+#endif
 #ifndef RM_ADAM_RPI
 #define RM_ADAM_RPI 2
 #endif
@@ -121,57 +124,71 @@ struct AdamFragArgs {
 
 // One parameter tensor's part of the tile: rows co0 .. co0+15, input channels ci0 .. ci0+15, TAPS taps each.  A row is
 // ncols * TAPS contiguous floats (16-byte aligned when ci is a multiple of 4: taps * 16 * 4 bytes per ci tile, and every row
-// starts a multiple of ci * taps floats in).  Updated in place; the new value goes to lds[tap][row][col] as bf16.
+// starts a multiple of ci * taps floats in).  Updated in place; the new value goes to LDS as bf16 IN THE PARAMETER'S OWN ORDER,
+// lds[row][col * TAPS + tap] (row stride AfRow<TAPS>::RS): a thread's four consecutive floats are one 8-byte LDS write and a
+// wave's writes are consecutive -- the [tap][row][col] staging this replaces put a wave's 2-byte writes 4 taps = 2 KB apart,
+// all 64 lanes in one bank.  The transposition happens on the READ side (below), where the odd tap count spreads the
+// lanes' (row, col) strides over all banks.
+template <int TAPS>
+struct AfRow {
+  static constexpr int RS = AF_T * TAPS + 4;       // bf16 elements per staged row (+4: the co-pair reads of the data-gradient
+};                                                 // role, 2 RS apart, then fall into 8 different banks instead of 4)
+
 template <int TAPS, int NT>
 __device__ __forceinline__ void adam_tile_rows(const AdamHyper& h, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, int co_n, int ci_n, int co0, int ci0, bf16_t* lds) {
+  constexpr int RS = AfRow<TAPS>::RS;
   const int nrows = max(0, min(AF_T, co_n - co0)), ncols = max(0, min(AF_T, ci_n - ci0));
   const int run = ncols * TAPS;                                  // floats of a row inside the tile
   const bool vec = (((long)ci_n * TAPS) & 3) == 0 && ((ci0 * TAPS) & 3) == 0 && (run & 3) == 0 &&
                    (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
   // zero what the tile does not cover (ragged channel counts): the fragment tiles' padding must be zero
   if (nrows < AF_T || ncols < AF_T) {
-    for (int i = threadIdx.x; i < TAPS * AF_T * AF_T; i += NT) {
-      const int r = (i / AF_T) % AF_T, c = i % AF_T;
-      if (r >= nrows || c >= ncols) lds[i] = 0;
+    for (int i = threadIdx.x; i < AF_T * AF_T * TAPS; i += NT) {
+      const int r = i / (AF_T * TAPS), e = i - r * (AF_T * TAPS);
+      if (r >= nrows || e >= run) lds[r * RS + e] = 0;
     }
   }
   if (vec) {
-    const int nvec = run / 4;                                    // float4 items per row (TAPS = 125: 500, 27: 108)
-    constexpr int RPI = RM_ADAM_RPI;                             // rows in flight per iteration
-    for (int r0 = 0; r0 < nrows; r0 += RPI) {
-      for (int it0 = 0; it0 < nvec; it0 += NT) {
-        f32x4 P[RPI], G[RPI], M[RPI], V[RPI];
-        const int it = it0 + threadIdx.x;
+    // items = (row, float4 of the row's run), all rows of the tile in ONE index space (the 27-tap expert's rows are 108
+    // float4s: a loop per row kept 4/5 of the workgroup idle); RPI items in flight per thread and iteration
+    const int nvec = run / 4;                                    // float4 items per row (full tile: TAPS = 125: 500, 27: 108)
+    const int nitems = nrows * nvec;
+    constexpr int RPI = RM_ADAM_RPI;
+    for (int i0 = 0; i0 < nitems; i0 += RPI * NT) {
+      f32x4 P[RPI], G[RPI], M[RPI], V[RPI];
+      int row[RPI], it[RPI];
 #pragma unroll
-        for (int u = 0; u < RPI; ++u) {
-          const long o = ((long)(co0 + r0 + u) * ci_n + ci0) * TAPS + (long)it * 4;
-          if (it < nvec && r0 + u < nrows) {
-            P[u] = *reinterpret_cast<const f32x4*>(p + o);
-            G[u] = *reinterpret_cast<const f32x4*>(g + o);
-            M[u] = *reinterpret_cast<const f32x4*>(m + o);
-            V[u] = *reinterpret_cast<const f32x4*>(v + o);
-          }
+      for (int u = 0; u < RPI; ++u) {
+        const int item = i0 + u * NT + threadIdx.x;
+        row[u] = nvec == 4 * TAPS ? item / (4 * TAPS) : item / nvec;            // (full tiles: a constant divisor)
+        it[u] = item - row[u] * nvec;
+        if (item < nitems) {
+          const long o = ((long)(co0 + row[u]) * ci_n + ci0) * TAPS + (long)it[u] * 4;
+          P[u] = *reinterpret_cast<const f32x4*>(p + o);
+          G[u] = *reinterpret_cast<const f32x4*>(g + o);
+          M[u] = *reinterpret_cast<const f32x4*>(m + o);
+          V[u] = *reinterpret_cast<const f32x4*>(v + o);
         }
+      }
 #pragma unroll
-        for (int u = 0; u < RPI; ++u) {
-          if (it < nvec && r0 + u < nrows) {
-            const long o = ((long)(co0 + r0 + u) * ci_n + ci0) * TAPS + (long)it * 4;
+      for (int u = 0; u < RPI; ++u) {
+        const int item = i0 + u * NT + threadIdx.x;
+        if (item < nitems) {
+          const long o = ((long)(co0 + row[u]) * ci_n + ci0) * TAPS + (long)it[u] * 4;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              float pp = P[u][k], mm = M[u][k], vv = V[u][k];
-              adam_elem(h, pp, G[u][k], mm, vv);
-              P[u][k] = pp; M[u][k] = mm; V[u][k] = vv;
-            }
-            *reinterpret_cast<f32x4*>(p + o) = P[u];
-            *reinterpret_cast<f32x4*>(m + o) = M[u];
-            *reinterpret_cast<f32x4*>(v + o) = V[u];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int e = it * 4 + k, c = e / TAPS, t = e - c * TAPS;
-              lds[(t * AF_T + r0 + u) * AF_T + c] = f32_to_bf16(P[u][k]);
-            }
+          for (int k = 0; k < 4; ++k) {
+            float pp = P[u][k], mm = M[u][k], vv = V[u][k];
+            adam_elem(h, pp, G[u][k], mm, vv);
+            P[u][k] = pp; M[u][k] = mm; V[u][k] = vv;
           }
+          *reinterpret_cast<f32x4*>(p + o) = P[u];
+          *reinterpret_cast<f32x4*>(m + o) = M[u];
+          *reinterpret_cast<f32x4*>(v + o) = V[u];
+#if RM_ADAM_TIMING < 2
+          *reinterpret_cast<u32x2*>(lds + row[u] * RS + it[u] * 4) =
+              u32x2{pack_bf16x2(P[u][0], P[u][1]), pack_bf16x2(P[u][2], P[u][3])};
+#endif
         }
       }
     }
@@ -182,11 +199,22 @@ __device__ __forceinline__ void adam_tile_rows(const AdamHyper& h, float* __rest
         float pp = p[o], mm = m[o], vv = v[o];
         adam_elem(h, pp, g[o], mm, vv);
         p[o] = pp; m[o] = mm; v[o] = vv;
-        const int c = e / TAPS, t = e - c * TAPS;
-        lds[(t * AF_T + r) * AF_T + c] = f32_to_bf16(pp);
+        lds[r * RS + e] = f32_to_bf16(pp);
       }
     }
   }
+}
+
+// element (tap, row, col) and its right / lower neighbour of a staged tensor, packed as the operands' dword
+template <int TAPS>
+__device__ __forceinline__ uint32_t af_pair_cols(const bf16_t* lds, int tap, int row, int col) {     // (row, col), (row, col + 1)
+  const bf16_t* q = lds + row * AfRow<TAPS>::RS + col * TAPS + tap;
+  return (uint32_t)q[0] | ((uint32_t)q[TAPS] << 16);
+}
+template <int TAPS>
+__device__ __forceinline__ uint32_t af_pair_rows(const bf16_t* lds, int tap, int row, int col) {     // (row, col), (row + 1, col)
+  const bf16_t* q = lds + row * AfRow<TAPS>::RS + col * TAPS + tap;
+  return (uint32_t)q[0] | ((uint32_t)q[AfRow<TAPS>::RS] << 16);
 }
 
 // NT threads per workgroup: two workgroups share a CU's LDS (78 KB each) and a workgroup alternates "load + update + stage" /
@@ -194,11 +222,16 @@ __device__ __forceinline__ void adam_tile_rows(const AdamHyper& h, float* __rest
 // tools/adam_microbench.py, the six per-expert blocks of the network, 104.6 M elements: 256 threads 701 us = 4.85 TB/s,
 // 512 threads 660 us = 5.15 TB/s, 1024 threads (one workgroup per CU by registers) 745 us; rows in flight per iteration
 // 1 / 2 / 4: no difference.  The plain kernel, short workgroups at full occupancy, streams at 6.5 TB/s.)
+// Where the time goes (timing-only builds -DRM_ADAM_TIMING=1/2/3, one box, tools/sessions/r4_session14.sh): the whole pass
+// 620-640 us; without the operand write 551 (its 0.42 GB at the pass's own rate); without the staging either 552-561; without
+// the LDS reservation (8 workgroups per CU) 573: the update of 16 x 8 KB runs per tensor streams at 5.2 TB/s whatever the
+// occupancy -- the tile shape the operands' layout asks for, not the staging, is what separates it from the plain kernel.
+// Staging in parameter order instead of [tap][row][col] (conflict-free 8-byte LDS writes): 734 -> 717 us on one box.
 template <int NT>
 __global__ __launch_bounds__(NT) void adam_frags_kernel(AdamFragArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* s5 = reinterpret_cast<bf16_t*>(smem);                   // [125][16 co][16 ci]
-  bf16_t* s3 = s5 + AF_TAPS5 * AF_T * AF_T;                       // [27][16 co][16 ci]
+  bf16_t* s5 = reinterpret_cast<bf16_t*>(smem);                   // [16 co][16 ci x 125 taps (+4)]
+  bf16_t* s3 = s5 + AF_T * AfRow<AF_TAPS5>::RS;                   // [16 co][16 ci x 27 taps (+4)]
   int i = 0;
   while (i + 1 < a.nblocks && (int)blockIdx.x >= a.first[i + 1]) ++i;
   const int b = blockIdx.x - a.first[i];
@@ -210,6 +243,9 @@ __global__ __launch_bounds__(NT) void adam_frags_kernel(AdamFragArgs a) {
   const int co0 = ct_ * AF_T, ci0 = it_ * AF_T;
   adam_tile_rows<AF_TAPS5, NT>(a.h, a.p5[i], a.g5[i], a.m5[i], a.v5[i], co_n, ci_n, co0, ci0, s5);
   adam_tile_rows<AF_TAPS3, NT>(a.h, a.p3[i], a.g3[i], a.m3[i], a.v3[i], co_n, ci_n, co0, ci0, s3);
+#if RM_ADAM_TIMING >= 1
+  return;      // TIMING BUILDS ONLY (no operands written)
+#endif
   __syncthreads();
 
   // ---- the fragment-major operands (layouts: include/repmode_hip.h, repmode_expert_frags).  Forward role: rows = co,
@@ -222,15 +258,14 @@ __global__ __launch_bounds__(NT) void adam_frags_kernel(AdamFragArgs a) {
     const size_t tap_stride = (size_t)coP * ciP;                   // elements per tap of one slot
     const size_t tile = ((size_t)(co0 / 32) * (ciP / 16) + ci0 / 16) * (32 * 16) + (size_t)(co0 % 32) * 16;
     uint32_t* out = reinterpret_cast<uint32_t*>(a.wf[i] + tile);
-    const uint32_t* s5w = reinterpret_cast<const uint32_t*>(s5);
-    const uint32_t* s3w = reinterpret_cast<const uint32_t*>(s3);
+    const int row = t128 >> 3, col = 2 * (t128 & 7);              // this thread's dword: row co = row, ci pair (col, col + 1)
     for (int tap = half; tap < AF_TAPS5; tap += NG) {
-      out[(size_t)tap * tap_stride / 2 + t128] = s5w[tap * (AF_T * AF_T / 2) + t128];
+      out[(size_t)tap * tap_stride / 2 + t128] = af_pair_cols<AF_TAPS5>(s5, tap, row, col);
       const int dz = tap / 25, dy = (tap / 5) % 5, dx = tap % 5;
       if (dz >= 1 && dz <= 3 && dy >= 1 && dy <= 3) {               // slot 1: the rows a centred-3x3x3 convolution reads
         const bool in = dx >= 1 && dx <= 3;
         const int t3 = ((dz - 1) * 3 + (dy - 1)) * 3 + (dx - 1);
-        out[((size_t)AF_TAPS5 + tap) * tap_stride / 2 + t128] = in ? s3w[t3 * (AF_T * AF_T / 2) + t128] : 0u;
+        out[((size_t)AF_TAPS5 + tap) * tap_stride / 2 + t128] = in ? af_pair_cols<AF_TAPS3>(s3, t3, row, col) : 0u;
       }
     }
   }
@@ -243,17 +278,13 @@ __global__ __launch_bounds__(NT) void adam_frags_kernel(AdamFragArgs a) {
     uint32_t* out = reinterpret_cast<uint32_t*>(a.wd[i] + tile);
     const int row = t128 >> 3, kp = t128 & 7;                       // this thread's dword: row ci = row, co pair (2 kp, 2 kp + 1)
     for (int tap = half; tap < AF_TAPS5; tap += NG) {
-      const bf16_t* s = s5 + tap * (AF_T * AF_T);
-      const uint32_t w = (uint32_t)s[(2 * kp) * AF_T + row] | ((uint32_t)s[(2 * kp + 1) * AF_T + row] << 16);
       const int tap_out = AF_TAPS5 - 1 - tap;
-      out[(size_t)tap_out * tap_stride / 2 + t128] = w;
+      out[(size_t)tap_out * tap_stride / 2 + t128] = af_pair_rows<AF_TAPS5>(s5, tap, 2 * kp, row);
       const int dz = tap / 25, dy = (tap / 5) % 5, dx = tap % 5;
       if (dz >= 1 && dz <= 3 && dy >= 1 && dy <= 3) {
         const bool in = dx >= 1 && dx <= 3;
         const int t3 = ((dz - 1) * 3 + (dy - 1)) * 3 + (dx - 1);
-        const bf16_t* q = s3 + t3 * (AF_T * AF_T);
-        const uint32_t w3 = in ? ((uint32_t)q[(2 * kp) * AF_T + row] | ((uint32_t)q[(2 * kp + 1) * AF_T + row] << 16)) : 0u;
-        out[((size_t)AF_TAPS5 + tap_out) * tap_stride / 2 + t128] = w3;
+        out[((size_t)AF_TAPS5 + tap_out) * tap_stride / 2 + t128] = in ? af_pair_rows<AF_TAPS3>(s3, t3, 2 * kp, row) : 0u;
       }
     }
   }
@@ -262,7 +293,7 @@ __global__ __launch_bounds__(NT) void adam_frags_kernel(AdamFragArgs a) {
 #ifndef AF_THREADS
 #define AF_THREADS 512
 #endif
-constexpr int AF_LDS_BYTES = (AF_TAPS5 + AF_TAPS3) * AF_T * AF_T * 2;
+constexpr int AF_LDS_BYTES = AF_T * (AfRow<AF_TAPS5>::RS + AfRow<AF_TAPS3>::RS) * 2;
 
 int fill_hyper(AdamHyper* h, double lr, double beta1, double beta2, double eps, long step) {
   RM_REQUIRE(step >= 1, "adam: step count starts at 1 (got %ld)", step);
@@ -330,7 +361,7 @@ extern "C" int repmode_adam_expert_frags(int nblocks, float* const* p5, const fl
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&adam_frags_kernel<AF_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, AF_LDS_BYTES));
     attr_done[dev & 31] = true;
   }
-  hipLaunchKernelGGL(adam_frags_kernel<AF_THREADS>, dim3((unsigned)total), dim3(AF_THREADS), AF_LDS_BYTES, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(adam_frags_kernel<AF_THREADS>, dim3((unsigned)total), dim3(AF_THREADS), RM_ADAM_TIMING >= 3 ? 1024 : AF_LDS_BYTES, static_cast<hipStream_t>(stream), a);
   RM_LAUNCH_CHECK("adam_expert_frags");
   return REPMODE_OK;
 }
