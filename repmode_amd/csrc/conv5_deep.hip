@@ -257,6 +257,9 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_deep_kernel(DeepArgs a) {
         const int lx = m % BX, ly = (m / BX) % BY, lz = m / (BX * BY);
         const int gz = bz * BZ + lz, gy = by * BY + ly, gx = bx * BX + lx;
         if (gz >= D || gy >= H || gx >= W) continue;
+#ifdef RM_CONV_NOEPI
+        if (acc[p][vs][r] == 12345.678f)      // TIMING BUILD ONLY: the sums are computed and (practically) never written
+#endif
         unsafeAtomicAdd(yn + ((size_t)(gz * H + gy) * W + gx) * Cout, acc[p][vs][r]);
       }
     }

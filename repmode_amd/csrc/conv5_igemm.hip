@@ -785,6 +785,9 @@ __global__ __launch_bounds__(C::NT, (C::BX == 16 && !MERGE) ? RM_CONV_X16_WAVES 
           float* yp = static_cast<float*>(out2 ? a.y2 : a.y) + (((size_t)(n_out * D + gz) * H + gy) * W + gx) * cw +
                       (out2 ? co - Cout1 : co);
           if (ksplit > 1 || a.accum || (a.dual && !(a.dual & 4))) {
+#ifdef RM_CONV_NOEPI
+            if (acc[cs][vs][r] == 12345.678f)      // TIMING BUILD ONLY
+#endif
             unsafeAtomicAdd(yp, acc[cs][vs][r]);
           } else {
             float v = acc[cs][vs][r];

@@ -301,9 +301,19 @@ namespace {
 
 constexpr int KW_TM = 64;                       // coarse voxels per tile
 constexpr int KW_RS = KW_TM * 2 + 16;           // bytes per channel row in LDS (odd multiple of 16)
+constexpr int KW_NT = 512;                      // eight waves: 2 x 2 (a, b) quadrants x two halves of the taps; one workgroup per CU
+                                                // is the planner's sweet spot and its tile step is instruction issue, shared by 2 waves per SIMD
 
-#ifndef K2W_TARGET_BLOCKS
-#define K2W_TARGET_BLOCKS 512   // fewer, longer workgroups: every workgroup ends in 8*32*32 f32 atomics (1024 -> 512: 43 -> 23 us at level 1)
+// the launch planner's constants (repmode_k2s2_wgrad_ex): workgroups it wants in flight at once (one per CU), a
+// workgroup's fixed cost and a tile step, in microseconds
+#ifndef K2W_RESIDENT
+#define K2W_RESIDENT 256
+#endif
+#ifndef K2W_FIXED_US
+#define K2W_FIXED_US 4.0
+#endif
+#ifndef K2W_TILE_US
+#define K2W_TILE_US 1.2
 #endif
 struct K2WArgs {
   const bf16_t* coarse;
@@ -312,6 +322,7 @@ struct K2WArgs {
   int param_layout;
   long M;
   int d, h, wd, A, B, ntiles, tiles_per_block;
+  int direct;             // every (a, b) tile has ONE workgroup: plain stores, dw needs no clearing
 };
 
 __device__ __forceinline__ u32x4 kw_load8(const bf16_t* row, int c, int C, bool vec) {
@@ -328,72 +339,142 @@ __device__ __forceinline__ uint32_t kw_elem(const u32x4& v, int k) {
   return (k & 1) ? (w >> 16) : (w & 0xffffu);
 }
 
-__global__ __launch_bounds__(256) void k2s2_wgrad_kernel(K2WArgs a) {
+// VEC: both channel counts are multiples of 8 and both tensors < 2 GiB -- every row is fetched with 16-byte buffer loads whose
+// out-of-range cases (past the last voxel, past the last channel, threads without a coarse item) are an out-of-bounds OFFSET
+// (returns 0), not a branch: the generic loader's per-load predicates made the tile step ~2 k instructions of exec-mask
+// juggling per wave (1.9 us), which was the kernel's bound.
+template <bool VEC>
+__global__ __launch_bounds__(KW_NT) void k2s2_wgrad_kernel(K2WArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[(32 + 8 * 32) * KW_RS];
   unsigned char* cT = smem;                       // [32 a][64 voxels]
   unsigned char* fT = smem + 32 * KW_RS;          // [8 taps][32 b][64 voxels]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int aq = wave & 1, bq = wave >> 1, l15 = lane & 15, kg = lane >> 4;
+  const int aq = wave & 1, bq = (wave >> 1) & 1, th = wave >> 2, l15 = lane & 15, kg = lane >> 4;   // th: taps 4 th .. 4 th + 3
   const int at = blockIdx.y, bt = blockIdx.z;
   const bool vec_a = (a.A & 7) == 0, vec_b = (a.B & 7) == 0;
-  f32x4 acc[8];
+  f32x4 acc[4];
 #pragma unroll
-  for (int p = 0; p < 8; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < 4; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int t_begin = blockIdx.x * a.tiles_per_block;
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_block);
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    const long m0 = (long)tile * KW_TM;
-    __syncthreads();
-    // coarse^T: items = (voxel pair, channel group of 8)
-    for (int it = tid; it < (KW_TM / 2) * 4; it += 256) {
-      const int q = it % (KW_TM / 2), cg = it / (KW_TM / 2);
-      const long m = m0 + 2 * q;
-      const int c = at * 32 + cg * 8;
-      u32x4 v0 = u32x4{0u, 0u, 0u, 0u}, v1 = v0;
-      if (m < a.M) v0 = kw_load8(a.coarse + (size_t)m * a.A, c, a.A, vec_a);
-      if (m + 1 < a.M) v1 = kw_load8(a.coarse + (size_t)(m + 1) * a.A, c, a.A, vec_a);
+  // This thread's staging items, the same in every tile: the voxel pair q (coarse voxels m0 + 2q, + 1) and the channel group cg
+  // of the coarse tile (threads 0..127) and of two taps p = ph + 4k of the fine tile.  The pair is decoded ONCE per tile --
+  // the eight taps of a coarse voxel are fixed row offsets from its tap-0 fine row (the per-item fine_row() calls this
+  // replaces were ~40 integer divisions per thread and tile: the loop was bound by address arithmetic, not by memory).
+  const int q = tid & 31, cg = (tid >> 5) & 3, ph = tid >> 7;      // (512 threads: ph = 0..3)
+  struct Rows { u32x4 c0, c1, f0[2], f1[2]; };       // a tile's fetched rows on their way to LDS
+  Rows ra, rb;                                       // TWO tiles in flight: a tile step (~2.3 us with one) is fetch latency
+  constexpr uint32_t OOB = 0x80000000u;
+  uint32_t toffk[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int p = ph + 4 * k;
+    toffk[k] = (uint32_t)((p >> 2) * (2 * a.h) * (2 * a.wd) + ((p >> 1) & 1) * (2 * a.wd) + (p & 1));
+  }
+  auto fetch = [&](Rows& t, int tile) {
+    // (VEC: NO early exit for a tile past the range -- its loads are issued with out-of-bounds offsets and cost nothing.  With
+    // a conditional fetch the compiler cannot count the loads in flight and waits for ALL of them (vmcnt(0)) before each
+    // transposition: the second register set then hides nothing)
+    if (!VEC && tile >= t_end) return;
+    const long m = (long)tile * KW_TM + 2 * q;
+    // 32-bit decode (the launcher checks that the fine tensor has < 2^31 rows): 64-bit integer division is a ~200-instruction
+    // routine, three of them per fetch
+    const uint32_t mu = (uint32_t)m, uw = (uint32_t)a.wd, uh = (uint32_t)a.h, ud = (uint32_t)a.d;
+    const uint32_t xq = mu % uw, t1 = mu / uw, yq = t1 % uh, t2 = t1 / uh, zq = t2 % ud, nq = t2 / ud;
+    const uint32_t r0 = ((nq * 2 * ud + 2 * zq) * (2 * uh) + 2 * yq) * (2 * uw) + 2 * xq;
+    uint32_t r1 = r0 + 2;
+    if (xq + 1 >= uw) r1 = (uint32_t)fine_row(m + 1 < a.M ? m + 1 : m, 0, a.d, a.h, a.wd);     // (odd widths only)
+    if constexpr (VEC) {
+      const bool v0 = m < a.M && tile < t_end, v1 = m + 1 < a.M && tile < t_end;
+      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.coarse), 0, (int)(a.M * a.A * 2), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.fine), 0, (int)(a.M * 8 * a.B * 2), 0x00020000);
+      const int ca = at * 32 + cg * 8, cb = bt * 32 + cg * 8;
+      const bool ua = tid < 128 && ca < a.A, ub = cb < a.B;
+      const uint32_t oc = (mu * (uint32_t)a.A + (uint32_t)ca) * 2u;
+      t.c0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, (ua && v0) ? oc : OOB, 0, 0));
+      t.c1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rc, (ua && v1) ? oc + (uint32_t)a.A * 2u : OOB, 0, 0));
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const uint32_t o0 = ((r0 + toffk[k]) * (uint32_t)a.B + (uint32_t)cb) * 2u, o1 = ((r1 + toffk[k]) * (uint32_t)a.B + (uint32_t)cb) * 2u;
+        t.f0[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rf, (ub && v0) ? o0 : OOB, 0, 0));
+        t.f1[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rf, (ub && v1) ? o1 : OOB, 0, 0));
+      }
+    } else {
+      const u32x4 zero = u32x4{0u, 0u, 0u, 0u};
+      t.c0 = zero; t.c1 = zero;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { t.f0[k] = zero; t.f1[k] = zero; }
+      if (m >= a.M) return;
+      const bool two = m + 1 < a.M;
+      if (tid < 128) {
+        const int c = at * 32 + cg * 8;
+        t.c0 = kw_load8(a.coarse + (size_t)m * a.A, c, a.A, vec_a);
+        if (two) t.c1 = kw_load8(a.coarse + (size_t)(m + 1) * a.A, c, a.A, vec_a);
+      }
+      const int c = bt * 32 + cg * 8;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        t.f0[k] = kw_load8(a.fine + (size_t)(r0 + toffk[k]) * a.B, c, a.B, vec_b);
+        if (two) t.f1[k] = kw_load8(a.fine + (size_t)(r1 + toffk[k]) * a.B, c, a.B, vec_b);
+      }
+    }
+  };
+  auto stage = [&](const Rows& t) {
+    if (tid < 128) {
       unsigned char* dst = cT + (cg * 8) * KW_RS + q * 4;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) *reinterpret_cast<uint32_t*>(dst + k * KW_RS) = kw_elem(v0, k) | (kw_elem(v1, k) << 16);
+      for (int e = 0; e < 8; ++e) *reinterpret_cast<uint32_t*>(dst + e * KW_RS) = kw_elem(t.c0, e) | (kw_elem(t.c1, e) << 16);
     }
-    // fine^T per tap: items = (tap, voxel pair, channel group)
-    for (int it = tid; it < 8 * (KW_TM / 2) * 4; it += 256) {
-      const int q = it % (KW_TM / 2); int r = it / (KW_TM / 2);
-      const int cg = r & 3, p = r >> 2;
-      const long m = m0 + 2 * q;
-      const int c = bt * 32 + cg * 8;
-      u32x4 v0 = u32x4{0u, 0u, 0u, 0u}, v1 = v0;
-      if (m < a.M) v0 = kw_load8(a.fine + fine_row(m, p, a.d, a.h, a.wd) * a.B, c, a.B, vec_b);
-      if (m + 1 < a.M) v1 = kw_load8(a.fine + fine_row(m + 1, p, a.d, a.h, a.wd) * a.B, c, a.B, vec_b);
-      unsigned char* dst = fT + ((size_t)p * 32 + cg * 8) * KW_RS + q * 4;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) *reinterpret_cast<uint32_t*>(dst + k * KW_RS) = kw_elem(v0, k) | (kw_elem(v1, k) << 16);
+    for (int k = 0; k < 2; ++k) {
+      unsigned char* dst = fT + ((size_t)(ph + 4 * k) * 32 + cg * 8) * KW_RS + q * 4;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) *reinterpret_cast<uint32_t*>(dst + e * KW_RS) = kw_elem(t.f0[k], e) | (kw_elem(t.f1[k], e) << 16);
     }
-    __syncthreads();
+  };
+  auto mma = [&]() {
 #pragma unroll
     for (int ks = 0; ks < KW_TM / 32; ++ks) {
       const u32x4 af = *reinterpret_cast<const u32x4*>(cT + (aq * 16 + l15) * KW_RS + (ks * 32 + kg * 8) * 2);
 #pragma unroll
-      for (int p = 0; p < 8; ++p) {
-        const u32x4 bf = *reinterpret_cast<const u32x4*>(fT + ((size_t)p * 32 + bq * 16 + l15) * KW_RS + (ks * 32 + kg * 8) * 2);
+      for (int p = 0; p < 4; ++p) {
+        const u32x4 bf = *reinterpret_cast<const u32x4*>(fT + ((size_t)(th * 4 + p) * 32 + bq * 16 + l15) * KW_RS + (ks * 32 + kg * 8) * 2);
         acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf),
                                                          acc[p], 0, 0, 0);
       }
+    }
+  };
+  // tile t's rows are transposed into LDS two tile steps after they were requested
+  fetch(ra, t_begin);
+  fetch(rb, t_begin + 1);
+  for (int tile = t_begin; tile < t_end; tile += 2) {
+    __syncthreads();
+    stage(ra);
+    __syncthreads();
+    fetch(ra, tile + 2);
+    mma();
+    if (VEC || tile + 1 < t_end) {                   // (VEC: a tile past the range is all zeros -- straight-line code, see fetch)
+      __syncthreads();
+      stage(rb);
+      __syncthreads();
+      fetch(rb, tile + 3);
+      mma();
     }
   }
   // 16x16 C/D layout: column (b) = lane & 15, row (a) = (lane >> 4) * 4 + r
   const int bcol = bt * 32 + bq * 16 + l15;
   if (bcol < a.B) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p)
+    for (int pj = 0; pj < 4; ++pj)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int arow = at * 32 + aq * 16 + kg * 4 + r;
+        const int arow = at * 32 + aq * 16 + kg * 4 + r, p = th * 4 + pj;
         if (arow < a.A) {
           const size_t at = a.param_layout == 0 ? ((size_t)p * a.A + arow) * a.B + bcol
                           : a.param_layout == 1 ? ((size_t)arow * a.B + bcol) * 8 + p
                                                 : ((size_t)bcol * a.A + arow) * 8 + p;
-          unsafeAtomicAdd(a.dw + at, acc[p][r]);
+          if (a.direct) a.dw[at] = acc[pj][r];           // (one workgroup per (a, b) tile: nothing to add to)
+          else unsafeAtomicAdd(a.dw + at, acc[pj][r]);
         }
       }
   }
@@ -490,7 +571,7 @@ extern "C" int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float
     f.param_layout = param_layout;
     f.M = (long)n * d * h * wdim; f.d = d; f.h = h; f.wd = wdim; f.A = ca; f.B = cb;
     const int tiles = ceil_div(ca, 32) * ceil_div(cb, 32);
-    long chunks = (K2W_TARGET_BLOCKS + 8L * tiles - 1) / (8L * tiles);      // enough workgroups to fill the chip
+    long chunks = (512 + 8L * tiles - 1) / (8L * tiles);      // enough workgroups to fill the chip
     const long max_chunks = (f.M + 31) / 32;
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
@@ -506,16 +587,43 @@ extern "C" int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float
   a.coarse = static_cast<const bf16_t*>(coarse); a.fine = static_cast<const bf16_t*>(fine); a.dw = dw;
   a.param_layout = param_layout;
   a.M = (long)n * d * h * wdim; a.d = d; a.h = h; a.wd = wdim; a.A = ca; a.B = cb;
+  RM_REQUIRE(a.M * 8 < (1L << 31), "k2s2_wgrad: %ld fine voxels (the kernel decodes positions in 32 bits)", a.M * 8);
   a.ntiles = (int)((a.M + KW_TM - 1) / KW_TM);
   const int nat = ceil_div(ca, 32), nbt = ceil_div(cb, 32);
-  long want = (K2W_TARGET_BLOCKS + (long)nat * nbt - 1) / ((long)nat * nbt);
+  // The voxel range is split over `want` workgroups per (a, b) tile.  Every workgroup but a lone one ends in 8 x 32 x 32 float
+  // atomics (32 KB at the memory-side rate of ~1.2 TB/s; with one or two tiles all of them on the same few hundred lines), a
+  // tile step is ~1.2 us, one workgroup per CU is the sweet spot (measured: 512 workgroups of the level-0 up stage 49 us, 256
+  // 30 us): the split that minimises rounds x (fixed + steps + atomics) is taken.  Round 3's fixed 512 workgroups made every
+  // launch's atomics 16.8 MB = 13.6 us whatever the level.  Same box, us per launch round 3 -> now, batch 8 (tools/
+  // k2s2_microbench.py under rocprofv3): down stages 38.7 / 23.4 / 19.0 / 13.0 -> 22.9 / 15.5 / 11.1 / 8-12, up stages
+  // 64.2 / 34.2 / 22.6 / 18.7 -> 30.1 / 19.1 / 14.0 / 9.8.
+  static const int target_env = []() { const char* e = getenv("REPMODE_K2W_BLOCKS"); return e ? atoi(e) : 0; }();
+  long want = 1;
+  if (target_env > 0) {
+    want = (target_env + (long)nat * nbt - 1) / ((long)nat * nbt);
+  } else {
+    double best = 1e30;
+    for (long w = 1; w <= a.ntiles; w *= 2) {
+      const long wgs = w * nat * nbt;
+      const double rounds = (double)((wgs + K2W_RESIDENT - 1) / K2W_RESIDENT);
+      const double steps = (double)ceil_div(a.ntiles, (int)w);
+      const double per_wg = 0.012 + 0.02 * (nat * nbt >= 8 ? 8.0 / (nat * nbt) : 1.0);                 // us: the fewer tiles, the more adds meet on a line
+      const double atom = w > 1 ? per_wg * (double)(wgs < K2W_RESIDENT ? wgs : K2W_RESIDENT) : 0.0;     // the round's atomics
+      const double cost = rounds * (K2W_FIXED_US + steps * K2W_TILE_US + atom);
+      if (cost < best * 0.98) { best = cost; want = w; }
+      if (wgs >= 4 * K2W_RESIDENT) break;
+    }
+  }
   if (want > a.ntiles) want = a.ntiles;
   if (want < 1) want = 1;
   if (repmode_deterministic() && want > repmode_det_cap(RM_DET_K2S2)) want = repmode_det_cap(RM_DET_K2S2);             // (deterministic: at most two addends per element of the cleared dw)
   a.tiles_per_block = ceil_div(a.ntiles, (int)want);
   const int nchunks = ceil_div(a.ntiles, a.tiles_per_block);
-  if (!prezeroed) RM_HIP(hipMemsetAsync(dw, 0, (size_t)8 * ca * cb * sizeof(float), s));
-  hipLaunchKernelGGL(k2s2_wgrad_kernel, dim3(nchunks, nat, nbt), dim3(256), 0, s, a);
+  a.direct = nchunks == 1;
+  if (!prezeroed && !a.direct) RM_HIP(hipMemsetAsync(dw, 0, (size_t)8 * ca * cb * sizeof(float), s));
+  const bool vec = (ca & 7) == 0 && (cb & 7) == 0 && a.M * (long)ca * 2 < (1L << 31) && a.M * 8 * (long)cb * 2 < (1L << 31);
+  if (vec) hipLaunchKernelGGL(k2s2_wgrad_kernel<true>, dim3(nchunks, nat, nbt), dim3(KW_NT), 0, s, a);
+  else hipLaunchKernelGGL(k2s2_wgrad_kernel<false>, dim3(nchunks, nat, nbt), dim3(KW_NT), 0, s, a);
   RM_LAUNCH_CHECK("k2s2_wgrad");
   return REPMODE_OK;
 }

@@ -202,6 +202,48 @@ SAMPLED = ['conv_out.expert_conv5x5_conv', 'conv_out.gate.weight', 'decoder_bloc
            'encoder_block2.conv_down.0.weight', 'decoder_block3.convt.0.weight', 'encoder_block4.conv_more.conv1.subsequent_layer.0.weight']
 
 
+K2W_CASES = [  # (n, d, h, w coarse, A coarse channels, B fine channels)
+    (2, 2, 4, 4, 40, 24),        # ragged channel tiles (multiples of 8: the buffer-load form), few tiles
+    (1, 3, 5, 7, 32, 64),        # odd width: a voxel pair straddles two rows
+    (2, 3, 5, 7, 12, 20),        # channels not multiples of 8: the generic loader
+    (3, 4, 8, 16, 64, 32),       # many tiles, an odd tile count per workgroup
+    (8, 2, 4, 4, 256, 128),      # the deep up stage: few tiles, many (a, b) tiles
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,d,h,w,ca,cb', K2W_CASES)
+@pytest.mark.parametrize('deterministic', [False, True])
+def test_k2s2_filter_gradient_against_an_einsum(n, d, h, w, ca, cb, deterministic):
+    """Autograd of Conv3d(k2, s2) / ConvTranspose3d(k2, s2) w.r.t. the weight (RepMode.py:81, :98):
+    dw[p][a][b] = sum_m coarse[m][a] * fine[fine(m, p)][b] against a float64 einsum of the same bf16 inputs: the planned
+    split of the voxel range (float atomics, or plain stores where a tile has one workgroup) and the deterministic mode's
+    capped split (run-to-run bitwise)."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(n * 131 + w)
+    coarse = torch.randn(n, d, h, w, ca, generator=gen).bfloat16()
+    fine = torch.randn(n, 2 * d, 2 * h, 2 * w, cb, generator=gen).bfloat16()
+    f8 = fine.double().view(n, d, 2, h, 2, w, 2, cb)
+    want = torch.einsum('nzyxa,nzpyqxrb->pqrab', coarse.double(), f8).reshape(8, ca, cb)
+    got = ops.k2s2_wgrad(coarse.to(DEV), fine.to(DEV)).double().cpu()
+    assert rel_err(got, want) < 2e-6, rel_err(got, want)
+    d1 = ops.k2s2_wgrad(coarse.to(DEV), fine.to(DEV), param_layout=1).double().cpu()
+    assert rel_err(d1, want.view(2, 2, 2, ca, cb).permute(3, 4, 0, 1, 2)) < 2e-6
+    if deterministic:
+        from repmode_amd import _lib
+        lib = _lib.load()
+        prev = lib.repmode_get_deterministic()
+        lib.repmode_set_deterministic(1)            # caps the split (at most two addends per element)
+        try:
+            a = ops.k2s2_wgrad(coarse.to(DEV), fine.to(DEV)).cpu()
+            b = ops.k2s2_wgrad(coarse.to(DEV), fine.to(DEV)).cpu()
+        finally:
+            lib.repmode_set_deterministic(prev)
+        assert torch.equal(a, b)
+        assert rel_err(a.double(), want) < 2e-6
+
+
+
 @pytest.mark.timeout(1500)
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_train_iter_at_the_reference_patch_size(dtype):

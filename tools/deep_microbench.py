@@ -46,9 +46,13 @@ for shape, ci, co in LAYERS:
     def deep_d(): ops.conv5_deep(g2, wd, ci, two_in=True, out=dx, zeroed=True)
     def dual_f(): _lib.call('repmode_conv5_ex', P(x.data_ptr()), P(wf.data_ptr()), P(slot0.data_ptr()), P(y2.data_ptr()), n, d, h, w, ci, co, 1, 1, 2 | 8 | 32, stream())
     def dual_d(): _lib.call('repmode_conv5_ex', P(g2.data_ptr()), P(wd.data_ptr()), P(slot0.data_ptr()), P(dx.data_ptr()), n, d, h, w, co, ci, 1, 1, 2 | 8 | 16, stream())
-    r = {k: timed(f) for k, f in (('deep_f', deep_f), ('dual_f', dual_f), ('deep_d', deep_d), ('dual_d', dual_d))}
+    gy5, gy3 = g2[:n], g2[n:]
+    dk5, dk3 = torch.empty_like(k5), torch.empty_like(k3)
+    def wgrad(): _lib.call('repmode_conv5_wgrad_dual', P(x.data_ptr()), P(gy5.data_ptr()), P(gy3.data_ptr()), P(dk5.data_ptr()), P(dk3.data_ptr()), n, d, h, w, ci, co, 2, 3, stream())
+    r = {k: timed(f) for k, f in (('deep_f', deep_f), ('dual_f', dual_f), ('deep_d', deep_d), ('dual_d', dual_d), ('wgrad', wgrad))}
+    tot['wgrad'] = tot.get('wgrad', 0.0) + r['wgrad']
     tot['deep'] += r['deep_f'] + r['deep_d']
     tot['dual'] += r['dual_f'] + r['dual_d']
-    print('%s %4d->%4d  fwd: deep %6.1f us (%5.0f TF)  dual %6.1f us (%5.0f TF)   dgrad: deep %6.1f us  dual %6.1f us' %
-          (shape, ci, co, r['deep_f'], flop / r['deep_f'] / 1e6, r['dual_f'], flop / r['dual_f'] / 1e6, r['deep_d'], r['dual_d']))
-print('sum over the five shapes (fwd + dgrad): deep %.1f us, dual %.1f us' % (tot['deep'], tot['dual']))
+    print('%s %4d->%4d  fwd: deep %6.1f us (%5.0f TF)  dual %6.1f us (%5.0f TF)   dgrad: deep %6.1f us  dual %6.1f us   wgrad (both experts, their own layout) %6.1f us (%5.0f TF)' %
+          (shape, ci, co, r['deep_f'], flop / r['deep_f'] / 1e6, r['dual_f'], flop / r['dual_f'] / 1e6, r['deep_d'], r['dual_d'], r['wgrad'], flop / r['wgrad'] / 1e6))
+print('sum over the five shapes (fwd + dgrad): deep %.1f us, dual %.1f us; filter gradients %.1f us' % (tot['deep'], tot['dual'], tot['wgrad']))

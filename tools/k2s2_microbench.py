@@ -19,6 +19,7 @@ for (c, d, h, w) in [(32, 16, 32, 32), (64, 8, 16, 16), (128, 4, 8, 8), (256, 2,
     for _ in range(30):
         y = ops.k2s2(fine, fd, c, scatter=False)
         z = ops.k2s2(coarse2, fu, c, scatter=True)
-        g = ops.k2s2_wgrad(y, fine)
+        g = ops.k2s2_wgrad(y, fine)                 # down stage: coarse = dy [c], fine = x [c]
+        g2 = ops.k2s2_wgrad(coarse2, fine)          # up stage: coarse = x [2c], fine = dy [c]
     torch.cuda.synchronize()
     print('done', c, d, h, w)
