@@ -84,13 +84,13 @@ __device__ __forceinline__ void store_quad(T* row, int co, int Cout, float v0, f
 }
 
 // fine-grid row index of tap p = (pz, py, px) of coarse voxel m
-__device__ __forceinline__ size_t fine_row(long m, int p, int d, int h, int w) {
-  const int x = (int)(m % w); long t = m / w;
-  const int y = (int)(t % h); t /= h;
-  const int z = (int)(t % d);
-  const long n = t / d;
-  const int pz = p >> 2, py = (p >> 1) & 1, px = p & 1;
-  return (((size_t)n * (2 * d) + 2 * z + pz) * (2 * h) + 2 * y + py) * (size_t)(2 * w) + 2 * x + px;
+// (32-bit arithmetic: every launcher checks that the fine grid has < 2^31 voxels.  A 64-bit division by a run-time value is
+// a ~200-instruction routine, and these kernels' bodies are a few dozen instructions per voxel)
+__device__ __forceinline__ size_t fine_row(long m_, int p, int d, int h, int w) {
+  const uint32_t m = (uint32_t)m_, uw = (uint32_t)w, uh = (uint32_t)h, ud = (uint32_t)d;
+  const uint32_t x = m % uw, t = m / uw, y = t % uh, t2 = t / uh, z = t2 % ud, n = t2 / ud;
+  const uint32_t pz = (uint32_t)p >> 2, py = ((uint32_t)p >> 1) & 1u, px = (uint32_t)p & 1u;
+  return (size_t)(((n * 2u * ud + 2u * z + pz) * (2u * uh) + 2u * y + py) * (2u * uw) + 2u * x + px);
 }
 
 // workgroup = 4 waves = 4 x 32 coarse voxels; blockIdx.y = output-channel tile (32)
@@ -259,6 +259,7 @@ extern "C" int repmode_k2s2(const void* in, const void* w, void* out, int n, int
   K2Args a{};
   a.in = in; a.w = w; a.out = out;
   a.M = (long)n * d * h * wdim; a.d = d; a.h = h; a.wd = wdim;
+  RM_REQUIRE(a.M * 8 < (1L << 31), "k2s2: %ld fine voxels (the kernels decode positions in 32 bits)", a.M * 8);
   a.Cin = cin; a.Cout = cout;
   a.CinP = repmode_padded_channels(cin, dtype, 1);
   a.CoutP = repmode_padded_channels(cout, dtype, 0);
@@ -565,6 +566,7 @@ extern "C" int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float
   RM_REQUIRE(n > 0 && d > 0 && h > 0 && wdim > 0 && ca > 0 && cb > 0, "k2s2_wgrad: bad shape");
   RM_REQUIRE(((uintptr_t)coarse & 15) == 0 && ((uintptr_t)fine & 15) == 0, "k2s2_wgrad: pointers must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  RM_REQUIRE((long)n * d * h * wdim * 8 < (1L << 31), "k2s2_wgrad: %ld fine voxels (the kernels decode positions in 32 bits)", (long)n * d * h * wdim * 8);
   if (is_f32) {
     K2WArgsF f{};
     f.coarse = static_cast<const float*>(coarse); f.fine = static_cast<const float*>(fine); f.dw = dw;
@@ -587,7 +589,6 @@ extern "C" int repmode_k2s2_wgrad_ex(const void* coarse, const void* fine, float
   a.coarse = static_cast<const bf16_t*>(coarse); a.fine = static_cast<const bf16_t*>(fine); a.dw = dw;
   a.param_layout = param_layout;
   a.M = (long)n * d * h * wdim; a.d = d; a.h = h; a.wd = wdim; a.A = ca; a.B = cb;
-  RM_REQUIRE(a.M * 8 < (1L << 31), "k2s2_wgrad: %ld fine voxels (the kernel decodes positions in 32 bits)", a.M * 8);
   a.ntiles = (int)((a.M + KW_TM - 1) / KW_TM);
   const int nat = ceil_div(ca, 32), nbt = ceil_div(cb, 32);
   // The voxel range is split over `want` workgroups per (a, b) tile.  Every workgroup but a lone one ends in 8 x 32 x 32 float

@@ -1,0 +1,9 @@
+# the stride-2 filter gradient's rewrite on the whole step (round 3's kernel = variants/k2old), interleaved
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4s17; rm -rf $O; mkdir -p $O; cd $R
+timeout 900 python -m pytest tests/test_hip_round4.py tests/test_hip_parity.py -x -q -m gpu -k "k2 or down_up or deterministic" 2>&1 | tail -3
+for rep in 1 2 3; do for v in k2old product; do
+  if [ $v = product ]; then E=""; else E="REPMODE_LIB=$R/variants/$v/librepmode_hip.so REPMODE_TORCH_LIB=$R/variants/$v/librepmode_torch.so"; fi
+  env $E timeout 300 python bench.py --no-cpu-baseline --no-fwd --steps 60 --warmup 20 > $O/b_${v}_$rep.json 2>> $O/err.txt
+  python -c "
+import json; d=json.load(open('$O/b_${v}_$rep.json')); print('$v', round(d['ms_per_step'],3), 'ms/step', d['config'].get('final_loss'))"
+done; done
