@@ -38,8 +38,18 @@ struct Gemm3Args {
 
 // BF16: operands rounded to bfloat16 while staging, v_mfma_f32_16x16x32_bf16 (16x the f32 rate) -- the throughput mode,
 // whose other kernels multiply bf16 operands with f32 accumulation as well; !BF16: exact float32 (parity mode).
-template <bool BF16>
+// VEC (BF16, operand A K-contiguous: the forward and data-gradient shapes; the host checks every extent and non-unit stride
+// a multiple of 4, 16-byte aligned matrices below 2 GiB): an operand's 64 x 32 step is TWO 16-byte buffer loads per thread
+// along its contiguous axis instead of eight predicated 4-byte loads; out-of-range pieces (ragged last tile, K beyond this
+// slice) are an out-of-bounds OFFSET, which returns 0 without a branch; and the next step is fetched unconditionally (past the
+// end: all offsets out of bounds, no traffic), so the compiler can count the loads in flight instead of waiting for all of
+// them.  These launches are chains of a few K steps: their time is the instructions between two barriers.  Same box, GPU time
+// per launch (tools/sessions/r4_session19.sh): forward shapes 18.6 -> 14.7, 20.8 -> 13.5, 10.0 -> 8.5 us, data gradient 17.8 ->
+// 15.4, 14.8 -> 13.6; the filter-gradient shape (both operands K-strided: four rows per lane land on 4 LDS banks) loses
+// (17.0 -> 18.7) and keeps the scalar loader.
+template <bool BF16, bool VEC = false>
 __global__ __launch_bounds__(256) void gemm3_kernel(Gemm3Args g) {
+  static_assert(!VEC || BF16, "the vector path stages bf16");
   constexpr int KP = GK + 8;                                                   // bf16 row: K contiguous, 16 bytes of padding
   __shared__ __attribute__((aligned(16))) float As[BF16 ? GT * KP / 2 : GK * (GT + GPAD)];      // f32: [k][m]; bf16: [m][k]
   __shared__ __attribute__((aligned(16))) float Bs[BF16 ? GT * KP / 2 : GK * (GT + GPAD)];
@@ -65,6 +75,69 @@ __global__ __launch_bounds__(256) void gemm3_kernel(Gemm3Args g) {
   // grid fills the chip, each slice adding its part with float atomics.
   const int ksteps = (g.K + GK - 1) / GK;
   const int k_begin = (int)((long)kz * ksteps / g.ksplit) * GK, k_end = min(g.K, (int)((long)(kz + 1) * ksteps / g.ksplit) * GK);
+  auto mma_bf16 = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < GK; ks += 32) {
+      bf16x8 af[2], bf[2];                  // lane: row / column lane & 15, k = 8 (lane >> 4) .. + 7
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + (wm + i * 16 + l15) * KP + ks + 8 * kq);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bb + (wn + j * 16 + l15) * KP + ks + 8 * kq);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  if constexpr (VEC) {
+    constexpr uint32_t OOB = 0x80000000u;
+    constexpr int NV = GT * GK / 4 / 256;            // float4 pieces per operand, K step and thread (2)
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, 0x7fffffff, 0x00020000);
+    // this thread's pieces: K-contiguous operand -> (row f / 8, k 4 (f % 8)); row-contiguous -> (rows 4 (f % 16), k f / 16)
+    int prow[2][NV], pk[2][NV];
+    uint32_t poff[2][NV];                            // byte offset at k0 = 0 (OOB: the rows are outside the matrix)
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int f = u * 256 + tid;
+      prow[0][u] = a_kfast ? f / (GK / 4) : (f % (GT / 4)) * 4;  pk[0][u] = a_kfast ? (f % (GK / 4)) * 4 : f / (GT / 4);
+      prow[1][u] = b_kfast ? f / (GK / 4) : (f % (GT / 4)) * 4;  pk[1][u] = b_kfast ? (f % (GK / 4)) * 4 : f / (GT / 4);
+      poff[0][u] = m0 + prow[0][u] < g.M ? (uint32_t)(((long)(m0 + prow[0][u]) * g.a_ms + (long)pk[0][u] * g.a_ks) * 4) : OOB;
+      poff[1][u] = n0 + prow[1][u] < g.N ? (uint32_t)(((long)(n0 + prow[1][u]) * g.b_ns + (long)pk[1][u] * g.b_ks) * 4) : OOB;
+    }
+    const uint32_t kstep_a = (uint32_t)(g.a_ks * 4), kstep_b = (uint32_t)(g.b_ks * 4);      // bytes per unit of k
+    f32x4 va[NV], vb[NV];
+    auto fetchv = [&](int k0) {
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        va[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                  rsa, (poff[0][u] != OOB && k0 + pk[0][u] < k_end) ? poff[0][u] + (uint32_t)k0 * kstep_a : OOB, 0, 0));
+        vb[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                  rsb, (poff[1][u] != OOB && k0 + pk[1][u] < k_end) ? poff[1][u] + (uint32_t)k0 * kstep_b : OOB, 0, 0));
+      }
+    };
+    auto put = [&](bf16_t* dst, bool kfast, int row, int k, const f32x4& v) {
+      if (kfast) {        // four consecutive k of one row: one 8-byte write
+        *reinterpret_cast<u32x2*>(dst + row * KP + k) = u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+      } else {            // four consecutive rows at one k
+        const uint32_t lo = pack_bf16x2(v.x, v.y), hi = pack_bf16x2(v.z, v.w);
+        dst[(row + 0) * KP + k] = (bf16_t)(lo & 0xffffu); dst[(row + 1) * KP + k] = (bf16_t)(lo >> 16);
+        dst[(row + 2) * KP + k] = (bf16_t)(hi & 0xffffu); dst[(row + 3) * KP + k] = (bf16_t)(hi >> 16);
+      }
+    };
+    fetchv(k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += GK) {
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        put(Ab, a_kfast, prow[0][u], pk[0][u], va[u]);
+        put(Bb, b_kfast, prow[1][u], pk[1][u], vb[u]);
+      }
+      __syncthreads();
+      fetchv(k0 + GK);
+      mma_bf16();
+    }
+  } else {
   float ra[GLD], rb[GLD];
   auto fetch = [&](int k0) {
 #pragma unroll
@@ -97,18 +170,7 @@ __global__ __launch_bounds__(256) void gemm3_kernel(Gemm3Args g) {
     __syncthreads();
     if (k0 + GK < k_end) fetch(k0 + GK);
     if constexpr (BF16) {
-#pragma unroll
-      for (int ks = 0; ks < GK; ks += 32) {
-        bf16x8 af[2], bf[2];                  // lane: row / column lane & 15, k = 8 (lane >> 4) .. + 7
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ab + (wm + i * 16 + l15) * KP + ks + 8 * kq);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(Bb + (wn + j * 16 + l15) * KP + ks + 8 * kq);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-      }
+      mma_bf16();
     } else {
 #pragma unroll
       for (int ks = 0; ks < GK; ks += 4) {
@@ -123,6 +185,7 @@ __global__ __launch_bounds__(256) void gemm3_kernel(Gemm3Args g) {
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
     }
+  }
   }
   // 16x16 C/D layout: column = lane & 15, row = (lane >> 4) * 4 + r
 #pragma unroll
@@ -164,7 +227,14 @@ extern "C" int repmode_gemm3(const float* const* a, long a_ms, long a_ks, const 
   if (c_is_zero) while (tiles * ks < 512 && (k + GK - 1) / GK >= 4 * ks && ks < ks_max) ks *= 2;
   g.ksplit = ks;
   const dim3 grid((n + GT - 1) / GT, (m + GT - 1) / GT, 3 * ks);
-  if (bf16_mfma) hipLaunchKernelGGL(gemm3_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  // the vector path's conditions (see the kernel)
+  auto mult4 = [](long v) { return (v & 3) == 0; };
+  bool vec = bf16_mfma && a_ks == 1 && mult4(m) && mult4(n) && mult4(k) && mult4(a_ms) &&
+             (b_ks == 1 ? mult4(b_ns) : (b_ns == 1 && mult4(b_ks))) &&
+             ((long)m * a_ms + (long)k * a_ks) * 4 < (1L << 31) && ((long)n * b_ns + (long)k * b_ks) * 4 < (1L << 31);
+  for (int i = 0; i < 3; ++i) vec = vec && (((uintptr_t)a[i] | (uintptr_t)b[i]) & 15) == 0;
+  if (vec) hipLaunchKernelGGL((gemm3_kernel<true, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  else if (bf16_mfma) hipLaunchKernelGGL(gemm3_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
   else hipLaunchKernelGGL(gemm3_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
   RM_LAUNCH_CHECK("gemm3");
   return REPMODE_OK;
