@@ -99,70 +99,99 @@ __global__ __launch_bounds__(256) void box_sum_kernel(const float* __restrict__ 
 // sample and a group of CB channels, keeps the whole D x H x W volume in LDS and applies the three 1-D box sums
 // (5 + 5 + 5 LDS reads per output instead of 125 gathered global loads -- the direct kernel above is bound by L1
 // bandwidth: 152 float4 loads per output).
+// Round 4: BOTH box sums go through ONE sequence of phases (load, x, y, z: three barriers) with both inputs requested up
+// front and every item's (x, y, z) decoded once -- these launches move a few MB on 128-256 workgroups, so their time is the
+// length of the dependent chain: two passes of load / x / y / z with eight barriers and an index decode per item and phase
+// were 13-18 us per launch.
 namespace {
+constexpr int BOX_MAXI = 16;                     // items per thread (launcher guarantees items <= 256 * BOX_MAXI)
+
+struct BoxItems {
+  int n_items, c4n, W, H, D;
+  uint32_t xyz[BOX_MAXI];                        // x | y << 10 | z << 20 of item tid + 256 j
+  __device__ __forceinline__ void init(int V, int c4n_, int D_, int H_, int W_, int tid) {
+    n_items = V * c4n_; c4n = c4n_; W = W_; H = H_; D = D_;
+#pragma unroll
+    for (int j = 0; j < BOX_MAXI; ++j) {
+      const int i = tid + j * 256;
+      const int v = i / c4n, x = v % W, t = v / W, y = t % H, z = t / H;
+      xyz[j] = (uint32_t)x | ((uint32_t)y << 10) | ((uint32_t)z << 20);
+    }
+  }
+};
+
+// out[i] = sum over |d| <= R of in[i + d * step] where coordinate + d stays inside [0, extent)
+template <int R>
+__device__ __forceinline__ f32x4 box_line(const f32x4* in, int i, int step, int coord, int extent) {
+  f32x4 t = in[i];
+#pragma unroll
+  for (int d = 1; d <= R; ++d) {
+    if (coord - d >= 0) t += in[i - d * step];
+    if (coord + d < extent) t += in[i + d * step];
+  }
+  return t;
+}
+
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void box_sum_lds_kernel(const float* __restrict__ in3, const float* __restrict__ in5,
                                                           const float* __restrict__ add0, const float* __restrict__ add1,
                                                           void* __restrict__ out_, int D, int H, int W, int C, int CB) {
   extern __shared__ __attribute__((aligned(16))) unsigned char box_smem[];
   const int V = D * H * W, c4n = CB / 4, items = V * c4n;
-  f32x4* A = reinterpret_cast<f32x4*>(box_smem);
-  f32x4* B = A + items;
+  f32x4* A3 = reinterpret_cast<f32x4*>(box_smem);
+  f32x4* B3 = A3 + items;
+  f32x4* A5 = B3 + items;
+  f32x4* B5 = A5 + items;
   const int n = blockIdx.x, c0 = blockIdx.y * CB;
   const int tid = threadIdx.x;
-  constexpr int MAXI = 16;                       // items per thread (launcher guarantees items <= 256 * MAXI)
-  f32x4 res[MAXI];
+  BoxItems it;
+  it.init(V, c4n, D, H, W, tid);
+  const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ---- both inputs, all of this thread's items, before anything waits
 #pragma unroll
-  for (int j = 0; j < MAXI; ++j) res[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int pass = 0; pass < 2; ++pass) {
-    const float* src = pass ? in5 : in3;
-    if (!src) continue;                            // uniform
-    const int r = pass ? 2 : 1;
-    const float scale = pass ? 1.0f / 125.0f : 1.0f / 27.0f;
-    __syncthreads();
-    for (int i = tid; i < items; i += 256) {
-      const int v = i / c4n, q = i % c4n;
-      const int c = c0 + 4 * q;
-      A[i] = c < C ? *reinterpret_cast<const f32x4*>(src + ((size_t)n * V + v) * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
-    for (int i = tid; i < items; i += 256) {       // along x: A -> B
-      const int v = i / c4n, x = v % W;
-      f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int d = -r; d <= r; ++d)
-        if ((unsigned)(x + d) < (unsigned)W) t += A[i + d * c4n];
-      B[i] = t;
-    }
-    __syncthreads();
-    for (int i = tid; i < items; i += 256) {       // along y: B -> A
-      const int v = i / c4n, y = (v / W) % H;
-      f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int d = -r; d <= r; ++d)
-        if ((unsigned)(y + d) < (unsigned)H) t += B[i + d * W * c4n];
-      A[i] = t;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < MAXI; ++j) {               // along z: A -> registers
-      const int i = tid + j * 256;
-      if (i < items) {
-        const int v = i / c4n, z = v / (W * H);
-        f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int d = -r; d <= r; ++d)
-          if ((unsigned)(z + d) < (unsigned)D) t += A[i + d * H * W * c4n];
-        res[j] += t * scale;
-      }
+  for (int j = 0; j < BOX_MAXI; ++j) {
+    const int i = tid + j * 256;
+    if (i < items) {
+      const int v = i / c4n, q = i % c4n, c = c0 + 4 * q;
+      const size_t o = ((size_t)n * V + v) * C + c;
+      const f32x4 t3 = (in3 && c < C) ? *reinterpret_cast<const f32x4*>(in3 + o) : zero;
+      const f32x4 t5 = (in5 && c < C) ? *reinterpret_cast<const f32x4*>(in5 + o) : zero;
+      A3[i] = t3;
+      A5[i] = t5;
     }
   }
+  __syncthreads();
 #pragma unroll
-  for (int j = 0; j < MAXI; ++j) {
+  for (int j = 0; j < BOX_MAXI; ++j) {             // along x: A -> B
+    const int i = tid + j * 256;
+    if (i < items) {
+      const int x = (int)(it.xyz[j] & 1023u);
+      if (in3) B3[i] = box_line<1>(A3, i, c4n, x, W);
+      if (in5) B5[i] = box_line<2>(A5, i, c4n, x, W);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < BOX_MAXI; ++j) {             // along y: B -> A
+    const int i = tid + j * 256;
+    if (i < items) {
+      const int y = (int)((it.xyz[j] >> 10) & 1023u);
+      if (in3) A3[i] = box_line<1>(B3, i, W * c4n, y, H);
+      if (in5) A5[i] = box_line<2>(B5, i, W * c4n, y, H);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < BOX_MAXI; ++j) {             // along z: A -> out
     const int i = tid + j * 256;
     if (i >= items) continue;
-    const int v = i / c4n, q = i % c4n;
-    const int c = c0 + 4 * q;
+    const int v = i / c4n, q = i % c4n, c = c0 + 4 * q;
     if (c >= C) continue;
+    const int z = (int)(it.xyz[j] >> 20);
+    f32x4 r = zero;
+    if (in3) r += box_line<1>(A3, i, H * W * c4n, z, D) * (1.0f / 27.0f);
+    if (in5) r += box_line<2>(A5, i, H * W * c4n, z, D) * (1.0f / 125.0f);
     const size_t o = ((size_t)n * V + v) * C + c;
-    f32x4 r = res[j];
     if (add0) r += *reinterpret_cast<const f32x4*>(add0 + o);
     if (add1) r += *reinterpret_cast<const f32x4*>(add1 + o);
     if constexpr (OUT_BF16) {
@@ -175,26 +204,29 @@ __global__ __launch_bounds__(256) void box_sum_lds_kernel(const float* __restric
 }  // namespace
 
 // x (bf16 or float) -> out[0] = x, out[1] = box3(x), out[2] = box5(x), all float [n][v][c]: the inputs of the three 1x1
-// experts' GEMM in ONE launch (a widening copy and two box launches before).  Same separable scheme as above.
+// experts' GEMM in ONE launch (a widening copy and two box launches before).  Same separable scheme as above; x is staged
+// once and feeds both box sums.
 namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void box_expand_lds_kernel(const T* __restrict__ x, float* __restrict__ out, size_t estride, int D,
                                                              int H, int W, int C, int CB) {
   extern __shared__ __attribute__((aligned(16))) unsigned char box_smem[];
   const int V = D * H * W, c4n = CB / 4, items = V * c4n;
-  f32x4* A = reinterpret_cast<f32x4*>(box_smem);
-  f32x4* B = A + items;
+  f32x4* A = reinterpret_cast<f32x4*>(box_smem);         // x, later the 5-sum along (x, y)
+  f32x4* B3 = A + items;
+  f32x4* B5 = B3 + items;
+  f32x4* A3 = B5 + items;
   const int n = blockIdx.x, c0 = blockIdx.y * CB;
   const int tid = threadIdx.x;
-  constexpr int MAXI = 16;
-  for (int pass = 0; pass < 2; ++pass) {
-    const int r = pass ? 2 : 1;
-    const float scale = pass ? 1.0f / 125.0f : 1.0f / 27.0f;
-    __syncthreads();
-    for (int i = tid; i < items; i += 256) {
-      const int v = i / c4n, q = i % c4n;
-      const int c = c0 + 4 * q;
-      f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+  BoxItems it;
+  it.init(V, c4n, D, H, W, tid);
+  const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < BOX_MAXI; ++j) {
+    const int i = tid + j * 256;
+    if (i < items) {
+      const int v = i / c4n, q = i % c4n, c = c0 + 4 * q;
+      f32x4 t = zero;
       if (c < C) {
         const T* p = x + ((size_t)n * V + v) * C + c;
         if constexpr (sizeof(T) == 4) {
@@ -204,40 +236,46 @@ __global__ __launch_bounds__(256) void box_expand_lds_kernel(const T* __restrict
           t = f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
                     __uint_as_float(w.y & 0xffff0000u)};
         }
-        if (pass == 0) *reinterpret_cast<f32x4*>(out + ((size_t)n * V + v) * C + c) = t;
+        *reinterpret_cast<f32x4*>(out + ((size_t)n * V + v) * C + c) = t;
       }
       A[i] = t;
     }
-    __syncthreads();
-    for (int i = tid; i < items; i += 256) {       // along x: A -> B
-      const int v = i / c4n, xx = v % W;
-      f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int d = -r; d <= r; ++d)
-        if ((unsigned)(xx + d) < (unsigned)W) t += A[i + d * c4n];
-      B[i] = t;
-    }
-    __syncthreads();
-    for (int i = tid; i < items; i += 256) {       // along y: B -> A
-      const int v = i / c4n, y = (v / W) % H;
-      f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int d = -r; d <= r; ++d)
-        if ((unsigned)(y + d) < (unsigned)H) t += B[i + d * W * c4n];
-      A[i] = t;
-    }
-    __syncthreads();
-    float* dst = out + (size_t)(pass + 1) * estride;
+  }
+  __syncthreads();
 #pragma unroll
-    for (int j = 0; j < MAXI; ++j) {               // along z: A -> out
-      const int i = tid + j * 256;
-      if (i < items) {
-        const int v = i / c4n, q = i % c4n, z = v / (W * H);
-        const int c = c0 + 4 * q;
-        f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int d = -r; d <= r; ++d)
-          if ((unsigned)(z + d) < (unsigned)D) t += A[i + d * H * W * c4n];
-        if (c < C) *reinterpret_cast<f32x4*>(dst + ((size_t)n * V + v) * C + c) = t * scale;
-      }
+  for (int j = 0; j < BOX_MAXI; ++j) {             // along x: A -> B3, B5
+    const int i = tid + j * 256;
+    if (i < items) {
+      const int xx = (int)(it.xyz[j] & 1023u);
+      const f32x4 t3 = box_line<1>(A, i, c4n, xx, W);
+      f32x4 t5 = t3;                                  // the 5-sum = the 3-sum + the two outer taps
+      if (xx - 2 >= 0) t5 += A[i - 2 * c4n];
+      if (xx + 2 < W) t5 += A[i + 2 * c4n];
+      B3[i] = t3;
+      B5[i] = t5;
     }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < BOX_MAXI; ++j) {             // along y: B3 -> A3, B5 -> A
+    const int i = tid + j * 256;
+    if (i < items) {
+      const int y = (int)((it.xyz[j] >> 10) & 1023u);
+      A3[i] = box_line<1>(B3, i, W * c4n, y, H);
+      A[i] = box_line<2>(B5, i, W * c4n, y, H);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < BOX_MAXI; ++j) {             // along z: -> out[1], out[2]
+    const int i = tid + j * 256;
+    if (i >= items) continue;
+    const int v = i / c4n, q = i % c4n, c = c0 + 4 * q;
+    if (c >= C) continue;
+    const int z = (int)(it.xyz[j] >> 20);
+    const size_t o = ((size_t)n * V + v) * C + c;
+    *reinterpret_cast<f32x4*>(out + estride + o) = box_line<1>(A3, i, H * W * c4n, z, D) * (1.0f / 27.0f);
+    *reinterpret_cast<f32x4*>(out + 2 * estride + o) = box_line<2>(A, i, H * W * c4n, z, D) * (1.0f / 125.0f);
   }
 }
 }  // namespace
@@ -252,9 +290,9 @@ extern "C" int repmode_box_expand(const void* x, int dtype, float* out, int n, i
   int cb = 0;
   if ((c & 3) == 0)
     for (int t = 16; t >= 4; t >>= 1)
-      if (V * t * 4 * 2 <= 60 * 1024 && V * (t / 4) <= 256 * 16) { cb = t; break; }
+      if (V * t * 4 * 4 <= 64 * 1024 && V * (t / 4) <= 256 * BOX_MAXI && d < 1024 && h < 1024 && w < 1024) { cb = t; break; }
   RM_REQUIRE(cb > 0, "box_expand: the volume does not fit in LDS (or c %% 4 != 0)");
-  const size_t lds = (size_t)V * cb * 4 * 2;
+  const size_t lds = (size_t)V * cb * 4 * 4;          // four staging buffers
   const dim3 grid((unsigned)n, (unsigned)((c + cb - 1) / cb));
   const size_t estride = (size_t)n * V * c;
   if (dtype == REPMODE_BF16)
@@ -277,9 +315,9 @@ extern "C" int repmode_box_sum_ex(const float* in3, const float* in5, const floa
   int cb = 0;
   if ((c & 3) == 0)
     for (int t = 16; t >= 4; t >>= 1)
-      if (V * t * 4 * 2 <= 60 * 1024 && V * (t / 4) <= 256 * 16) { cb = t; break; }
+      if (V * t * 4 * 4 <= 64 * 1024 && V * (t / 4) <= 256 * BOX_MAXI && d < 1024 && h < 1024 && w < 1024) { cb = t; break; }
   if (cb) {
-    const size_t lds = (size_t)V * cb * 4 * 2;
+    const size_t lds = (size_t)V * cb * 4 * 4;          // four staging buffers
     const dim3 grid((unsigned)n, (unsigned)((c + cb - 1) / cb));
     if (out_dtype == REPMODE_BF16)
       hipLaunchKernelGGL(box_sum_lds_kernel<true>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), in3, in5, add0,

@@ -9,19 +9,25 @@
 // instead of a chain of broadcast-multiply / reduce / cast kernels with [5][N][V][Co] temporaries.
 #include "common.h"
 
+#ifndef RM_MIX_ITERS
+#define RM_MIX_ITERS 4
+#endif
+
 namespace {
 
 constexpr int E = REPMODE_NUM_EXPERTS;
 
 __global__ __launch_bounds__(256) void expert_mix_fwd_kernel(const float* __restrict__ p, const float* __restrict__ g,
                                                              float* __restrict__ y, int N, long V, int C) {
-  const int c4n = (C + 3) / 4;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)N * V * c4n;
+  // (32-bit index arithmetic: the launcher checks the element count; three 64-bit divisions were most of this kernel's
+  // instructions)
+  const uint32_t c4n = (uint32_t)(C + 3) / 4u;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = (uint32_t)N * (uint32_t)V * c4n;
   if (idx >= total) return;
   const int c = (int)(idx % c4n) * 4;
-  const long nv = idx / c4n;
-  const int n = (int)(nv / V);
+  const uint32_t nv = idx / c4n;
+  const int n = (int)(nv / (uint32_t)V);
   const size_t estride = (size_t)N * V * C;
   const size_t off = (size_t)nv * C + c;
   const bool vec = (C & 3) == 0;
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(256) void expert_mix_bwd_kernel(const float* __rest
 extern "C" int repmode_expert_mix_fwd(const float* p, const float* g, float* y, int n, long v, int c, void* stream) {
   RM_REQUIRE(p && g && y && n > 0 && v > 0 && c > 0, "expert_mix_fwd: bad argument");
   const long total = (long)n * v * ((c + 3) / 4);
+  RM_REQUIRE(total < (1L << 31), "expert_mix_fwd: %ld items (32-bit index arithmetic)", total);
   hipLaunchKernelGGL(expert_mix_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p, g, y, n, v, c);
   RM_LAUNCH_CHECK("expert_mix_fwd");
@@ -159,7 +166,9 @@ extern "C" int repmode_expert_mix_bwd_ex(const float* dy, const float* p, const 
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!prezeroed) RM_HIP(hipMemsetAsync(dg, 0, (size_t)n * E * c * sizeof(float), s));
   const int rows = 256 / ((c + 3) / 4);
-  long chunks = (v + rows * 4 - 1) / (rows * 4);          // >= 4 rows iterations per workgroup
+  // RM_MIX_ITERS row iterations per workgroup (level 3, in the step: 4 iterations on 128 workgroups 17.5 us; 1 iteration on
+  // 512 workgroups 22.1 us -- every workgroup ends in 5 C float atomics on the sample's gate gradients)
+  long chunks = (v + rows * RM_MIX_ITERS - 1) / (rows * RM_MIX_ITERS);
   if (chunks > 256) chunks = 256;
   const int det = repmode_deterministic() ? 1 : 0;
   if (chunks < 1) chunks = 1;
