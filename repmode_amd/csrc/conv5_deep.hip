@@ -268,6 +268,7 @@ __global__ __launch_bounds__(C::NT, 2) void conv5_deep_kernel(DeepArgs a) {
 
 // smallest input-channel split that gives at least `target` workgroups (REPMODE_DEEP_TARGET, default 512 = two per CU)
 static const int g_deep_target = []() { const char* e = getenv("REPMODE_DEEP_TARGET"); return e ? atoi(e) : 512; }();
+static const bool g_deep_target_set = getenv("REPMODE_DEEP_TARGET") != nullptr;      // (a sweep: no second-guessing of the split)
 
 template <typename C, bool TWO_IN>
 int launch_deep(DeepArgs a, bool y_is_zero, hipStream_t stream) {
@@ -282,6 +283,12 @@ int launch_deep(DeepArgs a, bool y_is_zero, hipStream_t stream) {
   int ks = 1;
   while (ks < nchunks && (long)a.G * a.ncot * ks < g_deep_target) ks *= 2;
   if (ks > nchunks) ks = nchunks;
+  // One brick per workgroup (level 3) and a single 16-channel chunk per slice: half the slices, two chunks each, on one
+  // workgroup per CU -- the same MFMA work per CU, half the float atomics of the epilogue, which are 35-50 % of such a launch
+  // (profiles/r04_split_atomics.txt).  Same box, 256 -> 256 at 4 x 8 x 8, batch 8: data gradient 63.2 -> 51.8 us, forward
+  // 90.6 -> 64.3.  With more chunks per workgroup the staging latency of a lone workgroup costs more than the atomics save
+  // (512 -> 256: 87 -> 107 us), and the level-4 bricks lose as well (33.8 -> 40.2): both keep two workgroups per CU.
+  if (C::SU == 1 && !g_deep_target_set && ks >= 2 && nchunks / ks == 1 && (long)a.G * a.ncot * ks >= 512) ks /= 2;
   a.ksplit = ks;
   const long nclass = (long)a.ncot * ks;
   a.xcd_classes = (nclass % 8 == 0) ? 1 : 0;
