@@ -502,6 +502,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
     int tl_ = 0;
 #endif
     if constexpr (WS) {
+      if constexpr (TZ == 1) {
       if (a.sk_total > 0) {
         // ---- stream-K (round 4): a launch is ONE sequence of tile steps -- units (slot, co tile, ci tile, dz plane) in the
         // order of the regular grid, inside a unit the samples of its slot, inside a sample the tiles whose input plane
@@ -511,7 +512,6 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
         // tile, which the loader waves have staged meanwhile -- the 6 k cycles of prologue and 25-30 k cycles of atomics
         // epilogue that every (unit, chunk) workgroup of the regular grid pays (a third of a level-1 workgroup's
         // time) are paid once per workgroup / overlapped, and no round of the grid is partly empty.
-        static_assert(TZ == 1, "stream-K: one z plane per tile");
         const int tpp = a.nty * a.ntx;                       // tiles of one z plane
         const int G2 = a.ncot * a.ncit;
         auto zlo = [&](int dzz) -> int { return max(0, 2 - dzz); };            // planes z with 0 <= z + dz - 2 < D
@@ -625,6 +625,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
           if (i + 1 < steps) next();
         }
         return;
+      }
       }
       // both roles walk the same tile sequence; barrier k separates "tile k staged in buffer k & 1" from its MFMAs, and a
       // buffer is staged again only after the barrier behind the MFMAs that read it
@@ -949,7 +950,24 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   RM_REQUIRE(grid < (1L << 31), "conv5_wgrad: grid too large");
   repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * n * a.D * a.H * a.W * (double)a.Cin * a.Cout * REPMODE_TAPS, s);
   // (levels with W < 16 hand a workgroup only a tile or two per sample: nothing to overlap, and the plain loop is ~15 % faster there)
-  if (ws)
+  // The per-expert levels' tiles (two z planes, x extent 8): the wave-specialised form with whole-range workgroups writing
+  // the experts' layout -- a tile step there is 100 MFMAs per wave (1.6 k cycles) against a 3-4 k-cycle fetch, a second
+  // register set does not fit beside the 100 accumulators (tried: 90 spilled dwords), so the fetch + transposition go to
+  // loader waves with registers of their own.  One workgroup per CU, so a launch is rounds of 256 workgroups, each with its
+  // own un-overlapped first fetch and epilogue: same box, both experts' gradients of a level-3 layer at batch 8, two-workgroup
+  // form -> this one: 128 -> 256 (256 units) 58.8 -> 45.9 us, 256 -> 256 (512) 74.0 -> 69.3, 512 -> 256 (1024) 130 -> 131;
+  // level 4 (2048 units of <= 8 short steps) 54.4 -> 64.4, 95.8 -> 120: taken for level 3 up to two rounds.
+  // REPMODE_WGRAD_WS8 (default 1).
+  static const int ws8_env = []() { const char* e = getenv("REPMODE_WGRAD_WS8"); return e ? atoi(e) : 1; }();
+  bool ws8 = false;
+  if constexpr (TZ == 2)      // (`vec` is off below WGRAD_PIPE_MINW: the two-workgroup form's own pipelining loses there)
+    ws8 = ws8_env != 0 && (a.Cin & 7) == 0 && (a.Cout & 7) == 0 &&
+          (size_t)a.D * a.H * a.W * (a.Cin > a.Cout ? a.Cin : a.Cout) * 2 < ((size_t)1 << 31) && a.layout != 0 &&
+          (!a.dy2 || a.layout2 != 0) && a.nchunks == 1 && TY == 8 && grid <= resident2;     // (two rounds of one workgroup per CU; measured: see above)
+  if (ws8) {
+    if constexpr (TZ == 2)
+      hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true, false, true>), dim3((unsigned)grid), dim3(512), 0, s, a);
+  } else if (ws)
     hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true, false, TX >= 32>), dim3((unsigned)grid), dim3(TX >= 32 ? 512 : 256), 0, s, a);      // (ws is only ever set for TX >= 32)
   else if (vec && dense)
     hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true, TX == 16>), dim3((unsigned)grid), dim3(256), 0, s, a);
