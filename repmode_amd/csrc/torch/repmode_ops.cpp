@@ -1002,7 +1002,12 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
       // atomics) write the parameters' [Co][Ci][taps] layout directly; the others accumulate tap-major + one transpose launch.
       const int64_t tiles = ((co + 31) / 32) * ((ci + 31) / 32);
       Tensor lo0 = lo[0], lo1 = lo[1];
-      const bool direct5 = dt == at::kBFloat16 && tiles * 5 >= 512, direct3 = dt == at::kBFloat16 && tiles * 3 >= 512;
+      bool direct5 = dt == at::kBFloat16 && tiles * 5 >= 512, direct3 = dt == at::kBFloat16 && tiles * 3 >= 512;
+      // In the dual launch the two jobs fill the grid TOGETHER (tiles x (5 + 3) units): from REPMODE_WGRAD_DIRECT_UNITS units
+      // (default 256 = one per CU) both write the experts' layout -- no tap-major accumulators in the step's pooled memset
+      // (level 3 at batch 8: 57 M floats of its 131 M), no transposition launches, and the wave-specialised form applies.
+      static const int64_t direct_units = []() { const char* e = getenv("REPMODE_WGRAD_DIRECT_UNITS"); return e ? (int64_t)atol(e) : (int64_t)256; }();
+      if (dt == at::kBFloat16 && g_dual_launch && g_dual_wgrad && tiles * 8 >= direct_units) direct5 = direct3 = true;
       if (dt == at::kBFloat16 && g_dual_launch && g_dual_wgrad) {
         // both experts' filter gradients from ONE launch (the 3x3x3 job alone is 27 taps on three planes: latency)
         dk5 = grad_out(k5);
