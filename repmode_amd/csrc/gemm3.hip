@@ -224,7 +224,8 @@ extern "C" int repmode_gemm3(const float* const* a, long a_ms, long a_ks, const 
   // (deterministic mode: no split.  Two slices -- two addends on a cleared C, which commute -- did NOT reproduce bitwise
   // here (tools/r3_session12.sh: the only site of the seven that failed with two), so this one stays whole)
   const int ks_max = repmode_deterministic() ? 1 : 32;
-  if (c_is_zero) while (tiles * ks < 512 && (k + GK - 1) / GK >= 4 * ks && ks < ks_max) ks *= 2;
+  static const long split_target = []() { const char* e = getenv("REPMODE_GEMM3_TARGET"); return e ? atol(e) : 512L; }();
+  if (c_is_zero) while (tiles * ks < split_target && (k + GK - 1) / GK >= 4 * ks && ks < ks_max) ks *= 2;
   g.ksplit = ks;
   const dim3 grid((n + GT - 1) / GT, (m + GT - 1) / GT, 3 * ks);
   // the vector path's conditions (see the kernel)
