@@ -96,6 +96,21 @@ __device__ __forceinline__ void store_row(T* row, int c, int C, bool vec, const 
 
 // All kernels use CV = 8 channels per thread; ngroups = ceil(C / 8) threads cover a row.
 constexpr int CV = 8;
+// grid caps of the reduction / normalisation kernels (workgroups)
+// Every workgroup starts by totalling the 16 partial-sum slices of ALL channels (the normalisation kernels) or ends in 2 C float
+// atomics (the reductions): a fixed cost of a microsecond or two, which a workgroup with 8-16 KB to stream does not amortise.
+// Tensors of >= BN_BIG_ELEMS elements (level 0 at batch 8) keep the wide grids, where bytes in flight matter more.  Same box,
+// whole step, caps (reduce / apply) 1024 / 2048 everywhere -> 512 / 1024: 9.911 / 9.928 -> 9.861 / 9.865 ms; 256 / 512: 9.98;
+// 2048 / 4096: 10.06 (tools/sessions/r4_session25.sh).
+#ifndef BN_REDUCE_CAP
+#define BN_REDUCE_CAP 512
+#endif
+#ifndef BN_APPLY_CAP
+#define BN_APPLY_CAP 1024
+#endif
+#ifndef BN_BIG_ELEMS
+#define BN_BIG_ELEMS (16L << 20)
+#endif
 
 struct Geom {
   int ngroups, rows_per_iter;
@@ -512,7 +527,8 @@ int grid_for_reduce(long M, int C) {
   const int ngroups = (C + CV - 1) / CV;
   const int rows_per_iter = BN_THREADS / ngroups;
   long blocks = (M + rows_per_iter - 1) / rows_per_iter;
-  if (blocks > 1024) blocks = 1024;
+  const long cap = (long)M * C >= BN_BIG_ELEMS ? 2 * BN_REDUCE_CAP : BN_REDUCE_CAP;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
@@ -534,7 +550,8 @@ int grid_for(long M, int C) {
   const int ngroups = (C + CV - 1) / CV;
   const int rows_per_iter = BN_THREADS / ngroups;
   long blocks = (M + rows_per_iter - 1) / rows_per_iter;
-  if (blocks > 2048) blocks = 2048;   // grid-stride beyond 8 workgroups per CU
+  const long cap = (long)M * C >= BN_BIG_ELEMS ? 2 * BN_APPLY_CAP : BN_APPLY_CAP;   // grid-stride beyond 4 (8) workgroups per CU
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
