@@ -101,12 +101,13 @@ constexpr int CV = 8;
 // atomics (the reductions): a fixed cost of a microsecond or two, which a workgroup with 8-16 KB to stream does not amortise.
 // Tensors of >= BN_BIG_ELEMS elements (level 0 at batch 8) keep the wide grids, where bytes in flight matter more.  Same box,
 // whole step, caps (reduce / apply) 1024 / 2048 everywhere -> 512 / 1024: 9.911 / 9.928 -> 9.861 / 9.865 ms; 256 / 512: 9.98;
-// 2048 / 4096: 10.06 (tools/sessions/r4_session25.sh).
+// 2048 / 4096: 10.06; then with the wide grids kept above BN_BIG_ELEMS 10.00 -> 9.91, and 512 / 768: 9.765 / 9.716 ->
+// 9.689 / 9.702 on another box (tools/sessions/r4_session25*.sh).
 #ifndef BN_REDUCE_CAP
 #define BN_REDUCE_CAP 512
 #endif
 #ifndef BN_APPLY_CAP
-#define BN_APPLY_CAP 1024
+#define BN_APPLY_CAP 768
 #endif
 #ifndef BN_BIG_ELEMS
 #define BN_BIG_ELEMS (16L << 20)
@@ -550,7 +551,7 @@ int grid_for(long M, int C) {
   const int ngroups = (C + CV - 1) / CV;
   const int rows_per_iter = BN_THREADS / ngroups;
   long blocks = (M + rows_per_iter - 1) / rows_per_iter;
-  const long cap = (long)M * C >= BN_BIG_ELEMS ? 2 * BN_APPLY_CAP : BN_APPLY_CAP;   // grid-stride beyond 4 (8) workgroups per CU
+  const long cap = (long)M * C >= BN_BIG_ELEMS ? 2 * BN_APPLY_CAP : BN_APPLY_CAP;   // grid-stride beyond 3 (6) workgroups per CU
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
