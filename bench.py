@@ -58,8 +58,16 @@ NUM_TASKS = 12
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
 FWD_FLOP_PER_VOXEL = 2083520.0                    # whole forward; MoDE convs alone 2,072,000
 FWD_CONV_FLOP_PER_VOXEL = 2072000.0
-CONV_KINDS = ('conv5_ws', 'conv5_igemm', 'conv5_deep', 'conv5_thin')     # the forward / data-gradient convolution kernels of the MoDE blocks
-MAIN_KINDS = ('conv5_ws', 'conv5_igemm')      # conv5_igemm.hip: the wave-specialised kernel (levels 0-2) + the general one (the per-expert levels' pair)
+# the forward / data-gradient convolution kernels of the MoDE blocks
+CONV_KINDS = ('conv5_ws', 'conv5_igemm', 'deep_mode', 'conv5_deep', 'conv5_thin')
+# the MoDE convolution, forward and data gradient, of every block but the two one-channel ends: the wave-specialised kernel
+# (levels 0-2), the per-expert blocks' one-launch kernel (levels 3-4, round 5) and whatever still goes through the general kernel
+MAIN_KINDS = ('conv5_ws', 'conv5_igemm', 'deep_mode')
+# the MoDE blocks' small kernels (box means, the 1x1 experts' GEMMs, the gate mix, the skip concatenation of the per-expert
+# decoder block): they are part of "GatRep + conv as one unit"
+HELPER_KIND = 'helper'
+KERNEL_SYMBOL = {'conv5_ws': 'conv5_ws_kernel', 'conv5_igemm': 'conv5_igemm_kernel', 'deep_mode': 'deep_mode_kernel',
+                 'conv5_wgrad': 'conv5_wgrad_bf16_kernel'}
 
 
 class Opts:
@@ -93,13 +101,17 @@ def pmc_traffic(kind, batch, dtype):
     return None, None
 
 
-def conv5_igemm_algorithmic_bytes(batch, nslots):
-    """Algorithmic HBM bytes per train step of the forward / data-gradient launches of conv5_igemm.hip at the default policy,
-    and their count: every tensor once -- bf16 input, output (bf16 where the kernel library writes the element
-    type -- `repmode_conv5_elem_out`: levels 0-1, and since round 4 level 2 at this batch --, float where the reduction is split
-    over workgroups) and the filter (one per slot: 125 taps x Cin x Cout bf16; the per-expert pair of levels 3-4: 125 + 27
-    taps, shared by the batch).  Merged levels: forward + data gradient of every merged block but the two one-channel layers
-    (own kernels); levels 3-4: the forward pair (their data gradient runs in conv5_deep)."""
+def conv_algorithmic_bytes(batch, nslots, deep_mode):
+    """Algorithmic HBM bytes per train step of the MoDE convolution's forward / data-gradient launches, per kernel kind, as
+    {kind: (bytes, launches)}: every tensor once -- the bf16 input, the output (bf16 where the kernel library
+    writes the element type -- `repmode_conv5_elem_out`: levels 0-2 at the benchmarked batch --, float where the reduction is
+    split over workgroups or the consumer wants float) and the filter (merged levels: one per slot, 125 taps x Cin x Cout
+    bf16; per-expert levels 3-4: 125 + 27 taps bf16 + three 1x1 experts float, shared by the batch).
+    ``deep_mode``: the per-expert blocks run as one launch per direction (round 5: forward reads x, writes float y; the data
+    gradient reads the two gate-scaled bf16 output gradients and writes bf16 dx) -- the float P_e tensors the forward keeps
+    for the gate gradient and the box-mean operands are NOT algorithmic: they show up in traffic_over_algorithmic.
+    Otherwise (round 4's launches): the forward pair through conv5_igemm (two float outputs); its data gradient runs in
+    conv5_deep, which has no entry."""
     from repmode_amd import _lib
     lib = _lib.load()
     dims = [(PATCH[0] >> l, PATCH[1] >> l, PATCH[2] >> l) for l in range(5)]
@@ -107,21 +119,24 @@ def conv5_igemm_algorithmic_bytes(batch, nslots):
     merged = [(0, 32, 32), (0, 64, 32), (0, 32, 32), (1, 32, 64), (1, 64, 64), (1, 128, 64), (1, 64, 64),
               (2, 64, 128), (2, 128, 128), (2, 256, 128), (2, 128, 128)]
     pair = [(3, 128, 256), (3, 256, 256), (3, 512, 256), (3, 256, 256), (4, 256, 512), (4, 512, 512)]
-    total, n = 0.0, 0
-    wide = [0.0, 0]                                              # the launches of conv5_ws_kernel (element-typed output)
+    acc = {'conv5_ws': [0.0, 0], 'conv5_igemm': [0.0, 0], 'deep_mode': [0.0, 0]}
     for l, ci, co in merged:
         for a, b in ((ci, co), (co, ci)):                       # forward, data gradient
             elem = lib.repmode_conv5_elem_out(batch, *dims[l], a, b, _lib.BF16) != 0
             t = batch * v[l] * (a * 2 + b * (2 if elem else 4)) + nslots * 125 * ci * co * 2
-            total += t
-            n += 1
-            if elem:
-                wide[0] += t; wide[1] += 1
+            k = 'conv5_ws' if elem else 'conv5_igemm'
+            acc[k][0] += t
+            acc[k][1] += 1
     for l, ci, co in pair:
-        total += batch * v[l] * (ci * 2 + 2 * co * 4) + (125 + 27) * ci * co * 2
-        n += 1
-    conv5_igemm_algorithmic_bytes.by_kernel = {'conv5_ws': (wide[0], wide[1]), 'conv5_igemm': (total - wide[0], n - wide[1])}
-    return total, n
+        filt = (125 + 27) * ci * co * 2 + 3 * ci * co * 4
+        if deep_mode:
+            acc['deep_mode'][0] += batch * v[l] * (ci * 2 + co * 4) + filt            # forward
+            acc['deep_mode'][0] += batch * v[l] * (2 * co * 2 + ci * 2) + filt        # data gradient
+            acc['deep_mode'][1] += 2
+        else:
+            acc['conv5_igemm'][0] += batch * v[l] * (ci * 2 + 2 * co * 4) + (125 + 27) * ci * co * 2
+            acc['conv5_igemm'][1] += 1
+    return {k: (b, n) for k, (b, n) in acc.items()}
 
 
 def conv5_wgrad_algorithmic_bytes(batch, nslots):
@@ -307,7 +322,8 @@ def main():
     torch.cuda.synchronize()
     train_prof = {}
     if not args.no_prof and rank == 0:
-        for kind in ('conv5_ws', 'conv5_igemm', 'conv5_deep', 'conv5_thin', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd'):
+        for kind in ('conv5_ws', 'conv5_igemm', 'deep_mode', 'conv5_deep', 'conv5_thin', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd',
+                     HELPER_KIND):
             train_prof[kind] = _lib.prof_summary(kind)
         train_recs = _lib.prof_records() if args.dump_launches else None
     _lib.prof_enable(False)
@@ -378,23 +394,30 @@ def main():
             for _ in range(2):
                 net(signal, task)
             torch.cuda.synchronize()
-        # every forward convolution launch of the MoDE blocks: conv5_igemm, the deep levels' conv5_deep, the thin layers' own
+        # every launch of the MoDE blocks in a forward pass: the convolution kernels (conv5_ws, deep_mode, conv5_igemm /
+        # conv5_deep where round 4's launches still run, the thin layers' own), gate softmax + GatRep (+ expert layout), and the
+        # blocks' helper kernels (box means, gemm3, expert_mix, the per-expert decoder block's concatenation)
         n_c, ms_c, fl_c = (sum(v) for v in zip(*(_lib.prof_summary(k) for k in CONV_KINDS)))
         n_g, ms_g, _ = _lib.prof_summary('gatrep_fwd')
+        n_h, ms_h, _ = _lib.prof_summary(HELPER_KIND)
         _lib.prof_enable(False)
         vps = b * PATCH[0] * PATCH[1] * PATCH[2] * kf / dt_f
         peak = PEAK_TFLOPS[args.dtype]
-        unit_tflops = fl_c / ((ms_c + ms_g) * 1e-3) / 1e12 if (ms_c + ms_g) > 0 else 0.0
+        ms_unit = ms_c + ms_g + ms_h
+        unit_tflops = fl_c / (ms_unit * 1e-3) / 1e12 if ms_unit > 0 else 0.0
         out['fwd'] = {'value': vps, 'unit': 'voxels/s', 'ms_per_pass': 1e3 * dt_f / kf,
                       'whole_pass_tflops': vps * FWD_FLOP_PER_VOXEL / 1e12,
                       'whole_pass_frac': vps * FWD_FLOP_PER_VOXEL / 1e12 / peak,
-                      'gatrep_conv_unit': {'what': 'gate softmax + GatRep (+ expert layout) + every MoDE convolution launch (conv5_igemm, conv5_deep, '
-                                                   'the one-channel layers\' kernels) of one forward pass, '
-                                                   'event-timed; FLOPs = the MoDE convs\' algorithmic 2*V*Cin*Cout*125',
-                                           'conv_ms': ms_c / 2, 'gatrep_ms': ms_g / 2, 'conv_launches': n_c // 2,
-                                           'gatrep_launches': n_g // 2, 'achieved': unit_tflops, 'peak': peak,
-                                           'unit': 'TFLOP/s', 'frac': unit_tflops / peak,
-                                           'conv_only_frac': (fl_c / (ms_c * 1e-3) / 1e12 / peak) if ms_c > 0 else 0.0}}
+                      'gatrep_conv_unit': {
+                          'what': 'EVERY kernel the 19 MoDE blocks launch in one forward pass up to (not including) BatchNorm: gate '
+                                  'softmax + GatRep (+ expert layout), every convolution launch (conv5_ws, deep_mode, conv5_igemm, '
+                                  'conv5_deep, the one-channel layers\' kernels) and the helper kernels (box means, 1x1-expert GEMMs, '
+                                  'gate mix, skip concatenation of the per-expert decoder block), event-timed one by one; FLOPs = '
+                                  'the MoDE convs\' algorithmic 2*V*Cin*Cout*125',
+                          'conv_ms': ms_c / 2, 'gatrep_ms': ms_g / 2, 'helper_ms': ms_h / 2, 'conv_launches': n_c // 2,
+                          'gatrep_launches': n_g // 2, 'helper_launches': n_h // 2, 'achieved': unit_tflops, 'peak': peak,
+                          'unit': 'TFLOP/s', 'frac': unit_tflops / peak,
+                          'conv_only_frac': (fl_c / (ms_c * 1e-3) / 1e12 / peak) if ms_c > 0 else 0.0}}
 
     if rank == 0:
         if not args.no_prof:
@@ -411,23 +434,26 @@ def main():
             tr_parts = [(pmc_traffic(k, b, args.dtype), train_prof[k][0]) for k in MAIN_KINDS if train_prof[k][0]]
             traffic_file = next((t[1] for t, _ in tr_parts if t[1]), None)
             traffic = (sum(t[0] * c for t, c in tr_parts) / sum(c for _, c in tr_parts)) if tr_parts and all(t[0] for t, _ in tr_parts) else None
-            alg_bytes, alg_n = conv5_igemm_algorithmic_bytes(b, len(set(task.tolist())))
-            by_kernel = {}
-            # (round 4) the filter gradient -- the step's largest kernel family -- beside them: its launches per profiled step
-            # carry the whole step's algorithmic bytes (a skip connection's layer is two launches over one filter gradient)
+            nslots = len(set(task.tolist()))
+            alg = conv_algorithmic_bytes(b, nslots, train_prof['deep_mode'][0] > 0)
+            alg_bytes = sum(alg[k][0] for k in MAIN_KINDS)
+            alg_n = max(sum(alg[k][1] for k in MAIN_KINDS), 1)
+            # the filter gradient -- the step's largest kernel family after conv5_ws -- beside them: its launches per profiled
+            # step carry the whole step's algorithmic bytes (a skip connection's layer is two launches over one filter gradient)
             wg_n = train_prof['conv5_wgrad'][0]
-            conv5_igemm_algorithmic_bytes.by_kernel['conv5_wgrad'] = (
-                conv5_wgrad_algorithmic_bytes(b, len(set(task.tolist()))) * max(profiled_steps, 1), wg_n)
-            for k, sym in (('conv5_ws', 'conv5_ws_kernel'), ('conv5_igemm', 'conv5_igemm_kernel'), ('conv5_wgrad', 'conv5_wgrad_bf16_kernel')):
+            alg['conv5_wgrad'] = (conv5_wgrad_algorithmic_bytes(b, nslots) * max(profiled_steps, 1), wg_n)
+            by_kernel = {}
+            for k in ('conv5_ws', 'deep_mode', 'conv5_igemm', 'conv5_wgrad'):
                 kn, kms, kfl = train_prof[k]
                 if kn:
-                    ab, an = conv5_igemm_algorithmic_bytes.by_kernel[k]
+                    ab, an = alg[k]
                     ktr = pmc_traffic(k, b, args.dtype)[0]
-                    by_kernel[sym] = {'launches': kn, 'avg_launch_ms': kms / kn, 'achieved': kfl / (kms * 1e-3) / 1e12,
-                                      'frac': kfl / (kms * 1e-3) / 1e12 / peak, 'traffic': ktr,
-                                      'algorithmic_bytes_per_launch': ab / max(an, 1),
-                                      'traffic_over_algorithmic': (ktr / (ab / an)) if ktr and an else None}
-            out['roofline'] = {'kernel': 'conv5_ws_kernel + conv5_igemm_kernel (conv5_igemm.hip: the MoDE convolution, forward and data gradient)',
+                    by_kernel[KERNEL_SYMBOL[k]] = {'launches': kn, 'avg_launch_ms': kms / kn, 'achieved': kfl / (kms * 1e-3) / 1e12,
+                                                   'frac': kfl / (kms * 1e-3) / 1e12 / peak, 'traffic': ktr,
+                                                   'algorithmic_bytes_per_launch': ab / max(an, 1),
+                                                   'traffic_over_algorithmic': (ktr / (ab / an)) if ktr and an else None}
+            out['roofline'] = {'kernel': ' + '.join(KERNEL_SYMBOL[k] for k in MAIN_KINDS if train_prof[k][0]) +
+                                         ' (the MoDE convolution, forward and data gradient, of every block but the one-channel ends)',
                                'by_kernel': by_kernel, 'bound': 'mfma', 'achieved': achieved, 'peak': peak,
                                'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_file,
                                'launches': n, 'avg_launch_ms': ms / max(n, 1),

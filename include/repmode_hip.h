@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define REPMODE_ABI_VERSION 9
+#define REPMODE_ABI_VERSION 10
 
 /* element types of activations / merged filters */
 #define REPMODE_F32 0  /* float in, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)          */
@@ -148,6 +148,34 @@ int repmode_conv5_ex(const void* x, const void* w, const int32_t* sample_slot, v
 int repmode_conv5_deep(const void* x, const void* w, float* y, int n, int d, int h, int wdim, int cin, int cout, int flags,
                        void* stream);
 int repmode_conv5_deep_supported(int wdim, int cin, int dtype);
+
+/* A whole MoDE block of the deep U-Net levels in the per-expert formulation as ONE launch per direction
+ * (csrc/deep_mode.hip; RepMode.py:171-192 by linearity + :204-208, and their autograd for the input):
+ *   forward        P_e[n] = conv(x[n], K_e) (e = 0..4),  y[n] = sum_e g[n,e,:] * P_e[n]
+ *   data gradient  dx[n]  = sum_e conv(G_e[n], flip(K_e)^T),  G_e = g[n,e,:] * dy[n]
+ * replacing repmode_conv5_deep / the dual-expert launch + repmode_gemm3 + repmode_expert_mix_fwd (forward) and
+ * repmode_conv5_deep + repmode_gemm3 + repmode_box_sum_ex (data gradient).  A workgroup owns a 64-voxel x 32-channel output
+ * tile and the whole reduction; its waves split the input-channel chunks and meet in LDS, so outputs are written with plain
+ * stores unless the grid would not fill the chip.
+ * repmode_deep_mode_plan(dir, ...): dir 0 forward, 1 data gradient.  Returns 0 when the shape is not taken (bf16 only, volumes
+ *   of at most 4 x 8 x 8 or 2 x 4 x 4 voxels, reduction channels % 8 == 0, output channels % 4 == 0, not in deterministic
+ *   mode), 1 when every output element has ONE writer, k > 1 when k workgroups ADD into each element: the float outputs
+ *   (p and y / dx) must then be zero on entry.
+ * repmode_deep_mode_fwd:   x bf16 [n][d][h][w][cin]; wf = repmode_expert_frags' forward role; xs = repmode_box_expand's
+ *   float [3][n][d][h][w][cin] (x, box3(x)/27, box5(x)/125); k1 / a3 / a5 the 1x1 experts' parameters float [cout][cin];
+ *   gate float [n][5][cout] (per SAMPLE); outputs p float [5][n][d][h][w][cout] (kept for the gate gradient) and y float
+ *   [n][d][h][w][cout].
+ * repmode_deep_mode_dgrad: g2 bf16 [2][n][d][h][w][cout] = the two conv experts' gate-scaled output gradients
+ *   (repmode_expert_mix_bwd's dye_lo); wd = repmode_expert_frags' data-gradient role; s0 = G_2, s1 = box3(G_3)/27, s2 =
+ *   box5(G_4)/125, float [n][d][h][w][cout] each (repmode_expert_mix_bwd's dye_hi[0], repmode_box_pair of dye_hi[1..2]);
+ *   dx [n][d][h][w][cin] in dx_dtype (REPMODE_BF16 only when the plan says 1).  Deferred small jobs (REPMODE_DEFER) ride in
+ *   this launch as in repmode_conv5_ex. */
+int repmode_deep_mode_plan(int dir, int n, int d, int h, int w, int cin, int cout, int dtype);
+int repmode_deep_mode_fwd(const void* x, const void* wf, const float* xs, const float* k1, const float* a3, const float* a5,
+                          const float* gate, float* p, float* y, int n, int d, int h, int w, int cin, int cout, void* stream);
+int repmode_deep_mode_dgrad(const void* g2, const void* wd, const float* s0, const float* s1, const float* s2, const float* k1,
+                            const float* a3, const float* a5, void* dx, int dx_dtype, int n, int d, int h, int w, int cin, int cout,
+                            void* stream);
 
 /* EXPERIMENT, not on the product path: the forward convolution of a merged-formulation block with
  * GatRep INSIDE the kernel (RepMode.py:171-192 fused into :204-208): the filter fragment of every tap is built in registers
@@ -363,6 +391,14 @@ int repmode_box_sum_ex(const float* in3, const float* in5, const float* add0, co
 /* x (dtype) -> out[0] = x widened, out[1] = box3(x), out[2] = box5(x), float [3][n][d][h][w][c]: the three 1x1 experts'
  * GEMM inputs from one launch.  Only for volumes that fit in LDS with c % 4 == 0 (REPMODE_EINVAL otherwise). */
 int repmode_box_expand(const void* x, int dtype, float* out, int n, int d, int h, int w, int c, void* stream);
+/* out3 = box3(in3) / 27 and out5 = box5(in5) / 125 apart, float [n][d][h][w][c] each, one launch: the avg-pool experts'
+ * operands of repmode_deep_mode_dgrad (autograd of RepMode.py:176-180; the box mean is self-adjoint and commutes with the
+ * 1x1 channel mixing).  Volumes that fit in LDS with c % 4 == 0. */
+int repmode_box_pair(const float* in3, const float* in5, float* out3, float* out5, int n, int d, int h, int w, int c, void* stream);
+/* out[row] = a[row] | b[row]: the channel concatenation of two channels-last tensors (RepMode.py:106, torch.cat((skip, up), 1))
+ * for the decoder block that takes the per-expert formulation (its kernels read one input tensor).  a [rows][ca_bytes],
+ * b [rows][cb_bytes], byte counts multiples of 16. */
+int repmode_concat_channels(const void* a, const void* b, void* out, long rows, int ca_bytes, int cb_bytes, void* stream);
 /* Filter gradient from the kernels' tap-major layout to the experts' parameter layout: out[m][t] = in[tap(t)][m]
  * for the m = Co*Ci channel pairs; ntaps_out = 125 (all taps), 27 (the centred 3x3x3 taps of the [125][m] input)
  * or 8 (the 2x2x2 stride-2 filters, input [8][m]). */
@@ -476,7 +512,9 @@ int repmode_expert_frags_multi(int nblocks, const float* const* k5, const float*
 #define REPMODE_PROF_CONV5_DEEP 5 /* conv5_deep (per-expert formulation, deep levels) */
 #define REPMODE_PROF_CONV5_THIN 6 /* the one-channel first / last layers' own kernels */
 #define REPMODE_PROF_CONV5_WS 7   /* conv5_ws_kernel / conv5_pipe_kernel: the wide levels' pipelined convolution (conv5_igemm.hip) */
-#define REPMODE_PROF_KINDS 8
+#define REPMODE_PROF_DEEP_MODE 8  /* deep_mode_kernel: a per-expert MoDE block of the deep levels, one launch per direction */
+#define REPMODE_PROF_HELPER 9     /* the MoDE blocks' small kernels: box sums, gemm3, expert_mix, gate softmax, expert layout */
+#define REPMODE_PROF_KINDS 10
 int repmode_prof_enable(int on);
 /* Suspend (1) / resume (0) recording; the records so far are kept (sampling a subset of the steps). */
 int repmode_prof_pause(int paused);

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('REPMODE_LIB') or os.path.join(_HERE, 'librepmode_hip.
 
 F32, BF16 = 0, 1
 DEFER = 1        # REPMODE_DEFER: queue the job for the next conv5 launch on the stream (include/repmode_hip.h)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _c = ctypes
 _P = _c.c_void_p
@@ -46,6 +46,9 @@ _SIGNATURES = {
     'repmode_conv5_ex': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_deep': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_deep_supported': [_I, _I, _I],
+    'repmode_deep_mode_plan': [_I] * 8,
+    'repmode_deep_mode_fwd': [_P] * 9 + [_I] * 6 + [_P],
+    'repmode_deep_mode_dgrad': [_P] * 9 + [_I] * 7 + [_P],
     'repmode_conv5_thin_in1': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'repmode_conv5_thin_out1': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'repmode_conv5_merged': [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -77,6 +80,8 @@ _SIGNATURES = {
     'repmode_expert_mix_bwd_ex': [_P, _P, _P, _P, _P, _P, _c.c_long, _I, _c.c_long, _I, _I, _P],
     'repmode_gemm3': [_P, _c.c_long, _c.c_long, _P, _c.c_long, _c.c_long, _P, _I, _I, _I, _I, _I, _I, _P],
     'repmode_box_expand': [_P, _I, _P, _I, _I, _I, _I, _I, _P],
+    'repmode_box_pair': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'repmode_concat_channels': [_P, _P, _P, _c.c_long, _I, _I, _P],
     'repmode_box_sum': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'repmode_box_sum_ex': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'repmode_tap_transpose': [_P, _P, _c.c_long, _I, _P],
@@ -186,7 +191,7 @@ def device_arch(dev=0):
 
 
 PROF_KINDS = {'conv5_igemm': 0, 'conv5_wgrad': 1, 'gatrep_fwd': 2, 'gatrep_bwd': 3, 'conv5_wgrad_thin': 4, 'conv5_deep': 5,
-              'conv5_thin': 6, 'conv5_ws': 7}
+              'conv5_thin': 6, 'conv5_ws': 7, 'deep_mode': 8, 'helper': 9}
 
 
 def prof_enable(on):

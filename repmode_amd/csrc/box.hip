@@ -135,7 +135,8 @@ __device__ __forceinline__ f32x4 box_line(const f32x4* in, int i, int step, int 
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void box_sum_lds_kernel(const float* __restrict__ in3, const float* __restrict__ in5,
                                                           const float* __restrict__ add0, const float* __restrict__ add1,
-                                                          void* __restrict__ out_, int D, int H, int W, int C, int CB) {
+                                                          void* __restrict__ out_, float* __restrict__ out5_, int D, int H, int W, int C,
+                                                          int CB) {
   extern __shared__ __attribute__((aligned(16))) unsigned char box_smem[];
   const int V = D * H * W, c4n = CB / 4, items = V * c4n;
   f32x4* A3 = reinterpret_cast<f32x4*>(box_smem);
@@ -188,10 +189,15 @@ __global__ __launch_bounds__(256) void box_sum_lds_kernel(const float* __restric
     const int v = i / c4n, q = i % c4n, c = c0 + 4 * q;
     if (c >= C) continue;
     const int z = (int)(it.xyz[j] >> 20);
+    const size_t o = ((size_t)n * V + v) * C + c;
+    if (out5_) {      // the two box means apart (repmode_box_pair): float outputs, nothing added
+      *reinterpret_cast<f32x4*>(static_cast<float*>(out_) + o) = box_line<1>(A3, i, H * W * c4n, z, D) * (1.0f / 27.0f);
+      *reinterpret_cast<f32x4*>(out5_ + o) = box_line<2>(A5, i, H * W * c4n, z, D) * (1.0f / 125.0f);
+      continue;
+    }
     f32x4 r = zero;
     if (in3) r += box_line<1>(A3, i, H * W * c4n, z, D) * (1.0f / 27.0f);
     if (in5) r += box_line<2>(A5, i, H * W * c4n, z, D) * (1.0f / 125.0f);
-    const size_t o = ((size_t)n * V + v) * C + c;
     if (add0) r += *reinterpret_cast<const f32x4*>(add0 + o);
     if (add1) r += *reinterpret_cast<const f32x4*>(add1 + o);
     if constexpr (OUT_BF16) {
@@ -295,12 +301,14 @@ extern "C" int repmode_box_expand(const void* x, int dtype, float* out, int n, i
   const size_t lds = (size_t)V * cb * 4 * 4;          // four staging buffers
   const dim3 grid((unsigned)n, (unsigned)((c + cb - 1) / cb));
   const size_t estride = (size_t)n * V * c;
+  repmode_prof_begin(REPMODE_PROF_HELPER, (double)estride * (dtype == REPMODE_BF16 ? 14.0 : 16.0), static_cast<hipStream_t>(stream));
   if (dtype == REPMODE_BF16)
     hipLaunchKernelGGL(box_expand_lds_kernel<bf16_t>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), (const bf16_t*)x, out,
                        estride, d, h, w, c, cb);
   else
     hipLaunchKernelGGL(box_expand_lds_kernel<float>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), (const float*)x, out,
                        estride, d, h, w, c, cb);
+  repmode_prof_end(static_cast<hipStream_t>(stream));
   RM_LAUNCH_CHECK("box_expand");
   return REPMODE_OK;
 }
@@ -312,6 +320,8 @@ extern "C" int repmode_box_sum_ex(const float* in3, const float* in5, const floa
   RM_REQUIRE(out_dtype == REPMODE_F32 || out_dtype == REPMODE_BF16, "box_sum: bad dtype %d", out_dtype);
   // volumes that fit in LDS with at least 4 channels: separable kernel
   const long V = (long)d * h * w;
+  repmode_prof_begin(REPMODE_PROF_HELPER, (double)n * V * c * 4.0 * ((in3 ? 1 : 0) + (in5 ? 1 : 0) + (add0 ? 1 : 0) + (add1 ? 1 : 0) + 1),
+                     static_cast<hipStream_t>(stream));
   int cb = 0;
   if ((c & 3) == 0)
     for (int t = 16; t >= 4; t >>= 1)
@@ -321,10 +331,11 @@ extern "C" int repmode_box_sum_ex(const float* in3, const float* in5, const floa
     const dim3 grid((unsigned)n, (unsigned)((c + cb - 1) / cb));
     if (out_dtype == REPMODE_BF16)
       hipLaunchKernelGGL(box_sum_lds_kernel<true>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), in3, in5, add0,
-                         add1, out, d, h, w, c, cb);
+                         add1, out, (float*)nullptr, d, h, w, c, cb);
     else
       hipLaunchKernelGGL(box_sum_lds_kernel<false>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), in3, in5, add0,
-                         add1, out, d, h, w, c, cb);
+                         add1, out, (float*)nullptr, d, h, w, c, cb);
+    repmode_prof_end(static_cast<hipStream_t>(stream));
     RM_LAUNCH_CHECK("box_sum(lds)");
     return REPMODE_OK;
   }
@@ -335,7 +346,31 @@ extern "C" int repmode_box_sum_ex(const float* in3, const float* in5, const floa
   else
     hipLaunchKernelGGL(box_sum_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), in3, in5, add0, add1, out, n, d, h, w, c);
+  repmode_prof_end(static_cast<hipStream_t>(stream));
   RM_LAUNCH_CHECK("box_sum");
+  return REPMODE_OK;
+}
+
+// out3 = box3(in3) / 27, out5 = box5(in5) / 125 (zero padding), float [n][d][h][w][c] each, in ONE launch: the avg-pool
+// experts' operands of repmode_deep_mode_dgrad (the box mean commutes with the 1x1 channel mixing and with the gate scale).
+// Volumes that fit in LDS with c % 4 == 0 (the deep levels); REPMODE_EINVAL otherwise.
+extern "C" int repmode_box_pair(const float* in3, const float* in5, float* out3, float* out5, int n, int d, int h, int w, int c,
+                                void* stream) {
+  RM_REQUIRE(in3 && in5 && out3 && out5, "box_pair: null pointer");
+  RM_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && c > 0, "box_pair: bad shape");
+  const long V = (long)d * h * w;
+  int cb = 0;
+  if ((c & 3) == 0)
+    for (int t = 16; t >= 4; t >>= 1)
+      if (V * t * 4 * 4 <= 64 * 1024 && V * (t / 4) <= 256 * BOX_MAXI && d < 1024 && h < 1024 && w < 1024) { cb = t; break; }
+  RM_REQUIRE(cb > 0, "box_pair: the volume does not fit in LDS (or c %% 4 != 0)");
+  const size_t lds = (size_t)V * cb * 4 * 4;
+  const dim3 grid((unsigned)n, (unsigned)((c + cb - 1) / cb));
+  repmode_prof_begin(REPMODE_PROF_HELPER, (double)n * V * c * 16.0, static_cast<hipStream_t>(stream));
+  hipLaunchKernelGGL(box_sum_lds_kernel<false>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), in3, in5,
+                     (const float*)nullptr, (const float*)nullptr, (void*)out3, out5, d, h, w, c, cb);
+  repmode_prof_end(static_cast<hipStream_t>(stream));
+  RM_LAUNCH_CHECK("box_pair");
   return REPMODE_OK;
 }
 
@@ -377,4 +412,33 @@ extern "C" int repmode_tap_transpose_ex(const float* in, float* out, long m, int
 
 extern "C" int repmode_tap_transpose(const float* in, float* out, long m, int ntaps_out, void* stream) {
   return repmode_tap_transpose_ex(in, out, m, ntaps_out, 0, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[row] = a[row] | b[row] along the channel axis of two channels-last tensors (RepMode.py:106 torch.cat((skip, up), 1) for
+// the block that takes the per-expert formulation: its kernels read ONE input tensor).  16-byte pieces.
+namespace {
+__global__ __launch_bounds__(256) void concat2_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b, u32x4* __restrict__ out,
+                                                      uint32_t total, uint32_t ca, uint32_t cb) {
+  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= total) return;
+  const uint32_t ct = ca + cb, row = idx / ct, c = idx % ct;
+  out[idx] = c < ca ? a[(size_t)row * ca + c] : b[(size_t)row * cb + (c - ca)];
+}
+}  // namespace
+
+// a: [rows][ca_bytes], b: [rows][cb_bytes] -> out: [rows][ca_bytes + cb_bytes]; byte counts multiples of 16.
+extern "C" int repmode_concat_channels(const void* a, const void* b, void* out, long rows, int ca_bytes, int cb_bytes, void* stream) {
+  RM_REQUIRE(a && b && out && rows > 0 && ca_bytes > 0 && cb_bytes > 0, "concat_channels: bad argument");
+  RM_REQUIRE((ca_bytes & 15) == 0 && (cb_bytes & 15) == 0, "concat_channels: row pieces must be multiples of 16 bytes (%d, %d)", ca_bytes, cb_bytes);
+  RM_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "concat_channels: pointers must be 16-byte aligned");
+  const long total = rows * ((ca_bytes + cb_bytes) / 16);
+  RM_REQUIRE(total < (1L << 32) - 256, "concat_channels: %ld pieces (32-bit index arithmetic)", total);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  repmode_prof_begin(REPMODE_PROF_HELPER, 2.0 * (double)rows * (ca_bytes + cb_bytes), s);
+  hipLaunchKernelGGL(concat2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, static_cast<const u32x4*>(a),
+                     static_cast<const u32x4*>(b), static_cast<u32x4*>(out), (uint32_t)total, (uint32_t)(ca_bytes / 16), (uint32_t)(cb_bytes / 16));
+  repmode_prof_end(s);
+  RM_LAUNCH_CHECK("concat_channels");
+  return REPMODE_OK;
 }

@@ -140,8 +140,10 @@ extern "C" int repmode_expert_mix_fwd(const float* p, const float* g, float* y, 
   RM_REQUIRE(p && g && y && n > 0 && v > 0 && c > 0, "expert_mix_fwd: bad argument");
   const long total = (long)n * v * ((c + 3) / 4);
   RM_REQUIRE(total < (1L << 31), "expert_mix_fwd: %ld items (32-bit index arithmetic)", total);
+  repmode_prof_begin(REPMODE_PROF_HELPER, (double)n * v * c * 4.0 * (E + 1), static_cast<hipStream_t>(stream));
   hipLaunchKernelGGL(expert_mix_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p, g, y, n, v, c);
+  repmode_prof_end(static_cast<hipStream_t>(stream));
   RM_LAUNCH_CHECK("expert_mix_fwd");
   return REPMODE_OK;
 }
@@ -175,12 +177,14 @@ extern "C" int repmode_expert_mix_bwd_ex(const float* dy, const float* p, const 
   if (det && chunks > repmode_det_cap(RM_DET_MIX)) chunks = repmode_det_cap(RM_DET_MIX);
   const long vchunk = (v + chunks - 1) / chunks;
   const dim3 grid((unsigned)((v + vchunk - 1) / vchunk), (unsigned)n);
+  repmode_prof_begin(REPMODE_PROF_HELPER, (double)n * v * c * (4.0 * (E + 1) + 3 * 4.0 + 2 * (dtype == REPMODE_F32 ? 4.0 : 2.0)), s);
   if (dtype == REPMODE_F32)
     hipLaunchKernelGGL(expert_mix_bwd_kernel<float>, grid, dim3(256), 0, s, dy, p, g, dg, static_cast<float*>(dye_lo), dye_hi,
                        n, v, c, vchunk, hi_stride, det);
   else
     hipLaunchKernelGGL(expert_mix_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, dy, p, g, dg, static_cast<bf16_t*>(dye_lo),
                        dye_hi, n, v, c, vchunk, hi_stride, det);
+  repmode_prof_end(s);
   RM_LAUNCH_CHECK("expert_mix_bwd");
   return REPMODE_OK;
 }

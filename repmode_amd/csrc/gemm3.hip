@@ -234,9 +234,11 @@ extern "C" int repmode_gemm3(const float* const* a, long a_ms, long a_ks, const 
              (b_ks == 1 ? mult4(b_ns) : (b_ns == 1 && mult4(b_ks))) &&
              ((long)m * a_ms + (long)k * a_ks) * 4 < (1L << 31) && ((long)n * b_ns + (long)k * b_ks) * 4 < (1L << 31);
   for (int i = 0; i < 3; ++i) vec = vec && (((uintptr_t)a[i] | (uintptr_t)b[i]) & 15) == 0;
+  repmode_prof_begin(REPMODE_PROF_HELPER, 12.0 * ((double)m * k + (double)n * k + (double)m * n), static_cast<hipStream_t>(stream));
   if (vec) hipLaunchKernelGGL((gemm3_kernel<true, true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
   else if (bf16_mfma) hipLaunchKernelGGL(gemm3_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
   else hipLaunchKernelGGL(gemm3_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  repmode_prof_end(static_cast<hipStream_t>(stream));
   RM_LAUNCH_CHECK("gemm3");
   return REPMODE_OK;
 }

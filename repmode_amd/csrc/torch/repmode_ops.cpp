@@ -298,6 +298,13 @@ int64_t g_deep_fwd_min = []() {
   const char* e = std::getenv("REPMODE_DEEP_FWD_MIN");
   return e ? (int64_t)std::atoll(e) : (int64_t)6000;
 }();
+// A per-expert block as ONE launch per direction (csrc/deep_mode.hip: the five experts, the gate mix and the cross-wave
+// reduction in one kernel; round 5) where repmode_deep_mode_plan takes the shape; REPMODE_DEEP_MODE=0 / set_deep_mode(0):
+// round 4's five launches (conv5_deep / dual-expert launch + box + gemm3 + expert_mix).  Bit 0: forward, bit 1: data gradient.
+int64_t g_deep_mode = []() {
+  const char* e = std::getenv("REPMODE_DEEP_MODE");
+  return e ? (int64_t)std::atoi(e) : (int64_t)3;
+}();
 bool g_dual_wgrad = []() {          // (REPMODE_DUAL_WGRAD=0: the two filter gradients of a per-expert block as two launches)
   const char* e = std::getenv("REPMODE_DUAL_WGRAD");
   return e ? std::atoi(e) != 0 : true;
@@ -924,6 +931,33 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
       gn = gate_softmax(gw, gb, plan.sample_task, plan.n, plan.num_tasks, co);
       fr = expert_frags(k5, k3, x_cl.scalar_type(), need_dx);
     }
+    const int dm = ((g_deep_mode & 1) && x_cl.scalar_type() == at::kBFloat16)
+                       ? repmode_deep_mode_plan(0, (int)n, (int)d, (int)h, (int)w, (int)ci, (int)co, REPMODE_BF16) : 0;
+    if (dm) {
+      // ONE launch: the five experts' convolutions, the gate mix and the stores of P_e (csrc/deep_mode.hip); the avg experts'
+      // operands come from the box kernel.  dm > 1: that many workgroups add into each output element (level 4): zeroed
+      // float outputs out of the step's pooled memset
+      Tensor xb = box_expand(x_cl);
+      Tensor p, y;
+      if (dm == 1) {
+        p = at::empty({E, n, d, h, w, co}, x_cl.options().dtype(at::kFloat));
+        y = at::empty({n, d, h, w, co}, x_cl.options().dtype(at::kFloat));
+      } else {
+        auto tp = g_pool.take({E, n, d, h, w, co}, x_cl);
+        auto ty = g_pool.take({n, d, h, w, co}, x_cl);
+        p = tp.first;
+        y = ty.first;
+        if (!tp.second) p.zero_();
+        if (!ty.second) y.zero_();
+      }
+      RM_CALL(repmode_deep_mode_fwd, x_cl.data_ptr(), fr.first.data_ptr(), xb.data_ptr<float>(), k1.data_ptr<float>(), a3.data_ptr<float>(),
+              a5.data_ptr<float>(), gn.data_ptr<float>(), p.data_ptr<float>(), y.data_ptr<float>(), (int)n, (int)d, (int)h, (int)w, (int)ci,
+              (int)co, stream_handle());
+      ctx->save_for_backward({x_cl, k5, k3, k1, a3, a5, gn, xb, p, fr.second.defined() ? fr.second : Tensor()});
+      ctx->saved_data["sample_task"] = plan.sample_task;
+      ctx->saved_data["num_tasks"] = plan.num_tasks;
+      return y;
+    }
     Tensor s0 = single_slot(n, 0, x_cl), s1 = single_slot(n, 1, x_cl);
     auto tk = g_pool.take({E, n, d, h, w, co}, x_cl);                                     // expert outputs P_e
     Tensor p = tk.first;
@@ -1052,7 +1086,28 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     }
     fork.to_main();
     Tensor dx;
-    if (need_dx) {
+    const int dmb = (need_dx && (g_deep_mode & 2) && dt == at::kBFloat16)
+                        ? repmode_deep_mode_plan(1, (int)n, (int)d, (int)h, (int)w, (int)ci, (int)co, REPMODE_BF16) : 0;
+    if (dmb) {
+      // ONE launch: all five experts' data gradients into one accumulator (csrc/deep_mode.hip).  The avg experts' parts go
+      // through the box means of their gate-scaled output gradients (the box mean commutes with the 1x1 channel mixing).
+      Tensor hb = at::empty({2, m, co}, x_cl.options().dtype(at::kFloat));
+      RM_CALL(repmode_box_pair, hi[1].data_ptr<float>(), hi[2].data_ptr<float>(), hb[0].data_ptr<float>(), hb[1].data_ptr<float>(), (int)n,
+              (int)d, (int)h, (int)w, (int)co, stream_handle());
+      Tensor dxo;
+      if (dmb == 1) {
+        dxo = at::empty({n, d, h, w, ci}, x_cl.options().dtype(dt));
+      } else {
+        auto tk = g_pool.take({n, d, h, w, ci}, x_cl);
+        dxo = tk.first;
+        if (!tk.second) dxo.zero_();
+      }
+      RM_CALL(repmode_deep_mode_dgrad, lo.data_ptr(), wd2.data_ptr(), hi[0].data_ptr<float>(), hb[0].data_ptr<float>(), hb[1].data_ptr<float>(),
+              k1.data_ptr<float>(), a3.data_ptr<float>(), a5.data_ptr<float>(), dxo.data_ptr(), dtype_code(dxo.scalar_type()), (int)n, (int)d,
+              (int)h, (int)w, (int)ci, (int)co, stream_handle());
+      if (defer) RM_CALL(repmode_tail_flush, stream_handle());
+      dx = dxo.scalar_type() == dt ? dxo : dxo.to(dt);
+    } else if (need_dx) {
       Tensor lo0 = lo[0], lo1 = lo[1];
       Tensor dxf;
       if (g_deep && g_dual_launch && repmode_conv5_deep_supported((int)w, (int)co, dtype_code(dt)) != 0) {
@@ -1292,6 +1347,33 @@ void check_params(const Tensor& x_cl, const Tensor* x2_cl, const Tensor& k5, con
   }
 }
 
+// torch.cat((skip, up), 1) (RepMode.py:106) on channels-last tensors as a kernel of the library (one launch, visible to the
+// library's per-launch timing); the gradient is the two channel ranges of the incoming one.
+struct Cat2 : public torch::autograd::Function<Cat2> {
+  static Tensor forward(AutogradContext* ctx, Tensor a, Tensor b) {
+    const int64_t ca = a.size(-1), cb = b.size(-1), rows = a.numel() / ca;
+    const int64_t es = (int64_t)a.element_size();
+    std::vector<int64_t> shape = a.sizes().vec();
+    shape.back() = ca + cb;
+    Tensor out = at::empty(shape, a.options());
+    RM_CALL(repmode_concat_channels, a.data_ptr(), b.data_ptr(), out.data_ptr(), (long)rows, (int)(ca * es), (int)(cb * es), stream_handle());
+    ctx->saved_data["ca"] = ca;
+    ctx->saved_data["cb"] = cb;
+    return out;
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const int64_t ca = ctx->saved_data["ca"].toInt(), cb = ctx->saved_data["cb"].toInt();
+    return {grads[0].narrow(-1, 0, ca), grads[0].narrow(-1, ca, cb)};
+  }
+};
+
+inline Tensor cat_channels(const Tensor& a, const Tensor& b) {
+  const int64_t es = (int64_t)a.element_size();
+  if (a.is_contiguous() && b.is_contiguous() && (a.size(-1) * es) % 16 == 0 && (b.size(-1) * es) % 16 == 0 && a.numel() + b.numel() < (1LL << 31))
+    return Cat2::apply(a, b);
+  return at::cat({a, b}, -1);
+}
+
 // Heuristic: small volumes (levels 3-4) with several distinct tasks in the batch take the per-expert formulation.
 inline bool use_unmerged(const Tensor& x_cl, const Plan& plan) { return plan.training && plan.nslots > 2 && x_cl.size(3) <= g_unmerged_max_w; }
 
@@ -1317,7 +1399,7 @@ Tensor mode_conv3d_cl(const Tensor& x_cl_in, const OptTensor& x2_cl_in, const Te
     TORCH_CHECK(mode != 3 || shapes_ok, "mode_conv3d: the two-tensor form needs ", x_cl.size(4), " % 32 == 0 and ", x2_cl.size(4), " % 16 (8) == 0");
     if (mode == 3 || (mode == 1 && shapes_ok) || (mode == 0 && shapes_ok && !use_unmerged(x_cl, plan)))
       return ModeConvPair::apply(x_cl, x2_cl, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan, out_f32, grad_enabled, epi);
-    x_cl = at::cat({x_cl, x2_cl}, -1);      // per-expert formulation / odd channel counts: the concatenated tensor
+    x_cl = cat_channels(x_cl, x2_cl);       // per-expert formulation / odd channel counts: the concatenated tensor
   }
   if (mode == 0) mode = use_unmerged(x_cl, plan) ? 2 : 1;
   if (mode == 2) {
@@ -1795,6 +1877,8 @@ void op_set_bn_epilogue(int64_t mask) { g_bn_epilogue = mask; }
 void op_set_unmerged_max_w(int64_t w) { g_unmerged_max_w = w; }
 void op_set_dual_launch(bool on) { g_dual_launch = on; }
 void op_set_deep_conv(bool on) { g_deep = on; }
+void op_set_deep_mode(int64_t mask) { g_deep_mode = mask; }
+int64_t op_get_deep_mode() { return g_deep_mode; }
 void op_set_deep_fwd_min(int64_t v) { g_deep_fwd_min = v; }
 void op_set_thin_kernels(bool on) { g_thin = on; }
 bool op_get_deep_conv() { return g_deep; }
@@ -1895,6 +1979,8 @@ TORCH_LIBRARY(repmode, m) {
   m.def("set_unmerged_max_w(int w) -> ()", &rm::op_set_unmerged_max_w);
   m.def("set_dual_launch(bool on) -> ()", &rm::op_set_dual_launch);
   m.def("set_deep_conv(bool on) -> ()", &rm::op_set_deep_conv);
+  m.def("set_deep_mode(int mask) -> ()", &rm::op_set_deep_mode);
+  m.def("get_deep_mode() -> int", &rm::op_get_deep_mode);
   m.def("set_deep_fwd_min(int v) -> ()", &rm::op_set_deep_fwd_min);
   m.def("set_thin_kernels(bool on) -> ()", &rm::op_set_thin_kernels);
   m.def("get_deep_conv() -> bool", &rm::op_get_deep_conv);

@@ -108,6 +108,16 @@ def get_deep_conv():
     return bool(torch_ops().get_deep_conv())
 
 
+def set_deep_mode(mask):
+    """Per-expert blocks as ONE launch per direction (csrc/deep_mode.hip) where ``deep_mode_plan`` takes the shape: bit 0 the
+    forward, bit 1 the data gradient (default 3; 0 = round 4's five launches; REPMODE_DEEP_MODE)."""
+    torch_ops().set_deep_mode(int(mask))
+
+
+def get_deep_mode():
+    return int(torch_ops().get_deep_mode())
+
+
 def set_deterministic(on):
     """Run-to-run bitwise reproducible results (REPMODE_DETERMINISTIC=1): every float sum of the path gets a fixed order --
     see ``repmode_set_deterministic`` in include/repmode_hip.h; slower (the splits it removes are there for parallelism)."""
@@ -430,6 +440,60 @@ def conv5_deep(x_cl, w2, cout, two_in=False, out=None, zeroed=False):
     _lib.call('repmode_conv5_deep', _ptr(x_cl), _ptr(w2), _ptr(y), n, d, h, wd_, cin, cout,
               (1 if two_in else 0) | (2 if zeroed else 0), _stream())
     return y
+
+
+def deep_mode_plan(direction, n, d, h, w, cin, cout, dtype=torch.bfloat16):
+    """0: ``deep_mode_fwd`` (direction 0) / ``deep_mode_dgrad`` (1) does not take the shape; 1: plain stores; k > 1: k workgroups
+    add into every output element (float outputs, zero on entry)."""
+    if dtype != torch.bfloat16:
+        return 0
+    return int(_lib.load().repmode_deep_mode_plan(direction, n, d, h, w, cin, cout, dtype_code(dtype)))
+
+
+def box_expand(x_cl):
+    """float [3, N, D, H, W, C] = (x, box3(x) / 27, box5(x) / 125): the 1x1 experts' operands (RepMode.py:139-142, 176-180)."""
+    n, d, h, w, c = x_cl.shape
+    out = torch.empty((3, n, d, h, w, c), dtype=torch.float32, device=x_cl.device)
+    _lib.call('repmode_box_expand', _ptr(x_cl), dtype_code(x_cl.dtype), _ptr(out), n, d, h, w, c, _stream())
+    return out
+
+
+def box_pair(in3, in5):
+    """(box3(in3) / 27, box5(in5) / 125) of two float channels-last tensors, one launch."""
+    n, d, h, w, c = in3.shape
+    out = torch.empty((2, n, d, h, w, c), dtype=torch.float32, device=in3.device)
+    _lib.call('repmode_box_pair', _ptr(in3), _ptr(in5), _ptr(out[0]), _ptr(out[1]), n, d, h, w, c, _stream())
+    return out[0], out[1]
+
+
+def deep_mode_fwd(x_cl, wf, xs, k1, a3, a5, gn):
+    """A per-expert MoDE block's forward in one launch (csrc/deep_mode.hip): x bf16 [N,D,H,W,Ci], ``wf`` = ``expert_frags``'
+    forward role, ``xs`` = ``box_expand(x)``, the 1x1 experts' parameters [Co,Ci], ``gn`` [N,5,Co] the gate probabilities per
+    sample -> (P [5,N,D,H,W,Co] float, y [N,D,H,W,Co] float)."""
+    n, d, h, w, ci = x_cl.shape
+    co = gn.shape[2]
+    plan = deep_mode_plan(0, n, d, h, w, ci, co)
+    alloc = torch.zeros if plan > 1 else torch.empty
+    p = alloc((NUM_EXPERTS, n, d, h, w, co), dtype=torch.float32, device=x_cl.device)
+    y = alloc((n, d, h, w, co), dtype=torch.float32, device=x_cl.device)
+    _lib.call('repmode_deep_mode_fwd', _ptr(x_cl), _ptr(wf), _ptr(xs), _ptr(k1), _ptr(a3), _ptr(a5), _ptr(gn), _ptr(p), _ptr(y),
+              n, d, h, w, ci, co, _stream())
+    return p, y
+
+
+def deep_mode_dgrad(lo, wd, s0, s1, s2, k1, a3, a5, cin, out_dtype=torch.bfloat16):
+    """A per-expert MoDE block's data gradient in one launch: ``lo`` bf16 [2,N,D,H,W,Co] (the conv experts' gate-scaled output
+    gradients), ``wd`` = ``expert_frags``' data-gradient role, s0 / s1 / s2 float [N,D,H,W,Co] = G_2, box3(G_3)/27,
+    box5(G_4)/125 -> dx [N,D,H,W,Ci] (float when the plan splits the reduction over workgroups)."""
+    _, n, d, h, w, co = lo.shape
+    plan = deep_mode_plan(1, n, d, h, w, cin, co)
+    if plan > 1:
+        dx = torch.zeros((n, d, h, w, cin), dtype=torch.float32, device=lo.device)
+    else:
+        dx = torch.empty((n, d, h, w, cin), dtype=out_dtype, device=lo.device)
+    _lib.call('repmode_deep_mode_dgrad', _ptr(lo), _ptr(wd), _ptr(s0), _ptr(s1), _ptr(s2), _ptr(k1), _ptr(a3), _ptr(a5), _ptr(dx),
+              dtype_code(dx.dtype), n, d, h, w, cin, co, _stream())
+    return dx
 
 
 def conv5_merged(x_cl, w2, k1, a3, a5, g, sample_slot, cout):

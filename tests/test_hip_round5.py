@@ -1,0 +1,179 @@
+"""Round-5 kernels against the CPU oracle (through the C ABI and the operator library): a per-expert MoDE block of the deep
+levels as ONE launch per direction (csrc/deep_mode.hip; RepMode.py:171-192 by linearity + :204-208 and their autograd), the
+box-mean pair that feeds its data gradient.  Needs a real MI355X: every test is marked ``gpu``.  Tolerances as
+tests/test_hip_parity.py states them (bf16 operands rounded on both sides, float accumulation: 1e-4 of the tensor's max)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import record, rel_err
+from oracle import repmode_oracle as orc
+from test_hip_parity import DEV, TOL_BF16_ACC, _ops, _rand_experts
+
+pytestmark = pytest.mark.gpu
+
+
+DM_CASES = [
+    # (n, (d, h, w), ci, co)
+    (8, (2, 4, 4), 64, 128),      # two whole samples per tile; the reduction split over workgroups (zeroed outputs)
+    (5, (1, 2, 2), 32, 32),       # smaller than the 2 x 4 x 4 brick, an odd sample count (a half-empty last tile)
+    (24, (2, 4, 4), 32, 64),      # batch 24
+    (3, (4, 8, 8), 48, 96),       # one 8 x 8 plane per tile; channel counts that are no tile multiples (3 chunks, 8 waves)
+    (2, (4, 8, 8), 128, 256),     # a real level-3 layer's width: 8 chunks = one per wave
+    (3, (2, 4, 8), 16, 40),       # the plane tile on a volume smaller than it, a single chunk
+    (2, (3, 6, 7), 24, 36),       # ragged in every direction, a half-filled last chunk
+    (8, (4, 8, 8), 256, 256),     # enc4.conv2 / dec4.conv2 at the benchmarked batch: plain stores
+    (8, (2, 4, 4), 256, 512),     # bottle.conv1 at the benchmarked batch: 4 slices of the reduction
+    (1, (4, 8, 8), 512, 256),     # dec4.conv1's width, four chunks per wave
+]
+
+
+def _box(x, k):
+    """zero-padded k^3 box mean of [N, C, D, H, W] (RepMode.py:161-163, 176-180)."""
+    c = x.shape[1]
+    return F.conv3d(x, x.new_full((c, 1, k, k, k), 1.0 / k ** 3), padding=k // 2, groups=c)
+
+
+def _bf(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize('case', DM_CASES)
+def test_deep_mode_fwd_vs_oracle(case):
+    """P_e = conv(x, K_e) for the five experts and y = sum_e g_e * P_e from ONE launch against F.conv3d on the same
+    bf16-rounded operands (the avg experts' box means as the box kernel hands them over, themselves checked against the
+    oracle's depthwise form)."""
+    ops = _ops()
+    n, shape, ci, co = case
+    d, h, w = shape
+    assert ops.deep_mode_plan(0, n, d, h, w, ci, co) >= 1
+    gen = torch.Generator().manual_seed(n * 1000 + ci + co + w)
+    k5, k3, k1, a3, a5 = _rand_experts(co, ci, gen)[:5]
+    x = _bf(torch.randn(n, ci, *shape, generator=gen))
+    gn = torch.softmax(torch.randn(n, 5, co, generator=gen), 1)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    wf, _ = ops.expert_frags(k5.to(DEV), k3.to(DEV), torch.bfloat16, want_wd=False)
+    xs = ops.box_expand(x_cl)
+    xs_c = xs.cpu().permute(0, 1, 5, 2, 3, 4)                       # [3, N, C, D, H, W]
+    assert rel_err(xs_c[0], x) == 0.0
+    assert rel_err(xs_c[1], _box(x, 3)) < 1e-5 and rel_err(xs_c[2], _box(x, 5)) < 1e-5
+    k1d, a3d, a5d = (t.reshape(co, ci).contiguous().to(DEV) for t in (k1, a3, a5))
+    p, y = ops.deep_mode_fwd(x_cl, wf, xs, k1d, a3d, a5d, gn.to(DEV))
+    refs = [F.conv3d(x, _bf(k5), padding=2), F.conv3d(x, _bf(k3), padding=1), F.conv3d(x, _bf(k1)),
+            F.conv3d(_bf(xs_c[1]), _bf(a3)), F.conv3d(_bf(xs_c[2]), _bf(a5))]
+    p_c = p.cpu().permute(0, 1, 5, 2, 3, 4)
+    errs = [rel_err(p_c[e], refs[e]) for e in range(5)]
+    y_ref = sum(gn[:, e, :, None, None, None] * refs[e] for e in range(5))
+    ey = rel_err(y.cpu().permute(0, 4, 1, 2, 3), y_ref)
+    record('test_deep_mode_fwd_vs_oracle', case=str(case), p_err=max(errs), y_err=ey)
+    assert max(errs) < TOL_BF16_ACC, errs
+    assert ey < TOL_BF16_ACC
+
+
+@pytest.mark.parametrize('case', DM_CASES)
+def test_deep_mode_dgrad_vs_oracle(case):
+    """dx = conv(G_0, flip K5^T) + conv(G_1, flip pad(K3)^T) + G_2 K1 + box3(G_3)/27 A3 + box5(G_4)/125 A5 from ONE launch
+    against the oracle's transposed convolutions on the same bf16-rounded operands; float output 1e-4, bf16 output one
+    rounding (4e-3)."""
+    ops = _ops()
+    n, shape, ci, co = case
+    d, h, w = shape
+    plan = ops.deep_mode_plan(1, n, d, h, w, ci, co)
+    assert plan >= 1
+    gen = torch.Generator().manual_seed(n * 999 + ci + co + h)
+    k5, k3, k1, a3, a5 = _rand_experts(co, ci, gen)[:5]
+    lo = _bf(torch.randn(2, n, co, *shape, generator=gen))
+    s = torch.randn(3, n, co, *shape, generator=gen)
+    _, wd = ops.expert_frags(k5.to(DEV), k3.to(DEV), torch.bfloat16, want_wd=True)
+    lo_cl = lo.permute(0, 1, 3, 4, 5, 2).contiguous().to(DEV, torch.bfloat16)
+    s_cl = s.permute(0, 1, 3, 4, 5, 2).contiguous().to(DEV)
+    k1d, a3d, a5d = (t.reshape(co, ci).contiguous().to(DEV) for t in (k1, a3, a5))
+    dx_ref = (F.conv_transpose3d(lo[0], _bf(k5), padding=2) + F.conv_transpose3d(lo[1], _bf(k3), padding=1) +
+              F.conv_transpose3d(_bf(s[0]), _bf(k1)) + F.conv_transpose3d(_bf(s[1]), _bf(a3)) + F.conv_transpose3d(_bf(s[2]), _bf(a5)))
+    dxf = ops.deep_mode_dgrad(lo_cl, wd, s_cl[0], s_cl[1], s_cl[2], k1d, a3d, a5d, ci, out_dtype=torch.float32)
+    ef = rel_err(dxf.cpu().permute(0, 4, 1, 2, 3), dx_ref)
+    record('test_deep_mode_dgrad_vs_oracle', case=str(case), plan=plan, err_f32=ef)
+    assert dxf.dtype == torch.float32 and ef < TOL_BF16_ACC
+    if plan == 1:
+        dxb = ops.deep_mode_dgrad(lo_cl, wd, s_cl[0], s_cl[1], s_cl[2], k1d, a3d, a5d, ci, out_dtype=torch.bfloat16)
+        assert dxb.dtype == torch.bfloat16
+        assert rel_err(dxb.float().cpu().permute(0, 4, 1, 2, 3), dx_ref) < 4e-3
+        # the element-typed output is the float one rounded once (the waves' sums meet in another order: a few flips)
+        flips = (dxb.float() != dxf.bfloat16().float()).float().mean().item()
+        assert flips < 1e-2, flips
+
+
+def test_deep_mode_refuses_what_it_does_not_take():
+    """Shapes outside the two tiles, float32 and the deterministic mode answer 0 (the operator library then keeps round 4's
+    launches); calling the kernel anyway is an error, not a wrong answer."""
+    ops = _ops()
+    from repmode_amd import _lib
+    assert ops.deep_mode_plan(0, 2, 6, 10, 8, 16, 32) == 0          # several bricks per sample
+    assert ops.deep_mode_plan(0, 2, 8, 8, 8, 16, 32) == 0           # deeper than four planes
+    assert ops.deep_mode_plan(1, 2, 4, 8, 16, 16, 32) == 0          # wider than the plane tile
+    assert ops.deep_mode_plan(0, 2, 4, 8, 8, 12, 32) == 0           # reduction channels % 8
+    assert ops.deep_mode_plan(0, 2, 4, 8, 8, 16, 32, torch.float32) == 0
+    assert ops.deep_mode_plan(0, 2, 4, 8, 8, 16, 32) == 1
+    ops.set_deterministic(True)
+    try:
+        assert ops.deep_mode_plan(0, 2, 4, 8, 8, 16, 32) == 0
+    finally:
+        ops.set_deterministic(False)
+    x = torch.zeros(2, 6, 10, 8, 16, device=DEV, dtype=torch.bfloat16)
+    z = torch.zeros(16, device=DEV)
+    with pytest.raises(_lib.RepModeHipError):
+        _lib.call('repmode_deep_mode_fwd', x.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(),
+                  z.data_ptr(), z.data_ptr(), 2, 6, 10, 8, 16, 32, None)
+
+
+@pytest.mark.parametrize('shape,c', [((4, 8, 8), 64), ((2, 4, 4), 256), ((3, 6, 7), 24), ((1, 2, 2), 8)])
+def test_box_pair_vs_oracle(shape, c):
+    """box3(a) / 27 and box5(b) / 125 of two different tensors from one launch (autograd of RepMode.py:176-180: the box mean is
+    self-adjoint)."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(c + shape[2])
+    a = torch.randn(3, c, *shape, generator=gen)
+    b = torch.randn(3, c, *shape, generator=gen)
+    o3, o5 = ops.box_pair(a.permute(0, 2, 3, 4, 1).contiguous().to(DEV), b.permute(0, 2, 3, 4, 1).contiguous().to(DEV))
+    assert rel_err(o3.cpu().permute(0, 4, 1, 2, 3), _box(a, 3)) < 1e-5
+    assert rel_err(o5.cpu().permute(0, 4, 1, 2, 3), _box(b, 5)) < 1e-5
+
+
+@pytest.mark.parametrize('ci,co,shape,n', [(64, 64, (2, 4, 4), 8), (48, 96, (4, 8, 8), 3), (256, 128, (4, 8, 8), 8), (128, 256, (4, 8, 8), 8),
+                                           (256, 512, (2, 4, 4), 8)])
+def test_deep_mode_in_the_operator(ci, co, shape, n):
+    """The per-expert block through the operator library as one launch per direction (default) and as round 4's five: output,
+    data gradient and every parameter gradient agree (bf16: a summation-order difference can flip a rounding), and the
+    one-launch form matches the oracle's block on the bf16-rounded input."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(ci + co + n)
+    ps = _rand_experts(co, ci, gen)
+    tasks = [(5 * i + 2) % 12 for i in range(n)]
+    x = torch.randn(n, *shape, ci, generator=gen).bfloat16()
+    r = torch.randn(n, *shape, co, generator=gen)
+    res = []
+    before = ops.get_deep_mode()
+    try:
+        for mask in (3, 0, 1, 2):
+            ops.set_deep_mode(mask)
+            dev = [p.to(DEV).requires_grad_(True) for p in ps]
+            xd = x.to(DEV).requires_grad_(True)
+            plan = ops.TaskPlan(tasks, 12, DEV, training=True)
+            y = ops.mode_conv3d(xd, *dev, plan, mode='unmerged')
+            (y.float() * r.to(DEV)).sum().backward()
+            res.append([y.detach().float().cpu(), xd.grad.float().cpu()] + [p.grad.cpu() for p in dev])
+    finally:
+        ops.set_deep_mode(before)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert rel_err(a, b) < 1e-2
+    xr = x.float().permute(0, 4, 1, 2, 3).contiguous().requires_grad_(True)
+    pr = [p.clone().requires_grad_(True) for p in ps]
+    y_ref = orc.mode_conv_pre_bn(xr, *pr, torch.tensor(tasks), training=True)
+    (y_ref * r.permute(0, 4, 1, 2, 3)).sum().backward()
+    errs = {'y': rel_err(res[0][0].permute(0, 4, 1, 2, 3), y_ref.detach()), 'dx': rel_err(res[0][1].permute(0, 4, 1, 2, 3), xr.grad)}
+    for i, (got, p) in enumerate(zip(res[0][2:], pr)):
+        errs['p%d' % i] = rel_err(got, p.grad)
+    record('test_deep_mode_in_the_operator', case='%d->%d %s n=%d' % (ci, co, shape, n), **errs)
+    assert max(errs.values()) < 2e-2, errs
