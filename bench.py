@@ -355,8 +355,10 @@ def main():
                    'hip_graph': bool(model.hip_graph), 'steps_launched_kernel_by_kernel': profiled_steps},
     }
 
-    # ---- N > 1: the same ranks, batch and run without the gradient all-reduce (what the collectives cost at this batch)
+    # ---- N > 1: what the process group looked like (so that a scaling record can show that RCCL saw N ranks), then the same
+    # ranks, batch and run without the gradient all-reduce (what the collectives cost at this batch)
     if world > 1:
+        out['config']['comm'] = dist_.comm_info(model)
         k = max(5, min(args.steps, 20))
         module = model.ddp if model.ddp is not None else None
         ctx = module.no_sync() if module is not None else None

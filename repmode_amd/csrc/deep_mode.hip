@@ -31,6 +31,10 @@
 #include <atomic>
 #include <cstdlib>
 
+#ifndef DM_PF
+#define DM_PF 1      // tap rows of filter fragments in flight ahead of the MFMAs
+#endif
+
 namespace {
 
 constexpr int E = REPMODE_NUM_EXPERTS;
@@ -98,29 +102,52 @@ __device__ __forceinline__ void row_voxel(int m, int piece, int& lz, int& ly, in
 // vb[vs]: LDS slot of sub-tile vs' voxel at tap (0,0,0); wrow: this lane's filter fragment at tap 0 of the chunk.
 template <typename C, int P>
 __device__ __forceinline__ void tap_pass(const u32x4* __restrict__ lds, const int (&vb)[C::VW], const bf16_t* __restrict__ wrow,
-                                         size_t tap_stride, int dz_lo, int dz_hi, int dy_lo, int dy_hi, f32x16 (&acc)[C::VW]) {
+                                         size_t tap_stride, int dz_lo, int dz_hi, int dy_lo, int dy_hi, int rot, f32x16 (&acc)[C::VW]) {
   constexpr int VW = C::VW, BXH = C::BXH, PP = C::PP;
   constexpr int DX0 = P ? 1 : 0, NDX = P ? 3 : 5;
   if (dz_lo > dz_hi || dy_lo > dy_hi) return;
   auto wfrag = [&](int tap) -> u32x4 { return *reinterpret_cast<const u32x4*>(wrow + (size_t)tap * tap_stride); };
-  const int nrows = (dz_hi - dz_lo + 1) * (dy_hi - dy_lo + 1);
-  int dz = dz_lo, dy = dy_lo;
-  u32x4 a_cur[NDX], a_nxt[NDX], b_cur[VW], b_nxt[VW];
+  const int ny = dy_hi - dy_lo + 1;
+  const int nrows = (dz_hi - dz_lo + 1) * ny;
+  // the tap rows in a rotated order (sums commute): the workgroups that share an output-channel tile -- and with it every
+  // filter byte -- run on one XCD at one time; starting all at tap row 0 they would ask for the same line in the same
+  // microsecond and all wait for the one fetch from HBM (measured: 117 us per launch, 2.4 MB of filters per XCD at the
+  // rate of 16 latency-bound streams)
+#ifdef DM_NOROT
+  const int r0 = 0;
+#else
+  const int r0 = rot % nrows;
+#endif
+  int dz = dz_lo + r0 / ny, dy = dy_lo + r0 % ny;
+  auto next_row = [&](int& z, int& y) {
+    if (++y > dy_hi) { y = dy_lo; if (++z > dz_hi) z = dz_lo; }
+  };
+  // filter fragments DM_PF tap rows ahead (a fetch that misses L2 comes from the Infinity Cache / HBM: 1-2 us), voxel
+  // fragments one tap ahead
+  u32x4 a_q[DM_PF + 1][NDX], b_cur[VW], b_nxt[VW];
+  int qz = dz, qy = dy;
 #pragma unroll
-  for (int i = 0; i < NDX; ++i) a_cur[i] = wfrag((dz * 5 + dy) * 5 + DX0 + i);
+  for (int q = 0; q < DM_PF; ++q) {
+    if (q < nrows) {
+#pragma unroll
+      for (int i = 0; i < NDX; ++i) a_q[q][i] = wfrag((qz * 5 + qy) * 5 + DX0 + i);
+    }
+    next_row(qz, qy);
+  }
   {
     const int off0 = dz * PP + dy * BXH + DX0;
 #pragma unroll
     for (int vs = 0; vs < VW; ++vs) b_cur[vs] = lds[vb[vs] + off0];
   }
   for (int row = 0; row < nrows; ++row) {
-    int dzn = dz, dyn = dy + 1;
-    if (dyn > dy_hi) { dyn = dy_lo; dzn = dz + 1; }
+    int dzn = dz, dyn = dy;
+    next_row(dzn, dyn);
     const bool more = row + 1 < nrows;
-    if (more) {
+    if (row + DM_PF < nrows) {
 #pragma unroll
-      for (int i = 0; i < NDX; ++i) a_nxt[i] = wfrag((dzn * 5 + dyn) * 5 + DX0 + i);
+      for (int i = 0; i < NDX; ++i) a_q[DM_PF][i] = wfrag((qz * 5 + qy) * 5 + DX0 + i);
     }
+    next_row(qz, qy);
     const int rowoff = dz * PP + dy * BXH + DX0;
     const int rowoff_n = more ? dzn * PP + dyn * BXH + DX0 : rowoff;
 #pragma unroll
@@ -131,13 +158,15 @@ __device__ __forceinline__ void tap_pass(const u32x4* __restrict__ lds, const in
       // (fences: the next tap's LDS reads stay AHEAD of this tap's MFMAs, as in conv5_deep.hip)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int vs = 0; vs < VW; ++vs) mma_bf16(b_cur[vs], a_cur[i], acc[vs]);      // A = voxels, B = filter rows
+      for (int vs = 0; vs < VW; ++vs) mma_bf16(b_cur[vs], a_q[0][i], acc[vs]);      // A = voxels, B = filter rows
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int vs = 0; vs < VW; ++vs) b_cur[vs] = b_nxt[vs];
     }
 #pragma unroll
-    for (int i = 0; i < NDX; ++i) a_cur[i] = a_nxt[i];
+    for (int q = 0; q < DM_PF; ++q)
+#pragma unroll
+      for (int i = 0; i < NDX; ++i) a_q[q][i] = a_q[q + 1][i];
     dz = dzn;
     dy = dyn;
   }
@@ -250,24 +279,33 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[p][vs][r] = 0.f;
 
-  const int c_first = c_begin + wave;
-  if (c_first < c_end) fetch(a.x0, c_first);
-  for (int chunk = c_first; chunk < c_end; chunk += nw) {
+  // position i of this workgroup's chunk range -> chunk, rotated by the tile index (same reason as the tap rows' rotation)
+  const int nc = c_end - c_begin;
+#ifdef DM_NOROT
+  const int rotc = 0;
+#else
+  const int rotc = nc > 0 ? g % nc : 0;
+#endif
+  auto chunk_at = [&](int i) -> int { const int t = i + rotc; return c_begin + (t >= nc ? t - nc : t); };
+  const int rot = g * 7 + wave * 3;
+  if (wave < nc) fetch(a.x0, chunk_at(wave));
+  for (int i = wave; i < nc; i += nw) {
+    const int chunk = chunk_at(i);
     const bf16_t* wchunk = wrow0 + (size_t)chunk * (32 * 16);
-    const int next = chunk + nw;
+    const bool has_next = i + nw < nc;
     stage();
     if constexpr (FWD) {
-      if (next < c_end) fetch(a.x0, next);
-      tap_pass<C, 0>(lds, vb, wchunk, tap_stride, dz_lo, dz_hi, dy_lo, dy_hi, acc[0]);
+      if (has_next) fetch(a.x0, chunk_at(i + nw));
+      tap_pass<C, 0>(lds, vb, wchunk, tap_stride, dz_lo, dz_hi, dy_lo, dy_hi, rot, acc[0]);
       tap_pass<C, 1>(lds, vb, wchunk + (size_t)REPMODE_TAPS * tap_stride, tap_stride, max(dz_lo, 1), min(dz_hi, 3), max(dy_lo, 1),
-                     min(dy_hi, 3), acc[1]);
+                     min(dy_hi, 3), rot, acc[1]);
     } else {
       fetch(a.x1, chunk);
-      tap_pass<C, 0>(lds, vb, wchunk, tap_stride, dz_lo, dz_hi, dy_lo, dy_hi, acc[0]);
+      tap_pass<C, 0>(lds, vb, wchunk, tap_stride, dz_lo, dz_hi, dy_lo, dy_hi, rot, acc[0]);
       stage();
-      if (next < c_end) fetch(a.x0, next);
+      if (has_next) fetch(a.x0, chunk_at(i + nw));
       tap_pass<C, 1>(lds, vb, wchunk + (size_t)REPMODE_TAPS * tap_stride, tap_stride, max(dz_lo, 1), min(dz_hi, 3), max(dy_lo, 1),
-                     min(dy_hi, 3), acc[0]);
+                     min(dy_hi, 3), rot, acc[0]);
     }
   }
 
@@ -295,7 +333,12 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
     }
     const int o = cot * 32 + l31;
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int chunk = c_first; chunk < c_end; chunk += nw) {
+#ifdef DM_NO1X1      // TIMING BUILD ONLY: the 1x1 experts' pass never runs
+    for (int i = wave; i < nc && a.N < 0; i += nw) {
+#else
+    for (int i = wave; i < nc; i += nw) {
+#endif
+      const int chunk = chunk_at(i);
       const int r0 = chunk * 16 + khalf * 8;
       const bool rin = r0 < R;
 #pragma unroll
@@ -327,73 +370,92 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
     }
   }
 
-  // ---- the waves' partial sums meet in LDS (the images are dead: barrier first)
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);      // [NE][64 voxels][32 channels]
-  for (int i = tid; i < NE * 2048; i += nt) red[i] = 0.f;
-  __syncthreads();
-  if (c_first < c_end) {
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-#pragma unroll
-      for (int vs = 0; vs < VW; ++vs)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (r & 3) + 8 * (r >> 2) + 4 * khalf;      // 32x32 C/D layout: row of register r, column = l31
-          float v;
-          if constexpr (FWD) {
-            if (e < 2) v = acc[e & 1][vs][r];
-            else v = acc1[e >= 2 ? e - 2 : 0][vs][r];
-          } else {
-            v = acc[0][vs][r];
-          }
-          atomicAdd(&red[(e * 64 + vs * 32 + m) * 32 + l31], v);
-        }
-  }
-  __syncthreads();
-
-  // ---- stores: a thread owns 4 channels of a voxel row (8 threads = one 128-byte row of the tile)
+  // ---- the waves' partial sums meet in LDS: every wave writes its 64 x 32 tiles into a slab of its own (plain
+  // ds_write_b32, conflict-free), the owner threads add the slabs -- two accumulator sets per round (LDS float atomics
+  // onto one shared tile measured ~64 cycles per wave-instruction: 40 us of a forward launch with eight waves).
+  // A thread owns 4 channels of a voxel row (8 threads = one 128-byte row of the tile).
+  constexpr int SPR = 2;                                   // sets per round: nw * SPR * 8 KB <= the waves' image regions
+  float* red = reinterpret_cast<float*>(smem);             // [wave][SPR][64 voxels][32 channels]
+  const int nwa = min(nw, nc);                             // waves that had chunks
   const size_t estride = (size_t)N * V * O;
   const bool split = a.ksplit > 1;
-  for (int q = tid; q < 512; q += nt) {
-    const int vox = q >> 3, c4 = (q & 7) * 4;
-    const int vs = vox >> 5, m = vox & 31;
-    const int ul = vs / TU, piece = vs % TU;
-    int lz, ly, lx;
-    row_voxel<C>(m, piece, lz, ly, lx);
-    const int unit = g * SU + ul, gz = zmin + lz, o = cot * 32 + c4;
-    if (unit >= a.nunits || gz >= D || ly >= H || lx >= W || o >= O) continue;
-    const int n = unit / a.nbz;
-    const size_t off = ((size_t)n * V + (gz * H + ly) * W + lx) * O + o;
-    if constexpr (FWD) {
-      f32x4 yv = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 yv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // forward: y of this thread's (<= 2) items
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const f32x4 pe = *reinterpret_cast<const f32x4*>(&red[(e * 64 + vox) * 32 + c4]);
-        const f32x4 ge = *reinterpret_cast<const f32x4*>(a.gate + ((size_t)n * E + e) * O + o);
-        yv += ge * pe;
-        float* pp = a.p + e * estride + off;
-        if (split) {
-          unsafeAtomicAdd(pp, pe.x); unsafeAtomicAdd(pp + 1, pe.y); unsafeAtomicAdd(pp + 2, pe.z); unsafeAtomicAdd(pp + 3, pe.w);
-        } else {
-          *reinterpret_cast<f32x4*>(pp) = pe;
+  for (int e0 = 0; e0 < NE; e0 += SPR) {
+    __syncthreads();        // the images (first round) / the previous round's slabs are dead
+    if (wave < nc) {
+#pragma unroll
+      for (int sr = 0; sr < SPR; ++sr) {
+        const int e = e0 + sr;
+        if (e < NE) {
+#pragma unroll
+          for (int vs = 0; vs < VW; ++vs)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = (r & 3) + 8 * (r >> 2) + 4 * khalf;      // 32x32 C/D layout: row of register r, column = l31
+              float v;
+              if constexpr (FWD) {
+                if (e < 2) v = acc[e & 1][vs][r];
+                else v = acc1[e >= 2 ? e - 2 : 0][vs][r];
+              } else {
+                v = acc[0][vs][r];
+              }
+              red[(((wave * SPR + sr) * 64) + vs * 32 + m) * 32 + l31] = v;
+            }
         }
       }
-      float* yp = static_cast<float*>(a.y) + off;
-      if (split) {
-        unsafeAtomicAdd(yp, yv.x); unsafeAtomicAdd(yp + 1, yv.y); unsafeAtomicAdd(yp + 2, yv.z); unsafeAtomicAdd(yp + 3, yv.w);
-      } else {
-        *reinterpret_cast<f32x4*>(yp) = yv;
-      }
-    } else {
-      const f32x4 dv = *reinterpret_cast<const f32x4*>(&red[vox * 32 + c4]);
-      if (split) {
-        float* yp = static_cast<float*>(a.y) + off;
-        unsafeAtomicAdd(yp, dv.x); unsafeAtomicAdd(yp + 1, dv.y); unsafeAtomicAdd(yp + 2, dv.z); unsafeAtomicAdd(yp + 3, dv.w);
-      } else if (a.y_bf16) {
-        *reinterpret_cast<u32x2*>(static_cast<bf16_t*>(a.y) + off) = u32x2{pack_bf16x2(dv.x, dv.y), pack_bf16x2(dv.z, dv.w)};
-      } else {
-        *reinterpret_cast<f32x4*>(static_cast<float*>(a.y) + off) = dv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int q = tid + k * nt;
+      if (q >= 512) break;
+      const int vox = q >> 3, c4 = (q & 7) * 4;
+      const int vs = vox >> 5, m = vox & 31;
+      const int ul = vs / TU, piece = vs % TU;
+      int lz, ly, lx;
+      row_voxel<C>(m, piece, lz, ly, lx);
+      const int unit = g * SU + ul, gz = zmin + lz, o = cot * 32 + c4;
+      if (unit >= a.nunits || gz >= D || ly >= H || lx >= W || o >= O) continue;
+#ifdef DM_NOSTORE     // TIMING BUILD ONLY: the sums are computed and (practically) never written
+      if (a.N > 0) continue;
+#endif
+      const int n = unit / a.nbz;
+      const size_t off = ((size_t)n * V + (gz * H + ly) * W + lx) * O + o;
+#pragma unroll
+      for (int sr = 0; sr < SPR; ++sr) {
+        const int e = e0 + sr;
+        if (e >= NE) break;
+        f32x4 pe = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int wv = 0; wv < nwa; ++wv) pe += *reinterpret_cast<const f32x4*>(&red[(((wv * SPR + sr) * 64) + vox) * 32 + c4]);
+        if constexpr (FWD) {
+          const f32x4 ge = *reinterpret_cast<const f32x4*>(a.gate + ((size_t)n * E + e) * O + o);
+          yv[k] += ge * pe;
+          float* pp = a.p + e * estride + off;
+          if (split) {
+            unsafeAtomicAdd(pp, pe.x); unsafeAtomicAdd(pp + 1, pe.y); unsafeAtomicAdd(pp + 2, pe.z); unsafeAtomicAdd(pp + 3, pe.w);
+          } else {
+            *reinterpret_cast<f32x4*>(pp) = pe;
+          }
+          if (e == NE - 1) {
+            float* yp = static_cast<float*>(a.y) + off;
+            const f32x4 t = yv[k];
+            if (split) {
+              unsafeAtomicAdd(yp, t.x); unsafeAtomicAdd(yp + 1, t.y); unsafeAtomicAdd(yp + 2, t.z); unsafeAtomicAdd(yp + 3, t.w);
+            } else {
+              *reinterpret_cast<f32x4*>(yp) = t;
+            }
+          }
+        } else {
+          if (split) {
+            float* yp = static_cast<float*>(a.y) + off;
+            unsafeAtomicAdd(yp, pe.x); unsafeAtomicAdd(yp + 1, pe.y); unsafeAtomicAdd(yp + 2, pe.z); unsafeAtomicAdd(yp + 3, pe.w);
+          } else if (a.y_bf16) {
+            *reinterpret_cast<u32x2*>(static_cast<bf16_t*>(a.y) + off) = u32x2{pack_bf16x2(pe.x, pe.y), pack_bf16x2(pe.z, pe.w)};
+          } else {
+            *reinterpret_cast<f32x4*>(static_cast<float*>(a.y) + off) = pe;
+          }
+        }
       }
     }
   }
@@ -402,8 +464,11 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
 using MCfgP8 = MCfg<1, 8, 8, 1>;      // level 3: a tile = one 8 x 8 z plane of a sample
 using MCfgS4 = MCfg<2, 4, 4, 2>;      // level 4: a tile = two whole 2 x 4 x 4 samples
 
-// REPMODE_DEEP_MODE_TARGET: workgroups a launch should reach before the reduction stops being split over workgroups
+// REPMODE_DEEP_MODE_TARGET: workgroups a data-gradient launch should reach before the reduction stops being split over
+// workgroups (default: one per CU); REPMODE_DEEP_MODE_TARGET_FWD: the same for the forward, whose SIX outputs (P_0..4, y)
+// all pay for a split with float atomics
 static const int g_dm_target = []() { const char* e = getenv("REPMODE_DEEP_MODE_TARGET"); return e ? atoi(e) : 0; }();
+static const int g_dm_target_fwd = []() { const char* e = getenv("REPMODE_DEEP_MODE_TARGET_FWD"); return e ? atoi(e) : 64; }();
 // REPMODE_DEEP_MODE_WAVES: 4 / 8 forces the waves of a workgroup (a sweep)
 static const int g_dm_waves = []() { const char* e = getenv("REPMODE_DEEP_MODE_WAVES"); return e ? atoi(e) : 0; }();
 
@@ -424,7 +489,7 @@ static int cu_count() {
 }
 
 // r: reduction channels, o: output channels of this direction
-static DmPlan dm_plan(int n, int d, int h, int w, int r, int o) {
+static DmPlan dm_plan(int n, int d, int h, int w, int r, int o, bool fwd) {
   DmPlan p{};
   if (repmode_deterministic()) return p;      // (the waves' partial sums meet through float atomics in LDS)
   if (n <= 0 || d <= 0 || h <= 0 || w <= 0 || r <= 0 || o <= 0 || (r & 7) || (o & 3)) return p;
@@ -442,7 +507,7 @@ static DmPlan dm_plan(int n, int d, int h, int w, int r, int o) {
   }
   p.ncot = ceil_div(o, 32);
   const int nchunks = round_up(r, 16) / 16;
-  const int target = g_dm_target > 0 ? g_dm_target : cu_count();
+  const int target = fwd ? g_dm_target_fwd : (g_dm_target > 0 ? g_dm_target : cu_count());
   int ks = 1;
   while ((long)p.G * p.ncot * ks < target && ks * 2 <= nchunks) ks *= 2;
   p.ksplit = ks;
@@ -464,12 +529,12 @@ int launch_dm(DmArgs a, const DmPlan& p, bool hosts_tail, double alg, hipStream_
   if (hosts_tail) repmode_tail_take(stream, &a.tail);
   const long grid = nclass * p.G + a.tail.nblocks;
   RM_REQUIRE(grid > 0 && grid < (1L << 31), "deep_mode: grid %ld out of range", grid);
-  constexpr int RED_BYTES = (FWD ? E : 1) * 64 * 32 * 4;
+  const int red_bytes = p.nw * 2 * 64 * 32 * 4;      // the epilogue's slabs: [wave][2 sets][64][32] floats
   int lds_bytes = p.nw * C::WSLOTS * 16;
-  if (lds_bytes < RED_BYTES) lds_bytes = RED_BYTES;
+  if (lds_bytes < red_bytes) lds_bytes = red_bytes;
   if (lds_bytes < TAIL_LDS_BYTES) lds_bytes = TAIL_LDS_BYTES;
   constexpr int LDS_MAX = 8 * C::WSLOTS * 16;
-  static_assert(LDS_MAX <= 160 * 1024 && LDS_MAX >= RED_BYTES && LDS_MAX >= TAIL_LDS_BYTES, "LDS budget");
+  static_assert(LDS_MAX <= 160 * 1024 && LDS_MAX >= 8 * 2 * 64 * 32 * 4 && LDS_MAX >= TAIL_LDS_BYTES, "LDS budget");
   static std::atomic<unsigned> attr_set{0};
   int dev = 0;
   RM_HIP(hipGetDevice(&dev));
@@ -493,14 +558,14 @@ static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // dir 0: forward (reduction = cin), 1: data gradient (reduction = cout).
 extern "C" int repmode_deep_mode_plan(int dir, int n, int d, int h, int w, int cin, int cout, int dtype) {
   if (dtype != REPMODE_BF16) return 0;
-  const DmPlan p = dir ? dm_plan(n, d, h, w, cout, cin) : dm_plan(n, d, h, w, cin, cout);
+  const DmPlan p = dir ? dm_plan(n, d, h, w, cout, cin, false) : dm_plan(n, d, h, w, cin, cout, true);
   return p.cfg ? p.ksplit : 0;
 }
 
 extern "C" int repmode_deep_mode_fwd(const void* x, const void* wf, const float* xs, const float* k1, const float* a3, const float* a5,
                                      const float* gate, float* p, float* y, int n, int d, int h, int w, int cin, int cout, void* stream) {
   RM_REQUIRE(x && wf && xs && k1 && a3 && a5 && gate && p && y, "deep_mode_fwd: null pointer");
-  const DmPlan pl = dm_plan(n, d, h, w, cin, cout);
+  const DmPlan pl = dm_plan(n, d, h, w, cin, cout, true);
   RM_REQUIRE(pl.cfg != 0, "deep_mode_fwd: shape [%d][%d][%d][%d] %d -> %d not supported (repmode_deep_mode_plan)", n, d, h, w, cin, cout);
   RM_REQUIRE(aligned16(x) && aligned16(wf) && aligned16(xs) && aligned16(k1) && aligned16(a3) && aligned16(a5) && aligned16(gate) &&
                  aligned16(p) && aligned16(y), "deep_mode_fwd: pointers must be 16-byte aligned");
@@ -531,7 +596,7 @@ extern "C" int repmode_deep_mode_dgrad(const void* g2, const void* wd, const flo
                                        int cout, void* stream) {
   RM_REQUIRE(g2 && wd && s0 && s1 && s2 && k1 && a3 && a5 && dx, "deep_mode_dgrad: null pointer");
   RM_REQUIRE(dx_dtype == REPMODE_F32 || dx_dtype == REPMODE_BF16, "deep_mode_dgrad: bad dtype %d", dx_dtype);
-  const DmPlan pl = dm_plan(n, d, h, w, cout, cin);
+  const DmPlan pl = dm_plan(n, d, h, w, cout, cin, false);
   RM_REQUIRE(pl.cfg != 0, "deep_mode_dgrad: shape [%d][%d][%d][%d] %d <- %d not supported (repmode_deep_mode_plan)", n, d, h, w, cin, cout);
   RM_REQUIRE(pl.ksplit == 1 || dx_dtype == REPMODE_F32, "deep_mode_dgrad: this shape splits its reduction %d ways: dx must be float (and zero)", pl.ksplit);
   RM_REQUIRE(aligned16(g2) && aligned16(wd) && aligned16(s0) && aligned16(s1) && aligned16(s2) && aligned16(k1) && aligned16(a3) &&

@@ -75,6 +75,53 @@ def wrap_ddp(net, device=None, grad_compress=None):
     return ddp
 
 
+XGMI_LINK_GBPS = 153.0      # one xGMI link, per direction (MI355X: 7 links per GPU, point to point)
+COMPRESS_IF_RING_OVER = 0.6  # of the measured backward pass
+
+
+def ring_allreduce_ms(nbytes, world, link_gbps=XGMI_LINK_GBPS):
+    """Per-link bound of a ring all-reduce of ``nbytes`` over ``world`` GPUs: every byte crosses a link 2 (W - 1) / W times."""
+    if world <= 1:
+        return 0.0
+    return 2.0 * (world - 1) / world * nbytes / (link_gbps * 1e9) * 1e3
+
+
+def pick_grad_dtype(grad_bytes_fp32, world, backward_ms, backend):
+    """The rule that chooses the gradient buckets' dtype: bfloat16 when the per-link ring estimate of
+    the float32 all-reduce exceeds COMPRESS_IF_RING_OVER of the measured backward pass -- it could no longer hide under it
+    -- and the transport is RCCL (the link model is xGMI's; gloo keeps float32).  Returns 'bf16' or None."""
+    if backend != 'nccl' or world <= 1 or backward_ms <= 0:
+        return None
+    return 'bf16' if ring_allreduce_ms(grad_bytes_fp32, world) > COMPRESS_IF_RING_OVER * backward_ms else None
+
+
+def comm_info(model):
+    """What the process group actually looks like, for the bench line's ``config.comm``: backend, the ranks a collective
+    saw (an all-reduce of ones), bucket size / count and the buckets' dtype."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    dev = model.device
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    nparam = sum(p.numel() for p in model.net.parameters() if p.requires_grad)
+    info = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'ranks_seen': int(ones.item()),
+            'bucket_mb': BUCKET_MB, 'dtype': 'bf16' if model.grad_compress == 'bf16' else 'f32',
+            'dtype_rule': getattr(model, 'grad_compress_rule', None), 'grad_bytes_fp32': 4 * nparam,
+            'ring_estimate_ms_fp32': ring_allreduce_ms(4 * nparam, dist.get_world_size())}
+    if model.reducer is not None:
+        info['n_buckets'] = len(model.reducer.buckets)
+        info['scheme'] = 'GradReducer'
+    elif model.ddp is not None:
+        info['scheme'] = 'DistributedDataParallel'
+        try:
+            data = model.ddp._get_ddp_logging_data()
+            sizes = data.get('rebuilt_bucket_sizes') or data.get('bucket_sizes') or ''
+            info['n_buckets'] = len([v for v in str(sizes).split(',') if v.strip()])
+        except Exception:                         # (a private accessor: the count is informative only)
+            info['n_buckets'] = None
+    return info
+
+
 class _Bucket:
     __slots__ = ('flat', 'entries', 'ready', 'stray', 'work', 'comm')
 

@@ -71,15 +71,20 @@ class Model(object):
         self.dtype = dtype
         self.distributed = distributed
         # grad_compress='bf16' (or REPMODE_GRAD_COMPRESS=bf16): the gradient buckets cross the links as bfloat16
-        gc = grad_compress or os.environ.get('REPMODE_GRAD_COMPRESS') or None
-        if gc is not None:        # one spelling for both data-parallel paths (advisor round 3: a typo ran uncompressed silently)
-            if gc in (torch.bfloat16, 'bf16', 'bfloat16'):
-                gc = 'bf16'
-            elif gc in ('none', 'fp32', 'f32', torch.float32):
-                gc = None
-            else:
-                raise ValueError("grad_compress / REPMODE_GRAD_COMPRESS must be 'bf16' or unset, got %r" % (gc,))
-        self.grad_compress = gc
+        # The buckets' dtype is chosen by RULE (distributed.pick_grad_dtype): float32 until two measured
+        # backward passes say that the per-link ring estimate of the float32 all-reduce exceeds 0.6 of the backward it has to hide
+        # under; then the wrapper is rebuilt with bfloat16 buckets.  grad_compress='bf16' / 'fp32' (or REPMODE_GRAD_COMPRESS)
+        # pins it instead.
+        gc = grad_compress or os.environ.get('REPMODE_GRAD_COMPRESS') or 'auto'
+        if gc in (torch.bfloat16, 'bf16', 'bfloat16'):     # one spelling for both data-parallel paths (a typo must not run silently)
+            gc = 'bf16'
+        elif gc in ('none', 'fp32', 'f32', torch.float32):
+            gc = None
+        elif gc != 'auto':
+            raise ValueError("grad_compress / REPMODE_GRAD_COMPRESS must be 'bf16', 'fp32' or 'auto', got %r" % (gc,))
+        self.grad_compress_rule = 'auto' if gc == 'auto' else 'pinned'
+        self.grad_compress = None if gc == 'auto' else gc
+        self._bwd_events = []                                  # (start, end) of the first distributed backward passes
         # hip_graph: replay the whole train step (forward, backward, Adam: ~415 launches, 13 ms of host time) as ONE
         # HIP graph per (input shape, number of distinct tasks) -- see _graph_train_iter.  Single-GPU training only.
         self.hip_graph = bool(hip_graph)
@@ -88,6 +93,7 @@ class Model(object):
         self._graphs = {}
         self._graph_pool = None
         self._capture_stream = None
+        self.count_dist_steps = 0
         self.criterion = criterion_fn(reduction='none')        # fnet_model.py:36
         self._fused_mse = criterion_fn is torch.nn.MSELoss     # the reference's criterion: fused HIP pass (csrc/pipeline.hip)
         self._last_log = None
@@ -185,13 +191,50 @@ class Model(object):
             loss = torch.mean(loss_nomean)
             loss_sample = torch.mean(loss_nomean.detach(), dim=(1, 2, 3, 4))
             task_mean = task_count = None
+        measure = self.grad_compress_rule == 'auto' and self.distributed and self.count_dist_steps < self.RULE_STEPS
+        if measure:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         loss.backward()
+        if measure:
+            ev[1].record()
+            self._bwd_events.append(ev)
         if self.reducer is not None:
             self.reducer.finish()
         self.optimizer.step()
+        if self.distributed:
+            self.count_dist_steps += 1
+            if self.grad_compress_rule == 'auto' and self.count_dist_steps == self.RULE_STEPS:
+                self._apply_grad_dtype_rule()
         self.last_loss = loss.detach()
         self._last_log = (self.last_loss, loss_sample, task_mean, task_count, plan.tasks_host)
         return output.detach(), loss_sample
+
+    RULE_STEPS = 4      # distributed steps before the buckets' dtype is chosen (the first two warm the allocator and are skipped)
+
+    def _apply_grad_dtype_rule(self):
+        """Choose the gradient buckets' dtype from what was measured (distributed.pick_grad_dtype); every rank takes the MAX of
+        the backward times, so all ranks decide alike.  One synchronisation, once."""
+        import torch.distributed as tdist
+        from . import distributed as dist_
+        self.grad_compress_rule = 'auto: float32 kept'
+        if not (tdist.is_available() and tdist.is_initialized()) or not self._bwd_events:
+            return
+        torch.cuda.synchronize(self.device)
+        ms = [a.elapsed_time(b) for a, b in self._bwd_events[2:]] or [a.elapsed_time(b) for a, b in self._bwd_events]
+        self._bwd_events = []
+        bwd = dist_.max_over_ranks(float(np.median(ms)), self.device)
+        nbytes = 4 * sum(p.numel() for p in self.net.parameters() if p.requires_grad)
+        world = tdist.get_world_size()
+        pick = dist_.pick_grad_dtype(nbytes, world, bwd, tdist.get_backend())
+        self.grad_compress_rule = 'auto: ring estimate %.2f ms vs backward %.2f ms -> %s' % (
+            dist_.ring_allreduce_ms(nbytes, world), bwd, pick or 'float32')
+        if pick == 'bf16' and self.grad_compress != 'bf16':
+            self.grad_compress = 'bf16'
+            if self.reducer is not None:
+                self.reducer.comm_dtype = torch.bfloat16
+            elif self.ddp is not None:
+                self.ddp = dist_.wrap_ddp(self.net, self.device, grad_compress='bf16')      # (the comm hook is fixed at construction)
 
     def loss_log(self):
         """The dict the reference hands to ``wandb.log`` and its per-sample DataFrame (fnet_model.py:115-130) for the last

@@ -161,3 +161,18 @@ def test_grad_reducer_adopts_bucket_slices_single_process():
     finally:
         ops.set_grad_sink(None)
         red.remove()
+
+
+def test_gradient_dtype_rule():
+    """distributed.pick_grad_dtype: bfloat16 buckets when the per-link ring estimate of the float32
+    all-reduce exceeds 0.6 of the measured backward pass, on RCCL only."""
+    from repmode_amd import distributed as dist_
+    nbytes = 4 * 123877633                                   # the network's gradients (SURVEY.md section 8e)
+    ring8 = dist_.ring_allreduce_ms(nbytes, 8)
+    assert abs(ring8 - 2 * 7 / 8 * nbytes / 153e9 * 1e3) < 1e-9 and 5.6 < ring8 < 5.8      # SURVEY: ~5.7 ms
+    assert dist_.ring_allreduce_ms(nbytes, 1) == 0.0
+    assert dist_.pick_grad_dtype(nbytes, 8, 15.0, 'nccl') is None          # configs[3]: 24 patches per rank, ~15 ms backward
+    assert dist_.pick_grad_dtype(nbytes, 8, 6.5, 'nccl') == 'bf16'         # 8 patches per rank: the ring is as long as the backward
+    assert dist_.pick_grad_dtype(nbytes, 2, 6.5, 'nccl') is None           # two ranks: 3.2 ms hides
+    assert dist_.pick_grad_dtype(nbytes, 8, 6.5, 'gloo') is None
+    assert dist_.pick_grad_dtype(nbytes, 1, 6.5, 'nccl') is None

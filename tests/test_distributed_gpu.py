@@ -140,3 +140,35 @@ def test_reducer_buckets_hold_the_kernels_gradients_single_process():
         ops.set_grad_sink(None)
     for k in res[1]:
         assert torch.equal(res[0][k], res[1][k]), k
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py's N > 1 branch (BASELINE configs[3]'s code path: one process per rank through torch.distributed.run, the
+    DistributedDataParallel step, the max-over-ranks clock, the no_sync() leg behind ``config.no_comm_value``, ``config.comm``)
+    on a one-GPU box: both ranks on cuda:0 over gloo (REPMODE_BENCH_SHARE_GPU=1 -- a check of the code path, never a
+    measurement).  The line must parse and describe a two-rank job."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, REPMODE_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '1',
+           '--batch', '2', '--no-cpu-baseline', '--no-fwd']
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 5 and d['warmup'] == 1 and d['scaling'] == 'weak'
+    assert d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2'
+    for k in ('value', 'ms_per_step'):
+        assert d[k] > 0 and d[k] == d[k]
+    cfg = d['config']
+    assert cfg['no_comm_value'] > 0 and cfg['no_comm_ms_per_step'] > 0
+    comm = cfg['comm']
+    assert comm['backend'] == 'gloo' and comm['world_size'] == 2 and comm['ranks_seen'] == 2
+    assert comm['scheme'] == 'DistributedDataParallel' and comm['bucket_mb'] == 48 and comm['dtype'] == 'f32'
+    assert comm['dtype_rule'].startswith('auto')                 # (gloo keeps float32: the link model is xGMI's)
+    assert abs(comm['grad_bytes_fp32'] - 4 * 123877633) < 8

@@ -985,6 +985,9 @@ def test_full_size_bf16_blocks_at_bench_config(batch, ntasks):
     names = list(seen) if batch == 8 else FULL_SIZE_BLOCKS_B24
     mods = dict(net.named_modules())
     worst = {}
+    from repmode_amd import _lib as _lib_mod
+    lib = _lib_mod.load()
+    elem_checked, injected = [], []
     for name in names:
         blk = mods[name]
         xa, xb = seen[name]
@@ -1021,9 +1024,29 @@ def test_full_size_bf16_blocks_at_bench_config(batch, ntasks):
             errs['dx2'] = rel_err(b.grad.float().permute(0, 4, 1, 2, 3).cpu(), br.grad)
         for pn, u, v in zip(['k5', 'k3', 'k1', 'a3', 'a5', 'gate_w', 'gate_b'], dev, ref):
             errs['d' + pn] = rel_err(u.grad.cpu(), v.grad)
+        # ---- the forward the NETWORK runs: where the kernel library writes the element type (repmode_conv5_elem_out: levels
+        # 0-2 at these batches) the block's output comes from conv5_ws_kernel's bf16 epilogue (packed converts, permlane swap,
+        # 16-byte stores), not from the float-output kernel above: the oracle's output rounded once, same bound
+        cin = xa.shape[1] + (xb.shape[1] if xb is not None else 0)
+        if lib.repmode_conv5_elem_out(batch, *xa.shape[2:], cin, co, _lib_mod.BF16) != 0:
+            with torch.no_grad():
+                yb = (ops.mode_conv3d_pair(a, b, *dev, plan, out_f32=False) if xb is not None else
+                      ops.mode_conv3d(a, *dev, plan, out_f32=False))
+            assert yb.dtype == torch.bfloat16, name
+            errs['y_bf16'] = rel_err(yb.float().permute(0, 4, 1, 2, 3).cpu(), yr.detach().bfloat16().float())
+            elem_checked.append(name)
         worst[name] = max(errs.values())
         assert worst[name] < TOL_BF16, (name, errs)
+        # ---- the bound can see a systematic error: 10 % on one deep per-expert block's 5x5x5-expert gradient and on one merged
+        # level-2 block's gate-weight gradient is outside it (as test_bf16_end_to_end_gpu.py asserts for conv_out)
+        if name in ('bottle_block.conv2', 'encoder_block3.conv_more.conv2'):
+            pn = 0 if name.startswith('bottle') else 5
+            assert rel_err(1.1 * dev[pn].grad.cpu(), ref[pn].grad) > TOL_BF16, name
+            assert rel_err(0.9 * dev[pn].grad.cpu(), ref[pn].grad) > TOL_BF16, name
+            injected.append(name)
         del ref, ar, br, xin, yr, dev, a, b, y
+    assert len(elem_checked) >= (10 if batch == 8 else 3), elem_checked       # the level 0-2 blocks at batch 8
+    assert batch != 8 or sorted(injected) == ['bottle_block.conv2', 'encoder_block3.conv_more.conv2'], injected
     print('full-size bf16 blocks, batch %d: worst relative error %.3g (%s)' % (batch, max(worst.values()), max(worst, key=worst.get)))
 
 

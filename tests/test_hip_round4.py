@@ -283,7 +283,14 @@ def test_train_iter_at_the_reference_patch_size(dtype):
         assert max(errs.values()) < 2e-2, errs
     else:
         assert max(v for k, v in errs.items() if k.startswith('conv_out.')) < 5e-2, errs
-        assert max(errs.values()) < 0.9, errs
+        # every sampled tensor against the emulation's OWN sensitivity at this size (the emulation with its parameters perturbed
+        # by 1e-6: test_bf16_end_to_end_gpu.py), the bound the 16x64x64 cases use: 3 x noise + 3e-2
+        from test_bf16_end_to_end_gpu import _emulated_run
+        _, _, pert = _emulated_run(state, x, tgt, tasks, perturb_seed=1)
+        noise = {k: _rel2(pert[k], want[k].grad) for k in SAMPLED}
+        record('train_iter_32x128x128_noise', by_tensor={k: [round(errs[k], 4), round(noise[k], 4)] for k in SAMPLED})
+        worst = max(SAMPLED, key=lambda k: errs[k] / (3 * noise[k] + 3e-2))
+        assert errs[worst] < 3 * noise[worst] + 3e-2, (worst, errs[worst], noise[worst])
 
 
 @pytest.mark.timeout(1100)

@@ -22,7 +22,7 @@ DM_CASES = [
     (3, (4, 8, 8), 48, 96),       # one 8 x 8 plane per tile; channel counts that are no tile multiples (3 chunks, 8 waves)
     (2, (4, 8, 8), 128, 256),     # a real level-3 layer's width: 8 chunks = one per wave
     (3, (2, 4, 8), 16, 40),       # the plane tile on a volume smaller than it, a single chunk
-    (2, (3, 6, 7), 24, 36),       # ragged in every direction, a half-filled last chunk
+    (2, (3, 6, 7), 24, 40),       # ragged in every direction, a half-filled last chunk
     (8, (4, 8, 8), 256, 256),     # enc4.conv2 / dec4.conv2 at the benchmarked batch: plain stores
     (8, (2, 4, 4), 256, 512),     # bottle.conv1 at the benchmarked batch: 4 slices of the reduction
     (1, (4, 8, 8), 512, 256),     # dec4.conv1's width, four chunks per wave
