@@ -456,6 +456,17 @@ int repmode_adam_expert_frags(int nblocks, float* const* p5, const float* const*
                               float* const* p3, const float* const* g3, float* const* m3, float* const* v3, const int* co,
                               const int* ci, void* const* wf, void* const* wd, double lr, double beta1, double beta2, double eps,
                               long step, void* stream);
+/* The same two passes for a CAPTURED train step (a HIP-graph replay runs no host code, so the step count cannot travel in the
+ * launch arguments): repmode_adam_hyper_dev increments the device-resident step count *step_dev (int64) and writes that step's
+ * constants (bias corrections in double, as the host path computes them) into hyper_dev (REPMODE_ADAM_HYPER_FLOATS floats,
+ * 16-byte aligned); the *_dev passes read them from there.  torch.optim.Adam(capturable=True)'s role, fnet_model.py:55, 112. */
+#define REPMODE_ADAM_HYPER_FLOATS 8
+int repmode_adam_hyper_dev(long* step_dev, float* hyper_dev, double lr, double beta1, double beta2, double eps, void* stream);
+int repmode_adam_multi_dev(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                           const long* numel, const float* hyper_dev, void* stream);
+int repmode_adam_expert_frags_dev(int nblocks, float* const* p5, const float* const* g5, float* const* m5, float* const* v5,
+                                  float* const* p3, const float* const* g3, float* const* m3, float* const* v3, const int* co,
+                                  const int* ci, void* const* wf, void* const* wd, const float* hyper_dev, void* stream);
 
 /* Developer / test switch of the convolution's pipelined form (csrc/conv5_igemm.hip, conv5_pipe_kernel; also REPMODE_CONV_PIPE):
  * bit 0 = on, bit 1 = one channel sub-tile per wave everywhere, bit 2 = also on grids smaller than the chip, bit 3 = the
@@ -497,6 +508,13 @@ int repmode_patch_blend(const void* out, int dtype, const float* gauss, const in
  * wd[i] may be NULL, or wf[i] when wd[i] is given.  nblocks <= REPMODE_GATREP_MULTI_MAX. */
 int repmode_expert_frags_multi(int nblocks, const float* const* k5, const float* const* k3, const int* co, const int* ci,
                                void* const* wf, void* const* wd, void* stream);
+/* Operands KEPT across steps checked against their parameters on the device, and repaired: flags[i] (device int[nblocks]) <-
+ * whether block i's forward-role operand differs from its parameters (rounded as the layout rounds them) at 1024 sampled
+ * positions per expert tensor; then repmode_expert_frags_multi's layout for the flagged blocks only.  Two launches, no host
+ * synchronisation -- catches parameter writes that move no autograd version counter (p.data.copy_(), a broadcast, a foreign
+ * kernel).  Every block needs its wf. */
+int repmode_expert_frags_refresh_multi(int nblocks, const float* const* k5, const float* const* k3, const int* co, const int* ci,
+                                       void* const* wf, void* const* wd, int* flags, void* stream);
 
 /* ---- measurement: per-launch HIP-event timing of the library's kernels on their own stream.
  * repmode_prof_enable(1) clears the records and starts recording every kind, (2) records the MFMA kernels of the MoDE

@@ -34,6 +34,9 @@ _SIGNATURES = {
     'repmode_conv5_elem_out': [_I] * 7,
     'repmode_adam_multi': [_I, _P, _P, _P, _P, _P, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _c.c_long, _P],
     'repmode_adam_expert_frags': [_I] + [_P] * 12 + [_c.c_double] * 4 + [_c.c_long, _P],
+    'repmode_adam_hyper_dev': [_P, _P, _c.c_double, _c.c_double, _c.c_double, _c.c_double, _P],
+    'repmode_adam_multi_dev': [_I, _P, _P, _P, _P, _P, _P, _P],
+    'repmode_adam_expert_frags_dev': [_I] + [_P] * 12 + [_P, _P],
     'repmode_set_wgrad_ws': [_I],
     'repmode_get_wgrad_ws': [],
     'repmode_padded_channels': [_I, _I, _I],
@@ -94,6 +97,7 @@ _SIGNATURES = {
     'repmode_patch_gather': [_P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P],
     'repmode_patch_blend': [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P],
     'repmode_expert_frags_multi': [_I, _P, _P, _P, _P, _P, _P, _P],
+    'repmode_expert_frags_refresh_multi': [_I, _P, _P, _P, _P, _P, _P, _P, _P],
     'repmode_prof_enable': [_I],
     'repmode_prof_pause': [_I],
     'repmode_prof_summary': [_I, _P, _P, _P],

@@ -56,9 +56,11 @@ struct AdamMultiArgs {
   int first[ADAM_MAX + 1];       // first workgroup of tensor i
   int nt;
   AdamHyper h;
+  const AdamHyper* hd;           // non-null: the step's constants come from device memory (repmode_adam_hyper_dev: a captured step)
 };
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMultiArgs a) {
+  const AdamHyper h = a.hd ? *a.hd : a.h;
   int i = 0;
   while (i + 1 < a.nt && (int)blockIdx.x >= a.first[i + 1]) ++i;
   const long base = (long)((int)blockIdx.x - a.first[i]) * ADAM_CHUNK;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMultiArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float pp = P[u][k], mm = M[u][k], vv = V[u][k];
-        adam_elem(a.h, pp, G[u][k], mm, vv);
+        adam_elem(h, pp, G[u][k], mm, vv);
         P[u][k] = pp; M[u][k] = mm; V[u][k] = vv;
       }
       *reinterpret_cast<f32x4*>(p + o) = P[u];
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMultiArgs a) {
   const long end = base + ADAM_CHUNK < n ? base + ADAM_CHUNK : n;
   for (long o = base + threadIdx.x; o < end; o += 256) {
     float pp = p[o], mm = m[o], vv = v[o];
-    adam_elem(a.h, pp, g[o], mm, vv);
+    adam_elem(h, pp, g[o], mm, vv);
     p[o] = pp; m[o] = mm; v[o] = vv;
   }
 }
@@ -120,6 +122,7 @@ struct AdamFragArgs {
   int first[AF_MAX + 1];
   int nblocks;
   AdamHyper h;
+  const AdamHyper* hd;           // non-null: the step's constants come from device memory (a captured step)
 };
 
 // One parameter tensor's part of the tile: rows co0 .. co0+15, input channels ci0 .. ci0+15, TAPS taps each.  A row is
@@ -241,8 +244,9 @@ __global__ __launch_bounds__(NT) void adam_frags_kernel(AdamFragArgs a) {
   // workgroup -> tile: the ci tile fastest (a row of the parameter tensor is walked by consecutive workgroups)
   const int it_ = b % nit, ct_ = b / nit;
   const int co0 = ct_ * AF_T, ci0 = it_ * AF_T;
-  adam_tile_rows<AF_TAPS5, NT>(a.h, a.p5[i], a.g5[i], a.m5[i], a.v5[i], co_n, ci_n, co0, ci0, s5);
-  adam_tile_rows<AF_TAPS3, NT>(a.h, a.p3[i], a.g3[i], a.m3[i], a.v3[i], co_n, ci_n, co0, ci0, s3);
+  const AdamHyper h = a.hd ? *a.hd : a.h;
+  adam_tile_rows<AF_TAPS5, NT>(h, a.p5[i], a.g5[i], a.m5[i], a.v5[i], co_n, ci_n, co0, ci0, s5);
+  adam_tile_rows<AF_TAPS3, NT>(h, a.p3[i], a.g3[i], a.m3[i], a.v3[i], co_n, ci_n, co0, ci0, s3);
 #if RM_ADAM_TIMING >= 1
   return;      // TIMING BUILDS ONLY (no operands written)
 #endif
@@ -310,12 +314,42 @@ int fill_hyper(AdamHyper* h, double lr, double beta1, double beta2, double eps, 
 
 }  // namespace
 
-extern "C" int repmode_adam_multi(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v,
-                                  const long* numel, double lr, double beta1, double beta2, double eps, long step, void* stream) {
+// The step's constants on the DEVICE: *step_dev += 1, then the AdamHyper of that step count into hyper_dev -- what the host
+// computes in fill_hyper, in the same double arithmetic -- so that a captured train step (a HIP graph replay runs no host code)
+// advances its own step count.  One thread.
+namespace {
+__global__ void adam_hyper_kernel(long* __restrict__ step_dev, AdamHyper* __restrict__ out, double lr, double beta1, double beta2, double eps) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long t = *step_dev + 1;
+  *step_dev = t;
+  const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+  out->w1 = (float)(1.0 - beta1);
+  out->beta2 = (float)beta2;
+  out->w2 = (float)(1.0 - beta2);
+  out->bc2_sqrt = (float)sqrt(bc2);
+  out->eps = (float)eps;
+  out->neg_step = (float)(-(lr / bc1));
+}
+}  // namespace
+
+extern "C" int repmode_adam_hyper_dev(long* step_dev, float* hyper_dev, double lr, double beta1, double beta2, double eps, void* stream) {
+  RM_REQUIRE(step_dev && hyper_dev, "adam_hyper_dev: null pointer");
+  RM_REQUIRE(((uintptr_t)step_dev & 7) == 0 && ((uintptr_t)hyper_dev & 15) == 0, "adam_hyper_dev: misaligned buffers");
+  RM_REQUIRE(lr >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0, "adam: bad hyper-parameters");
+  static_assert(sizeof(AdamHyper) <= REPMODE_ADAM_HYPER_FLOATS * sizeof(float), "hyper_dev holds an AdamHyper");
+  hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), step_dev, reinterpret_cast<AdamHyper*>(hyper_dev),
+                     lr, beta1, beta2, eps);
+  RM_LAUNCH_CHECK("adam_hyper_dev");
+  return REPMODE_OK;
+}
+
+static int adam_multi_impl(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v, const long* numel,
+                           double lr, double beta1, double beta2, double eps, long step, const float* hyper_dev, void* stream) {
   RM_REQUIRE(p && g && m && v && numel, "adam_multi: null pointer");
   RM_REQUIRE(ntensors > 0 && ntensors <= ADAM_MAX, "adam_multi: 1..%d tensors per call, got %d", ADAM_MAX, ntensors);
   AdamMultiArgs a{};
-  if (int rc = fill_hyper(&a.h, lr, beta1, beta2, eps, step)) return rc;
+  if (hyper_dev) a.hd = reinterpret_cast<const AdamHyper*>(hyper_dev);
+  else if (int rc = fill_hyper(&a.h, lr, beta1, beta2, eps, step)) return rc;
   a.nt = ntensors;
   long total = 0;
   for (int i = 0; i < ntensors; ++i) {
@@ -332,14 +366,26 @@ extern "C" int repmode_adam_multi(int ntensors, float* const* p, const float* co
   return REPMODE_OK;
 }
 
-extern "C" int repmode_adam_expert_frags(int nblocks, float* const* p5, const float* const* g5, float* const* m5, float* const* v5,
-                                         float* const* p3, const float* const* g3, float* const* m3, float* const* v3, const int* co,
-                                         const int* ci, void* const* wf, void* const* wd, double lr, double beta1, double beta2,
-                                         double eps, long step, void* stream) {
+extern "C" int repmode_adam_multi(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                  const long* numel, double lr, double beta1, double beta2, double eps, long step, void* stream) {
+  return adam_multi_impl(ntensors, p, g, m, v, numel, lr, beta1, beta2, eps, step, nullptr, stream);
+}
+
+extern "C" int repmode_adam_multi_dev(int ntensors, float* const* p, const float* const* g, float* const* m, float* const* v,
+                                      const long* numel, const float* hyper_dev, void* stream) {
+  RM_REQUIRE(hyper_dev, "adam_multi_dev: null pointer");
+  return adam_multi_impl(ntensors, p, g, m, v, numel, 0, 0, 0, 0, 0, hyper_dev, stream);
+}
+
+static int adam_expert_frags_impl(int nblocks, float* const* p5, const float* const* g5, float* const* m5, float* const* v5,
+                                  float* const* p3, const float* const* g3, float* const* m3, float* const* v3, const int* co,
+                                  const int* ci, void* const* wf, void* const* wd, double lr, double beta1, double beta2,
+                                  double eps, long step, const float* hyper_dev, void* stream) {
   RM_REQUIRE(p5 && g5 && m5 && v5 && p3 && g3 && m3 && v3 && co && ci && wf && wd, "adam_expert_frags: null pointer");
   RM_REQUIRE(nblocks > 0 && nblocks <= AF_MAX, "adam_expert_frags: 1..%d blocks per call, got %d", AF_MAX, nblocks);
   AdamFragArgs a{};
-  if (int rc = fill_hyper(&a.h, lr, beta1, beta2, eps, step)) return rc;
+  if (hyper_dev) a.hd = reinterpret_cast<const AdamHyper*>(hyper_dev);
+  else if (int rc = fill_hyper(&a.h, lr, beta1, beta2, eps, step)) return rc;
   a.nblocks = nblocks;
   long total = 0;
   for (int i = 0; i < nblocks; ++i) {
@@ -364,4 +410,18 @@ extern "C" int repmode_adam_expert_frags(int nblocks, float* const* p5, const fl
   hipLaunchKernelGGL(adam_frags_kernel<AF_THREADS>, dim3((unsigned)total), dim3(AF_THREADS), RM_ADAM_TIMING >= 3 ? 1024 : AF_LDS_BYTES, static_cast<hipStream_t>(stream), a);
   RM_LAUNCH_CHECK("adam_expert_frags");
   return REPMODE_OK;
+}
+
+extern "C" int repmode_adam_expert_frags(int nblocks, float* const* p5, const float* const* g5, float* const* m5, float* const* v5,
+                                         float* const* p3, const float* const* g3, float* const* m3, float* const* v3, const int* co,
+                                         const int* ci, void* const* wf, void* const* wd, double lr, double beta1, double beta2,
+                                         double eps, long step, void* stream) {
+  return adam_expert_frags_impl(nblocks, p5, g5, m5, v5, p3, g3, m3, v3, co, ci, wf, wd, lr, beta1, beta2, eps, step, nullptr, stream);
+}
+
+extern "C" int repmode_adam_expert_frags_dev(int nblocks, float* const* p5, const float* const* g5, float* const* m5, float* const* v5,
+                                             float* const* p3, const float* const* g3, float* const* m3, float* const* v3, const int* co,
+                                             const int* ci, void* const* wf, void* const* wd, const float* hyper_dev, void* stream) {
+  RM_REQUIRE(hyper_dev, "adam_expert_frags_dev: null pointer");
+  return adam_expert_frags_impl(nblocks, p5, g5, m5, v5, p3, g3, m3, v3, co, ci, wf, wd, 0, 0, 0, 0, 0, hyper_dev, stream);
 }

@@ -468,7 +468,7 @@ using MCfgS4 = MCfg<2, 4, 4, 2>;      // level 4: a tile = two whole 2 x 4 x 4 s
 // workgroups (default: one per CU); REPMODE_DEEP_MODE_TARGET_FWD: the same for the forward, whose SIX outputs (P_0..4, y)
 // all pay for a split with float atomics
 static const int g_dm_target = []() { const char* e = getenv("REPMODE_DEEP_MODE_TARGET"); return e ? atoi(e) : 0; }();
-static const int g_dm_target_fwd = []() { const char* e = getenv("REPMODE_DEEP_MODE_TARGET_FWD"); return e ? atoi(e) : 64; }();
+static const int g_dm_target_fwd = []() { const char* e = getenv("REPMODE_DEEP_MODE_TARGET_FWD"); return e ? atoi(e) : 128; }();
 // REPMODE_DEEP_MODE_WAVES: 4 / 8 forces the waves of a workgroup (a sweep)
 static const int g_dm_waves = []() { const char* e = getenv("REPMODE_DEEP_MODE_WAVES"); return e ? atoi(e) : 0; }();
 

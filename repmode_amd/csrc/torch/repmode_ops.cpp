@@ -512,7 +512,9 @@ Tensor conv5_wgrad(const Tensor& x_cl, const Tensor& dy_cl, const Tensor& sample
   const bool thin = x_cl.scalar_type() == at::kBFloat16 && ((cin == 1) != (cout == 1)) && !centre3;
   // a launch that writes every element with plain stores needs no cleared buffer: it stays out of the step's pooled memset
   int direct = 0;
-  if (!thin && x_cl.scalar_type() == at::kBFloat16)
+  // (not the centre3 job: it writes the dz in [1, 3] planes only -- 50 of the 125 taps per (co, ci) would be uninitialised memory
+  // for any consumer that reads more than the centred taps; that job keeps a cleared buffer)
+  if (!thin && !centre3 && x_cl.scalar_type() == at::kBFloat16)
     RM_CALL(repmode_conv5_wgrad_plan, (int)nslots, (int)n, (int)d, (int)h, (int)wd_, (int)cin, (int)cout, REPMODE_BF16, centre3 ? 1 : 0, &direct);
   if (direct) {
     Tensor dw = at::empty({nslots, TAPS, cout, cin}, x_cl.options().dtype(at::kFloat));
@@ -1258,18 +1260,22 @@ struct Up2 : public torch::autograd::Function<Up2> {
 // share the atomics' target (the finish kernel leaves it zero again)
 Tensor mse_sums_ws(const Tensor& like) {
   static std::mutex mu;
-  static std::unordered_map<std::string, Tensor> ws;
+  static std::unordered_map<std::string, std::pair<Tensor, bool>> ws;       // accumulator, pinned (a captured graph holds its address)
   const std::string key = std::to_string(like.device().index()) + ":" + std::to_string((uintptr_t)stream_handle());
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(static_cast<hipStream_t>(stream_handle()), &cap);
   std::lock_guard<std::mutex> lock(mu);
   auto it = ws.find(key);
   if (it == ws.end()) {
-    // (advisor round 3) one 4 KB accumulator per stream a loss ever ran on would otherwise live for the process: the map is
-    // bounded -- a stream's accumulator is all zero between calls, so forgetting it costs one allocation on its next use.
-    // A graph capture should find its stream's entry already made: Model runs its warm-up steps on the capture stream.
-    if (ws.size() >= 16) ws.clear();
-    it = ws.emplace(key, at::zeros({1024}, like.options().dtype(at::kFloat))).first;
+    // One 4 KB accumulator per stream a loss ever ran on would otherwise live for the process: the map is bounded -- a stream's
+    // accumulator is all zero between calls, so forgetting it costs one allocation on its next use.  NOT the entries a capture
+    // has seen (advisor round 4): a replayed graph keeps adding into the address it captured; those stay for the process.
+    if (ws.size() >= 16)
+      for (auto e = ws.begin(); e != ws.end();) e = e->second.second ? std::next(e) : ws.erase(e);
+    it = ws.emplace(key, std::make_pair(at::zeros({1024}, like.options().dtype(at::kFloat)), false)).first;
   }
-  return it->second;
+  if (cap != hipStreamCaptureStatusNone) it->second.second = true;
+  return it->second.first;
 }
 
 struct MseLoss : public torch::autograd::Function<MseLoss> {
@@ -1564,6 +1570,14 @@ bool g_frag_keep = []() {          // (REPMODE_FRAG_STORE=0: lay the experts out
   return e ? std::atoi(e) != 0 : true;
 }();
 
+// REPMODE_FRAG_VERIFY=0 / set_frag_verify(False): trust version counters + the optimizer hook alone (round 4's behaviour)
+bool g_frag_verify = []() {
+  const char* e = std::getenv("REPMODE_FRAG_VERIFY");
+  return e ? std::atoi(e) != 0 : true;
+}();
+Tensor g_frag_flags[32];        // per device: int32[REPMODE_GATREP_MULTI_MAX], the check's verdicts (device-side only)
+void op_set_frag_verify(bool on) { g_frag_verify = on; }
+
 void op_clear_frag_store() {
   std::lock_guard<std::mutex> lock(g_frag_mu);
   g_frag_store.clear();
@@ -1584,8 +1598,12 @@ int64_t op_frag_store_size() {
 // (csrc/adam.hip): the 5x5x5 / 3x3x3 experts of the blocks whose last forward pass ran the per-expert formulation go
 // through repmode_adam_expert_frags (update + the conv operands of the next forward pass), everything else through
 // repmode_adam_multi.  `step`: the 1-based count of this update (all tensors of a call share it).
-void op_adam_step(const std::vector<Tensor>& params, const std::vector<Tensor>& grads, const std::vector<Tensor>& exp_avgs,
-                  const std::vector<Tensor>& exp_avg_sqs, double lr, double beta1, double beta2, double eps, int64_t step) {
+// hyper_dev != nullptr: a capturable step -- the step count lives on the device (step_dev, int64[1]); repmode_adam_hyper_dev
+// advances it and leaves the step's constants in hyper_dev, which both passes read (no host scalar in the launch arguments,
+// so a HIP-graph replay of the step takes the next step count).
+void adam_step_impl(const std::vector<Tensor>& params, const std::vector<Tensor>& grads, const std::vector<Tensor>& exp_avgs,
+                    const std::vector<Tensor>& exp_avg_sqs, double lr, double beta1, double beta2, double eps, int64_t step,
+                    const Tensor* step_dev, const Tensor* hyper_dev) {
   const size_t n = params.size();
   TORCH_CHECK(grads.size() == n && exp_avgs.size() == n && exp_avg_sqs.size() == n, "adam_step: list lengths differ");
   if (n == 0) return;
@@ -1598,12 +1616,25 @@ void op_adam_step(const std::vector<Tensor>& params, const std::vector<Tensor>& 
                   "adam_step: parameter ", i, ": float32 contiguous tensors of one shape on one device (parameter, gradient, exp_avg, exp_avg_sq)");
     index[params[i].data_ptr()] = i;
   }
+  const float* hd = nullptr;
+  if (hyper_dev) {
+    TORCH_CHECK(step_dev && step_dev->is_cuda() && step_dev->scalar_type() == at::kLong && step_dev->numel() == 1 && hyper_dev->is_cuda() &&
+                    hyper_dev->scalar_type() == at::kFloat && hyper_dev->numel() >= REPMODE_ADAM_HYPER_FLOATS && hyper_dev->is_contiguous(),
+                "adam_step_dev: step_dev int64[1] and hyper_dev float[", REPMODE_ADAM_HYPER_FLOATS, "] on the device");
+    RM_CALL(repmode_adam_hyper_dev, reinterpret_cast<long*>(step_dev->data_ptr<int64_t>()), hyper_dev->data_ptr<float>(), lr, beta1, beta2, eps,
+            stream_handle());
+    hd = hyper_dev->data_ptr<float>();
+  }
   std::vector<char> done(n, 0);
   // ---- the per-expert blocks
   struct Blk { size_t i5, i3; FragEntry* fe; };
   std::vector<Blk> blks;
   {
     std::lock_guard<std::mutex> lock(g_frag_mu);
+    try {
+    // entries whose parameters are gone (a network that was rebuilt or freed) give their operands back (advisor round 4)
+    for (auto it = g_frag_store.begin(); it != g_frag_store.end();)
+      it = (it->second.w5.expired() || it->second.w3.expired()) ? g_frag_store.erase(it) : std::next(it);
     for (auto& kv : g_frag_store) {
       FragEntry& fe = kv.second;
       if (!fe.used) continue;
@@ -1632,8 +1663,12 @@ void op_adam_step(const std::vector<Tensor>& params, const std::vector<Tensor>& 
         wd.push_back(b.fe->wd.defined() ? b.fe->wd.data_ptr() : nullptr);
         done[b.i5] = done[b.i3] = 1;
       }
-      RM_CALL(repmode_adam_expert_frags, cnt, p5.data(), g5.data(), m5.data(), v5.data(), p3.data(), g3.data(), m3.data(), v3.data(),
-              co.data(), ci.data(), wf.data(), wd.data(), lr, beta1, beta2, eps, (long)step, stream_handle());
+      if (hd)
+        RM_CALL(repmode_adam_expert_frags_dev, cnt, p5.data(), g5.data(), m5.data(), v5.data(), p3.data(), g3.data(), m3.data(), v3.data(),
+                co.data(), ci.data(), wf.data(), wd.data(), hd, stream_handle());
+      else
+        RM_CALL(repmode_adam_expert_frags, cnt, p5.data(), g5.data(), m5.data(), v5.data(), p3.data(), g3.data(), m3.data(), v3.data(),
+                co.data(), ci.data(), wf.data(), wd.data(), lr, beta1, beta2, eps, (long)step, stream_handle());
     }
     // ---- every other tensor
     std::vector<float*> p, m, v;
@@ -1641,8 +1676,11 @@ void op_adam_step(const std::vector<Tensor>& params, const std::vector<Tensor>& 
     std::vector<long> numel;
     auto flush = [&]() {
       if (p.empty()) return;
-      RM_CALL(repmode_adam_multi, (int)p.size(), p.data(), g.data(), m.data(), v.data(), numel.data(), lr, beta1, beta2, eps, (long)step,
-              stream_handle());
+      if (hd)
+        RM_CALL(repmode_adam_multi_dev, (int)p.size(), p.data(), g.data(), m.data(), v.data(), numel.data(), hd, stream_handle());
+      else
+        RM_CALL(repmode_adam_multi, (int)p.size(), p.data(), g.data(), m.data(), v.data(), numel.data(), lr, beta1, beta2, eps, (long)step,
+                stream_handle());
       p.clear(); g.clear(); m.clear(); v.clear(); numel.clear();
     };
     for (size_t i = 0; i < n; ++i) {
@@ -1662,7 +1700,24 @@ void op_adam_step(const std::vector<Tensor>& params, const std::vector<Tensor>& 
       b.fe->wd_valid = b.fe->wd.defined();
       b.fe->used = false;
     }
+    } catch (...) {
+      // a launch failed half way: some parameters are updated, some are not -- say so to autograd, and no stored operand
+      // may pass for current
+      for (size_t i = 0; i < n; ++i) params[i].unsafeGetTensorImpl()->bump_version();
+      g_frag_store.clear();
+      throw;
+    }
   }
+}
+
+void op_adam_step(const std::vector<Tensor>& params, const std::vector<Tensor>& grads, const std::vector<Tensor>& exp_avgs,
+                  const std::vector<Tensor>& exp_avg_sqs, double lr, double beta1, double beta2, double eps, int64_t step) {
+  adam_step_impl(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, step, nullptr, nullptr);
+}
+void op_adam_step_dev(const std::vector<Tensor>& params, const std::vector<Tensor>& grads, const std::vector<Tensor>& exp_avgs,
+                      const std::vector<Tensor>& exp_avg_sqs, double lr, double beta1, double beta2, double eps, const Tensor& step_dev,
+                      const Tensor& hyper_dev) {
+  adam_step_impl(params, grads, exp_avgs, exp_avg_sqs, lr, beta1, beta2, eps, 0, &step_dev, &hyper_dev);
 }
 
 // All blocks' forward filters on the `prep` stream, ahead of the forward pass (see PrepEntry).  w_in[i]: the x extent of
@@ -1707,9 +1762,13 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
       hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
       (void)hipStreamIsCapturing(c10::hip::getCurrentHIPStream(k5[0].device().index()).stream(), &cap_status);
       const bool capturing = cap_status != hipStreamCaptureStatusNone;
+      std::vector<const float*> v5, v3;          // entries of the store taken as current: verified (and repaired) on the device
+      std::vector<void*> vwf, vwd;
+      std::vector<int> vco, vci;
       std::vector<const float*> ggw, ggb;       // the per-expert blocks' gates (per SAMPLE), all from one launch
       std::vector<float*> ggo;
       std::vector<int> gco;
+      try {      // (entries of the store are marked current below, ahead of the launches that make them so: any failure empties it)
       for (size_t i = 0; i < nb && dt == at::kBFloat16; ++i) {
         if (!(plan.training && plan.nslots > 2 && w_in[i] <= g_unmerged_max_w)) continue;
         Tensor K5 = k5[i].contiguous(), K3 = k3[i].contiguous();
@@ -1727,7 +1786,18 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
           ggo.push_back(e.g.data_ptr<float>()); gco.push_back((int)co);
         }
         bool ready = false;
-        if (g_frag_keep && !capturing && K5.is_same(k5[i]) && K3.is_same(k3[i])) {
+        bool use_store = g_frag_keep && K5.is_same(k5[i]) && K3.is_same(k3[i]);
+        if (use_store && capturing) {
+          // Under stream capture the store is used only where an entry is READY (laid out and kept current by the eager warm-up
+          // steps of the build's own optimizer): the captured optimizer pass then keeps it current in every replay
+          // (repmode_adam_expert_frags_dev writes these very buffers), and nothing is allocated or laid out for the store
+          // inside a graph.  Otherwise the graph lays the operands out into its own tensors at every replay.
+          std::lock_guard<std::mutex> lock(g_frag_mu);
+          auto it = g_frag_store.find(K5.data_ptr());
+          use_store = it != g_frag_store.end() && it->second.current(K5, K3) && it->second.co == co && it->second.ci == ci &&
+                      it->second.wf_valid && it->second.wf.defined() && (!need_dx[i] || (it->second.wd_valid && it->second.wd.defined()));
+        }
+        if (use_store) {
           // the layouts live across steps (FragEntry): the optimizer pass leaves them current; otherwise lay out into them
           std::lock_guard<std::mutex> lock(g_frag_mu);
           auto it = g_frag_store.find(K5.data_ptr());
@@ -1755,6 +1825,12 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
             x5.push_back(K5.data_ptr<float>()); x3.push_back(K3.data_ptr<float>());
             xwf.push_back(fe.wf.data_ptr()); xwd.push_back(fe.wd.defined() ? fe.wd.data_ptr() : nullptr);
             xco.push_back((int)co); xci.push_back((int)ci);
+          } else {
+            // kept from the last step: checked against the parameters' BYTES on the device below (a write that moved no
+            // version counter -- p.data.copy_(), a broadcast, a foreign kernel -- must not leave stale filters in use)
+            v5.push_back(K5.data_ptr<float>()); v3.push_back(K3.data_ptr<float>());
+            vwf.push_back(fe.wf.data_ptr()); vwd.push_back(fe.wd.defined() ? fe.wd.data_ptr() : nullptr);
+            vco.push_back((int)co); vci.push_back((int)ci);
           }
         } else {
           e.wf = at::empty({2, TAPS, padded(co, code, false), padded(ci, code, true)}, K5.options().dtype(dt));
@@ -1772,13 +1848,24 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
       }
       for (size_t b0 = 0; b0 < x5.size(); b0 += REPMODE_GATREP_MULTI_MAX) {
         const int cnt = (int)std::min<size_t>(REPMODE_GATREP_MULTI_MAX, x5.size() - b0);
-        try {
-          RM_CALL(repmode_expert_frags_multi, cnt, x5.data() + b0, x3.data() + b0, xco.data() + b0, xci.data() + b0, xwf.data() + b0,
-                  xwd.data() + b0, stream_handle());
-        } catch (...) {
-          op_clear_frag_store();          // (entries were marked current for a layout that did not run)
-          throw;
+        RM_CALL(repmode_expert_frags_multi, cnt, x5.data() + b0, x3.data() + b0, xco.data() + b0, xci.data() + b0, xwf.data() + b0,
+                xwd.data() + b0, stream_handle());
+      }
+      if (g_frag_verify && !v5.empty()) {
+        Tensor& flags = g_frag_flags[k5[0].device().index() & 31];
+        if (!flags.defined()) {
+          TORCH_CHECK(!capturing, "prepare_filters: the operand check's flag buffer must exist before a capture (run a step launch by launch first)");
+          flags = at::zeros({REPMODE_GATREP_MULTI_MAX}, k5[0].options().dtype(at::kInt));
         }
+        for (size_t b0 = 0; b0 < v5.size(); b0 += REPMODE_GATREP_MULTI_MAX) {
+          const int cnt = (int)std::min<size_t>(REPMODE_GATREP_MULTI_MAX, v5.size() - b0);
+          RM_CALL(repmode_expert_frags_refresh_multi, cnt, v5.data() + b0, v3.data() + b0, vco.data() + b0, vci.data() + b0, vwf.data() + b0,
+                  vwd.data() + b0, flags.data_ptr<int>(), stream_handle());
+        }
+      }
+      } catch (...) {
+        op_clear_frag_store();          // (an allocation or a launch failed: no entry may claim operands that were never written)
+        throw;
       }
       std::lock_guard<std::mutex> lock(g_prep_mu);
       for (size_t i = 0; i < xe.size(); ++i) g_prep[xk[i]] = xe[i];
@@ -1972,9 +2059,12 @@ TORCH_LIBRARY(repmode, m) {
   m.def("finish_prepared(Tensor like) -> ()", &rm::op_finish_prepared);
   m.def("adam_step(Tensor[] params, Tensor[] grads, Tensor[] exp_avgs, Tensor[] exp_avg_sqs, float lr, float beta1, float beta2, "
         "float eps, int step) -> ()", &rm::op_adam_step);
+  m.def("adam_step_dev(Tensor[] params, Tensor[] grads, Tensor[] exp_avgs, Tensor[] exp_avg_sqs, float lr, float beta1, float beta2, "
+        "float eps, Tensor(a!) step_dev, Tensor(b!) hyper_dev) -> ()", &rm::op_adam_step_dev);
   m.def("clear_frag_store() -> ()", &rm::op_clear_frag_store);
   m.def("set_frag_store(bool on) -> ()", &rm::op_set_frag_store);
   m.def("frag_store_size() -> int", &rm::op_frag_store_size);
+  m.def("set_frag_verify(bool on) -> ()", &rm::op_set_frag_verify);
   m.def("set_bn_epilogue(int mask) -> ()", &rm::op_set_bn_epilogue);
   m.def("set_unmerged_max_w(int w) -> ()", &rm::op_set_unmerged_max_w);
   m.def("set_dual_launch(bool on) -> ()", &rm::op_set_dual_launch);

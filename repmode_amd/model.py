@@ -120,18 +120,21 @@ class Model(object):
         # process-wide (one training process per GPU): where the MoDE gradient kernels put the parameter gradients
         ops_.set_grad_sink(self.reducer)
         ops_.torch_ops().clear_frag_store()          # (expert operands kept across steps belong to the previous network)
-        # process-wide, like the gradient sink (one training process per GPU): a graph replay updates the parameters with no
-        # version counter and no optimizer hook to say so -- a model that replays its step lays the per-expert blocks'
-        # operands out at every forward pass, as the captured step does
-        ops_.torch_ops().set_frag_store(not self.hip_graph and os.environ.get('REPMODE_FRAG_STORE', '1') != '0')
-        if self.hip_graph or os.environ.get('REPMODE_ADAM', '1') == '0':
-            # (capturable: the step counters live on the device, so optimizer.step() can be part of a HIP graph -- the build's
-            # own pass takes the step count from the host; REPMODE_ADAM=0: the stock fused optimizer, for A/B)
+        # process-wide, like the gradient sink (one training process per GPU).  A graph replay updates the parameters with no
+        # version counter and no optimizer hook to say so: with the STOCK optimizer a model that replays its step lays the
+        # per-expert blocks' operands out at every forward pass (store off); with the build's own optimizer the captured pass
+        # writes the stored operands itself, replay after replay (repmode_ops.cpp op_prepare_filters)
+        own_adam = os.environ.get('REPMODE_ADAM', '1') != '0'
+        ops_.torch_ops().set_frag_store((own_adam or not self.hip_graph) and os.environ.get('REPMODE_FRAG_STORE', '1') != '0')
+        if not own_adam:
+            # (REPMODE_ADAM=0: the stock fused optimizer, for A/B; capturable: its step counters live on the device)
             self.optimizer = torch.optim.Adam(self.net.parameters(), lr=self.lr, fused=True, capturable=self.hip_graph)
         else:
-            # fnet_model.py:55 through the build's own kernels (csrc/adam.hip): same state layout as torch.optim.Adam
+            # fnet_model.py:55 through the build's own kernels (csrc/adam.hip): same state layout as torch.optim.Adam.  Under
+            # hip_graph the step count also lives on the device (capturable) and the captured pass keeps the per-expert blocks'
+            # operands current in every replay: the graph IS the eager step, operand store included.
             from .optim import Adam
-            self.optimizer = Adam(self.net.parameters(), lr=self.lr)
+            self.optimizer = Adam(self.net.parameters(), lr=self.lr, capturable=self.hip_graph)
 
     # ---- checkpoint: fnet_model.py:57-94 (same keys)
     def get_state(self):

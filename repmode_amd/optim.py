@@ -34,15 +34,34 @@ def install_foreign_step_hook():
 
 
 class Adam(torch.optim.Adam):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
+        """``capturable``: the step count ALSO lives on the device (one int64 for the whole parameter list) and the kernels take
+        the step's constants from device memory (``repmode_adam_hyper_dev``), so that ``step()`` can be part of a captured HIP
+        graph: a replay advances the count itself.  The host counters of ``state`` are brought up to date by ``sync_steps()``
+        (``state_dict()`` calls it).  The learning rate is a launch argument: changing it needs a new capture."""
         # (the stock single-tensor bookkeeping: `step` counters are host scalars -- no device read to learn the step count)
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False,
                          capturable=False)
+        self.device_step = bool(capturable)
+        self._step_dev = self._hyper_dev = None
+
+    def sync_steps(self):
+        """Device step count -> the host counters of ``state`` (after graph replays, which run no host code).  One device read."""
+        if self._step_dev is not None:
+            t = int(self._step_dev.item())
+            for st in self.state.values():
+                if 'step' in st:
+                    st['step'] = torch.tensor(float(t))
+
+    def state_dict(self):
+        self.sync_steps()
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         """As torch.optim.Adam; `step` counters that a fused / capturable optimizer kept on the device come to the host (one
         copy at load time, so that ``step()`` never reads the device to learn the step count)."""
         super().load_state_dict(state_dict)
+        self._step_dev = self._hyper_dev = None            # (re-created from the loaded counters by the next step)
         for group in self.param_groups:            # (a stock optimizer's groups say fused / capturable; this one's bookkeeping is neither)
             group['fused'], group['capturable'], group['foreach'] = False, False, False
         for st in self.state.values():
@@ -65,6 +84,23 @@ class Adam(torch.optim.Adam):
                 continue
             beta1, beta2 = group['betas']
             lr = float(group['lr'])
+            if self.device_step:
+                if len(self.param_groups) != 1:
+                    raise RuntimeError('repmode_amd.optim.Adam(capturable=True): one parameter group (one device step count)')
+                if self._step_dev is None:
+                    # first step (launch by launch, never under capture): the device count starts where the host counters are
+                    t0 = {int(s) for s in steps}
+                    if len(t0) != 1:
+                        raise RuntimeError('repmode_amd.optim.Adam(capturable=True): every parameter must have seen the same number of steps')
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError('repmode_amd.optim.Adam(capturable=True): run one step launch by launch before capturing')
+                    self._step_dev = torch.full((1,), t0.pop(), dtype=torch.int64, device=params[0].device)
+                    self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=params[0].device)
+                for s in steps:
+                    s += 1                                          # (host mirror: exact while steps run launch by launch; sync_steps() after replays)
+                ops_.torch_ops().adam_step_dev(params, grads, exp_avgs, exp_avg_sqs, lr, float(beta1), float(beta2), float(group['eps']),
+                                               self._step_dev, self._hyper_dev)
+                continue
             # parameters that have seen the same number of updates go together (normally: all of them)
             by_step = {}
             for i, s in enumerate(steps):

@@ -177,3 +177,98 @@ def test_deep_mode_in_the_operator(ci, co, shape, n):
         errs['p%d' % i] = rel_err(got, p.grad)
     record('test_deep_mode_in_the_operator', case='%d->%d %s n=%d' % (ci, co, shape, n), **errs)
     assert max(errs.values()) < 2e-2, errs
+
+
+@pytest.mark.timeout(600)
+def test_hip_graph_step_with_the_builds_own_optimizer():
+    """Model(hip_graph=True) replays the ROUND-5 step: the build's own optimizer pass (repmode_amd.optim.Adam, capturable: the
+    step count on the device) is captured with forward + backward, and the per-expert blocks' operands kept across steps are the
+    ones the captured pass writes (no layout launch inside the graph).  A bf16 network whose deep levels take the per-expert
+    formulation, replayed against the same model stepping launch by launch: the same losses (the two differ by the order of
+    float atomics only), the same step count, an interchangeable optimizer state."""
+    from conftest import Opts
+    from repmode_amd.model import Model
+    from repmode_amd.optim import Adam
+    ops = _ops()
+    gen = torch.Generator().manual_seed(3)
+    n, shape = 4, (16, 32, 32)
+    tasks = torch.tensor([1, 5, 7, 1])
+    xs = [torch.randn(n, 1, *shape, generator=gen) for _ in range(7)]
+    ts = [torch.randn(n, 1, *shape, generator=gen) for _ in range(7)]
+    models = []
+    for graph in (True, False):
+        torch.manual_seed(0)
+        models.append(Model(Opts(), lr=1e-3, gpu_ids=0, mult_chan=8, dtype=torch.bfloat16, hip_graph=graph))
+    g, e = models
+    assert isinstance(g.optimizer, Adam) and g.optimizer.device_step and isinstance(e.optimizer, Adam) and not e.optimizer.device_step
+    e.net.load_state_dict(g.net.state_dict())
+    lg, le = [], []
+    for i in range(7):
+        g.do_train_iter(xs[i], ts[i], tasks)
+        lg.append(float(g.last_loss))
+        e.do_train_iter(xs[i], ts[i], tasks)
+        le.append(float(e.last_loss))
+        if i == 1:
+            assert ops.torch_ops().frag_store_size() > 0          # warm-up steps left the per-expert blocks' operands in the store
+    st = next(iter(g._graphs.values()))
+    assert st['graph'] is not None and st['calls'] == Model.GRAPH_WARMUP + 1
+    record('hip_graph_own_adam', graph=lg, eager=le)
+    for a, b in zip(lg, le):
+        assert abs(a - b) < 2e-2 * abs(b), (lg, le)
+    assert le[-1] < le[0]                                         # (it trains)
+    # the step count: 7 on the device, the host mirror after sync_steps(), and in a state_dict a stock optimizer can load
+    assert int(g.optimizer._step_dev.item()) == 7
+    sd = g.optimizer.state_dict()
+    assert all(int(s['step']) == 7 for s in sd['state'].values())
+    stock = torch.optim.Adam(g.net.parameters(), lr=1e-3)
+    stock.load_state_dict(sd)
+    # parameters after 7 steps: graph vs launch by launch (bf16 kernels, atomics order: loose)
+    pg = torch.cat([p.detach().reshape(-1) for p in g.net.parameters()])
+    pe = torch.cat([p.detach().reshape(-1) for p in e.net.parameters()])
+    assert float((pg - pe).norm() / pe.norm()) < 2e-2
+
+
+def test_stale_expert_operands_are_caught_on_the_device():
+    """The per-expert blocks' bf16 operands are kept across steps and trusted on autograd's version counters + an optimizer
+    hook; a write that moves neither (``p.data.mul_``, a collective's broadcast, a foreign kernel) used to leave stale filters
+    in use (advisor, round 4).  Every forward pass now compares sampled parameter bytes with the stored operands ON THE DEVICE and
+    lays the block out again where they differ: the forward after such a write equals the forward after an explicit
+    ``clear_frag_store()``, and with the check switched off it demonstrably does not."""
+    from conftest import Opts
+    from repmode_amd.model import Model
+    ops = _ops()
+    t = ops.torch_ops()
+    gen = torch.Generator().manual_seed(5)
+    n, shape = 4, (16, 32, 32)
+    tasks = torch.tensor([1, 5, 7, 1])
+    x, tgt = torch.randn(n, 1, *shape, generator=gen), torch.randn(n, 1, *shape, generator=gen)
+    torch.manual_seed(0)
+    m = Model(Opts(), lr=1e-3, gpu_ids=0, mult_chan=8, dtype=torch.bfloat16)
+    for _ in range(2):
+        m.do_train_iter(x, tgt, tasks)
+    assert t.frag_store_size() > 0
+    k5 = m.net.bottle_block.conv1.expert_conv5x5_conv
+    xd = x.to(DEV)
+
+    def fwd():
+        with torch.no_grad():
+            return m.net(xd, tasks).float().cpu()
+    y0 = fwd()
+    for verify in (False, True):
+        t.set_frag_verify(verify)
+        try:
+            ver = k5._version
+            k5.data.mul_(-2.0)                         # `.data` has a version counter of its own: the parameter's does not move
+            assert k5._version == ver
+            y1 = fwd()
+            t.clear_frag_store()
+            y2 = fwd()                                 # operands laid out afresh from the parameters
+        finally:
+            t.set_frag_verify(True)
+        changed = rel_err(y2, y0)
+        assert changed > 1e-2, changed                 # the write matters
+        if verify:
+            assert rel_err(y1, y2) < 2e-3, rel_err(y1, y2)         # caught: same as a fresh layout (up to the order of float atomics)
+        else:
+            assert rel_err(y1, y2) > 1e-2              # not caught without the check: what the advisor described
+        y0 = y2
