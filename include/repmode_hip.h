@@ -508,11 +508,11 @@ int repmode_patch_blend(const void* out, int dtype, const float* gauss, const in
  * wd[i] may be NULL, or wf[i] when wd[i] is given.  nblocks <= REPMODE_GATREP_MULTI_MAX. */
 int repmode_expert_frags_multi(int nblocks, const float* const* k5, const float* const* k3, const int* co, const int* ci,
                                void* const* wf, void* const* wd, void* stream);
-/* Operands KEPT across steps checked against their parameters on the device, and repaired: flags[i] (device int[nblocks]) <-
- * whether block i's forward-role operand differs from its parameters (rounded as the layout rounds them) at 1024 sampled
- * positions per expert tensor; then repmode_expert_frags_multi's layout for the flagged blocks only.  Two launches, no host
- * synchronisation -- catches parameter writes that move no autograd version counter (p.data.copy_(), a broadcast, a foreign
- * kernel).  Every block needs its wf. */
+/* Operands KEPT across steps checked against their parameters on the device, and repaired, in ONE launch: every block's
+ * forward-role operand is compared with its parameters (rounded as the layout rounds them) at 1024 sampled positions per expert
+ * tensor; a block that differs is laid out again, both roles.  flags (device int[nblocks], may be NULL) receives the verdicts.
+ * No host synchronisation -- catches parameter writes that move no autograd version counter (p.data.copy_(), a broadcast, a
+ * foreign kernel).  Every block needs its wf. */
 int repmode_expert_frags_refresh_multi(int nblocks, const float* const* k5, const float* const* k3, const int* co, const int* ci,
                                        void* const* wf, void* const* wd, int* flags, void* stream);
 

@@ -32,12 +32,13 @@ def main():
         print('%-80s calls %5s  %8.3f ms/step  avg %8.1f us  %5.1f%%' % (
             short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6 / steps, float(r['AverageNs']) / 1e3,
             100 * float(r['TotalDurationNs']) / tot))
-    ig = [r for r in rows if 'conv5_igemm_kernel' in r['Name'] or 'conv5_ws_kernel' in r['Name'] or 'conv5_pipe_kernel' in r['Name']]
+    ig = [r for r in rows if 'conv5_igemm_kernel' in r['Name'] or 'conv5_ws_kernel' in r['Name'] or 'conv5_pipe_kernel' in r['Name'] or
+          'deep_mode_kernel' in r['Name']]
     if ig:
         calls = sum(int(r['Calls']) for r in ig)
-        print('conv5_ws_kernel + conv5_igemm_kernel, all %d instantiations: %d calls, %.1f us average  (compare bench.py roofline.avg_launch_ms)'
+        print('conv5_ws_kernel + deep_mode_kernel + conv5_igemm_kernel, all %d instantiations: %d calls, %.1f us average  (compare bench.py roofline.avg_launch_ms)'
               % (len(ig), calls, sum(float(r['TotalDurationNs']) for r in ig) / calls / 1e3))
-    for key in ('conv5_ws', 'conv5_igemm', 'conv5_deep', 'thin_', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd', 'bn_', 'k2s2', 'expert_mix', 'box_sum'):
+    for key in ('conv5_ws', 'conv5_igemm', 'deep_mode', 'conv5_deep', 'thin_', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd', 'bn_', 'k2s2', 'expert_mix', 'box_sum'):
         ks = [r for r in tr if key in r['Kernel_Name']]
         if not ks:
             continue
@@ -46,7 +47,12 @@ def main():
     families(tr)
 
 
-FAMILIES = [('conv5_deep level 3 (per-expert pair)', 'conv5_deep_kernel<DCfg<4, 8, 8'), ('conv5_deep level 4 (per-expert pair)', 'conv5_deep_kernel<DCfg<2, 4, 4'),
+FAMILIES = [('deep_mode level 3 forward (one launch per per-expert block)', ('deep_mode_kernel<MCfg<1, 8, 8', 'true>')),
+            ('deep_mode level 3 data gradient', ('deep_mode_kernel<MCfg<1, 8, 8', 'false>')),
+            ('deep_mode level 4 forward', ('deep_mode_kernel<MCfg<2, 4, 4', 'true>')),
+            ('deep_mode level 4 data gradient', ('deep_mode_kernel<MCfg<2, 4, 4', 'false>')),
+            ('operand check (expert_frags_verify)', 'expert_frags_verify'), ('skip concatenation', 'concat2'),
+            ('conv5_deep level 3 (per-expert pair)', 'conv5_deep_kernel<DCfg<4, 8, 8'), ('conv5_deep level 4 (per-expert pair)', 'conv5_deep_kernel<DCfg<2, 4, 4'),
             ('thin layers (own kernels)', 'thin_in1_kernel'), ('thin layers (own kernels)', 'thin_out1_kernel'),
             ('conv5_ws level 2 (16-voxel bricks)', ('conv5_ws_kernel', ', 16>')),
             ('conv5_ws level 0-1 (wave-specialised)', 'conv5_ws_kernel'), ('conv5_pipe level 0-1', 'conv5_pipe_kernel'),
@@ -60,7 +66,7 @@ FAMILIES = [('conv5_deep level 3 (per-expert pair)', 'conv5_deep_kernel<DCfg<4, 
             ('expert_frags', 'expert_frags'), ('gate softmax / backward', 'gate_'), ('BatchNorm+ReLU', 'bn_'),
             ('k2s2 (stride-2 stages)', 'k2'), ('Adam (torch fused)', 'FusedAdam'), ('Adam + expert operands (adam.hip)', 'adam_'), ('box_sum', 'box_sum'),
             ('expert_mix', 'expert_mix'), ('tap_transpose', 'tap_transpose'), ('thin-layer helpers', 'shift5'),
-            ('thin-layer helpers', 'thin_pack'), ('1x1 experts (gemm3)', 'gemm3'), ('box_sum', 'box_expand'),
+            ('thin-layer helpers', 'thin_pack'), ('1x1 experts (gemm3)', 'gemm3'), ('box_sum', 'box_expand'), ('box_sum', 'box_'),
             ('loss (fused MSE)', 'mse_'), ('crop + flip', 'crop_flip'), ('rocBLAS', 'Cijk'), ('cat', 'CatArray'),
             ('pooled memset / fills', 'FillFunctor'), ('other PyTorch elementwise', 'at::native')]
 

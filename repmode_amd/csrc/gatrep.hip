@@ -888,13 +888,11 @@ struct XfMultiArgs {
   int first[XM_MAX + 1];
   int nblocks;
   int order;
-  const int* flags;      // non-null: block i is laid out only where flags[i] != 0 (repmode_expert_frags_refresh_multi)
 };
 __global__ __launch_bounds__(256) void expert_frags_multi_kernel(XfMultiArgs a) {
   __shared__ XfLds L;
   int i = 0;
   while (i + 1 < a.nblocks && (int)blockIdx.x >= a.first[i + 1]) ++i;
-  if (a.flags && a.flags[i] == 0) return;
   int b = blockIdx.x - a.first[i];
   // (as in gatrep_fwd_multi_kernel: the four row quarters of one 1 KiB tile -- 256-byte pieces per tap -- on one XCD, dispatched
   // together: workgroups b, b + 8, b + 16, b + 24 of a block of 32)
@@ -924,25 +922,26 @@ __global__ __launch_bounds__(256) void expert_frags_multi_kernel(XfMultiArgs a) 
 }
 }  // namespace
 
-// Do the stored operands still belong to the parameters?  One workgroup per block samples XC_SAMPLES elements of each expert
-// tensor, rounds them as the layout does and compares with the forward-role operand; flags[i] = 1 on any difference.  What
-// keeps operands across steps (the operator library's store) learns about parameter writes from autograd's version counters
-// and an optimizer hook -- `p.data.copy_()`, a collective's broadcast into the parameters or a foreign kernel move neither;
-// this check looks at the BYTES, on the device, with no host synchronisation.
+// Do the stored operands still belong to the parameters?  XC_WGS workgroups per block each sample the same XC_SAMPLES
+// elements of each expert tensor, round them as the layout does and compare with the forward-role operand -- so all of a
+// block's workgroups reach the same verdict without talking to each other -- and, on any difference, lay the block out again
+// between them (every XC_WGS-th tile quarter each, both roles): check and repair are ONE launch whose common case is a few
+// thousand scattered loads.  What keeps operands across steps (the operator library's store) learns about parameter writes
+// from autograd's version counters and an optimizer hook -- `p.data.copy_()`, a collective's broadcast into the parameters
+// or a foreign kernel move neither; this looks at the BYTES, on the device, with no host synchronisation.
 namespace {
 constexpr int XC_SAMPLES = 1024;      // per tensor and block: a dense write is caught with certainty, a sparse one by chance
+constexpr int XC_WGS = 64;            // workgroups per block (the repair's parallelism; the check is redundant across them)
 struct XfCheckArgs {
   const float* k5[XM_MAX]; const float* k3[XM_MAX];
-  const bf16_t* wf[XM_MAX];
-  int co[XM_MAX], ci[XM_MAX], nrt[XM_MAX], nkc[XM_MAX];
+  bf16_t* wf[XM_MAX]; bf16_t* wd[XM_MAX];
+  int co[XM_MAX], ci[XM_MAX], nrt_f[XM_MAX], nkc_f[XM_MAX], nrt_d[XM_MAX], nkc_d[XM_MAX];
   int* flags;
 };
-__global__ __launch_bounds__(256) void expert_frags_check_kernel(XfCheckArgs a) {
-  __shared__ int bad;
-  const int i = blockIdx.x, tid = threadIdx.x;
-  if (tid == 0) bad = 0;
-  __syncthreads();
-  const int co = a.co[i], ci = a.ci[i], nrt = a.nrt[i], nkc = a.nkc[i];
+__global__ __launch_bounds__(256) void expert_frags_verify_kernel(XfCheckArgs a) {
+  __shared__ XfLds L;
+  const int i = blockIdx.x / XC_WGS, j = blockIdx.x % XC_WGS, tid = threadIdx.x;
+  const int co = a.co[i], ci = a.ci[i], nrt = a.nrt_f[i], nkc = a.nkc_f[i];
   const size_t tap_stride = (size_t)nrt * nkc * 512;
   const unsigned long long n5 = (unsigned long long)co * ci * TAPS, n3 = (unsigned long long)co * ci * 27;
   int diff = 0;
@@ -966,19 +965,31 @@ __global__ __launch_bounds__(256) void expert_frags_check_kernel(XfCheckArgs a) 
       diff |= (a.wf[i][fi] != (bf16_t)(pack_bf16x2(a.k3[i][idx], 0.f) & 0xffffu));
     }
   }
-  if (diff) bad = 1;
-  __syncthreads();
-  if (tid == 0) a.flags[i] = bad;
+  const int bad = __syncthreads_or(diff);
+  if (j == 0 && tid == 0 && a.flags) a.flags[i] = bad ? 1 : 0;
+  if (!bad) return;
+  // ---- repair (rare): this workgroup's share of the tile quarters of both roles
+  const int ntf = nkc * nrt * 4;
+  for (int t = j; t < ntf; t += XC_WGS) {
+    expert_frags_body<false>(L, a.k5[i], a.k3[i], co, ci, nrt, nkc, a.wf[i], t % nkc, (t / nkc) % nrt, t / (nkc * nrt));
+    __syncthreads();
+  }
+  if (a.wd[i]) {
+    const int nrd = a.nrt_d[i], nkd = a.nkc_d[i], ntd = nkd * nrd * 4;
+    for (int t = j; t < ntd; t += XC_WGS) {
+      expert_frags_body<true>(L, a.k5[i], a.k3[i], co, ci, nrd, nkd, a.wd[i], t % nkd, (t / nkd) % nrd, t / (nkd * nrd));
+      __syncthreads();
+    }
+  }
 }
 }  // namespace
 
 static int expert_frags_multi_impl(int nblocks, const float* const* k5, const float* const* k3, const int* co, const int* ci,
-                                   void* const* wf, void* const* wd, int* flags, void* stream) {
+                                   void* const* wf, void* const* wd, bool verify, int* flags, void* stream) {
   RM_REQUIRE(k5 && k3 && co && ci && wf && wd, "expert_frags_multi: null pointer");
   RM_REQUIRE(nblocks > 0 && nblocks <= XM_MAX, "expert_frags_multi: 1..%d blocks per call, got %d", XM_MAX, nblocks);
   XfMultiArgs a{};
   a.nblocks = nblocks;
-  a.flags = flags;
   static const int order = []() { const char* e = getenv("REPMODE_GATREP_ORDER"); return e ? atoi(e) : 1; }();
   a.order = order;
   long total = 0;
@@ -987,7 +998,7 @@ static int expert_frags_multi_impl(int nblocks, const float* const* k5, const fl
   c.flags = flags;
   for (int i = 0; i < nblocks; ++i) {
     RM_REQUIRE(k5[i] && k3[i] && (wf[i] || wd[i]) && co[i] > 0 && ci[i] > 0, "expert_frags_multi: bad block %d", i);
-    RM_REQUIRE(!flags || wf[i], "expert_frags_refresh_multi: block %d has no forward-role operand to check", i);
+    RM_REQUIRE(!verify || wf[i], "expert_frags_refresh_multi: block %d has no forward-role operand to check", i);
     a.k5[i] = k5[i]; a.k3[i] = k3[i]; a.wf[i] = static_cast<bf16_t*>(wf[i]); a.wd[i] = static_cast<bf16_t*>(wd[i]);
     a.co[i] = co[i]; a.ci[i] = ci[i];
     a.nrt_f[i] = repmode_padded_channels(co[i], REPMODE_BF16, 0) / 32; a.nkc_f[i] = repmode_padded_channels(ci[i], REPMODE_BF16, 1) / 16;
@@ -996,15 +1007,18 @@ static int expert_frags_multi_impl(int nblocks, const float* const* k5, const fl
     a.first[i] = (int)total;
     total += a.nwf[i] + (wd[i] ? (long)a.nkc_d[i] * a.nrt_d[i] * 4 : 0);
     bytes += (double)co[i] * ci[i] * (152.0 * 4 + (125.0 + 45.0) * 2 * ((wf[i] ? 1 : 0) + (wd[i] ? 1 : 0)));
-    c.k5[i] = k5[i]; c.k3[i] = k3[i]; c.wf[i] = a.wf[i]; c.co[i] = co[i]; c.ci[i] = ci[i]; c.nrt[i] = a.nrt_f[i]; c.nkc[i] = a.nkc_f[i];
+    c.k5[i] = k5[i]; c.k3[i] = k3[i]; c.wf[i] = a.wf[i]; c.wd[i] = a.wd[i]; c.co[i] = co[i]; c.ci[i] = ci[i];
+    c.nrt_f[i] = a.nrt_f[i]; c.nkc_f[i] = a.nkc_f[i]; c.nrt_d[i] = a.nrt_d[i]; c.nkc_d[i] = a.nkc_d[i];
   }
   a.first[nblocks] = (int)total;
   RM_REQUIRE(total < (1L << 31), "expert_frags_multi: grid too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (flags) {
-    bytes = (double)nblocks * XC_SAMPLES * 2 * 6.0;      // (what the check moves; the layout behind it normally exits at once)
-    hipLaunchKernelGGL(expert_frags_check_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, c);
-    RM_LAUNCH_CHECK("expert_frags_check");
+  if (verify) {
+    repmode_prof_begin(REPMODE_PROF_GATREP_FWD, (double)nblocks * XC_WGS * XC_SAMPLES * 2 * 6.0, s);
+    hipLaunchKernelGGL(expert_frags_verify_kernel, dim3((unsigned)(nblocks * XC_WGS)), dim3(256), 0, s, c);
+    RM_LAUNCH_CHECK("expert_frags_verify");
+    repmode_prof_end(s);
+    return REPMODE_OK;
   }
   repmode_prof_begin(REPMODE_PROF_GATREP_FWD, bytes, s);
   hipLaunchKernelGGL(expert_frags_multi_kernel, dim3((unsigned)total), dim3(256), 0, s, a);
@@ -1015,17 +1029,16 @@ static int expert_frags_multi_impl(int nblocks, const float* const* k5, const fl
 
 extern "C" int repmode_expert_frags_multi(int nblocks, const float* const* k5, const float* const* k3, const int* co, const int* ci,
                                           void* const* wf, void* const* wd, void* stream) {
-  return expert_frags_multi_impl(nblocks, k5, k3, co, ci, wf, wd, nullptr, stream);
+  return expert_frags_multi_impl(nblocks, k5, k3, co, ci, wf, wd, false, nullptr, stream);
 }
 
-// Check-and-repair of operands kept across steps: flags[i] (device, int[nblocks]) <- whether block i's stored forward-role
-// operand still equals its parameters rounded to bf16 at XC_SAMPLES sampled positions per expert tensor; then the layout of
-// repmode_expert_frags_multi runs for the blocks whose flag is set (its workgroups of the other blocks exit at once).  Two
-// launches, no host synchronisation.
+// Check-and-repair of operands kept across steps in ONE launch (expert_frags_verify_kernel): whether block i's stored
+// forward-role operand still equals its parameters rounded to bf16 at XC_SAMPLES sampled positions per expert tensor; where it
+// does not, the block is laid out again (both roles).  flags (device int[nblocks], may be NULL): the verdicts, for whoever wants
+// to look.  No host synchronisation.
 extern "C" int repmode_expert_frags_refresh_multi(int nblocks, const float* const* k5, const float* const* k3, const int* co,
                                                   const int* ci, void* const* wf, void* const* wd, int* flags, void* stream) {
-  RM_REQUIRE(flags, "expert_frags_refresh_multi: null pointer");
-  return expert_frags_multi_impl(nblocks, k5, k3, co, ci, wf, wd, flags, stream);
+  return expert_frags_multi_impl(nblocks, k5, k3, co, ci, wf, wd, true, flags, stream);
 }
 
 // wf: [2][125][CoP/32][CiP/16][32][16] bf16 (rows = co), wd: [2][125][CiP/32][CoP/16][32][16] (rows = ci, taps
