@@ -158,7 +158,8 @@ def conv5_wgrad_algorithmic_bytes(batch, nslots):
 
 def cpu_baseline():
     """Oracle train step (forward + backward + Adam, fp32) on the host cores: batch 2 of the headline patches (two
-    different tasks), up to 32 host threads (see below), >= 3 timed steps (~17 s on the GPU box) of each organisation after a small warm-up -- the reference's
+    different tasks), up to 32 host threads (see below), >= 3 timed steps (~17 s on the GPU box) of each organisation after a small
+    warm-up -- the reference's
     own (one merged filter + one batch-1 conv per sample in a Python loop, RepMode.py:182-190, 204-208) and the
     vectorised restatement (gather + one contraction + one grouped conv).  Bounded: ~2 x 17 s on a 32+ core host (40 s cap each)."""
     from oracle import repmode_oracle as orc
@@ -209,7 +210,8 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--batch', type=int, default=0, help='patches per GPU (default: 8 on one GPU = configs[1], 24 per rank on several = configs[3])')
+    ap.add_argument('--batch', type=int, default=0,
+                    help='patches per GPU (default: 8 on one GPU = configs[1], 24 per rank on several = configs[3])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--host-inputs', action='store_true', help='inputs start in pinned host memory every step (PCIe-inclusive rate)')
     ap.add_argument('--device-volumes', action='store_true',
@@ -435,7 +437,9 @@ def main():
             peak = PEAK_TFLOPS[args.dtype]
             tr_parts = [(pmc_traffic(k, b, args.dtype), train_prof[k][0]) for k in MAIN_KINDS if train_prof[k][0]]
             traffic_file = next((t[1] for t, _ in tr_parts if t[1]), None)
-            traffic = (sum(t[0] * c for t, c in tr_parts) / sum(c for _, c in tr_parts)) if tr_parts and all(t[0] for t, _ in tr_parts) else None
+            traffic = None
+            if tr_parts and all(t[0] for t, _ in tr_parts):
+                traffic = sum(t[0] * c for t, c in tr_parts) / sum(c for _, c in tr_parts)
             nslots = len(set(task.tolist()))
             alg = conv_algorithmic_bytes(b, nslots, train_prof['deep_mode'][0] > 0)
             alg_bytes = sum(alg[k][0] for k in MAIN_KINDS)

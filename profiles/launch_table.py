@@ -7,7 +7,7 @@ import sys
 L = json.load(open(sys.argv[1]))
 tot = {}
 for i, l in enumerate(L):
-    unit = 'TB/s' if l['kind'].startswith('gatrep') else 'TFLOP/s'
+    unit = 'TB/s' if l['kind'].startswith('gatrep') or l['kind'] == 'helper' else 'TFLOP/s'
     work = l['work'] / (1e6 if unit == 'TB/s' else 1e9)
     print('%3d %-18s %8.1f us  %8.1f %-7s  %10.2f %s' % (i, l['kind'], l['us'], l['rate'] or 0, unit, work,
                                                           'MB' if unit == 'TB/s' else 'GFLOP'))
@@ -18,4 +18,4 @@ for i, l in enumerate(L):
 print()
 for k, (n, us, w) in tot.items():
     print('%-18s %3d launches  %8.0f us/step  %8.1f %s aggregate' % (k, n, us, w / us / 1e6,
-                                                                  'TB/s' if k.startswith('gatrep') else 'TFLOP/s'))
+                                                                  'TB/s' if k.startswith('gatrep') or k == 'helper' else 'TFLOP/s'))

@@ -22,7 +22,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KINDS = ['conv5_ws', 'conv5_pipe', 'conv5_igemm', 'conv5_deep', 'thin_in1', 'thin_out1', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd', 'bn_', 'k2s2', 'gemm3', 'multi_tensor_apply', 'adam_']
+KINDS = ['conv5_ws', 'conv5_pipe', 'conv5_igemm', 'deep_mode', 'conv5_deep', 'thin_in1', 'thin_out1', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd', 'bn_', 'k2s2', 'gemm3', 'multi_tensor_apply', 'adam_']
 
 
 def rows(d, name):

@@ -72,7 +72,8 @@ struct MCfg {
   static constexpr int IMG = 2 * PLS;                         // one unit's image: two channel groups of 8
   static constexpr int WSLOTS = SU * IMG;                     // a wave's private region
   static constexpr int MAXI = 8;                              // staged 16-byte items per lane and image
-  static_assert(VW == 2 && NV % 32 == 0, "a tile is two 32-voxel sub-tiles");
+  static constexpr int NVOX = 32 * VW;                        // voxels of a tile
+  static_assert((VW == 1 || VW == 2) && NV % 32 == 0, "a tile is one or two 32-voxel sub-tiles");
 };
 
 __device__ __forceinline__ void mma_bf16(const u32x4& a, const u32x4& b, f32x16& c) {
@@ -279,6 +280,65 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[p][vs][r] = 0.f;
 
+  // ---- the three 1x1 experts: one MFMA per (expert, sub-tile, chunk) on operands read straight from L2.  Forward: their own
+  // accumulators, after the conv experts' loop (three more sets would not fit beside it); data gradient: the shared accumulator,
+  // inside the chunk loop -- the loads' latency then hides under the SIMD's other wave instead of standing at the launch's end.
+  f32x16 acc1[FWD ? 3 : 1][VW];
+  if constexpr (FWD) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+#pragma unroll
+      for (int vs = 0; vs < VW; ++vs)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[e][vs][r] = 0.f;
+  }
+  int voff[VW];                       // element offset of this lane's voxel row in s[e], -1 outside the volume
+#pragma unroll
+  for (int vs = 0; vs < VW; ++vs) {
+    const int ul = vs / TU, piece = vs % TU;
+    int lz, ly, lx;
+    row_voxel<C>(l31, piece, lz, ly, lx);
+    const int unit = g * SU + ul;
+    const int gz = zmin + lz;
+    voff[vs] = -1;
+    if (unit < a.nunits && gz < D && ly < H && lx < W) voff[vs] = ((unit / a.nbz) * V + (gz * H + ly) * W + lx) * R;
+  }
+  auto one_by_one = [&](int chunk) {
+#ifdef DM_NO1X1      // TIMING BUILD ONLY: the 1x1 experts' pass never runs
+    if (a.N > 0) return;
+#endif
+    const int o = cot * 32 + l31;
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r0 = chunk * 16 + khalf * 8;
+    const bool rin = r0 < R;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      f32x4 b0 = z4, b1 = z4;
+      if (rin && o < O) {
+        const float* kp = a.k[e] + (size_t)o * a.kso + (size_t)r0 * a.ksr;
+        if (a.ksr == 1) {
+          b0 = *reinterpret_cast<const f32x4*>(kp);
+          b1 = *reinterpret_cast<const f32x4*>(kp + 4);
+        } else {
+          b0 = f32x4{kp[0], kp[a.ksr], kp[2 * a.ksr], kp[3 * a.ksr]};
+          b1 = f32x4{kp[4 * a.ksr], kp[5 * a.ksr], kp[6 * a.ksr], kp[7 * a.ksr]};
+        }
+      }
+      const u32x4 bf = pack8(b0, b1);
+#pragma unroll
+      for (int vs = 0; vs < VW; ++vs) {
+        f32x4 a0 = z4, a1 = z4;
+        if (rin && voff[vs] >= 0) {
+          const float* sp = a.s[e] + (size_t)voff[vs] + r0;
+          a0 = *reinterpret_cast<const f32x4*>(sp);
+          a1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        }
+        if constexpr (FWD) mma_bf16(pack8(a0, a1), bf, acc1[e][vs]);
+        else mma_bf16(pack8(a0, a1), bf, acc[0][vs]);
+      }
+    }
+  };
+
   // position i of this workgroup's chunk range -> chunk, rotated by the tile index (same reason as the tap rows' rotation)
   const int nc = c_end - c_begin;
 #ifdef DM_NOROT
@@ -301,6 +361,7 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
                      min(dy_hi, 3), rot, acc[1]);
     } else {
       fetch(a.x1, chunk);
+      one_by_one(chunk);
       tap_pass<C, 0>(lds, vb, wchunk, tap_stride, dz_lo, dz_hi, dy_lo, dy_hi, rot, acc[0]);
       stage();
       if (has_next) fetch(a.x0, chunk_at(i + nw));
@@ -309,65 +370,8 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
     }
   }
 
-  // ---- the three 1x1 experts: one MFMA per (expert, sub-tile, chunk) on operands read straight from L2
-  f32x16 acc1[FWD ? 3 : 1][VW];
   if constexpr (FWD) {
-#pragma unroll
-    for (int e = 0; e < 3; ++e)
-#pragma unroll
-      for (int vs = 0; vs < VW; ++vs)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[e][vs][r] = 0.f;
-  }
-  {
-    int voff[VW];                       // element offset of this lane's voxel row in s[e], -1 outside the volume
-#pragma unroll
-    for (int vs = 0; vs < VW; ++vs) {
-      const int ul = vs / TU, piece = vs % TU;
-      int lz, ly, lx;
-      row_voxel<C>(l31, piece, lz, ly, lx);
-      const int unit = g * SU + ul;
-      const int gz = zmin + lz;
-      voff[vs] = -1;
-      if (unit < a.nunits && gz < D && ly < H && lx < W) voff[vs] = ((unit / a.nbz) * V + (gz * H + ly) * W + lx) * R;
-    }
-    const int o = cot * 32 + l31;
-    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef DM_NO1X1      // TIMING BUILD ONLY: the 1x1 experts' pass never runs
-    for (int i = wave; i < nc && a.N < 0; i += nw) {
-#else
-    for (int i = wave; i < nc; i += nw) {
-#endif
-      const int chunk = chunk_at(i);
-      const int r0 = chunk * 16 + khalf * 8;
-      const bool rin = r0 < R;
-#pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        f32x4 b0 = z4, b1 = z4;
-        if (rin && o < O) {
-          const float* kp = a.k[e] + (size_t)o * a.kso + (size_t)r0 * a.ksr;
-          if (a.ksr == 1) {
-            b0 = *reinterpret_cast<const f32x4*>(kp);
-            b1 = *reinterpret_cast<const f32x4*>(kp + 4);
-          } else {
-            b0 = f32x4{kp[0], kp[a.ksr], kp[2 * a.ksr], kp[3 * a.ksr]};
-            b1 = f32x4{kp[4 * a.ksr], kp[5 * a.ksr], kp[6 * a.ksr], kp[7 * a.ksr]};
-          }
-        }
-        const u32x4 bf = pack8(b0, b1);
-#pragma unroll
-        for (int vs = 0; vs < VW; ++vs) {
-          f32x4 a0 = z4, a1 = z4;
-          if (rin && voff[vs] >= 0) {
-            const float* sp = a.s[e] + (size_t)voff[vs] + r0;
-            a0 = *reinterpret_cast<const f32x4*>(sp);
-            a1 = *reinterpret_cast<const f32x4*>(sp + 4);
-          }
-          if constexpr (FWD) mma_bf16(pack8(a0, a1), bf, acc1[e][vs]);
-          else mma_bf16(pack8(a0, a1), bf, acc[0][vs]);
-        }
-      }
-    }
+    for (int i = wave; i < nc; i += nw) one_by_one(chunk_at(i));
   }
 
   // ---- the waves' partial sums meet in LDS: every wave writes its 64 x 32 tiles into a slab of its own (plain
@@ -375,7 +379,8 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
   // onto one shared tile measured ~64 cycles per wave-instruction: 40 us of a forward launch with eight waves).
   // A thread owns 4 channels of a voxel row (8 threads = one 128-byte row of the tile).
   constexpr int SPR = 2;                                   // sets per round: nw * SPR * 8 KB <= the waves' image regions
-  float* red = reinterpret_cast<float*>(smem);             // [wave][SPR][64 voxels][32 channels]
+  constexpr int NVOX = C::NVOX;
+  float* red = reinterpret_cast<float*>(smem);             // [wave][SPR][NVOX voxels][32 channels]
   const int nwa = min(nw, nc);                             // waves that had chunks
   const size_t estride = (size_t)N * V * O;
   const bool split = a.ksplit > 1;
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
               } else {
                 v = acc[0][vs][r];
               }
-              red[(((wave * SPR + sr) * 64) + vs * 32 + m) * 32 + l31] = v;
+              red[(((wave * SPR + sr) * NVOX) + vs * 32 + m) * 32 + l31] = v;
             }
         }
       }
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int q = tid + k * nt;
-      if (q >= 512) break;
+      if (q >= NVOX * 8) break;
       const int vox = q >> 3, c4 = (q & 7) * 4;
       const int vs = vox >> 5, m = vox & 31;
       const int ul = vs / TU, piece = vs % TU;
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
         const int e = e0 + sr;
         if (e >= NE) break;
         f32x4 pe = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int wv = 0; wv < nwa; ++wv) pe += *reinterpret_cast<const f32x4*>(&red[(((wv * SPR + sr) * 64) + vox) * 32 + c4]);
+        for (int wv = 0; wv < nwa; ++wv) pe += *reinterpret_cast<const f32x4*>(&red[(((wv * SPR + sr) * NVOX) + vox) * 32 + c4]);
         if constexpr (FWD) {
           const f32x4 ge = *reinterpret_cast<const f32x4*>(a.gate + ((size_t)n * E + e) * O + o);
           yv[k] += ge * pe;
@@ -463,17 +468,20 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
 
 using MCfgP8 = MCfg<1, 8, 8, 1>;      // level 3: a tile = one 8 x 8 z plane of a sample
 using MCfgS4 = MCfg<2, 4, 4, 2>;      // level 4: a tile = two whole 2 x 4 x 4 samples
+using MCfgS1 = MCfg<2, 4, 4, 1>;      // level 4, forward at small batches: one sample a tile -- twice the tiles, so that the grid fills
+                                      // without splitting the reduction over workgroups (six outputs' worth of float atomics)
 
 // REPMODE_DEEP_MODE_TARGET: workgroups a data-gradient launch should reach before the reduction stops being split over
 // workgroups (default: one per CU); REPMODE_DEEP_MODE_TARGET_FWD: the same for the forward, whose SIX outputs (P_0..4, y)
 // all pay for a split with float atomics
 static const int g_dm_target = []() { const char* e = getenv("REPMODE_DEEP_MODE_TARGET"); return e ? atoi(e) : 0; }();
 static const int g_dm_target_fwd = []() { const char* e = getenv("REPMODE_DEEP_MODE_TARGET_FWD"); return e ? atoi(e) : 128; }();
+static const bool g_dm_no_s1 = []() { const char* e = getenv("REPMODE_DEEP_MODE_S1"); return e && atoi(e) == 0; }();      // (A/B)
 // REPMODE_DEEP_MODE_WAVES: 4 / 8 forces the waves of a workgroup (a sweep)
 static const int g_dm_waves = []() { const char* e = getenv("REPMODE_DEEP_MODE_WAVES"); return e ? atoi(e) : 0; }();
 
 struct DmPlan {
-  int cfg;        // 0 unsupported, 1 the 8 x 8 plane, 2 two 2 x 4 x 4 samples
+  int cfg;        // 0 unsupported, 1 the 8 x 8 plane, 2 two 2 x 4 x 4 samples, 3 one 2 x 4 x 4 sample
   int ksplit, nw, G, ncot, nbz;
 };
 
@@ -508,8 +516,15 @@ static DmPlan dm_plan(int n, int d, int h, int w, int r, int o, bool fwd) {
   p.ncot = ceil_div(o, 32);
   const int nchunks = round_up(r, 16) / 16;
   const int target = fwd ? g_dm_target_fwd : (g_dm_target > 0 ? g_dm_target : cu_count());
-  int ks = 1;
-  while ((long)p.G * p.ncot * ks < target && ks * 2 <= nchunks) ks *= 2;
+  auto split_for = [&](int tiles) { int k = 1; while ((long)tiles * p.ncot * k < target && k * 2 <= nchunks) k *= 2; return k; };
+  int ks = split_for(p.G);
+  if (fwd && p.cfg == 2 && ks > 1 && !g_dm_no_s1 && split_for(n) < ks && (long)r * o <= 256L * 512) {
+    // forward, two-sample tiles would split: one sample a tile -- no float atomics for twice the filter traffic through L2,
+    // which pays while the filters are small (same box, batch 8: 256 -> 512 40.1 -> 33.1 us, 512 -> 512 57.3 -> 60.7)
+    p.cfg = 3;
+    p.G = n;
+    ks = split_for(n);
+  }
   p.ksplit = ks;
   const int per = ceil_div(nchunks, ks);
   p.nw = per > 4 ? 8 : 4;
@@ -529,12 +544,12 @@ int launch_dm(DmArgs a, const DmPlan& p, bool hosts_tail, double alg, hipStream_
   if (hosts_tail) repmode_tail_take(stream, &a.tail);
   const long grid = nclass * p.G + a.tail.nblocks;
   RM_REQUIRE(grid > 0 && grid < (1L << 31), "deep_mode: grid %ld out of range", grid);
-  const int red_bytes = p.nw * 2 * 64 * 32 * 4;      // the epilogue's slabs: [wave][2 sets][64][32] floats
+  const int red_bytes = p.nw * 2 * C::NVOX * 32 * 4;      // the epilogue's slabs: [wave][2 sets][NVOX][32] floats
   int lds_bytes = p.nw * C::WSLOTS * 16;
   if (lds_bytes < red_bytes) lds_bytes = red_bytes;
   if (lds_bytes < TAIL_LDS_BYTES) lds_bytes = TAIL_LDS_BYTES;
-  constexpr int LDS_MAX = 8 * C::WSLOTS * 16;
-  static_assert(LDS_MAX <= 160 * 1024 && LDS_MAX >= 8 * 2 * 64 * 32 * 4 && LDS_MAX >= TAIL_LDS_BYTES, "LDS budget");
+  constexpr int LDS_MAX = (8 * C::WSLOTS * 16 > 8 * 2 * C::NVOX * 32 * 4) ? 8 * C::WSLOTS * 16 : 8 * 2 * C::NVOX * 32 * 4;
+  static_assert(LDS_MAX <= 160 * 1024 && LDS_MAX >= TAIL_LDS_BYTES, "LDS budget");
   static std::atomic<unsigned> attr_set{0};
   int dev = 0;
   RM_HIP(hipGetDevice(&dev));
@@ -584,6 +599,7 @@ extern "C" int repmode_deep_mode_fwd(const void* x, const void* wf, const float*
   a.OP = repmode_padded_channels(cout, REPMODE_BF16, 0);
   const double alg = 2.0 * n * d * h * w * (double)cin * cout * REPMODE_TAPS;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (pl.cfg == 3) return launch_dm<MCfgS1, true>(a, pl, false, alg, s);
   if (pl.cfg == 2) return launch_dm<MCfgS4, true>(a, pl, false, alg, s);
   return launch_dm<MCfgP8, true>(a, pl, false, alg, s);
 }

@@ -249,7 +249,8 @@ class Model(object):
         loss, loss_sample, task_mean, task_count, tasks = self._last_log
         names = self.opts.adopted_datasets
         per = loss_sample.float().cpu().numpy()
-        log = {'X-axis/iter': self.count_iter, 'loss/iter': float(loss)}     # (count_iter is the caller's: main.py:250 sets it before the call)
+        # (count_iter is the caller's: main.py:250 sets it before the call)
+        log = {'X-axis/iter': self.count_iter, 'loss/iter': float(loss)}
         if task_mean is not None:
             tm = task_mean.cpu().numpy()
             for i in sorted(set(tasks)):

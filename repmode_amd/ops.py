@@ -141,8 +141,8 @@ def get_reserve_cus():
 def set_conv_pipe(mode):
     """The convolution's pipelined one-wave-per-SIMD form on volumes 32 or more voxels wide (csrc/conv5_igemm.hip,
     ``conv5_pipe_kernel`` / ``conv5_ws_kernel``): bit 0 on, bit 1 one channel sub-tile per wave everywhere, bit 2 also on grids
-    smaller than the chip (tests), bit 3 the wave-specialised kernel, bit 4 its items along z first, bit 5 row-stationary tap order on 32-channel layers;
-    default 57.  0: the two-workgroup form everywhere.
+    smaller than the chip (tests), bit 3 the wave-specialised kernel, bit 4 its items along z first, bit 5 row-stationary tap order
+    on 32-channel layers; default 57.  0: the two-workgroup form everywhere.
     Results do not depend on bits 0-4; bit 5 changes the float summation order of the taps."""
     _lib.call('repmode_set_conv_pipe', int(mode))
 
@@ -333,7 +333,8 @@ def adam_expert_frags(k5s, k3s, lr, beta1, beta2, eps, step, want_wd=True):
     outs, cos, cis = [], [], []
     for (p5, _, _, _) in k5s:
         co, ci = p5.shape[0], p5.shape[1]
-        wf = torch.empty((2, TAPS, _lib.padded_channels(co, code, False), _lib.padded_channels(ci, code, True)), dtype=torch.bfloat16, device=p5.device)
+        wf = torch.empty((2, TAPS, _lib.padded_channels(co, code, False), _lib.padded_channels(ci, code, True)), dtype=torch.bfloat16,
+                         device=p5.device)
         wd = torch.empty((2, TAPS, _lib.padded_channels(ci, code, False), _lib.padded_channels(co, code, True)), dtype=torch.bfloat16,
                          device=p5.device) if want_wd else None
         outs.append((wf, wd)); cos.append(co); cis.append(ci)

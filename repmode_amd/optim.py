@@ -91,13 +91,14 @@ class Adam(torch.optim.Adam):
                     # first step (launch by launch, never under capture): the device count starts where the host counters are
                     t0 = {int(s) for s in steps}
                     if len(t0) != 1:
-                        raise RuntimeError('repmode_amd.optim.Adam(capturable=True): every parameter must have seen the same number of steps')
+                        raise RuntimeError('repmode_amd.optim.Adam(capturable=True): every parameter must have seen the same '
+                                           'number of steps')
                     if torch.cuda.is_current_stream_capturing():
                         raise RuntimeError('repmode_amd.optim.Adam(capturable=True): run one step launch by launch before capturing')
                     self._step_dev = torch.full((1,), t0.pop(), dtype=torch.int64, device=params[0].device)
                     self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=params[0].device)
                 for s in steps:
-                    s += 1                                          # (host mirror: exact while steps run launch by launch; sync_steps() after replays)
+                    s += 1              # (host mirror: exact while steps run launch by launch; sync_steps() after replays)
                 ops_.torch_ops().adam_step_dev(params, grads, exp_avgs, exp_avg_sqs, lr, float(beta1), float(beta2), float(group['eps']),
                                                self._step_dev, self._hyper_dev)
                 continue
