@@ -173,6 +173,12 @@ int repmode_conv5_deep_supported(int wdim, int cin, int dtype);
 int repmode_deep_mode_plan(int dir, int n, int d, int h, int w, int cin, int cout, int dtype);
 int repmode_deep_mode_fwd(const void* x, const void* wf, const float* xs, const float* k1, const float* a3, const float* a5,
                           const float* gate, float* p, float* y, int n, int d, int h, int w, int cin, int cout, void* stream);
+/* want_stats: the per-channel sum / sum of squares of the stored y also go to the library's BatchNorm scratch (as
+ * repmode_conv5_epi's want_stats does); *stats_half receives the half to hand to repmode_bn_relu_fwd_ex, which then skips its
+ * statistics pass -- or -1 where the plan splits the reduction over workgroups (no single writer of y). */
+int repmode_deep_mode_fwd_ex(const void* x, const void* wf, const float* xs, const float* k1, const float* a3, const float* a5,
+                             const float* gate, float* p, float* y, int n, int d, int h, int w, int cin, int cout, int want_stats,
+                             int* stats_half, void* stream);
 int repmode_deep_mode_dgrad(const void* g2, const void* wd, const float* s0, const float* s1, const float* s2, const float* k1,
                             const float* a3, const float* a5, void* dx, int dx_dtype, int n, int d, int h, int w, int cin, int cout,
                             void* stream);

@@ -51,6 +51,7 @@ _SIGNATURES = {
     'repmode_conv5_deep_supported': [_I, _I, _I],
     'repmode_deep_mode_plan': [_I] * 8,
     'repmode_deep_mode_fwd': [_P] * 9 + [_I] * 6 + [_P],
+    'repmode_deep_mode_fwd_ex': [_P] * 9 + [_I] * 7 + [_P, _P],
     'repmode_deep_mode_dgrad': [_P] * 9 + [_I] * 7 + [_P],
     'repmode_conv5_thin_in1': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'repmode_conv5_thin_out1': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -51,6 +51,8 @@ struct DmArgs {
   float* p;              // forward: P [5][N][V][O]
   void* y;               // forward: y float [N][V][O];  data gradient: dx [N][V][O] float or bf16
   int y_bf16;
+  float* stats;          // forward, plain stores only: per-channel sum / sum of squares of y go to this half of the library's
+  float* stats_clear;    //   BatchNorm scratch (16 slices x 2 x O), and the other half is put back to zero (as bn_stats_kernel does)
   int N, D, H, W, R, O, RP, OP;
   int nbz, nunits, G, ncot, ksplit, xcd_classes;
   TailJobs tail;         // deferred small jobs riding in this launch (tail_jobs.h)
@@ -210,6 +212,10 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
   }
   const int kz = c % a.ksplit, cot = c / a.ksplit;
   const int D = a.D, H = a.H, W = a.W, R = a.R, O = a.O, RP = a.RP, OP = a.OP, N = a.N;
+  if constexpr (FWD) {
+    if (a.stats_clear)
+      for (int i = cb * nt + tid; i < (int)REPMODE_SCRATCH_BN_HALF; i += nblocks * nt) a.stats_clear[i] = 0.f;
+  }
   const int V = D * H * W;
 
   // ---- this wave's chunks of the reduction
@@ -464,6 +470,37 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
       }
     }
   }
+  // ---- the BatchNorm behind the block gets its batch statistics from here (RepMode.py:146-149, 212: sum and sum of squares
+  // of the stored y per channel): on the deep levels the separate statistics pass is a launch of pure latency.  Lanes l, l + 8,
+  // ... of a wave hold the same four channels: butterfly, then the waves' partials through LDS, 64 float atomics per workgroup
+  // into slice (workgroup % 16) -- the layout bn_apply_relu_kernel totals (conv5_igemm.hip's epilogue does the same).
+  if constexpr (FWD) {
+    if (a.stats) {
+      float sv[8];
+      const f32x4 t0 = yv[0], t1 = yv[1];
+      sv[0] = t0.x + t1.x; sv[1] = t0.y + t1.y; sv[2] = t0.z + t1.z; sv[3] = t0.w + t1.w;
+      sv[4] = t0.x * t0.x + t1.x * t1.x; sv[5] = t0.y * t0.y + t1.y * t1.y;
+      sv[6] = t0.z * t0.z + t1.z * t1.z; sv[7] = t0.w * t0.w + t1.w * t1.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) sv[j] += __shfl_xor(sv[j], off, 64);
+      __syncthreads();                                  // the last round's slabs are dead
+      float* part = reinterpret_cast<float*>(smem);     // [wave][8 lanes][8 values]
+      if (lane < 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[(wave * 8 + lane) * 8 + j] = sv[j];
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const int l8 = tid >> 3, j = tid & 7;
+        float tot = 0.f;
+        for (int wv = 0; wv < nw; ++wv) tot += part[(wv * 8 + l8) * 8 + j];
+        const int o = cot * 32 + l8 * 4 + (j & 3);
+        if (o < O) unsafeAtomicAdd(a.stats + (size_t)(cb & 15) * 2 * O + (size_t)(j >> 2) * O + o, tot);
+      }
+    }
+  }
 }
 
 using MCfgP8 = MCfg<1, 8, 8, 1>;      // level 3: a tile = one 8 x 8 z plane of a sample
@@ -577,9 +614,11 @@ extern "C" int repmode_deep_mode_plan(int dir, int n, int d, int h, int w, int c
   return p.cfg ? p.ksplit : 0;
 }
 
-extern "C" int repmode_deep_mode_fwd(const void* x, const void* wf, const float* xs, const float* k1, const float* a3, const float* a5,
-                                     const float* gate, float* p, float* y, int n, int d, int h, int w, int cin, int cout, void* stream) {
+extern "C" int repmode_deep_mode_fwd_ex(const void* x, const void* wf, const float* xs, const float* k1, const float* a3, const float* a5,
+                                        const float* gate, float* p, float* y, int n, int d, int h, int w, int cin, int cout, int want_stats,
+                                        int* stats_half, void* stream) {
   RM_REQUIRE(x && wf && xs && k1 && a3 && a5 && gate && p && y, "deep_mode_fwd: null pointer");
+  RM_REQUIRE(!want_stats || stats_half, "deep_mode_fwd: stats_half must be given with want_stats");
   const DmPlan pl = dm_plan(n, d, h, w, cin, cout, true);
   RM_REQUIRE(pl.cfg != 0, "deep_mode_fwd: shape [%d][%d][%d][%d] %d -> %d not supported (repmode_deep_mode_plan)", n, d, h, w, cin, cout);
   RM_REQUIRE(aligned16(x) && aligned16(wf) && aligned16(xs) && aligned16(k1) && aligned16(a3) && aligned16(a5) && aligned16(gate) &&
@@ -599,9 +638,24 @@ extern "C" int repmode_deep_mode_fwd(const void* x, const void* wf, const float*
   a.OP = repmode_padded_channels(cout, REPMODE_BF16, 0);
   const double alg = 2.0 * n * d * h * w * (double)cin * cout * REPMODE_TAPS;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (stats_half) *stats_half = -1;
+  if (want_stats && pl.ksplit == 1 && cout <= 512) {
+    // (only where every y element has ONE writer: a split reduction's partial y has no sum of squares to offer)
+    float* scratch = repmode_zero_scratch(s);
+    if (!scratch) return REPMODE_ELAUNCH;
+    const int half = repmode_bn_scratch_half(s);
+    a.stats = scratch + (size_t)half * REPMODE_SCRATCH_BN_HALF;
+    a.stats_clear = scratch + (size_t)(1 - half) * REPMODE_SCRATCH_BN_HALF;
+    *stats_half = half;
+  }
   if (pl.cfg == 3) return launch_dm<MCfgS1, true>(a, pl, false, alg, s);
   if (pl.cfg == 2) return launch_dm<MCfgS4, true>(a, pl, false, alg, s);
   return launch_dm<MCfgP8, true>(a, pl, false, alg, s);
+}
+
+extern "C" int repmode_deep_mode_fwd(const void* x, const void* wf, const float* xs, const float* k1, const float* a3, const float* a5,
+                                     const float* gate, float* p, float* y, int n, int d, int h, int w, int cin, int cout, void* stream) {
+  return repmode_deep_mode_fwd_ex(x, wf, xs, k1, a3, a5, gate, p, y, n, d, h, w, cin, cout, 0, nullptr, stream);
 }
 
 // g2: bf16 [2][n][v][cout] (G_0 then G_1, expert_mix_bwd's dye_lo); s0 / s1 / s2: float [n][v][cout] = G_2, box3(G_3)/27,

@@ -300,10 +300,11 @@ int64_t g_deep_fwd_min = []() {
 }();
 // A per-expert block as ONE launch per direction (csrc/deep_mode.hip: the five experts, the gate mix and the cross-wave
 // reduction in one kernel; round 5) where repmode_deep_mode_plan takes the shape; REPMODE_DEEP_MODE=0 / set_deep_mode(0):
-// round 4's five launches (conv5_deep / dual-expert launch + box + gemm3 + expert_mix).  Bit 0: forward, bit 1: data gradient.
+// round 4's five launches (conv5_deep / dual-expert launch + box + gemm3 + expert_mix).  Bit 0: forward, bit 1: data gradient,
+// bit 2: the forward also leaves the BatchNorm statistics of its output (no statistics pass behind a per-expert block).
 int64_t g_deep_mode = []() {
   const char* e = std::getenv("REPMODE_DEEP_MODE");
-  return e ? (int64_t)std::atoi(e) : (int64_t)3;
+  return e ? (int64_t)std::atoi(e) : (int64_t)7;
 }();
 bool g_dual_wgrad = []() {          // (REPMODE_DUAL_WGRAD=0: the two filter gradients of a per-expert block as two launches)
   const char* e = std::getenv("REPMODE_DUAL_WGRAD");
@@ -919,10 +920,11 @@ Tensor single_slot(int64_t n, int64_t slot, const Tensor& like) {
 // activations and per-task merged filters / filter gradients are pure HBM traffic.
 struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
   static Tensor forward(AutogradContext* ctx, Tensor x_cl, Tensor k5, Tensor k3, Tensor k1, Tensor a3, Tensor a5, Tensor gw, Tensor gb,
-                        Plan plan, bool grad_enabled) {
+                        Plan plan, bool grad_enabled, bool want_stats) {
     const int64_t co = k5.size(0), ci = k5.size(1);
     const int64_t n = x_cl.size(0), d = x_cl.size(1), h = x_cl.size(2), w = x_cl.size(3);
     const bool need_dx = grad_enabled && x_cl.requires_grad();
+    tl_stats_half = -1;
     Tensor gn;                                                                            // g per SAMPLE [N, 5, Co]
     std::pair<Tensor, Tensor> fr;
     Merged pm;
@@ -952,9 +954,11 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
         if (!tp.second) p.zero_();
         if (!ty.second) y.zero_();
       }
-      RM_CALL(repmode_deep_mode_fwd, x_cl.data_ptr(), fr.first.data_ptr(), xb.data_ptr<float>(), k1.data_ptr<float>(), a3.data_ptr<float>(),
+      int half = -1;
+      RM_CALL(repmode_deep_mode_fwd_ex, x_cl.data_ptr(), fr.first.data_ptr(), xb.data_ptr<float>(), k1.data_ptr<float>(), a3.data_ptr<float>(),
               a5.data_ptr<float>(), gn.data_ptr<float>(), p.data_ptr<float>(), y.data_ptr<float>(), (int)n, (int)d, (int)h, (int)w, (int)ci,
-              (int)co, stream_handle());
+              (int)co, want_stats ? 1 : 0, &half, stream_handle());
+      tl_stats_half = half;          // (the BatchNorm behind the block skips its statistics pass: op_mode_block)
       ctx->save_for_backward({x_cl, k5, k3, k1, a3, a5, gn, xb, p, fr.second.defined() ? fr.second : Tensor()});
       ctx->saved_data["sample_task"] = plan.sample_task;
       ctx->saved_data["num_tasks"] = plan.num_tasks;
@@ -1140,7 +1144,7 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
       dx = box_sum(&t1, &t2, &dxf, &t0, c10::nullopt, dt);
     }
     fork.join();
-    return {dx, dk5, dk3, dk1, da3, da5, dgw, dgb, Tensor(), Tensor()};
+    return {dx, dk5, dk3, dk1, da3, da5, dgw, dgb, Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -1410,8 +1414,7 @@ Tensor mode_conv3d_cl(const Tensor& x_cl_in, const OptTensor& x2_cl_in, const Te
   if (mode == 0) mode = use_unmerged(x_cl, plan) ? 2 : 1;
   if (mode == 2) {
     TORCH_CHECK(!epi.bias.defined() && !epi.relu, "the per-expert formulation is a training-mode path: no folded BatchNorm");
-    tl_stats_half = -1;
-    return ModeConvUnmerged::apply(x_cl, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan, grad_enabled);
+    return ModeConvUnmerged::apply(x_cl, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan, grad_enabled, epi.stats);
   }
   return ModeConvMerged::apply(x_cl, ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6], plan, out_f32, grad_enabled, epi);
 }
@@ -1476,11 +1479,16 @@ Tensor op_mode_block(const Tensor& x, const OptTensor& x2, const Tensor& k5, con
   if (has_bn) TORCH_CHECK(bn_b.has_value() && bn_rm.has_value() && bn_rv.has_value(), "MoDE block: incomplete BatchNorm state");
   Epi epi;
   bool folded = false;
-  if (has_bn && g_bn_epilogue) {
+  const bool unmerged = use_unmerged(x_cl, plan);
+  if (has_bn && bn_batch_stats && unmerged) {
+    // a per-expert block (the deep levels): the one-launch forward (csrc/deep_mode.hip) leaves the statistics of its output in
+    // the BatchNorm scratch wherever it writes y with plain stores -- there the statistics pass is a launch of pure latency
+    epi.stats = (g_deep_mode & 4) && (g_deep_mode & 1) && dt == at::kBFloat16 && k5.size(0) <= 512;
+  } else if (has_bn && g_bn_epilogue) {
     if (bn_batch_stats && (g_bn_epilogue & 2)) {
       // training: the batch statistics come out of the conv's epilogue where the conv writes the element-typed tensor the
       // BatchNorm normalises (bf16, levels 0-1: 94 % of the normalised bytes); elsewhere the separate statistics pass
-      epi.stats = dt == at::kBFloat16 && !out_f32 && !use_unmerged(x_cl, plan) && k5.size(0) <= 512;
+      epi.stats = dt == at::kBFloat16 && !out_f32 && k5.size(0) <= 512;
     } else if (!bn_batch_stats && (g_bn_epilogue & 1) && !plan.training && !at::GradMode::is_enabled() &&
                ((dt == at::kBFloat16 && !out_f32) || dt == at::kFloat)) {
       // eval, no autograd: y = relu(gamma (conv - mean) / sqrt(var + eps) + beta) = relu(conv with scaled filter + bias).
