@@ -112,14 +112,15 @@ __device__ __forceinline__ void tap_pass(const u32x4* __restrict__ lds, const in
   auto wfrag = [&](int tap) -> u32x4 { return *reinterpret_cast<const u32x4*>(wrow + (size_t)tap * tap_stride); };
   const int ny = dy_hi - dy_lo + 1;
   const int nrows = (dz_hi - dz_lo + 1) * ny;
-  // the tap rows in a rotated order (sums commute): the workgroups that share an output-channel tile -- and with it every
-  // filter byte -- run on one XCD at one time; starting all at tap row 0 they would ask for the same line in the same
-  // microsecond and all wait for the one fetch from HBM (measured: 117 us per launch, 2.4 MB of filters per XCD at the
-  // rate of 16 latency-bound streams)
-#ifdef DM_NOROT
-  const int r0 = 0;
-#else
+  // The workgroups that share an output-channel tile -- and with it every filter byte -- run on one XCD at one time and walk
+  // the tap rows IN STEP: a line is fetched from HBM once and serves all of them while it is hot.  (-DDM_ROT: every workgroup
+  // starts at another tap row / chunk -- built on the suspicion that the lockstep makes them all wait for the one fetch;
+  // measured 6 % SLOWER, same box, fwd 270 -> 286 us and data gradient 220 -> 238 us over the five layer shapes, and 4 x the
+  // filters' bytes from HBM: the phases spread over the whole 2.4 MB slice and the XCD's L2 no longer holds what they share.)
+#ifdef DM_ROT
   const int r0 = rot % nrows;
+#else
+  const int r0 = 0;
 #endif
   int dz = dz_lo + r0 / ny, dy = dy_lo + r0 % ny;
   auto next_row = [&](int& z, int& y) {
@@ -345,12 +346,12 @@ __global__ __launch_bounds__(512) void deep_mode_kernel(DmArgs a) {
     }
   };
 
-  // position i of this workgroup's chunk range -> chunk, rotated by the tile index (same reason as the tap rows' rotation)
+  // position i of this workgroup's chunk range -> chunk (-DDM_ROT: rotated by the tile index, as the tap rows)
   const int nc = c_end - c_begin;
-#ifdef DM_NOROT
-  const int rotc = 0;
-#else
+#ifdef DM_ROT
   const int rotc = nc > 0 ? g % nc : 0;
+#else
+  const int rotc = 0;
 #endif
   auto chunk_at = [&](int i) -> int { const int t = i + rotc; return c_begin + (t >= nc ? t - nc : t); };
   const int rot = g * 7 + wave * 3;
