@@ -156,12 +156,18 @@ def test_expert_operands_kept_across_steps_and_invalidated_by_outside_writes():
     torch.manual_seed(0)
     m = Model(Opts(), lr=1e-3, gpu_ids=0, mult_chan=32, dtype=torch.bfloat16)
     counts = []
-    for s in range(3):
-        _lib.prof_enable(1)
-        m.do_train_iter(x, tgt, tasks)
-        torch.cuda.synchronize()
-        counts.append(_lib.prof_summary('gatrep_fwd')[0])
-        _lib.prof_enable(False)
+    # (round 5's on-device check of the kept operands is one more launch of this family on every pass that uses the store:
+    # off while the launches are counted -- tests/test_hip_round5.py::test_stale_expert_operands_are_caught_on_the_device is its test)
+    ops.torch_ops().set_frag_verify(False)
+    try:
+        for s in range(3):
+            _lib.prof_enable(1)
+            m.do_train_iter(x, tgt, tasks)
+            torch.cuda.synchronize()
+            counts.append(_lib.prof_summary('gatrep_fwd')[0])
+            _lib.prof_enable(False)
+    finally:
+        ops.torch_ops().set_frag_verify(True)
     assert ops.torch_ops().frag_store_size() == 6, ops.torch_ops().frag_store_size()    # enc4.conv1/2, bottle.conv1/2, dec4.conv1/2
     assert counts[0] > counts[1] == counts[2], counts        # the expert-layout launch is gone after the first optimizer pass
     m.net.train()
