@@ -50,6 +50,31 @@ def test_argument_validation_without_gpu():
             _lib.call('repmode_device_arch', 0, buf, 16)
 
 
+def test_deep_mode_plan_answers_without_gpu():
+    """repmode_deep_mode_plan (host logic only: which shapes the one-launch per-expert block takes, and whether its outputs have
+    one writer): the network's level 3 / 4 layers at the benchmarked batch, what it refuses, and that calling the kernels with a
+    refused shape or null pointers is an error code, not a crash."""
+    from repmode_amd import _lib
+    lib = _lib.load()
+    plan = lambda *a: lib.repmode_deep_mode_plan(*a)
+    if torch.cuda.is_available():
+        pytest.skip('answers depend on the device\'s CU count; the GPU suite checks them there')
+    # (no device: the plan assumes 256 CUs)
+    assert plan(0, 8, 4, 8, 8, 256, 256, _lib.BF16) == 1          # enc4.conv2 forward: 32 planes x 8 channel tiles = one per CU
+    assert plan(1, 8, 4, 8, 8, 128, 256, _lib.BF16) == 2          # enc4.conv1 data gradient: 4 channel tiles -> two slices
+    assert plan(0, 8, 2, 4, 4, 256, 512, _lib.BF16) == 1          # bottle.conv1 forward: one-sample tiles, no split
+    assert plan(0, 8, 2, 4, 4, 512, 512, _lib.BF16) == 2          # bottle.conv2 forward: two slices of the reduction
+    assert plan(1, 8, 2, 4, 4, 512, 512, _lib.BF16) == 4
+    assert plan(0, 2, 6, 10, 8, 16, 32, _lib.BF16) == 0 and plan(0, 2, 8, 8, 8, 16, 32, _lib.BF16) == 0
+    assert plan(0, 2, 4, 8, 8, 12, 32, _lib.BF16) == 0 and plan(0, 2, 4, 8, 8, 16, 32, _lib.F32) == 0
+    with pytest.raises(_lib.RepModeHipError, match='null pointer'):
+        _lib.call('repmode_deep_mode_fwd', None, None, None, None, None, None, None, None, None, 2, 4, 8, 8, 16, 32, None)
+    with pytest.raises(_lib.RepModeHipError, match='null pointer'):
+        _lib.call('repmode_box_pair', None, None, None, None, 1, 4, 8, 8, 16, None)
+    with pytest.raises(_lib.RepModeHipError):
+        _lib.call('repmode_concat_channels', 16, 16, 16, 4, 24, 16, None)      # a row piece that is no multiple of 16 bytes
+
+
 def test_task_plan_grouping():
     from repmode_amd.ops import TaskPlan
     p = TaskPlan(torch.tensor([7, 2, 7, 11, 2]), 12, 'cpu', training=True)
