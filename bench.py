@@ -19,18 +19,19 @@ Workloads (BASELINE.json ``configs``):
   ``--batch B`` overrides the per-GPU batch for either.
 
 Also reported in the same line:
-  roofline      the MoDE convolution of conv5_igemm.hip (forward + data-gradient launches; the dominant kernel): two symbols --
-                conv5_ws_kernel (levels 0-2 since round 4: 22 launches, 93 % of the conv FLOPs) and conv5_igemm_kernel (the
-                per-expert levels' forward pair), together and each under ``by_kernel``; beside them (round 4) the filter
-                gradient conv5_wgrad_bf16_kernel, the step's largest kernel family, with its own algorithmic bytes: algorithmic
-                FLOPs (the layer's merged 125-tap convolution, 2 * voxels * Cin * Cout * 125, once per layer and
-                direction) / HIP-event duration on the launch stream, against the dense bf16 MFMA peak;
-                ``all_conv_kernels``: the same + conv5_deep (levels 3-4) + the one-channel layers' kernels.  ``traffic``: HBM bytes per
-                launch from rocprofv3 PMC passes of THIS build (profiles/*_pmc_traffic.json carries the hash of
-                the kernel sources it was taken on), else null.
-  fwd           forward only (BASELINE's ">= 40 % MFMA on fused GatRep+Conv3d forward"): voxels/s of the whole
-                forward pass, and the MFMA fraction of gate softmax + GatRep + convolution as ONE unit (their
-                summed event-timed durations against the forward's algorithmic conv FLOPs).
+  roofline      the MoDE convolution, forward + data-gradient launches, of every block but the two one-channel ends (the
+                dominant kernel family): conv5_ws_kernel (levels 0-2: 22 launches, 93 % of the conv FLOPs) and deep_mode_kernel
+                (levels 3-4, round 5: a per-expert block as one launch per direction), together and each under ``by_kernel``;
+                beside them the filter gradient conv5_wgrad_bf16_kernel, the step's second-largest family, with its own
+                algorithmic bytes: algorithmic FLOPs (the layer's merged 125-tap convolution, 2 * voxels * Cin * Cout * 125,
+                once per layer and direction) / HIP-event duration on the launch stream, against the dense bf16 MFMA peak;
+                ``all_conv_kernels``: the same + the one-channel layers' kernels (+ conv5_deep / conv5_igemm where round 4's
+                launches still run).  ``traffic``: HBM bytes per launch from rocprofv3 PMC passes of THIS build
+                (profiles/*_pmc_traffic.json carries the hash of the kernel sources it was taken on), else null.
+  fwd           forward only (BASELINE's ">= 40 % MFMA on fused GatRep+Conv3d forward"): voxels/s of the whole forward pass, and
+                the MFMA fraction of EVERY kernel the MoDE blocks launch in a pass as ONE unit -- gate softmax + GatRep, the
+                convolutions, and the helper kernels (box means, 1x1-expert GEMMs, gate mix, skip concatenation): their summed
+                event-timed durations against the forward's algorithmic conv FLOPs.
   cpu_baseline  the CPU oracle (oracle/repmode_oracle.py, a port -- the reference's Python cannot travel) timed on
                 this box's host cores, rank 0 at N = 1 only: batch 2 of the same patches, both organisations of the
                 arithmetic (the reference's per-sample Python loop, and the vectorised one).
