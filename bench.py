@@ -60,15 +60,18 @@ PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # dense MFMA peaks, MI355X_MIC
 FWD_FLOP_PER_VOXEL = 2083520.0                    # whole forward; MoDE convs alone 2,072,000
 FWD_CONV_FLOP_PER_VOXEL = 2072000.0
 # the forward / data-gradient convolution kernels of the MoDE blocks
-CONV_KINDS = ('conv5_ws', 'conv5_igemm', 'deep_mode', 'conv5_deep', 'conv5_thin')
+CONV_KINDS = ('conv5_ws', 'conv5_igemm', 'deep_mode', 'deep_mode_dgrad', 'conv5_deep', 'conv5_thin')
 # the MoDE convolution, forward and data gradient, of every block but the two one-channel ends: the wave-specialised kernel
 # (levels 0-2), the per-expert blocks' one-launch kernel (levels 3-4, round 5) and whatever still goes through the general kernel
-MAIN_KINDS = ('conv5_ws', 'conv5_igemm', 'deep_mode')
+MAIN_KINDS = ('conv5_ws', 'conv5_igemm', 'deep_mode', 'deep_mode_dgrad')
+# round 4's `roofline` covered conv5_ws + the per-expert levels' FORWARD pair (their data gradient ran in conv5_deep, outside it):
+# the same launches of this build, for a like-for-like figure (`roofline.round4_scope`)
+ROUND4_SCOPE = ('conv5_ws', 'conv5_igemm', 'deep_mode')
 # the MoDE blocks' small kernels (box means, the 1x1 experts' GEMMs, the gate mix, the skip concatenation of the per-expert
 # decoder block): they are part of "GatRep + conv as one unit"
 HELPER_KIND = 'helper'
 KERNEL_SYMBOL = {'conv5_ws': 'conv5_ws_kernel', 'conv5_igemm': 'conv5_igemm_kernel', 'deep_mode': 'deep_mode_kernel',
-                 'conv5_wgrad': 'conv5_wgrad_bf16_kernel'}
+                 'deep_mode_dgrad': 'deep_mode_kernel', 'conv5_wgrad': 'conv5_wgrad_bf16_kernel'}
 
 
 class Opts:
@@ -120,7 +123,7 @@ def conv_algorithmic_bytes(batch, nslots, deep_mode):
     merged = [(0, 32, 32), (0, 64, 32), (0, 32, 32), (1, 32, 64), (1, 64, 64), (1, 128, 64), (1, 64, 64),
               (2, 64, 128), (2, 128, 128), (2, 256, 128), (2, 128, 128)]
     pair = [(3, 128, 256), (3, 256, 256), (3, 512, 256), (3, 256, 256), (4, 256, 512), (4, 512, 512)]
-    acc = {'conv5_ws': [0.0, 0], 'conv5_igemm': [0.0, 0], 'deep_mode': [0.0, 0]}
+    acc = {'conv5_ws': [0.0, 0], 'conv5_igemm': [0.0, 0], 'deep_mode': [0.0, 0], 'deep_mode_dgrad': [0.0, 0]}
     for l, ci, co in merged:
         for a, b in ((ci, co), (co, ci)):                       # forward, data gradient
             elem = lib.repmode_conv5_elem_out(batch, *dims[l], a, b, _lib.BF16) != 0
@@ -131,9 +134,10 @@ def conv_algorithmic_bytes(batch, nslots, deep_mode):
     for l, ci, co in pair:
         filt = (125 + 27) * ci * co * 2 + 3 * ci * co * 4
         if deep_mode:
-            acc['deep_mode'][0] += batch * v[l] * (ci * 2 + co * 4) + filt            # forward
-            acc['deep_mode'][0] += batch * v[l] * (2 * co * 2 + ci * 2) + filt        # data gradient
-            acc['deep_mode'][1] += 2
+            acc['deep_mode'][0] += batch * v[l] * (ci * 2 + co * 4) + filt                  # forward
+            acc['deep_mode'][1] += 1
+            acc['deep_mode_dgrad'][0] += batch * v[l] * (2 * co * 2 + ci * 2) + filt        # data gradient
+            acc['deep_mode_dgrad'][1] += 1
         else:
             acc['conv5_igemm'][0] += batch * v[l] * (ci * 2 + 2 * co * 4) + (125 + 27) * ci * co * 2
             acc['conv5_igemm'][1] += 1
@@ -325,8 +329,8 @@ def main():
     torch.cuda.synchronize()
     train_prof = {}
     if not args.no_prof and rank == 0:
-        for kind in ('conv5_ws', 'conv5_igemm', 'deep_mode', 'conv5_deep', 'conv5_thin', 'conv5_wgrad', 'gatrep_fwd', 'gatrep_bwd',
-                     HELPER_KIND):
+        for kind in ('conv5_ws', 'conv5_igemm', 'deep_mode', 'deep_mode_dgrad', 'conv5_deep', 'conv5_thin', 'conv5_wgrad', 'gatrep_fwd',
+                     'gatrep_bwd', HELPER_KIND):
             train_prof[kind] = _lib.prof_summary(kind)
         train_recs = _lib.prof_records() if args.dump_launches else None
     _lib.prof_enable(False)
@@ -436,13 +440,15 @@ def main():
             n, ms, flops = (sum(v) for v in zip(*(train_prof[k] for k in MAIN_KINDS)))
             achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             peak = PEAK_TFLOPS[args.dtype]
-            tr_parts = [(pmc_traffic(k, b, args.dtype), train_prof[k][0]) for k in MAIN_KINDS if train_prof[k][0]]
+            # (the PMC passes know kernel SYMBOLS: both directions of deep_mode_kernel share one per-launch average)
+            tr_parts = [(pmc_traffic({'deep_mode_dgrad': 'deep_mode'}.get(k, k), b, args.dtype), train_prof[k][0])
+                        for k in MAIN_KINDS if train_prof[k][0]]
             traffic_file = next((t[1] for t, _ in tr_parts if t[1]), None)
             traffic = None
             if tr_parts and all(t[0] for t, _ in tr_parts):
                 traffic = sum(t[0] * c for t, c in tr_parts) / sum(c for _, c in tr_parts)
             nslots = len(set(task.tolist()))
-            alg = conv_algorithmic_bytes(b, nslots, train_prof['deep_mode'][0] > 0)
+            alg = conv_algorithmic_bytes(b, nslots, train_prof['deep_mode'][0] + train_prof['deep_mode_dgrad'][0] > 0)
             alg_bytes = sum(alg[k][0] for k in MAIN_KINDS)
             alg_n = max(sum(alg[k][1] for k in MAIN_KINDS), 1)
             # the filter gradient -- the step's largest kernel family after conv5_ws -- beside them: its launches per profiled
@@ -450,23 +456,40 @@ def main():
             wg_n = train_prof['conv5_wgrad'][0]
             alg['conv5_wgrad'] = (conv5_wgrad_algorithmic_bytes(b, nslots) * max(profiled_steps, 1), wg_n)
             by_kernel = {}
-            for k in ('conv5_ws', 'deep_mode', 'conv5_igemm', 'conv5_wgrad'):
-                kn, kms, kfl = train_prof[k]
-                if kn:
-                    ab, an = alg[k]
-                    ktr = pmc_traffic(k, b, args.dtype)[0]
-                    by_kernel[KERNEL_SYMBOL[k]] = {'launches': kn, 'avg_launch_ms': kms / kn, 'achieved': kfl / (kms * 1e-3) / 1e12,
-                                                   'frac': kfl / (kms * 1e-3) / 1e12 / peak, 'traffic': ktr,
-                                                   'algorithmic_bytes_per_launch': ab / max(an, 1),
-                                                   'traffic_over_algorithmic': (ktr / (ab / an)) if ktr and an else None}
-            out['roofline'] = {'kernel': ' + '.join(KERNEL_SYMBOL[k] for k in MAIN_KINDS if train_prof[k][0]) +
+
+            def entry(kinds_, traffic_kind):
+                kn, kms, kfl = (sum(v) for v in zip(*(train_prof[k] for k in kinds_)))
+                if not kn:
+                    return None
+                ab, an = sum(alg[k][0] for k in kinds_), sum(alg[k][1] for k in kinds_)
+                ktr = pmc_traffic(traffic_kind, b, args.dtype)[0] if traffic_kind else None
+                return {'launches': kn, 'avg_launch_ms': kms / kn, 'achieved': kfl / (kms * 1e-3) / 1e12,
+                        'frac': kfl / (kms * 1e-3) / 1e12 / peak, 'traffic': ktr, 'algorithmic_bytes_per_launch': ab / max(an, 1),
+                        'traffic_over_algorithmic': (ktr / (ab / an)) if ktr and an else None}
+            for sym, kinds_, tk in (('conv5_ws_kernel', ('conv5_ws',), 'conv5_ws'),
+                                    ('deep_mode_kernel', ('deep_mode', 'deep_mode_dgrad'), 'deep_mode'),
+                                    ('conv5_igemm_kernel', ('conv5_igemm',), 'conv5_igemm'),
+                                    ('conv5_wgrad_bf16_kernel', ('conv5_wgrad',), 'conv5_wgrad')):
+                e = entry(kinds_, tk)
+                if e:
+                    by_kernel[sym] = e
+            if 'deep_mode_kernel' in by_kernel:
+                # (the PMC pass cannot tell the two directions of one kernel symbol apart: no traffic on the halves)
+                by_kernel['deep_mode_kernel']['forward'] = entry(('deep_mode',), None)
+                by_kernel['deep_mode_kernel']['data_gradient'] = entry(('deep_mode_dgrad',), None)
+            r4n, r4ms, r4fl = (sum(v) for v in zip(*(train_prof[k] for k in ROUND4_SCOPE)))
+            out['roofline'] = {'kernel': ' + '.join(dict.fromkeys(KERNEL_SYMBOL[k] for k in MAIN_KINDS if train_prof[k][0])) +
                                          ' (the MoDE convolution, forward and data gradient, of every block but the one-channel ends)',
                                'by_kernel': by_kernel, 'bound': 'mfma', 'achieved': achieved, 'peak': peak,
                                'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_file,
                                'launches': n, 'avg_launch_ms': ms / max(n, 1),
                                'flops_per_launch': flops / max(n, 1),
                                'algorithmic_bytes_per_launch': alg_bytes / alg_n,
-                               'traffic_over_algorithmic': (traffic / (alg_bytes / alg_n)) if traffic else None}
+                               'traffic_over_algorithmic': (traffic / (alg_bytes / alg_n)) if traffic else None,
+                               'round4_scope': {'what': "rounds 1-4 quoted `roofline` over conv5_ws + the per-expert levels' FORWARD "
+                                                        'launches only (their data gradient ran in conv5_deep, outside the figure): '
+                                                        'the same scope on this build, for comparison with BENCH_r01..r04',
+                                                'launches': r4n, 'frac': (r4fl / (r4ms * 1e-3) / 1e12 / peak) if r4ms > 0 else None}}
             # all forward / data-gradient convolution kernels together (the dominant one above + the deep levels' + the thin layers')
             n_a, ms_a, fl_a = (sum(v) for v in zip(*(train_prof[k] for k in CONV_KINDS)))
             out['roofline']['all_conv_kernels'] = {'kernels': [k for k in CONV_KINDS if train_prof[k][0]], 'launches': n_a,

@@ -536,9 +536,10 @@ int repmode_expert_frags_refresh_multi(int nblocks, const float* const* k5, cons
 #define REPMODE_PROF_CONV5_DEEP 5 /* conv5_deep (per-expert formulation, deep levels) */
 #define REPMODE_PROF_CONV5_THIN 6 /* the one-channel first / last layers' own kernels */
 #define REPMODE_PROF_CONV5_WS 7   /* conv5_ws_kernel / conv5_pipe_kernel: the wide levels' pipelined convolution (conv5_igemm.hip) */
-#define REPMODE_PROF_DEEP_MODE 8  /* deep_mode_kernel: a per-expert MoDE block of the deep levels, one launch per direction */
+#define REPMODE_PROF_DEEP_MODE 8  /* deep_mode_kernel, forward: a per-expert MoDE block of the deep levels in one launch */
 #define REPMODE_PROF_HELPER 9     /* the MoDE blocks' small kernels: box sums, gemm3, expert_mix, gate softmax, expert layout */
-#define REPMODE_PROF_KINDS 10
+#define REPMODE_PROF_DEEP_MODE_DGRAD 10 /* deep_mode_kernel, data gradient */
+#define REPMODE_PROF_KINDS 11
 int repmode_prof_enable(int on);
 /* Suspend (1) / resume (0) recording; the records so far are kept (sampling a subset of the steps). */
 int repmode_prof_pause(int paused);

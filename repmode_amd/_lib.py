@@ -196,7 +196,7 @@ def device_arch(dev=0):
 
 
 PROF_KINDS = {'conv5_igemm': 0, 'conv5_wgrad': 1, 'gatrep_fwd': 2, 'gatrep_bwd': 3, 'conv5_wgrad_thin': 4, 'conv5_deep': 5,
-              'conv5_thin': 6, 'conv5_ws': 7, 'deep_mode': 8, 'helper': 9}
+              'conv5_thin': 6, 'conv5_ws': 7, 'deep_mode': 8, 'helper': 9, 'deep_mode_dgrad': 10}
 
 
 def prof_enable(on):

@@ -199,7 +199,7 @@ extern "C" int repmode_prof_enable(int on) {
   g_prof_on = on != 0;
   // 2: the forward / data-gradient convolution kernels only (least perturbation)
   g_prof_mask = (on == 2) ? ((1u << REPMODE_PROF_CONV5) | (1u << REPMODE_PROF_CONV5_DEEP) | (1u << REPMODE_PROF_CONV5_THIN) | (1u << REPMODE_PROF_CONV5_WS) |
-                               (1u << REPMODE_PROF_WGRAD) | (1u << REPMODE_PROF_WGRAD_THIN) | (1u << REPMODE_PROF_DEEP_MODE)) : ~0u;
+                               (1u << REPMODE_PROF_WGRAD) | (1u << REPMODE_PROF_WGRAD_THIN) | (1u << REPMODE_PROF_DEEP_MODE) | (1u << REPMODE_PROF_DEEP_MODE_DGRAD)) : ~0u;
   g_prof_open = false;
   g_prof_paused = false;
   return REPMODE_OK;

@@ -595,7 +595,7 @@ int launch_dm(DmArgs a, const DmPlan& p, bool hosts_tail, double alg, hipStream_
     RM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&deep_mode_kernel<C, FWD>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
   }
-  repmode_prof_begin(REPMODE_PROF_DEEP_MODE, alg, stream);
+  repmode_prof_begin(FWD ? REPMODE_PROF_DEEP_MODE : REPMODE_PROF_DEEP_MODE_DGRAD, alg, stream);
   hipLaunchKernelGGL((deep_mode_kernel<C, FWD>), dim3((unsigned)grid), dim3(64 * p.nw), lds_bytes, stream, a);
   repmode_prof_end(stream);
   RM_LAUNCH_CHECK("deep_mode");
