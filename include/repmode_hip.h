@@ -374,6 +374,12 @@ int repmode_expert_mix_bwd(const float* dy, const float* p, const float* g, floa
  * batched GEMMs behind them hit a pathological rocBLAS kernel at exactly 256 x 256 outputs). */
 int repmode_expert_mix_bwd_ex(const float* dy, const float* p, const float* g, float* dg, void* dye_lo,
                               float* dye_hi, long hi_stride, int n, long v, int c, int dtype, void* stream);
+/* expert_mix_bwd and the avg-pool experts' operands of repmode_deep_mode_dgrad in ONE launch: besides everything
+ * repmode_expert_mix_bwd_ex writes, hb3 = g[n][3] * box3(dy) / 27 and hb5 = g[n][4] * box5(dy) / 125, float [n][d][h][w][c] each
+ * (= repmode_box_pair of dye_hi[1], dye_hi[2]: the gate probability is constant over a sample's voxels, so the box means are
+ * taken of dy itself and need not wait for the gate-scaled tensors).  c % 4 == 0 and a volume that fits in LDS. */
+int repmode_expert_mix_bwd_box(const float* dy, const float* p, const float* g, float* dg, void* dye_lo, float* dye_hi,
+                               long hi_stride, float* hb3, float* hb5, int n, int d, int h, int w, int c, int dtype, void* stream);
 
 /* ---- the three 1x1x1 experts (conv1x1, avg3x3, avg5x5: RepMode.py:135-142, 175-180) of the per-expert formulation as
  * three small float32 GEMMs in one launch:  C_i[m][n] = sum_k A_i(m, k) * B_i(n, k),  i = 0..2,

@@ -82,6 +82,7 @@ _SIGNATURES = {
     'repmode_expert_mix_fwd': [_P, _P, _P, _I, _c.c_long, _I, _P],
     'repmode_expert_mix_bwd': [_P, _P, _P, _P, _P, _P, _I, _c.c_long, _I, _I, _P],
     'repmode_expert_mix_bwd_ex': [_P, _P, _P, _P, _P, _P, _c.c_long, _I, _c.c_long, _I, _I, _P],
+    'repmode_expert_mix_bwd_box': [_P, _P, _P, _P, _P, _P, _c.c_long, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'repmode_gemm3': [_P, _c.c_long, _c.c_long, _P, _c.c_long, _c.c_long, _P, _I, _I, _I, _I, _I, _I, _P],
     'repmode_box_expand': [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     'repmode_box_pair': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -301,10 +301,11 @@ int64_t g_deep_fwd_min = []() {
 // A per-expert block as ONE launch per direction (csrc/deep_mode.hip: the five experts, the gate mix and the cross-wave
 // reduction in one kernel; round 5) where repmode_deep_mode_plan takes the shape; REPMODE_DEEP_MODE=0 / set_deep_mode(0):
 // round 4's five launches (conv5_deep / dual-expert launch + box + gemm3 + expert_mix).  Bit 0: forward, bit 1: data gradient,
-// bit 2: the forward also leaves the BatchNorm statistics of its output (no statistics pass behind a per-expert block).
+// bit 2: the forward also leaves the BatchNorm statistics of its output (no statistics pass behind a per-expert block); bit 3:
+// the data gradient's box-mean operands come out of the gate mix's backward launch (no box launch).
 int64_t g_deep_mode = []() {
   const char* e = std::getenv("REPMODE_DEEP_MODE");
-  return e ? (int64_t)std::atoi(e) : (int64_t)7;
+  return e ? (int64_t)std::atoi(e) : (int64_t)15;
 }();
 bool g_dual_wgrad = []() {          // (REPMODE_DUAL_WGRAD=0: the two filter gradients of a per-expert block as two launches)
   const char* e = std::getenv("REPMODE_DUAL_WGRAD");
@@ -1022,9 +1023,26 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     Tensor dg = tdg.first;
     Tensor lo = at::empty({2, n, d, h, w, co}, x_cl.options().dtype(dt));
     Tensor hi = at::empty({3, m, co}, x_cl.options().dtype(at::kFloat));
-    RM_CALL(repmode_expert_mix_bwd_ex, dy.data_ptr<float>(), p.data_ptr<float>(), gn.data_ptr<float>(), dg.data_ptr<float>(), lo.data_ptr(),
-            hi.data_ptr<float>(), (long)((m + pad) * co), (int)n, (long)(d * h * w), (int)co, dtype_code(dt) | (tdg.second ? 16 : 0),
-            stream_handle());
+    // one-launch data gradient ahead (deep_mode.hip): the avg-pool experts' box-mean operands come out of the SAME launch as the
+    // gate mix's backward (both read dy and nothing of each other; bit 3 of REPMODE_DEEP_MODE off: box_pair as its own launch)
+    const bool need_dx_early = ctx->needs_input_grad(0) && wd2.defined();
+    const int dmb = (need_dx_early && (g_deep_mode & 2) && dt == at::kBFloat16)
+                        ? repmode_deep_mode_plan(1, (int)n, (int)d, (int)h, (int)w, (int)ci, (int)co, REPMODE_BF16) : 0;
+    Tensor hb;
+    bool hb_done = false;
+    if (dmb) {
+      hb = at::empty({2, m, co}, x_cl.options().dtype(at::kFloat));
+      if ((g_deep_mode & 8) && (co & 3) == 0 && d * h * w * 16 * 16 <= 64 * 1024) {
+        RM_CALL(repmode_expert_mix_bwd_box, dy.data_ptr<float>(), p.data_ptr<float>(), gn.data_ptr<float>(), dg.data_ptr<float>(), lo.data_ptr(),
+                hi.data_ptr<float>(), (long)((m + pad) * co), hb[0].data_ptr<float>(), hb[1].data_ptr<float>(), (int)n, (int)d, (int)h, (int)w,
+                (int)co, dtype_code(dt) | (tdg.second ? 16 : 0), stream_handle());
+        hb_done = true;
+      }
+    }
+    if (!hb_done)
+      RM_CALL(repmode_expert_mix_bwd_ex, dy.data_ptr<float>(), p.data_ptr<float>(), gn.data_ptr<float>(), dg.data_ptr<float>(), lo.data_ptr(),
+              hi.data_ptr<float>(), (long)((m + pad) * co), (int)n, (long)(d * h * w), (int)co, dtype_code(dt) | (tdg.second ? 16 : 0),
+              stream_handle());
     Tensor dgw = at::empty({E * co, num_tasks}, k5.options());
     Tensor dgb = at::empty({E * co}, k5.options());
     Tensor s0 = single_slot(n, 0, x_cl), s1 = single_slot(n, 1, x_cl);
@@ -1092,14 +1110,12 @@ struct ModeConvUnmerged : public torch::autograd::Function<ModeConvUnmerged> {
     }
     fork.to_main();
     Tensor dx;
-    const int dmb = (need_dx && (g_deep_mode & 2) && dt == at::kBFloat16)
-                        ? repmode_deep_mode_plan(1, (int)n, (int)d, (int)h, (int)w, (int)ci, (int)co, REPMODE_BF16) : 0;
     if (dmb) {
       // ONE launch: all five experts' data gradients into one accumulator (csrc/deep_mode.hip).  The avg experts' parts go
       // through the box means of their gate-scaled output gradients (the box mean commutes with the 1x1 channel mixing).
-      Tensor hb = at::empty({2, m, co}, x_cl.options().dtype(at::kFloat));
-      RM_CALL(repmode_box_pair, hi[1].data_ptr<float>(), hi[2].data_ptr<float>(), hb[0].data_ptr<float>(), hb[1].data_ptr<float>(), (int)n,
-              (int)d, (int)h, (int)w, (int)co, stream_handle());
+      if (!hb_done)
+        RM_CALL(repmode_box_pair, hi[1].data_ptr<float>(), hi[2].data_ptr<float>(), hb[0].data_ptr<float>(), hb[1].data_ptr<float>(), (int)n,
+                (int)d, (int)h, (int)w, (int)co, stream_handle());
       Tensor dxo;
       if (dmb == 1) {
         dxo = at::empty({n, d, h, w, ci}, x_cl.options().dtype(dt));
