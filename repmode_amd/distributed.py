@@ -76,7 +76,10 @@ def wrap_ddp(net, device=None, grad_compress=None):
 
 
 XGMI_LINK_GBPS = 153.0      # one xGMI link, per direction (MI355X: 7 links per GPU, point to point)
-COMPRESS_IF_RING_OVER = 0.6  # of the measured backward pass
+# of the measured backward pass (REPMODE_COMPRESS_IF_RING_OVER: another fraction; 0 = always compress)
+COMPRESS_IF_RING_OVER = float(os.environ.get('REPMODE_COMPRESS_IF_RING_OVER', '0.6'))
+# transports the link model speaks for (REPMODE_GRAD_RULE_BACKENDS=nccl,gloo lets a one-GPU box walk the rule's bf16 branch)
+RULE_BACKENDS = tuple(os.environ.get('REPMODE_GRAD_RULE_BACKENDS', 'nccl').split(','))
 
 
 def ring_allreduce_ms(nbytes, world, link_gbps=XGMI_LINK_GBPS):
@@ -90,7 +93,7 @@ def pick_grad_dtype(grad_bytes_fp32, world, backward_ms, backend):
     """The rule that chooses the gradient buckets' dtype: bfloat16 when the per-link ring estimate of
     the float32 all-reduce exceeds COMPRESS_IF_RING_OVER of the measured backward pass -- it could no longer hide under it
     -- and the transport is RCCL (the link model is xGMI's; gloo keeps float32).  Returns 'bf16' or None."""
-    if backend != 'nccl' or world <= 1 or backward_ms <= 0:
+    if backend not in RULE_BACKENDS or world <= 1 or backward_ms <= 0:
         return None
     return 'bf16' if ring_allreduce_ms(grad_bytes_fp32, world) > COMPRESS_IF_RING_OVER * backward_ms else None
 

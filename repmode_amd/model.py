@@ -237,6 +237,7 @@ class Model(object):
             if self.reducer is not None:
                 self.reducer.comm_dtype = torch.bfloat16
             elif self.ddp is not None:
+                self.ddp = None             # (the float32 wrapper's autograd hooks go before the next one registers its own)
                 self.ddp = dist_.wrap_ddp(self.net, self.device, grad_compress='bf16')      # (the comm hook is fixed at construction)
 
     def loss_log(self):

@@ -48,6 +48,14 @@ def _worker(rank, world, port, out_dir, how='ddp'):
     tasks = torch.tensor([1, 4, 4, 9])
     lo, hi = dist_.shard_batch(4, rank, world)
     ddp.train()
+    if how == 'ddp-rewrap-bf16':
+        # what Model._apply_grad_dtype_rule does when the rule picks bfloat16 after the first steps: a float32 wrapper has
+        # run (the gradients are views of ITS buckets), it is dropped and a bfloat16 one built over the same network
+        torch.nn.functional.mse_loss(ddp(x[lo:hi], tasks[lo:hi]), t[lo:hi]).backward()
+        net.zero_grad(set_to_none=True)
+        ddp = None
+        ddp = dist_.wrap_ddp(net, None, grad_compress='bf16')
+        ddp.train()
     loss = torch.nn.functional.mse_loss(ddp(x[lo:hi], tasks[lo:hi]), t[lo:hi])
     loss.backward()
     if not how.startswith('ddp'):
@@ -62,7 +70,7 @@ def _worker(rank, world, port, out_dir, how='ddp'):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('how', ['reducer', 'ddp', 'reducer-bf16', 'ddp-bf16'])
+@pytest.mark.parametrize('how', ['reducer', 'ddp', 'reducer-bf16', 'ddp-bf16', 'ddp-rewrap-bf16'])
 def test_two_rank_ddp_equals_single_process(tmp_path, how):
     world = 2
     mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), how), nprocs=world, join=True,

@@ -143,16 +143,21 @@ def test_reducer_buckets_hold_the_kernels_gradients_single_process():
 
 
 @pytest.mark.timeout(900)
-def test_bench_two_ranks_share_one_gpu():
+@pytest.mark.parametrize('rule', ['as measured', 'bf16 branch'])
+def test_bench_two_ranks_share_one_gpu(rule):
     """bench.py's N > 1 branch (BASELINE configs[3]'s code path: one process per rank through torch.distributed.run, the
     DistributedDataParallel step, the max-over-ranks clock, the no_sync() leg behind ``config.no_comm_value``, ``config.comm``)
     on a one-GPU box: both ranks on cuda:0 over gloo (REPMODE_BENCH_SHARE_GPU=1 -- a check of the code path, never a
-    measurement).  The line must parse and describe a two-rank job."""
+    measurement).  The line must parse and describe a two-rank job.  'bf16 branch': the buckets' dtype rule is made to pick
+    bfloat16 (threshold 0, gloo admitted), so that the wrapper is rebuilt mid-run -- in the steps before the timed region --
+    and the remaining steps travel as bfloat16: the branch an 8-GPU job takes at 8 patches per rank."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, REPMODE_BENCH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if rule == 'bf16 branch':
+        env.update(REPMODE_COMPRESS_IF_RING_OVER='0', REPMODE_GRAD_RULE_BACKENDS='nccl,gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '1',
            '--batch', '2', '--no-cpu-baseline', '--no-fwd']
@@ -169,6 +174,12 @@ def test_bench_two_ranks_share_one_gpu():
     assert cfg['no_comm_value'] > 0 and cfg['no_comm_ms_per_step'] > 0
     comm = cfg['comm']
     assert comm['backend'] == 'gloo' and comm['world_size'] == 2 and comm['ranks_seen'] == 2
-    assert comm['scheme'] == 'DistributedDataParallel' and comm['bucket_mb'] == 48 and comm['dtype'] == 'f32'
-    assert comm['dtype_rule'].startswith('auto')                 # (gloo keeps float32: the link model is xGMI's)
+    assert comm['scheme'] == 'DistributedDataParallel' and comm['bucket_mb'] == 48
+    assert comm['dtype_rule'].startswith('auto: ring estimate')  # (the rule ran: in the 3 setup steps + 1 warmup step)
+    assert cfg['setup_steps_before_warmup'] == 3
+    if rule == 'bf16 branch':
+        assert comm['dtype'] == 'bf16' and comm['dtype_rule'].endswith('-> bf16')
+    else:
+        assert comm['dtype'] == 'f32' and comm['dtype_rule'].endswith('-> float32')    # (gloo: the link model is xGMI's)
+    assert 0 < cfg['final_loss'] < 10
     assert abs(comm['grad_bytes_fp32'] - 4 * 123877633) < 8
