@@ -15,7 +15,10 @@ Workloads (BASELINE.json ``configs``):
           over RCCL under backward.  Per-GPU work is the same at N = 2, 4, 8 (weak scaling); it is NOT the N = 1
           line's batch, so the line also carries ``config.no_comm_value``: the same ranks, same batch, same run,
           stepping WITHOUT the gradient all-reduce -- the denominator for the collectives' cost at this batch
-          (``value / no_comm_value`` is the scaling efficiency that the N = 1 line cannot give).
+          (``value / no_comm_value`` is the scaling efficiency that the N = 1 line cannot give).  ``config.comm``: what the
+          process group looked like (backend, ranks a collective saw, buckets, their dtype and the rule that chose it).
+          The rule (distributed.pick_grad_dtype) reads the first four distributed steps: with a shorter --warmup the
+          missing ones run as setup BEFORE the warmup (``config.setup_steps_before_warmup``), never inside the timed region.
   ``--batch B`` overrides the per-GPU batch for either.
 
 Also reported in the same line:
