@@ -514,6 +514,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
+        barrier()               # (rank 0 prints after its forward-only leg: every rank leaves the group together)
         torch.distributed.destroy_process_group()
 
 

@@ -160,7 +160,9 @@ def test_bench_two_ranks_share_one_gpu(rule):
         env.update(REPMODE_COMPRESS_IF_RING_OVER='0', REPMODE_GRAD_RULE_BACKENDS='nccl,gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '1',
-           '--batch', '2', '--no-cpu-baseline', '--no-fwd']
+           '--batch', '2', '--no-cpu-baseline']
+    if rule == 'bf16 branch':
+        cmd.append('--no-fwd')          # ('as measured' keeps rank 0's forward-only leg: the other rank waits for it at the final barrier)
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -182,4 +184,5 @@ def test_bench_two_ranks_share_one_gpu(rule):
     else:
         assert comm['dtype'] == 'f32' and comm['dtype_rule'].endswith('-> float32')    # (gloo: the link model is xGMI's)
     assert 0 < cfg['final_loss'] < 10
+    assert ('fwd' in d) == (rule == 'as measured')
     assert abs(comm['grad_bytes_fp32'] - 4 * 123877633) < 8
