@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define REPMODE_ABI_VERSION 10
+#define REPMODE_ABI_VERSION 11
 
 /* element types of activations / merged filters */
 #define REPMODE_F32 0  /* float in, exact-f32 MFMA (v_mfma_f32_32x32x2_f32)          */
@@ -501,6 +501,15 @@ int repmode_conv5_elem_out(int n, int d, int h, int w, int cin, int cout, int dt
  * range is split over workgroups (float atomics) follows the form. */
 int repmode_set_wgrad_ws(int mode);
 int repmode_get_wgrad_ws(void);
+/* The column-walking form of the same filter gradient (csrc/conv5_wgrad_col.hip; also REPMODE_WGRAD_COL; ABI 11): a workgroup
+ * owns ALL 125 taps of a (slot, 16 co, 16 ci) tile and walks columns of output tiles along z with a ring of six x planes in LDS,
+ * so x and dy are staged once per z step instead of once per (z step, dz plane).  bf16, slot layout, all five planes, volumes
+ * >= 16 voxels wide, at most 64 samples; never in deterministic mode.  0 never, 1 (default) on the shapes it was measured to
+ * win (volumes 16 .. 31 voxels wide with enough (slot, co, ci) units to fill three quarters of the chip), 2 wherever eligible.
+ * With that many units a workgroup takes whole units and every element is written by plain stores (repmode_conv5_wgrad_plan
+ * reports it); otherwise workgroups share units through float atomics onto the cleared dw. */
+int repmode_set_wgrad_col(int mode);
+int repmode_get_wgrad_col(void);
 
 /* ---- sliding-window inference (fnet/fnet_model.py:149-223): the two ends of a batch of patches, SURVEY.md section 8f.3 ----
  * patch_gather: :196-205 -- out[n][pd][ph][pw] = vol[starts[3n..3n+2] + (z, y, x)], the batch's crops of the device-resident

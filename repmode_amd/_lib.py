@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('REPMODE_LIB') or os.path.join(_HERE, 'librepmode_hip.
 
 F32, BF16 = 0, 1
 DEFER = 1        # REPMODE_DEFER: queue the job for the next conv5 launch on the stream (include/repmode_hip.h)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c = ctypes
 _P = _c.c_void_p
@@ -39,6 +39,8 @@ _SIGNATURES = {
     'repmode_adam_expert_frags_dev': [_I] + [_P] * 12 + [_P, _P],
     'repmode_set_wgrad_ws': [_I],
     'repmode_get_wgrad_ws': [],
+    'repmode_set_wgrad_col': [_I],
+    'repmode_get_wgrad_col': [],
     'repmode_padded_channels': [_I, _I, _I],
     'repmode_gate_softmax': [_P, _P, _P, _I, _I, _I, _P, _P],
     'repmode_gate_softmax_multi': [_I, _P, _P, _P, _P, _I, _I, _P, _P],

@@ -13,7 +13,7 @@ objs=()
 for f in "$HERE"/*.hip; do
   o="$BUILD/$(basename "${f%.hip}").o"
   objs+=("$o")
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$HERE/tail_jobs.h" -nt "$o" ] || [ "$HERE/box_body.h" -nt "$o" ] || [ "$ROOT/include/repmode_hip.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$HERE/tail_jobs.h" -nt "$o" ] || [ "$HERE/box_body.h" -nt "$o" ] || [ "$HERE/wgrad_col.h" -nt "$o" ] || [ "$ROOT/include/repmode_hip.h" -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi

@@ -15,6 +15,7 @@
 // in different bank halves) and issues 25 MFMAs per 4-voxel K step.  Partial sums are added to dw
 // with f32 atomics (split-K over voxel chunks and over the samples of a slot).
 #include "common.h"
+#include "wgrad_col.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -1035,6 +1036,17 @@ extern "C" int repmode_conv5_wgrad_part(const void* x, const void* dy, const int
   a.layout = centre3 == 2 ? 1 : (centre3 == 3 ? 2 : 0);
   if (dtype == REPMODE_BF16) {
     RM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0, "conv5_wgrad: pointers must be 16-byte aligned");
+    if (centre3 == 0) {
+      // the column walk (csrc/conv5_wgrad_col.hip): a workgroup owns all 125 taps of a (slot, 16 co, 16 ci) tile
+      const WgColCall cc{x, dy, sample_slot, dw, n, d, h, wdim, cin, cout, cin_total, ci_off, nslots, a.prezeroed, nullptr};
+      if (repmode_wgrad_col_eligible(cc)) {
+        const int rc = repmode_wgrad_col_launch(cc, s);
+        if (rc != REPMODE_OK) return rc;
+        repmode_prof_end(s);
+        RM_LAUNCH_CHECK("conv5_wgrad_col");
+        return REPMODE_OK;
+      }
+    }
     int rc;
     if (wdim >= 32 && h >= 8) rc = launch_wgrad_bf16<1, 8, 32>(a, n, s);
     else if (wdim >= 32) rc = launch_wgrad_bf16<1, 4, 32>(a, n, s);
@@ -1078,6 +1090,10 @@ extern "C" int repmode_conv5_wgrad_plan(int nslots, int n, int d, int h, int wdi
   static const int enabled = []() { const char* e = getenv("REPMODE_WGRAD_PLAN"); return e ? atoi(e) : 1; }();   // (0: always a cleared buffer, for A/B)
   if (!enabled || dtype != REPMODE_BF16 || centre3 > 1) return REPMODE_OK;          // (float32 parity path / expert layouts: keep the cleared buffer)
   static const int32_t dummy_slot = 0;
+  if (centre3 == 0) {
+    WgColCall cc{nullptr, nullptr, &dummy_slot, nullptr, n, d, h, wdim, cin, cout, cin, 0, nslots, 0, direct};
+    if (repmode_wgrad_col_eligible(cc)) return repmode_wgrad_col_launch(cc, nullptr);
+  }
   WgradArgs a{};
   a.sample_slot = &dummy_slot;            // (only tested for NULL by the planner)
   a.N = n; a.D = d; a.H = h; a.W = wdim; a.Cin = cin; a.Cout = cout;

@@ -1,0 +1,529 @@
+// conv5_wgrad_col.hip -- the filter gradient of the merged 5x5x5 convolution (autograd of fnet/nn_modules/RepMode.py:207,
+// aten::convolution_backward weight grad) as a COLUMN WALK: one workgroup owns ALL 125 taps of a (slot, 16 co, 16 ci) tile
+// and walks a column of output tiles along z, so that x and dy cross HBM / L2 -> LDS once per z step instead of once per
+// (z step, dz plane) as in conv5_wgrad.hip's units (one dz plane each: VERDICT round 5, item 1).
+//
+//     dw[slot][tap][co][ci] = sum_{n in slot} sum_v dy[n][v][co] * x[n][v + tap][ci]
+//
+// * Unit = (slot, 16 output channels, 16 input channels): 125 accumulator tiles of v_mfma_f32_16x16x32_bf16, split over the
+//   four MFMA waves of the workgroup by contiguous tap ranges (32 / 31 / 31 / 31 tiles = 128 / 124 registers).
+// * A column is the (TY x TX) output tile at one (y, x) position of one sample for every z.  Step z of a column multiplies
+//   dy plane z with the x planes z-2 .. z+2: the x planes live in a RING of six halo planes in LDS (channel-major, the
+//   layout of conv5_wgrad.hip's xT: a tap shift along x is a register window, along y an immediate offset, along z another
+//   ring slot), the dy plane in one of two buffers.  Per step the four LOADER waves fetch and transpose ONE new x plane
+//   (16 channels) and ONE dy plane (16 channels) -- 22 KB for 1000 MFMAs; conv5_wgrad.hip's unit stages 43.6 KB for 800 --
+//   while the MFMA waves multiply; one barrier per step.  Columns follow each other without a bubble: the planes of the next
+//   column enter the ring as the last steps of the current one free its slots.
+// * A launch is ONE sequence of steps -- slots, units of a slot, samples of the slot, columns, z -- and every workgroup of a
+//   persistent grid (one per CU) takes an equal range of it (stream-K, as conv5_wgrad.hip's round-4 form).  The MFMA waves
+//   flush at the end of a unit: 16-byte plain stores when the whole unit ran in this workgroup (the operands are swapped --
+//   A = x window, B = dy -- so that a lane holds four consecutive ci of one co), float atomics onto the cleared dw otherwise.
+//   With enough units to fill the chip a workgroup takes WHOLE units (an equal range of the unit list): every flush is plain
+//   stores and dw needs no clearing (level 2 at batch 8: 512 units on 256 workgroups, the first unit's stores drain under the
+//   second unit's MFMAs).
+// * z planes outside the volume: the dz reads a plane of zeros kept beside the ring (straight-line MFMA code: a second,
+//   branching body for the edge steps cost 200-700 spilled registers; with contiguous tap ranges the busiest wave of a step
+//   has all its planes inside the volume anyway, so skipping would not shorten a step).
+#include "wgrad_col.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+int g_wgrad_col = []() { const char* e = getenv("REPMODE_WGRAD_COL"); return e ? atoi(e) : 1; }();
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int TY_, int TX_>
+struct ColTile {
+  static constexpr int TY = TY_, TX = TX_;
+  static constexpr int TV = TY * TX;                 // voxels of a tile = the K extent of a step
+  static constexpr int HY = TY + 4;
+  static constexpr int NGX = TX / 8;                 // 8-voxel groups per row
+  static constexpr int GPR = 4 / NGX;                // tile rows per K step (32 voxels)
+  static constexpr int RG = (TX + 4 + 7) / 8;        // 16-byte slots per stored halo row (x0-2 .. x0+TX+1)
+  static constexpr int KSTEPS = TV / 32;
+  static constexpr int NWROW = TY - GPR + 5;         // distinct compile-time halo-row offsets of the windows of a plane
+  static constexpr int NPAIR = TX / 2 + 2;           // x pairs of a halo row
+  static constexpr int PLANE = HY * RG * 16;         // bytes of one halo plane of one channel
+  static constexpr int RING = 6;
+  // (slot RING of a channel row is a plane of zeros: what a dz whose plane lies outside the volume reads)
+  // channel rows an odd multiple of 32 bytes apart: conflict-free ds_read_b128 (conv5_wgrad.hip, tools/lds_bank_check.py)
+  static constexpr int ROW_C = (RING + 1) * PLANE + (32 - ((RING + 1) * PLANE) % 64 + 64) % 64;
+  static constexpr int DYS = TV * 2 + 32;
+  static constexpr int DYBUF = 16 * DYS;
+  static constexpr int LDS = 16 * ROW_C + 2 * DYBUF;
+  static constexpr int NIT_X = HY * NPAIR * 2;       // x items of a plane: (halo row, x pair, channel group of 8)
+  static constexpr int NX = (NIT_X + 255) / 256;
+  static constexpr int NIT_DY = (TV / 2) * 2;        // dy items: (voxel pair, channel group of 8)
+  static constexpr int NDY = (NIT_DY + 255) / 256;
+  static_assert(TV % 32 == 0 && TX % 8 == 0 && TX <= 32 && NGX * GPR == 4 && RG >= NGX + 1, "tile shape");
+  static_assert(ROW_C % 64 == 32 && DYS % 64 == 32, "channel rows an odd multiple of 32 bytes apart");
+  static_assert(LDS <= 160 * 1024, "LDS");
+};
+
+// The taps of MFMA wave ROLE: [T0, T1) of the 125 (tap = dz * 25 + dy * 5 + dx), and which windows feed them.  Window w =
+// (dz, rr): the 12-element register window of halo row rr (+ the lane's own row) of plane dz; it feeds K step ks for the tap
+// row dy = rr - ks * GPR.
+template <typename G, int ROLE>
+struct RolePlan {
+  static constexpr int T0 = ROLE == 0 ? 0 : 32 + 31 * (ROLE - 1);
+  static constexpr int T1 = 32 + 31 * ROLE;
+  static constexpr int NT = T1 - T0;
+  static constexpr int NW = 5 * G::NWROW;
+  static constexpr bool mine(int dz, int dyi, int dxi) {
+    const int t = dz * 25 + dyi * 5 + dxi;
+    return dyi >= 0 && dyi < 5 && t >= T0 && t < T1;
+  }
+  static constexpr bool row_mine(int dz, int dyi) {
+    for (int dxi = 0; dxi < 5; ++dxi)
+      if (mine(dz, dyi, dxi)) return true;
+    return false;
+  }
+  static constexpr bool nonempty(int w) {
+    if (w < 0 || w >= NW) return false;
+    const int dz = w / G::NWROW, rr = w % G::NWROW;
+    for (int ks = 0; ks < G::KSTEPS; ++ks)
+      if (row_mine(dz, rr - ks * G::GPR)) return true;
+    return false;
+  }
+  static constexpr int next(int w) {                   // the next non-empty window behind w, -1: none
+    for (int v = w + 1; v < NW; ++v)
+      if (nonempty(v)) return v;
+    return -1;
+  }
+};
+
+struct ColArgs {
+  const bf16_t* x;
+  const bf16_t* dy;
+  const int32_t* sample_slot;
+  float* dw;
+  int N, D, H, W, Cin, Cout, CinTot, ci_off, nslots;
+  int ncot, ncit, nty, ntx, ncol;
+  long total;                    // steps of the launch: N * ncot * ncit * ncol * D
+  int aligned;                   // 1: a workgroup takes WHOLE units (an equal range of the unit list): plain stores only
+};
+
+// where a walk stands in the launch's sequence (all wave-uniform)
+struct ColCursor {
+  int slot, cot, cit, k, cnt, n, col;
+  unsigned long long mask;
+};
+
+// two x-adjacent voxels (8 channels each) -> eight 4-byte stores, one per channel row
+__device__ __forceinline__ void put8(unsigned char* dst, int stride, const u32x4& v0, const u32x4& v1) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    *reinterpret_cast<uint32_t*>(dst + (2 * j) * stride) = __builtin_amdgcn_perm(v1[j], v0[j], 0x05040100u);
+    *reinterpret_cast<uint32_t*>(dst + (2 * j + 1) * stride) = __builtin_amdgcn_perm(v1[j], v0[j], 0x07060302u);
+  }
+}
+
+template <int TY, int TX>
+__global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
+  using G = ColTile<TY, TX>;
+  constexpr int NGX = G::NGX, GPR = G::GPR, RG = G::RG, KSTEPS = G::KSTEPS, NWROW = G::NWROW, NPAIR = G::NPAIR;
+  constexpr int PLANE = G::PLANE, ROW_C = G::ROW_C, DYS = G::DYS, DYBUF = G::DYBUF, NX = G::NX, NDY = G::NDY;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
+  unsigned char* xT = smem;                            // [16 ci][6 ring planes][HY][RG * 16 B]
+  unsigned char* dyT = smem + 16 * ROW_C;              // [2][16 co][TV] bf16
+
+  const int tid = (int)(threadIdx.x & 255), lane = tid & 63, wave = tid >> 6;
+  const bool loader = threadIdx.x >= 256;
+  const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+
+  const int slot64 = a.sample_slot[min(lane, a.N - 1)];                 // (the host sends at most 64 samples here)
+  auto mask_of = [&](int sl) -> unsigned long long { return __ballot(lane < a.N && slot64 == sl); };
+  auto kth = [&](unsigned long long m, int kk) -> int {
+    for (int i = 0; i < kk; ++i) m &= m - 1;
+    return __ffsll((long long)m) - 1;
+  };
+  const int G2 = a.ncot * a.ncit, colsteps = a.ncol * D;
+  const long wg = xcd_remap(blockIdx.x, gridDim.x);    // neighbouring ranges (the same samples' planes) on one XCD
+  long g0, g1;
+  if (a.aligned) {
+    // whole units: units [U wg / G, U (wg + 1) / G) of the list (slot, cot, cit); a unit of slot s has cnt(s) * ncol * D steps
+    const long units = (long)a.nslots * G2;
+    auto steps_before = [&](long u) -> long {
+      const int su = (int)(u / G2);
+      long acc = 0;
+      for (int sl = 0; sl < su; ++sl) acc += (long)__popcll(mask_of(sl)) * colsteps * G2;
+      if (su < a.nslots) acc += (u % G2) * (long)__popcll(mask_of(su)) * colsteps;
+      return acc;
+    };
+    g0 = steps_before(units * wg / gridDim.x);
+    g1 = steps_before(units * (wg + 1) / gridDim.x);
+  } else {
+    g0 = a.total * wg / gridDim.x;
+    g1 = a.total * (wg + 1) / gridDim.x;
+  }
+  const int steps = (int)(g1 - g0);
+  if (steps <= 0) return;
+  ColCursor c0;
+  int zb;
+  {
+    long rem = g0;
+    int sl = 0, cnt;
+    unsigned long long m;
+    for (;;) {
+      m = mask_of(sl); cnt = __popcll(m);
+      const long span = (long)cnt * colsteps * G2;
+      if (rem < span) break;
+      rem -= span; ++sl;
+    }
+    const long per = (long)cnt * colsteps;
+    const int unit = (int)(rem / per);
+    rem -= (long)unit * per;
+    c0.slot = sl; c0.mask = m; c0.cnt = cnt;
+    c0.cot = unit / a.ncit; c0.cit = unit % a.ncit;
+    c0.k = (int)(rem / colsteps);
+    rem -= (long)c0.k * colsteps;
+    c0.col = (int)(rem / D);
+    zb = (int)(rem % D);
+    c0.n = kth(m, c0.k);
+  }
+  auto next_col = [&](ColCursor& c) {                  // (never called behind the launch's last column)
+    if (++c.col < a.ncol) return;
+    c.col = 0;
+    if (++c.k < c.cnt) { c.n = kth(c.mask, c.k); return; }
+    c.k = 0;
+    if (++c.cit == a.ncit) {
+      c.cit = 0;
+      if (++c.cot == a.ncot) {
+        c.cot = 0;
+        do { ++c.slot; c.mask = mask_of(c.slot); c.cnt = __popcll(c.mask); } while (c.cnt == 0 && c.slot < a.nslots);
+      }
+    }
+    c.n = kth(c.mask, 0);
+  };
+
+  if (loader) {
+    // ---- loader waves.  The stream of ELEMENTS of this workgroup's range: per column the planes p = 0 .. D + 1 (the first
+    // column from max(0, zb - 2)); element p = x plane p (p < D) + dy plane p - 2 (p >= 2).  Step (column, z) needs the
+    // elements up to z + 2.  An element is fetched two elements ahead of its transposition into LDS (register sets a / b)
+    // and staged as early as the ring allows: x plane V = column * D + p goes to ring slot V % 6 once the step the MFMA
+    // waves are at no longer reads plane V - 6 (V <= lowest plane of that step + 5), a dy plane at most one step ahead.
+    constexpr uint32_t OOB = 0x80000000u;
+    struct ElemRegs { u32x4 x0[NX], x1[NX], d0[NDY], d1[NDY]; };
+    struct ElemMeta { int hasx, hasdy, v, dystep; };
+    ElemRegs ra, rb;
+    ElemMeta ma{}, mb{};
+    // this thread's items
+    int x_hy[NX], x_px[NX], x_cg8[NX], x_dst[NX];
+    bool x_on[NX];
+#pragma unroll
+    for (int u = 0; u < NX; ++u) {
+      const int it = u * 256 + tid;
+      const int pr = it % NPAIR, r = it / NPAIR;
+      const int cg = r & 1, hy = r >> 1;
+      x_on[u] = it < G::NIT_X;
+      x_hy[u] = hy - 2; x_px[u] = 2 * pr - 2; x_cg8[u] = cg * 8;
+      x_dst[u] = (cg * 8) * ROW_C + (hy * RG + (pr >> 2)) * 16 + (pr & 3) * 4;
+    }
+    int d_yy[NDY], d_xx[NDY], d_cg8[NDY], d_dst[NDY];
+    bool d_on[NDY];
+#pragma unroll
+    for (int u = 0; u < NDY; ++u) {
+      const int it = u * 256 + tid;
+      const int q = it % (G::TV / 2), cg = it / (G::TV / 2);
+      d_on[u] = it < G::NIT_DY;
+      d_xx[u] = (2 * q) % TX; d_yy[u] = (2 * q) / TX; d_cg8[u] = cg * 8;
+      d_dst[u] = (cg * 8) * DYS + q * 4;
+    }
+    const uint32_t xbytes = (uint32_t)((size_t)D * H * W * Cin * 2), dybytes = (uint32_t)((size_t)D * H * W * Cout * 2);
+
+    // fetch cursor = the next element of the stream
+    ColCursor fc = c0;
+    int fp = max(0, zb - 2), fzs = zb, ebase = -zb, fcoD = 0;
+    auto elem_needed = [&]() -> bool { return ebase + max(fzs, fp - 2) <= steps - 1; };
+    auto elem_advance = [&]() {
+      if (++fp <= D + 1) return;
+      fp = 0; ebase += D; fzs = 0; fcoD += D;
+      if (ebase <= steps - 1) next_col(fc);            // (a column behind the range is never decoded)
+    };
+    auto fetch_to = [&](ElemRegs& r, ElemMeta& m) {
+      m.hasx = fp < D;
+      m.hasdy = fp >= 2 && fp - 2 >= fzs;
+      m.v = fcoD + fp;
+      m.dystep = ebase + fp - 2;
+      const int y0 = (fc.col / a.ntx) * TY, x0 = (fc.col % a.ntx) * TX;
+      if (m.hasx) {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(a.x) + (size_t)fc.n * D * H * W * Cin, 0, (int)xbytes, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+          const int gy = y0 + x_hy[u], gx = x0 + x_px[u], c = fc.cit * 16 + x_cg8[u];
+          const bool row_ok = x_on[u] && (unsigned)gy < (unsigned)H && c < Cin;
+          const uint32_t off = (uint32_t)((((fp * H + gy) * W + gx) * Cin + c) * 2);
+          r.x0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                      rx, (row_ok && (unsigned)gx < (unsigned)W) ? off : OOB, 0, 0));
+          r.x1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                      rx, (row_ok && (unsigned)(gx + 1) < (unsigned)W) ? off + (uint32_t)Cin * 2 : OOB, 0, 0));
+        }
+      }
+      if (m.hasdy) {
+        const int z = fp - 2;
+        const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(a.dy) + (size_t)fc.n * D * H * W * Cout, 0, (int)dybytes, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) {
+          const int gy = y0 + d_yy[u], gx = x0 + d_xx[u], c = fc.cot * 16 + d_cg8[u];
+          const bool row_ok = d_on[u] && gy < H && c < Cout;
+          const uint32_t off = (uint32_t)((((z * H + gy) * W + gx) * Cout + c) * 2);
+          r.d0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (row_ok && gx < W) ? off : OOB, 0, 0));
+          r.d1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                      rdy, (row_ok && gx + 1 < W) ? off + (uint32_t)Cout * 2 : OOB, 0, 0));
+        }
+      }
+    };
+    auto stage_from = [&](ElemRegs& r, const ElemMeta& m) {
+      if (m.hasx) {
+        unsigned char* base = xT + (m.v % G::RING) * PLANE;
+#pragma unroll
+        for (int u = 0; u < NX; ++u)
+          if (x_on[u]) put8(base + x_dst[u], ROW_C, r.x0[u], r.x1[u]);
+      }
+      if (m.hasdy) {
+        unsigned char* base = dyT + (m.dystep & 1) * DYBUF;
+#pragma unroll
+        for (int u = 0; u < NDY; ++u)
+          if (d_on[u]) put8(base + d_dst[u], DYS, r.d0[u], r.d1[u]);
+      }
+    };
+    // the step the MFMA waves are at during interval i (i = -1: the prologue, nobody reads yet -- same bound as step 0)
+    int scoD = 0, sz = zb, szs = max(0, zb - 2);
+    auto allowed = [&](const ElemMeta& m, int i) -> bool {
+      const int lo = scoD + max(sz - 2, szs);
+      return (!m.hasx || m.v <= lo + 5) && (!m.hasdy || m.dystep <= i + 1);
+    };
+    for (int i = tid; i < 16 * (PLANE / 16); i += 256)           // the plane of zeros (slot RING of every channel row)
+      *reinterpret_cast<u32x4*>(xT + (i / (PLANE / 16)) * ROW_C + G::RING * PLANE + (i % (PLANE / 16)) * 16) = u32x4{0u, 0u, 0u, 0u};
+    bool ha = elem_needed();
+    if (ha) { fetch_to(ra, ma); elem_advance(); }
+    bool hb = elem_needed();
+    if (hb) { fetch_to(rb, mb); elem_advance(); }
+    int cur = 0;
+    for (int i = -1; i < steps - 1; ++i) {
+      for (;;) {
+        if (cur == 0) {
+          if (!ha || !allowed(ma, i)) break;
+          stage_from(ra, ma);
+          ha = elem_needed();
+          if (ha) { fetch_to(ra, ma); elem_advance(); }
+          cur = 1;
+        } else {
+          if (!hb || !allowed(mb, i)) break;
+          stage_from(rb, mb);
+          hb = elem_needed();
+          if (hb) { fetch_to(rb, mb); elem_advance(); }
+          cur = 0;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (i >= 0 && ++sz == D) { sz = 0; scoD += D; szs = 0; }
+    }
+    return;
+  }
+
+  // ---- MFMA waves: wave w owns the taps of RolePlan<G, w>
+  auto run_role = [&](auto ROLE) {
+    using P = RolePlan<G, decltype(ROLE)::value>;
+    f32x4 acc[P::NT];
+#pragma unroll
+    for (int t = 0; t < P::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, kg = lane >> 4;
+    const unsigned char* xlane = xT + l15 * ROW_C + ((kg / NGX) * RG + kg % NGX) * 16;
+    const unsigned char* dlane = dyT + l15 * DYS + kg * 16;
+    ColCursor sc = c0;
+    int z = zb, m6 = zb % G::RING;
+    bool head = sc.k == 0 && sc.col == 0 && zb == 0;    // the current unit started in this workgroup, at its first step
+
+    for (int i = 0; i < steps; ++i) {
+      asm volatile("s_barrier" ::: "memory");
+      const unsigned char* db = dlane + (i & 1) * DYBUF;
+      bf16x8 bfr[KSTEPS];                                // B operand: dy[co = lane & 15][8 voxels of group kg]
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) bfr[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(db + ks * 64));
+      const unsigned char* xs[5];
+#pragma unroll
+      for (int dz = 0; dz < 5; ++dz) {
+        int sl = m6 + dz + 4;                            // plane z + dz - 2 -> ring slot (V + dz - 2) % 6
+        sl = sl >= 12 ? sl - 12 : sl >= 6 ? sl - 6 : sl;
+        if ((unsigned)(z + dz - 2) >= (unsigned)D) sl = G::RING;     // outside the volume: the plane of zeros
+        xs[dz] = xlane + sl * PLANE;
+      }
+      auto read_window = [&](auto WI, u32x4& lo, u32x2& hi) {
+        constexpr int w = decltype(WI)::value;
+        const unsigned char* xb = xs[w / NWROW] + (w % NWROW) * RG * 16;
+        lo = *reinterpret_cast<const u32x4*>(xb);          // elements 0..7 of the window (x0 + 8g - 2 ..)
+        hi = *reinterpret_cast<const u32x2*>(xb + 16);     // elements 8..11
+      };
+      {
+        u32x4 lo_n;
+        u32x2 hi_n;
+        constexpr int wfirst = P::next(-1);
+        read_window(std::integral_constant<int, wfirst>{}, lo_n, hi_n);
+        static_for<0, P::NW>([&](auto WI) {
+          constexpr int w = decltype(WI)::value;
+          constexpr int dz = w / NWROW, rr = w % NWROW;
+          if constexpr (P::nonempty(w)) {
+            u32x4 lo = lo_n;
+            u32x2 hi = hi_n;
+            asm volatile("" : "+v"(lo), "+v"(hi));     // a register value from here on (no re-reads from LDS)
+            constexpr int wn = P::next(w);
+            if constexpr (wn >= 0) read_window(std::integral_constant<int, wn>{}, lo_n, hi_n);
+            __builtin_amdgcn_sched_barrier(0);         // keep the request ahead of this window's MFMAs
+            const uint32_t a10 = __builtin_amdgcn_alignbit(lo.y, lo.x, 16);
+            const uint32_t a21 = __builtin_amdgcn_alignbit(lo.z, lo.y, 16);
+            const uint32_t a32 = __builtin_amdgcn_alignbit(lo.w, lo.z, 16);
+            const uint32_t a43 = __builtin_amdgcn_alignbit(hi.x, lo.w, 16);
+            const uint32_t a54 = __builtin_amdgcn_alignbit(hi.y, hi.x, 16);
+            const bf16x8 sh[5] = {
+                __builtin_bit_cast(bf16x8, lo),                                     // shift -2: elements 0..7
+                __builtin_bit_cast(bf16x8, (u32x4{a10, a21, a32, a43})),            // shift -1
+                __builtin_bit_cast(bf16x8, (u32x4{lo.y, lo.z, lo.w, hi.x})),        // shift  0
+                __builtin_bit_cast(bf16x8, (u32x4{a21, a32, a43, a54})),            // shift +1
+                __builtin_bit_cast(bf16x8, (u32x4{lo.z, lo.w, hi.x, hi.y}))};       // shift +2
+            static_for<0, KSTEPS>([&](auto KS) {
+              constexpr int ks = decltype(KS)::value;
+              constexpr int dyi = rr - ks * GPR;
+              if constexpr (dyi >= 0 && dyi < 5) {
+                static_for<0, 5>([&](auto DX) {
+                  constexpr int dxi = decltype(DX)::value;
+                  if constexpr (P::mine(dz, dyi, dxi)) {
+                    constexpr int t = dz * 25 + dyi * 5 + dxi - P::T0;
+                    // D[ci = 4 (lane >> 4) + r][co = lane & 15] += x window (A) * dy (B)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh[dxi], bfr[ks], acc[t], 0, 0, 0);
+                  }
+                });
+              }
+            });
+          }
+        });
+      }
+
+      const bool last = z == D - 1 && sc.col == a.ncol - 1 && sc.k == sc.cnt - 1;     // the unit's last step
+      if (last || i + 1 == steps) {
+        const bool atomic = !(head && last);
+        const int co = sc.cot * 16 + l15, ci0 = sc.cit * 16 + kg * 4;
+        if (co < Cout && ci0 < Cin) {
+          float* p = a.dw + (((size_t)sc.slot * REPMODE_TAPS + P::T0) * Cout + co) * a.CinTot + a.ci_off + ci0;
+          const size_t tstride = (size_t)Cout * a.CinTot;
+          if (atomic) {
+#pragma unroll
+            for (int t = 0; t < P::NT; ++t) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) unsafeAtomicAdd(p + r, acc[t][r]);
+              p += tstride;
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < P::NT; ++t) {
+              *reinterpret_cast<f32x4*>(p) = acc[t];
+              p += tstride;
+            }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < P::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        head = true;
+      }
+      if (i + 1 < steps) {
+        if (++z == D) { z = 0; next_col(sc); }
+        m6 = m6 == G::RING - 1 ? 0 : m6 + 1;
+      }
+    }
+  };
+  if (wave == 0) run_role(std::integral_constant<int, 0>{});
+  else if (wave == 1) run_role(std::integral_constant<int, 1>{});
+  else if (wave == 2) run_role(std::integral_constant<int, 2>{});
+  else run_role(std::integral_constant<int, 3>{});
+}
+
+struct DevInfo { int cus; };
+int device_cus() {
+  static int tab[32] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int& c = tab[dev & 31];
+  if (!c) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    c = cus;
+  }
+  return c;
+}
+
+// whole units per workgroup (plain stores only) when the unit list fills three quarters of the chip
+bool col_aligned(const WgColCall& c) {
+  const long units = (long)c.nslots * ceil_div(c.Cout, 16) * ceil_div(c.Cin, 16);
+  const long room = device_cus() - repmode_reserve_cus() > 8 ? device_cus() - repmode_reserve_cus() : 8;
+  return 4 * units >= 3 * room;
+}
+
+template <int TY, int TX>
+int launch_col(const WgColCall& c, hipStream_t s) {
+  ColArgs a{};
+  a.x = static_cast<const bf16_t*>(c.x); a.dy = static_cast<const bf16_t*>(c.dy);
+  a.sample_slot = c.sample_slot; a.dw = c.dw;
+  a.N = c.N; a.D = c.D; a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.Cout = c.Cout; a.CinTot = c.CinTot; a.ci_off = c.ci_off;
+  a.nslots = c.nslots;
+  a.ncot = ceil_div(c.Cout, 16); a.ncit = ceil_div(c.Cin, 16);
+  a.nty = ceil_div(c.H, TY); a.ntx = ceil_div(c.W, TX); a.ncol = a.nty * a.ntx;
+  a.total = (long)c.N * a.ncot * a.ncit * a.ncol * c.D;
+  const long room = device_cus() - repmode_reserve_cus() > 8 ? device_cus() - repmode_reserve_cus() : 8;
+  // Enough units to fill three quarters of the chip: a workgroup takes WHOLE units (an equal range of the unit list; the grid
+  // is the smallest that gives every workgroup ceil(units / CUs) of them) -- every flush is plain stores, dw needs no clearing,
+  // whatever the slots' sample counts.  Otherwise: an equal split of the step sequence; shared units are added with float
+  // atomics onto the cleared dw.
+  const long units = (long)c.nslots * a.ncot * a.ncit;
+  const bool direct = col_aligned(c);
+  long g;
+  if (direct) {
+    const long per = (units + room - 1) / room;
+    g = (units + per - 1) / per;
+    a.aligned = 1;
+  } else {
+    g = room;
+    if (g > a.total / 4) g = a.total / 4;
+    if (g < 1) g = 1;
+  }
+  if (c.plan_out) { *c.plan_out = direct ? 1 : 0; return REPMODE_OK; }
+  if (!direct && !c.prezeroed)
+    RM_HIP(hipMemsetAsync(c.dw, 0, (size_t)c.nslots * REPMODE_TAPS * c.Cout * c.CinTot * sizeof(float), s));
+  repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * c.N * c.D * c.H * c.W * (double)c.Cin * c.Cout * REPMODE_TAPS, s);
+  hipLaunchKernelGGL((conv5_wgrad_col_kernel<TY, TX>), dim3((unsigned)g), dim3(512), 0, s, a);
+  return REPMODE_OK;
+}
+
+}  // namespace
+
+int repmode_wgrad_col_mode() { return g_wgrad_col; }
+
+extern "C" int repmode_set_wgrad_col(int mode) { g_wgrad_col = mode; return REPMODE_OK; }
+extern "C" int repmode_get_wgrad_col(void) { return g_wgrad_col; }
+
+bool repmode_wgrad_col_eligible(const WgColCall& c) {
+  if (g_wgrad_col == 0 || repmode_deterministic()) return false;
+  if (c.W < 16 || (c.Cin & 7) || (c.Cout & 7) || (c.CinTot & 3) || (c.ci_off & 3) || c.N > 64 || !c.sample_slot) return false;
+  if ((size_t)c.D * c.H * c.W * (c.Cin > c.Cout ? c.Cin : c.Cout) * 2 >= ((size_t)1 << 31)) return false;
+  if (g_wgrad_col >= 2) return true;
+  // mode 1: the shapes it was measured to win on (profiles/r06_wgrad_col.txt) -- level 2 of the network (volumes 16 .. 31
+  // voxels wide) with enough units for whole-unit workgroups; where units are shared through float atomics (levels 0-1 at
+  // batch 8: 8 and 2-4 workgroups per unit) conv5_wgrad.hip's stream-K grid is faster
+  return c.W < 32 && col_aligned(c);
+}
+
+int repmode_wgrad_col_launch(const WgColCall& c, hipStream_t s) {
+  if (c.W >= 32) return launch_col<8, 32>(c, s);
+  if (c.H > 8) return launch_col<16, 16>(c, s);
+  return launch_col<8, 16>(c, s);
+}

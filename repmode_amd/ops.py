@@ -162,6 +162,16 @@ def get_wgrad_ws():
     return int(_lib.load().repmode_get_wgrad_ws())
 
 
+def set_wgrad_col(mode):
+    """The bf16 filter gradient's column-walking form (csrc/conv5_wgrad_col.hip: all 125 taps of a (slot, 16 co, 16 ci) tile
+    in one workgroup, a ring of x planes in LDS): 0 never, 1 (default) on the shapes it was measured to win, 2 wherever eligible."""
+    _lib.call('repmode_set_wgrad_col', int(mode))
+
+
+def get_wgrad_col():
+    return int(_lib.load().repmode_get_wgrad_col())
+
+
 def set_thin_kernels(on):
     """The one-channel first / last layers through their own kernels (csrc/thin_conv.hip; default) or round 2's fold of the x
     taps around the general kernel (REPMODE_THIN=0).  The operator library's switch (the ``thin_conv_*`` wrappers here

@@ -1,0 +1,130 @@
+"""Round-6 kernels against the CPU oracle (through the C ABI and the operator library).  Needs a real MI355X: every test is
+marked ``gpu``.  Tolerances as tests/test_hip_parity.py states them (bf16 operands rounded on both sides, float accumulation:
+1e-4 of the tensor's max)."""
+import ctypes
+
+import pytest
+import torch
+
+from conftest import record, rel_err
+from oracle import repmode_oracle as orc
+from test_hip_parity import DEV, TOL_BF16_ACC, _ops
+
+pytestmark = pytest.mark.gpu
+
+
+WGRAD_COL_CASES = [
+    # (N, D, H, W, Cin, Cout, tasks): the column-walking filter gradient (csrc/conv5_wgrad_col.hip) -- the 8 x 32 tile
+    (2, 6, 10, 40, 32, 32, [5, 9]),                         # ragged in y and x, one sample per slot
+    (3, 5, 9, 35, 16, 48, [5, 9, 5]),                       # a slot with two samples, one 16-channel tile of ci
+    (2, 4, 16, 64, 64, 32, [1, 1]),                         # one slot: ranges that share every unit (float atomics)
+    (6, 2, 8, 32, 40, 72, [3, 3, 7, 3, 0, 7]),              # D = 2: no step has all five planes; half-filled channel tiles
+    (1, 1, 4, 33, 8, 8, [2]),                               # D = 1, a half-filled 16-channel tile on both sides
+    (9, 8, 16, 32, 64, 64, [4, 4, 4, 8, 8, 1, 1, 1, 1]),    # slots of 3 / 2 / 4 samples
+    (2, 3, 8, 32, 16, 16, [0, 1]),                          # D = 3
+    # volumes 16 .. 31 voxels wide: the 16 x 16 tile (H > 8) and the 8 x 16 tile
+    (8, 8, 16, 16, 64, 128, [0, 1, 2, 3, 4, 5, 6, 7]),      # level 2 of the network at the benchmarked batch: plain stores only
+    (8, 8, 16, 16, 128, 128, [0, 1, 2, 3, 4, 5, 6, 7]),     # two whole units per workgroup
+    (8, 8, 16, 16, 128, 128, [0, 0, 0, 1, 2, 2, 3, 0]),     # whole units per workgroup with 4 / 1 / 2 / 1 samples per slot
+    (2, 6, 10, 20, 32, 32, [5, 9]),
+    (3, 5, 9, 17, 16, 48, [5, 9, 5]),
+    (4, 4, 8, 16, 32, 64, [2, 2, 3, 3]),                    # H = 8: the 8 x 16 tile
+    (2, 7, 5, 24, 24, 40, [6, 6]),
+]
+
+
+def _wgrad_reference(case, gen):
+    n, d, h, w, cin, cout, tasks = case
+    x = torch.randn(n, cin, d, h, w, generator=gen).bfloat16().float()
+    dy = torch.randn(n, cout, d, h, w, generator=gen).bfloat16().float()
+    uniq = sorted(set(tasks), key=tasks.index)
+    return x, dy, uniq
+
+
+@pytest.mark.parametrize('case', WGRAD_COL_CASES)
+def test_conv5_wgrad_column_form_vs_oracle(case):
+    """The filter gradient's column-walking form (mode 2: wherever eligible) against the oracle -- autograd of the per-sample
+    convolution, RepMode.py:207 -- and against conv5_wgrad.hip's regular grid (mode 0; same products, another split of the voxel
+    sums over workgroups: float summation order)."""
+    ops = _ops()
+    n, d, h, w, cin, cout, tasks = case
+    gen = torch.Generator().manual_seed(sum(case[:6]) + 11)
+    plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+    x = torch.randn(n, cin, d, h, w, generator=gen).bfloat16().float()
+    dy = torch.randn(n, cout, d, h, w, generator=gen).bfloat16().float()
+    wt = torch.zeros(plan.nslots, cout, cin, 5, 5, 5, requires_grad=True)
+    slots = torch.tensor([plan.slot_task_host.index(t) for t in tasks])
+    (orc.conv_per_sample(x, wt[slots]) * dy).sum().backward()
+    dw_ref = wt.grad.reshape(plan.nslots, cout, cin, 125).permute(0, 3, 1, 2)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    got = []
+    default = ops.get_wgrad_col()
+    try:
+        for mode in (2, 0):
+            ops.set_wgrad_col(mode)
+            got.append(ops.conv5_wgrad(x_cl, dy_cl, plan, cout).cpu())
+    finally:
+        ops.set_wgrad_col(default)
+    e = rel_err(got[0], dw_ref)
+    record('wgrad_col', case=list(case[:6]), err=e, vs_regular=rel_err(got[0], got[1]))
+    assert e < TOL_BF16_ACC
+    assert rel_err(got[0], got[1]) < 1e-4
+
+
+@pytest.mark.parametrize('tasks', [list(range(8)), [3, 3, 3, 5, 9, 9, 3, 5], list(range(12)) * 2])
+def test_conv5_wgrad_column_form_plain_stores_into_uninitialised_memory(tasks):
+    """With enough units to fill the chip a workgroup takes whole units and the planner promises plain stores only
+    (repmode_conv5_wgrad_plan), whatever the slots' sample counts: the launch must then overwrite EVERY element of a buffer full
+    of NaNs (mode bit 3: no memset)."""
+    ops = _ops()
+    from repmode_amd import _lib
+    n, d, h, w, cin, cout = len(tasks), 8, 16, 16, 128, 128        # (3 slots x 8 x 8 units: three quarters of the chip)
+    gen = torch.Generator().manual_seed(77)
+    plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+    x = torch.randn(n, cin, d, h, w, generator=gen).bfloat16().float()
+    dy = torch.randn(n, cout, d, h, w, generator=gen).bfloat16().float()
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    default = ops.get_wgrad_col()
+    try:
+        ops.set_wgrad_col(1)                 # (the default policy takes this shape)
+        direct = ctypes.c_int(-1)
+        _lib.call('repmode_conv5_wgrad_plan', plan.nslots, n, d, h, w, cin, cout, _lib.BF16, 0, ctypes.byref(direct))
+        assert direct.value == 1
+        dw = torch.full((plan.nslots, 125, cout, cin), float('nan'), device=DEV)
+        _lib.call('repmode_conv5_wgrad_ex', x_cl.data_ptr(), dy_cl.data_ptr(), plan.sample_slot.data_ptr(), plan.nslots,
+                  dw.data_ptr(), n, d, h, w, cin, cout, _lib.BF16, 8, torch.cuda.current_stream().cuda_stream)
+        ops.set_wgrad_col(0)
+        ref = ops.conv5_wgrad(x_cl, dy_cl, plan, cout)
+    finally:
+        ops.set_wgrad_col(default)
+    assert torch.isfinite(dw).all()
+    assert rel_err(dw.cpu(), ref.cpu()) < 1e-4
+
+
+def test_conv5_wgrad_column_form_channel_ranges_of_a_skip_connection():
+    """repmode_conv5_wgrad_part: the two tensors of a skip connection fill two input-channel ranges of ONE cleared dw -- against
+    the filter gradient of the concatenated tensor."""
+    ops = _ops()
+    from repmode_amd import _lib
+    n, d, h, w, ca, cb, cout = 3, 4, 16, 32, 32, 16, 32
+    tasks = [4, 7, 4]
+    gen = torch.Generator().manual_seed(5)
+    plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+    xa = torch.randn(n, d, h, w, ca, generator=gen).to(DEV, torch.bfloat16)
+    xb = torch.randn(n, d, h, w, cb, generator=gen).to(DEV, torch.bfloat16)
+    dy = torch.randn(n, d, h, w, cout, generator=gen).to(DEV, torch.bfloat16)
+    default = ops.get_wgrad_col()
+    try:
+        ops.set_wgrad_col(0)
+        ref = ops.conv5_wgrad(torch.cat((xa, xb), -1).contiguous(), dy, plan, cout)
+        ops.set_wgrad_col(2)
+        dw = torch.zeros((plan.nslots, 125, cout, ca + cb), device=DEV)
+        stream = torch.cuda.current_stream().cuda_stream
+        for part, off in ((xa, 0), (xb, ca)):
+            _lib.call('repmode_conv5_wgrad_part', part.data_ptr(), dy.data_ptr(), plan.sample_slot.data_ptr(), plan.nslots,
+                      dw.data_ptr(), n, d, h, w, part.shape[-1], ca + cb, off, cout, _lib.BF16, 8, stream)
+    finally:
+        ops.set_wgrad_col(default)
+    assert rel_err(dw.cpu(), ref.cpu()) < 1e-4

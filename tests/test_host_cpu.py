@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), 'librepmode_hip.so does not export %s' % name
     assert set(declared) == set(_lib.EXPORTS), (set(declared) ^ set(_lib.EXPORTS))
-    assert lib.repmode_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.repmode_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_padded_channels():
