@@ -334,6 +334,15 @@ int repmode_bn_relu_bwd(const void* x, const void* dy, const float* gamma, const
                         const float* save_mean, const float* save_invstd, void* dx, float* totals, long m, int c,
                         int training, int in_dtype, int out_dtype, void* stream);
 
+/* One launch per BatchNorm pass (csrc/bnrelu.hip, round 6; also REPMODE_BN_FUSED; ABI 11): training-mode passes over tensors
+ * small enough for a grid of at most one workgroup per CU to hold in registers (every tensor of the benchmarked step but
+ * level 0's) read the tensor ONCE -- partial sums, a grid-wide barrier, normalise / gradient from the registers -- instead of a
+ * statistics launch and an apply launch that reads it again.  1 (default) on, 0 the two-launch passes everywhere.  Same
+ * arithmetic: the sums are totalled in the same slices. */
+int repmode_set_bn_fused(int on);
+int repmode_get_bn_fused(void);
+
+
 /* ---- the stride-2 2x2x2 stages (RepMode.py:81 Conv3d k2 s2, :98 ConvTranspose3d k2 s2; both bias-free) as a
  * gather / scatter GEMM over the 8 disjoint taps p = (pz*2+py)*2+px of every coarse voxel m:
  *   scatter == 0:  out[m][co]         = sum_p sum_ci in[fine(m,p)][ci] * w[p][co][ci]   (in: fine grid, out: coarse)

@@ -110,8 +110,9 @@ float* repmode_zero_scratch(hipStream_t s) {
   auto it = g_scratch.find({dev, s});
   if (it != g_scratch.end()) return it->second;
   float* p = nullptr;
-  hipError_t e = hipMalloc(&p, REPMODE_ZERO_SCRATCH_FLOATS * sizeof(float));
-  if (e == hipSuccess) e = hipMemsetAsync(p, 0, REPMODE_ZERO_SCRATCH_FLOATS * sizeof(float), s);
+  const size_t bytes = (REPMODE_ZERO_SCRATCH_FLOATS + REPMODE_SCRATCH_TAIL_WORDS) * sizeof(float);
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e == hipSuccess) e = hipMemsetAsync(p, 0, bytes, s);
   if (e != hipSuccess) { repmode_set_error("zero_scratch: %s", hipGetErrorString(e)); return nullptr; }
   g_scratch[{dev, s}] = p;
   return p;

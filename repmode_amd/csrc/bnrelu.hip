@@ -14,6 +14,8 @@
 // against the six kernels plus separate ReLU / dtype-cast passes of the stock path.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int BN_THREADS = 256;
@@ -126,7 +128,7 @@ __device__ __forceinline__ Geom geom(int C) {
 // sums[c] += sum_rows a(row, c) ; sums[C + c] += sum_rows b(row, c)
 // nsl: partial-sum slices in use -- BN_SLICES, or (deterministic mode) half as many as the grid has workgroups: two writers each
 __device__ __forceinline__ void block_commit(float* lds, const float* s, const float* ss, int c0, int C, bool active,
-                                             float* __restrict__ sums, int nsl, bool det) {
+                                             float* __restrict__ sums, int nsl, bool det, bool returning = false) {
   if (det) {
     // fixed summation order: every thread's partial sums through LDS, channel i's total = its row groups in order; the
     // slice has at most two writers (grid <= 2 nsl): two addends on a zeroed entry commute
@@ -170,6 +172,15 @@ __device__ __forceinline__ void block_commit(float* lds, const float* s, const f
   }
   __syncthreads();
   float* slice = sums + (size_t)(blockIdx.x % nsl) * 2 * C;
+  if (returning) {
+    // (the one-launch passes: an atomic WITH return has been performed when its value is back -- the arrival at the grid-wide
+    // barrier that follows must not overtake these sums)
+    for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) {
+      const float old = atomicAdd(&slice[i], lds[i]);
+      asm volatile("" ::"v"(old));
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) atomicAdd(&slice[i], lds[i]);
 }
 
@@ -514,6 +525,254 @@ __global__ __launch_bounds__(BN_THREADS) void bn_small_bwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// ONE launch per pass with a grid-wide barrier (round 6).  Every tensor of the step but level 0's
+// is small enough for a grid of at most one workgroup per CU to hold ALL of it in registers -- a thread keeps up to
+// 16 rows of its 8 channels (raw: 4 registers per bf16 row) -- so a pass is: read the tensor once, partial sums
+// into the slices (as the two-launch pass), BARRIER, totals, normalise / gradient from the registers, write.  Against the
+// two launches: one launch less (5-10 us each on the deep levels, where both are latency), and the second read of x
+// (forward) or of x and dy (backward) is gone -- 50 instead of 84 MB for a level-1 backward pass.
+// The barrier (grid_barrier below): arrivals counted with agent-scope atomics in the stream's scratch (common.h), two levels, a
+// spin on the barrier's generation; the counters are back at zero before anybody leaves (graph replays find them zero).  All workgroups must
+// be resident: the grid never exceeds the CU count, a workgroup is 256 threads with a few KB of LDS (three fit a CU beside
+// each other), and it waits for nothing but its own grid -- two processes sharing a GPU (the tests' two ranks on one device)
+// cannot hold each other's last workgroups out.  After the barrier the slices are read with agent-scope loads (the sums were
+// added by atomics at the memory side; nothing else written before the barrier is read after it), so no cache is invalidated.
+// float rows take 8 registers each: fewer of them per thread, so that every variant leaves room for a second workgroup on
+// the CU (two processes' full grids fit the chip beside each other; float tensors are the parity mode's, and small)
+template <typename TI, typename TO>
+struct FuseRows { static constexpr int R = (sizeof(TI) == 2 && sizeof(TO) == 2) ? 16 : 4; };
+
+template <typename T>
+struct RowRaw;
+template <>
+struct RowRaw<bf16_t> {
+  u32x4 v;
+  __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void unpack(float* f) const {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f[2 * k] = __uint_as_float(v[k] << 16); f[2 * k + 1] = __uint_as_float(v[k] & 0xffff0000u); }
+  }
+};
+template <>
+struct RowRaw<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+  __device__ __forceinline__ void unpack(float* f) const {
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  }
+};
+
+// bar: [0 .. 7] * 32 the arrival counters of the eight workgroup classes (blockIdx % 8: one XCD each, a 128-byte line each),
+// [8 * 32] the counter of completed classes, [9 * 32] the generation.  Sense-reversing: a workgroup reads the generation, then
+// arrives; the last arrival of a class puts its counter back to zero and arrives at the top; the last class puts the top
+// counter back and advances the generation, on which everybody else spins.  Every counter is zero again before anybody
+// leaves, so the next launch (and a graph replay) starts from zeros.  Two levels because arrivals on ONE address are
+// serialised at the memory side (~40 ns each: a flat counter cost ~10 us for 256 workgroups -- measured, r06_bn_fused.txt).
+constexpr int BAR_STRIDE = 32;
+__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned nwg) {
+  __syncthreads();                 // (vmcnt(0) per wave: this workgroup's slice atomics have returned)
+  if (threadIdx.x == 0) {
+    unsigned* gen = bar + 9 * BAR_STRIDE;
+    const unsigned g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned cls = blockIdx.x & 7u, ncls = nwg < 8u ? nwg : 8u;
+    const unsigned members = (nwg - cls + 7u) / 8u;
+    unsigned* mine = bar + cls * BAR_STRIDE;
+    if (__hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+      __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned* top = bar + 8 * BAR_STRIDE;
+      if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ncls - 1u) {
+        __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);                       // both zeros are on their way before the generation moves
+        __hip_atomic_store(gen, g0 + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+}
+
+// total of the slices of entry i, read past every cache that another XCD's atomics do not reach
+__device__ __forceinline__ float slice_total_coherent(const float* sums, int i, int C) {
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < BN_SLICES; ++k) t += __hip_atomic_load(sums + (size_t)k * 2 * C + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return t;
+}
+
+// forward: statistics + normalise + ReLU.  C % 8 == 0; iters = rows per thread (<= BN_FUSE_ROWS); row j of a thread is
+// (j * gridDim + blockIdx) * rows_per_iter + r0.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(BN_THREADS) void bn_fused_fwd_kernel(
+    const TI* __restrict__ x, TO* __restrict__ out, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ sums, float* __restrict__ other, unsigned* bar, float* __restrict__ rmean, float* __restrict__ rvar,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, float eps, float momentum, long M, int C, int iters) {
+  constexpr int BN_FUSE_ROWS = FuseRows<TI, TO>::R;
+  __shared__ float lds[2 * BN_MAXC];
+  clear_other_half(other);
+  const Geom g = geom(C);
+  const int cg = threadIdx.x % g.ngroups, r0 = threadIdx.x / g.ngroups;
+  const bool active = r0 < g.rows_per_iter;
+  const int c0 = cg * CV;
+  RowRaw<TI> rows[BN_FUSE_ROWS];
+  float s[CV], ss[CV], x0[CV];
+#pragma unroll
+  for (int k = 0; k < CV; ++k) { s[k] = 0.f; ss[k] = 0.f; x0[k] = 0.f; }
+  const long stride = (long)gridDim.x * g.rows_per_iter;
+  const long rbase = (long)blockIdx.x * g.rows_per_iter + r0;
+  if (active) {
+    load_row<TI, CV>(x, c0, C, true, x0);          // shifted sums, as bn_stats_kernel
+#pragma unroll
+    for (int j = 0; j < BN_FUSE_ROWS; ++j) {
+      const long r = rbase + j * stride;
+      if (j < iters && r < M) rows[j].load(x + r * C + c0);
+    }
+#pragma unroll
+    for (int j = 0; j < BN_FUSE_ROWS; ++j) {
+      const long r = rbase + j * stride;
+      if (j < iters && r < M) {
+        float v[CV];
+        rows[j].unpack(v);
+#pragma unroll
+        for (int k = 0; k < CV; ++k) { const float d = v[k] - x0[k]; s[k] += d; ss[k] += d * d; }
+      }
+    }
+  }
+  block_commit(lds, s, ss, c0, C, active, sums, BN_SLICES, false, true);
+  grid_barrier(bar, gridDim.x);
+  float* sc = lds;
+  float* sh = lds + BN_MAXC;
+  for (int c = threadIdx.x; c < C; c += BN_THREADS) {
+    const float m1 = slice_total_coherent(sums, c, C) / (float)M;
+    const float var = fmaxf(slice_total_coherent(sums, C + c, C) / (float)M - m1 * m1, 0.f);
+    const float mean = m1 + to_f32<TI>(x[c]);
+    const float invstd = rsqrtf(var + eps);
+    if (blockIdx.x == 0) {
+      const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+      save_mean[c] = mean; save_invstd[c] = invstd;
+    }
+    const float a = gamma[c] * invstd;
+    sc[c] = a;
+    sh[c] = beta[c] - mean * a;
+  }
+  __syncthreads();
+  if (active) {
+    float scale[CV], shift[CV];
+#pragma unroll
+    for (int k = 0; k < CV; ++k) { scale[k] = sc[c0 + k]; shift[k] = sh[c0 + k]; }
+#pragma unroll
+    for (int j = 0; j < BN_FUSE_ROWS; ++j) {
+      const long r = rbase + j * stride;
+      if (j < iters && r < M) {
+        float v[CV];
+        rows[j].unpack(v);
+#pragma unroll
+        for (int k = 0; k < CV; ++k) v[k] = fmaxf(v[k] * scale[k] + shift[k], 0.f);
+        store_row<TO, CV>(out + r * C, c0, C, true, v);
+      }
+    }
+  }
+}
+
+// backward (training): sums of dz and dz * xhat, then dx, from ONE read of x and dy
+template <typename TI, typename TO>
+__global__ __launch_bounds__(BN_THREADS) void bn_fused_bwd_kernel(
+    const TI* __restrict__ x, const TO* __restrict__ dy, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ sums, float* __restrict__ other,
+    unsigned* bar, float* __restrict__ totals, long M, int C, int iters, TI* __restrict__ dx) {
+  constexpr int BN_FUSE_ROWS = FuseRows<TI, TO>::R;
+  __shared__ float lds[2 * BN_MAXC];
+  clear_other_half(other);
+  const Geom g = geom(C);
+  const int cg = threadIdx.x % g.ngroups, r0 = threadIdx.x / g.ngroups;
+  const bool active = r0 < g.rows_per_iter;
+  const int c0 = cg * CV;
+  RowRaw<TI> xr[BN_FUSE_ROWS];
+  RowRaw<TO> dr[BN_FUSE_ROWS];
+  float mu[CV], is[CV], ga[CV], be[CV], s[CV], ss[CV];
+#pragma unroll
+  for (int k = 0; k < CV; ++k) {
+    mu[k] = mean[c0 + k]; is[k] = invstd[c0 + k]; ga[k] = gamma[c0 + k]; be[k] = beta[c0 + k];
+    s[k] = 0.f; ss[k] = 0.f;
+  }
+  const long stride = (long)gridDim.x * g.rows_per_iter;
+  const long rbase = (long)blockIdx.x * g.rows_per_iter + r0;
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < BN_FUSE_ROWS; ++j) {
+      const long r = rbase + j * stride;
+      if (j < iters && r < M) { xr[j].load(x + r * C + c0); dr[j].load(dy + r * C + c0); }
+    }
+#pragma unroll
+    for (int j = 0; j < BN_FUSE_ROWS; ++j) {
+      const long r = rbase + j * stride;
+      if (j < iters && r < M) {
+        float v[CV], d[CV];
+        xr[j].unpack(v); dr[j].unpack(d);
+#pragma unroll
+        for (int k = 0; k < CV; ++k) {
+          const float xh = (v[k] - mu[k]) * is[k];
+          const float dz = (xh * ga[k] + be[k] > 0.f) ? d[k] : 0.f;
+          s[k] += dz;
+          ss[k] += dz * xh;
+        }
+      }
+    }
+  }
+  block_commit(lds, s, ss, c0, C, active, sums, BN_SLICES, false, true);
+  grid_barrier(bar, gridDim.x);
+  for (int i = threadIdx.x; i < 2 * C; i += BN_THREADS) {
+    const float t = slice_total_coherent(sums, i, C);
+    lds[i] = t;
+    if (blockIdx.x == 0) totals[i] = t;
+  }
+  __syncthreads();
+  if (active) {
+    float m1[CV], m2[CV];
+#pragma unroll
+    for (int k = 0; k < CV; ++k) { m1[k] = lds[c0 + k] / (float)M; m2[k] = lds[C + c0 + k] / (float)M; }
+#pragma unroll
+    for (int j = 0; j < BN_FUSE_ROWS; ++j) {
+      const long r = rbase + j * stride;
+      if (j < iters && r < M) {
+        float v[CV], d[CV];
+        xr[j].unpack(v); dr[j].unpack(d);
+#pragma unroll
+        for (int k = 0; k < CV; ++k) {
+          const float xh = (v[k] - mu[k]) * is[k];
+          const float dz = (xh * ga[k] + be[k] > 0.f) ? d[k] : 0.f;
+          v[k] = ga[k] * is[k] * (dz - m1[k] - xh * m2[k]);
+        }
+        store_row<TI, CV>(dx + r * C, c0, C, true, v);
+      }
+    }
+  }
+}
+
+// REPMODE_BN_FUSED (default 1; 0: always the two-launch passes).  The plan of a one-launch pass: grid (<= CUs) and rows per
+// thread; 0 = not eligible (level 0's tensors, channel counts that are no multiples of 8, the deterministic mode, whose
+// slices have one writer each).
+int g_bn_fused = []() { const char* e = getenv("REPMODE_BN_FUSED"); return e ? atoi(e) : 1; }();
+int fused_plan(long M, int C, int in_dtype, int out_dtype, int* iters) {
+  const int max_rows = (in_dtype == REPMODE_BF16 && out_dtype == REPMODE_BF16) ? FuseRows<bf16_t, bf16_t>::R : FuseRows<float, float>::R;
+  if (!g_bn_fused || (C % CV) != 0 || repmode_deterministic()) return 0;
+  static int cus_tab[32] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  int& cus = cus_tab[dev & 31];
+  if (!cus && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)) cus = 256;
+  const int gmax = cus - repmode_reserve_cus() > 8 ? cus - repmode_reserve_cus() : 8;
+  const int rows_per_iter = BN_THREADS / ((C + CV - 1) / CV);
+  const long need = (M + rows_per_iter - 1) / rows_per_iter;
+  // the smallest grid that holds the tensor (fewer arrivals at the barrier; a workgroup streams up to 64 KB)
+  const long grid = (need + max_rows - 1) / max_rows;
+  if (grid > gmax) return 0;
+  *iters = (int)((need + grid - 1) / grid);
+  return (int)grid;
+}
+
 // OFF: measured slower than the two-launch passes (one MI355X, batch 8: the train step went from 13.6 to 15.1 ms;
 // bn_small_fwd 50 us / bn_small_bwd 83 us per launch against 2 x 10-20 us) -- with one workgroup per 8 channels a lane
 // reads 16 bytes of a row that is 256 B - 1 KB long, and C / 8 workgroups (16-64) cannot stream even these few MB.
@@ -559,6 +818,9 @@ int grid_for(long M, int C) {
 
 }  // namespace
 
+extern "C" int repmode_set_bn_fused(int on) { g_bn_fused = on; return REPMODE_OK; }
+extern "C" int repmode_get_bn_fused(void) { return g_bn_fused; }
+
 // in_dtype: dtype of x (and dx); out_dtype: dtype of out (and dy).  REPMODE_F32 / REPMODE_BF16.
 extern "C" int repmode_bn_relu_fwd_ex(const void* x, void* out, const float* gamma, const float* beta, float* running_mean,
                                       float* running_var, float* save_mean, float* save_invstd, long m, int c, float eps,
@@ -597,6 +859,26 @@ extern "C" int repmode_bn_relu_fwd_ex(const void* x, void* out, const float* gam
     else RM_BN_SMALL(bf16_t, bf16_t);
 #undef RM_BN_SMALL
     RM_LAUNCH_CHECK("bn_small_fwd");
+    return REPMODE_OK;
+  }
+  int fiters = 0;
+  const int fgrid = (training && stats_half < 0) ? fused_plan(m, c, in_dtype, out_dtype, &fiters) : 0;
+  if (fgrid > 0) {
+    float* scratch = repmode_zero_scratch(s);
+    if (!scratch) return REPMODE_ELAUNCH;
+    const int half = repmode_bn_scratch_half(s);
+    own = scratch + (size_t)half * REPMODE_SCRATCH_BN_HALF;
+    float* other = scratch + (size_t)(1 - half) * REPMODE_SCRATCH_BN_HALF;
+    unsigned* bar = reinterpret_cast<unsigned*>(scratch + REPMODE_SCRATCH_BARRIER_OFF);
+#define RM_BN_FUSED(TI, TO)                                                                                              \
+    hipLaunchKernelGGL((bn_fused_fwd_kernel<TI, TO>), dim3(fgrid), dim3(BN_THREADS), 0, s, (const TI*)x, (TO*)out, gamma, beta, \
+                       own, other, bar, running_mean, running_var, save_mean, save_invstd, eps, momentum, m, c, fiters)
+    if (in_dtype == REPMODE_F32 && out_dtype == REPMODE_F32) RM_BN_FUSED(float, float);
+    else if (in_dtype == REPMODE_F32) RM_BN_FUSED(float, bf16_t);
+    else if (out_dtype == REPMODE_F32) RM_BN_FUSED(bf16_t, float);
+    else RM_BN_FUSED(bf16_t, bf16_t);
+#undef RM_BN_FUSED
+    RM_LAUNCH_CHECK("bn_fused_fwd");
     return REPMODE_OK;
   }
   if (training && stats_half >= 0) {
@@ -658,6 +940,21 @@ extern "C" int repmode_bn_relu_bwd(const void* x, const void* dy, const float* g
   const int half = repmode_bn_scratch_half(s);
   float* own = scratch + (size_t)half * REPMODE_SCRATCH_BN_HALF;
   float* other = scratch + (size_t)(1 - half) * REPMODE_SCRATCH_BN_HALF;
+  int fiters = 0;
+  const int fgrid = training ? fused_plan(m, c, in_dtype, out_dtype, &fiters) : 0;
+  if (fgrid > 0) {
+    unsigned* bar = reinterpret_cast<unsigned*>(scratch + REPMODE_SCRATCH_BARRIER_OFF);
+#define RM_BN_FUSED(TI, TO)                                                                                              \
+    hipLaunchKernelGGL((bn_fused_bwd_kernel<TI, TO>), dim3(fgrid), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy,   \
+                       save_mean, save_invstd, gamma, beta, own, other, bar, totals, m, c, fiters, (TI*)dx)
+    if (in_dtype == REPMODE_F32 && out_dtype == REPMODE_F32) RM_BN_FUSED(float, float);
+    else if (in_dtype == REPMODE_F32) RM_BN_FUSED(float, bf16_t);
+    else if (out_dtype == REPMODE_F32) RM_BN_FUSED(bf16_t, float);
+    else RM_BN_FUSED(bf16_t, bf16_t);
+#undef RM_BN_FUSED
+    RM_LAUNCH_CHECK("bn_fused_bwd");
+    return REPMODE_OK;
+  }
 #define RM_BN_BWD(TI, TO)                                                                                              \
   do {                                                                                                                 \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<TI, TO>), dim3(grid_for_reduce_det(m, c, nsl)), dim3(BN_THREADS), 0, s, (const TI*)x, (const TO*)dy, \

@@ -88,6 +88,10 @@ float* repmode_zero_scratch(hipStream_t s);
 // accumulator.  repmode_bn_scratch_half returns this call's half index (0/1) and flips the per-stream state.
 constexpr size_t REPMODE_SCRATCH_BN_HALF = 16 * 1024;                       // floats per BatchNorm half
 constexpr size_t REPMODE_SCRATCH_GATE_OFF = 2 * REPMODE_SCRATCH_BN_HALF;    // gate accumulator: the upper 32 K floats
+// behind the floats: the two counters of the grid-wide barrier of the one-launch BatchNorm passes (bnrelu.hip: arrivals,
+// departures; the last workgroup to leave puts the zeros back)
+constexpr size_t REPMODE_SCRATCH_BARRIER_OFF = REPMODE_ZERO_SCRATCH_FLOATS;
+constexpr size_t REPMODE_SCRATCH_TAIL_WORDS = 512;
 int repmode_bn_scratch_half(hipStream_t s);
 void repmode_prof_end(hipStream_t s);
 

@@ -162,6 +162,16 @@ def get_wgrad_ws():
     return int(_lib.load().repmode_get_wgrad_ws())
 
 
+def set_bn_fused(on):
+    """BatchNorm passes as ONE launch with a grid-wide barrier where the tensor fits the grid's registers (csrc/bnrelu.hip):
+    1 (default) on, 0 the two-launch passes."""
+    _lib.call('repmode_set_bn_fused', int(on))
+
+
+def get_bn_fused():
+    return int(_lib.load().repmode_get_bn_fused())
+
+
 def set_wgrad_col(mode):
     """The bf16 filter gradient's column-walking form (csrc/conv5_wgrad_col.hip: all 125 taps of a (slot, 16 co, 16 ci) tile
     in one workgroup, a ring of x planes in LDS): 0 never, 1 (default) on the shapes it was measured to win, 2 wherever eligible."""

@@ -128,3 +128,71 @@ def test_conv5_wgrad_column_form_channel_ranges_of_a_skip_connection():
     finally:
         ops.set_wgrad_col(default)
     assert rel_err(dw.cpu(), ref.cpu()) < 1e-4
+
+
+BN_FUSED_CASES = [
+    # (shape [N, D, H, W, C], in dtype, out dtype): tensors the one-launch pass takes (C % 8 == 0, rows per thread within the
+    # budget: 16 for bf16 / bf16, 4 otherwise)
+    ((8, 16, 32, 32, 64), torch.bfloat16, torch.bfloat16),     # a level-1 tensor at the benchmarked batch: 16 rows per thread, 256 workgroups
+    ((8, 8, 16, 16, 128), torch.bfloat16, torch.bfloat16),     # level 2
+    ((8, 2, 4, 4, 512), torch.bfloat16, torch.bfloat16),       # the bottleneck: 64 workgroups of one row per thread
+    ((3, 5, 7, 9, 40), torch.bfloat16, torch.bfloat16),        # a row count that is no multiple of anything
+    ((2, 4, 8, 8, 32), torch.float32, torch.float32),
+    ((2, 8, 16, 16, 64), torch.float32, torch.bfloat16),
+    ((1, 1, 1, 3, 8), torch.bfloat16, torch.float32),          # fewer rows than a workgroup has row slots
+]
+
+
+@pytest.mark.parametrize('shape,in_dtype,out_dtype', BN_FUSED_CASES)
+def test_batchnorm_pass_as_one_launch(shape, in_dtype, out_dtype):
+    """BatchNorm3d + ReLU (RepMode.py:146-149, 212; :80-84; :97-101), training mode, forward and backward as ONE launch each
+    (grid-wide barrier, the tensor held in registers) against torch's own BatchNorm3d on the CPU and against the two-launch
+    passes -- three times in a row on one stream: the barrier's counters must come back to zero."""
+    ops = _ops()
+    import copy
+    from test_hip_parity import nrm_err
+    c = shape[-1]
+    gen = torch.Generator().manual_seed(c + shape[1])
+    x = (torch.randn(*shape, generator=gen) * 1.5 + 0.3).to(in_dtype).float()
+    r = torch.randn(*shape, generator=gen).to(out_dtype).float()
+    bn = torch.nn.BatchNorm3d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=gen)
+        bn.bias.uniform_(-0.5, 0.5, generator=gen)
+    bn.train()
+    xr = x.clone().requires_grad_(True)
+    ref = copy.deepcopy(bn)
+    yr = torch.relu(ref(xr.permute(0, 4, 1, 2, 3))).permute(0, 2, 3, 4, 1)
+    (yr * r).sum().backward()
+    res = {}
+    default = ops.get_bn_fused()
+    try:
+        for fused in (1, 0):
+            ops.set_bn_fused(fused)
+            for rep in range(3 if fused else 1):
+                bd = copy.deepcopy(bn).to(DEV)
+                xd = x.to(DEV, in_dtype).requires_grad_(True)
+                y = ops.bn_relu(xd, bd, True, out_dtype)
+                (y.float() * r.to(DEV)).sum().backward()
+                torch.cuda.synchronize()
+                out = (y.detach().float().cpu(), xd.grad.float().cpu(), bd.weight.grad.cpu(), bd.bias.grad.cpu(),
+                       bd.running_mean.cpu(), bd.running_var.cpu())
+                if rep:       # (a stuck or half-reset barrier would show as a hang or as stale statistics)
+                    assert rel_err(out[4], res[fused][4]) < 1e-5 and rel_err(out[5], res[fused][5]) < 1e-5
+                res[fused] = out
+    finally:
+        ops.set_bn_fused(default)
+    y, dx, dg, db, rm, rv = res[1]
+    tol = 1e-4 if out_dtype == torch.float32 else 1e-2
+    assert rel_err(y, yr.detach()) < tol
+    err = rel_err if in_dtype == torch.float32 else nrm_err
+    gtol = 1e-3 if in_dtype == torch.float32 and out_dtype == torch.float32 else 3e-2
+    assert err(dx, xr.grad) < gtol
+    assert err(dg, ref.weight.grad) < gtol and err(db, ref.bias.grad) < gtol
+    # the two-launch passes: the same sums in the same slices, another order of the float atomics
+    # (bf16: a last-bit difference of a mean moves a few outputs by one bf16 step and flips a few ReLU masks)
+    low = out_dtype == torch.bfloat16 or in_dtype == torch.bfloat16
+    for i, (a, b) in enumerate(zip(res[1], res[0])):
+        e = (nrm_err if low and 1 <= i <= 3 else rel_err)(a, b)
+        assert e < (2e-2 if low else 1e-5), (i, e)
+    assert rel_err(rm, res[0][4]) < 1e-6 and rel_err(rv, res[0][5]) < 1e-6
