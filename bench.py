@@ -16,9 +16,14 @@ Workloads (BASELINE.json ``configs``):
           line's batch, so the line also carries ``config.no_comm_value``: the same ranks, same batch, same run,
           stepping WITHOUT the gradient all-reduce -- the denominator for the collectives' cost at this batch
           (``value / no_comm_value`` is the scaling efficiency that the N = 1 line cannot give).  ``config.comm``: what the
-          process group looked like (backend, ranks a collective saw, buckets, their dtype and the rule that chose it).
-          The rule (distributed.pick_grad_dtype) reads the first four distributed steps: with a shorter --warmup the
-          missing ones run as setup BEFORE the warmup (``config.setup_steps_before_warmup``), never inside the timed region.
+          process group looked like (backend, ranks a collective saw, the buckets DDP built and their sizes, their dtype, and
+          ``efficiency`` = value / no_comm_value).  The buckets are float32 (``--grad-compress fp32``, the default: what the
+          reference averages in); ``--grad-compress auto`` lets the rule (distributed.pick_grad_dtype) choose from the first
+          four distributed steps: with a shorter --warmup the missing ones run as setup BEFORE the warmup
+          (``config.setup_steps_before_warmup``), never inside the timed region.
+  ``config.ms_per_step_unprofiled``: the mean GPU time (HIP events at the step boundaries) of the timed steps that were NOT
+          launched kernel by kernel for the roofline's event pairs -- the steady-state step; ``ms_per_step`` / ``value`` keep
+          every timed step, the profiled ones included (pessimistic by about 1 %).
   ``--batch B`` overrides the per-GPU batch for either.
 
 Also reported in the same line:
@@ -227,6 +232,9 @@ def main():
                          'flips like the reference\'s data_aug, one launch) instead of re-using one synthetic batch')
     ap.add_argument('--no-prof', action='store_true', help='do not record per-launch HIP events')
     ap.add_argument('--no-fwd', action='store_true', help='skip the forward-only measurement')
+    ap.add_argument('--grad-compress', default='fp32', choices=['fp32', 'bf16', 'auto'],
+                    help="N > 1: the gradient buckets' dtype -- float32 (default: what the reference averages in), bfloat16, or "
+                         "'auto' = chosen by distributed.pick_grad_dtype from the first measured backward passes")
     ap.add_argument('--graph', action='store_true', help='replay the train step as one HIP graph (N = 1; DESIGN.md 3.5)')
     ap.add_argument('--prof-all', action='store_true', help='record HIP events for every library kernel, not only conv5_igemm')
     ap.add_argument('--dump-launches', default=None, help='write per-launch (kind, ms, TFLOP/s or TB/s) of the last timed step as JSON')
@@ -253,7 +261,7 @@ def main():
     opts.gpu_ids = local
     torch.manual_seed(0)                       # reference default seed (config.py:47); same init on every rank
     model = Model(opts, nn_module='RepMode', lr=1e-4, gpu_ids=local, mult_chan=MULT_CHAN, dtype=dtype,
-                  distributed=world > 1, hip_graph=world == 1 and args.graph)
+                  distributed=world > 1, hip_graph=world == 1 and args.graph, grad_compress=args.grad_compress)
     b = args.batch or (BATCH_1GPU if world == 1 else BATCH_MULTI)
     gen = torch.Generator(device=device).manual_seed(1000 + rank)
     signal = torch.randn(b, 1, *PATCH, device=device, generator=gen)
@@ -286,9 +294,9 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # N > 1: the gradient buckets' dtype is chosen from the first Model.RULE_STEPS distributed steps (and the wrapper rebuilt if
-    # the choice is bfloat16): a one-time setup that a short --warmup must not push into the timed region
-    settle = max(0, Model.RULE_STEPS - args.warmup) if world > 1 else 0
+    # N > 1 with --grad-compress auto: the gradient buckets' dtype is chosen from the first Model.RULE_STEPS distributed steps:
+    # a one-time setup (one synchronisation) that a short --warmup must not push into the timed region
+    settle = max(0, Model.RULE_STEPS - args.warmup) if (world > 1 and args.grad_compress == 'auto') else 0
     for _ in range(settle + args.warmup):
         model.do_train_iter(*next_batch())
     barrier()
@@ -300,8 +308,13 @@ def main():
     profiled_steps = 0
     overlap = ops_.get_overlap()
     hosted = ops_.get_tail_jobs()
+    # one event per step boundary (on the stream the step is launched on): the GPU time of every timed step, so that the line
+    # can also quote the steady-state step -- the mean over the steps that were NOT launched kernel by kernel
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    step_profiled = []
     t0 = time.perf_counter()
     for step in range(args.steps):
+        step_ev[step].record()
         if not args.no_prof:
             on = step % sample == 0
             _lib.prof_pause(not on)
@@ -314,13 +327,18 @@ def main():
             # around a conv5_igemm launch time the convolution alone
             ops_.set_tail_jobs(hosted and not on)
         # (a profiled step is launched kernel by kernel: the library's event pairs are not part of a captured graph)
+        step_profiled.append(bool(not args.no_prof and on))
         model.do_train_iter(*next_batch(), eager=not args.no_prof and on)
+    step_ev[args.steps].record()
     t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (includes waiting on a full queue)
     barrier()
     dt = time.perf_counter() - t0
     dt = dist_.max_over_ranks(dt, device)
     ops_.set_overlap(overlap)
     ops_.set_tail_jobs(hosted)
+    step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+    plain = [m for m, p_ in zip(step_ms, step_profiled) if not p_]
+    ms_unprofiled = sum(plain) / len(plain) if plain else None
     loss = float(model.last_loss)
     # what ENQUEUEING one step costs the host: timed with the GPU idle at the start of the step, so that nothing waits
     # on a full queue (over many back-to-back steps the host runs ahead until the runtime blocks it, and
@@ -366,6 +384,7 @@ def main():
                    'final_loss': loss, 'host_enqueue_ms_per_step': 1e3 * sorted(enq)[len(enq) // 2],
                    'host_issue_ms_per_step': 1e3 * t_issue / args.steps, 'kernel_overlap': overlap,
                    'hip_graph': bool(model.hip_graph), 'steps_launched_kernel_by_kernel': profiled_steps,
+                   'ms_per_step_unprofiled': ms_unprofiled,
                    'setup_steps_before_warmup': settle},
     }
 
@@ -388,6 +407,7 @@ def main():
                 dt_nc = dist_.max_over_ranks(time.perf_counter() - t1, device)
             out['config']['no_comm_value'] = vox_per_step * k / dt_nc
             out['config']['no_comm_ms_per_step'] = 1e3 * dt_nc / k
+            out['config']['comm']['efficiency'] = out['value'] / out['config']['no_comm_value']
             out['config']['note'] = ('per-GPU batch is 24 at every N > 1 (weak scaling, configs[3]) but 8 on the N = 1 line '
                                      '(configs[1]): use value / no_comm_value, not value / (N x the N = 1 value), as the '
                                      'scaling efficiency')

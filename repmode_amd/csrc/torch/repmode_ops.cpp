@@ -1578,6 +1578,7 @@ struct FragEntry {
   uint32_t ver5 = 0, ver3 = 0;
   bool wf_valid = false, wd_valid = false;
   bool used = false;             // a forward pass since the last optimizer step took it
+  bool pinned = false;           // a stream capture took wf / wd: replays hold their raw addresses (see op_pinned_operands)
   FragEntry(const Tensor& k5, const Tensor& k3)
       : w5(c10::intrusive_ptr<c10::TensorImpl>::reclaim_copy(k5.unsafeGetTensorImpl())),
         w3(c10::intrusive_ptr<c10::TensorImpl>::reclaim_copy(k3.unsafeGetTensorImpl())) {}
@@ -1589,6 +1590,22 @@ struct FragEntry {
 };
 std::mutex g_frag_mu;
 std::unordered_map<void*, FragEntry> g_frag_store;
+// Operand buffers that a captured graph reads and writes by raw address: when their entry leaves the store --
+// another optimizer stepped, another Model was built, a launch failed -- the buffers must outlive the graph, or its replays
+// would read filters from freed memory and write the bf16 operands into whatever the allocator put there.  So the holder of
+// the graph holds the tensors too: Model asks for them right after a capture (pinned_operands) and keeps them beside the
+// graph.  A replay after the entry left the store still finds CORRECT operands: the captured pass contains the on-device check
+// (expert_frags_refresh_multi), which lays a block out again when the stored operands no longer match the parameters' bytes.
+std::vector<Tensor> op_pinned_operands() {
+  std::lock_guard<std::mutex> lock(g_frag_mu);
+  std::vector<Tensor> out;
+  for (auto& kv : g_frag_store)
+    if (kv.second.pinned) {
+      if (kv.second.wf.defined()) out.push_back(kv.second.wf);
+      if (kv.second.wd.defined()) out.push_back(kv.second.wd);
+    }
+  return out;
+}
 bool g_frag_keep = []() {          // (REPMODE_FRAG_STORE=0: lay the experts out at every forward pass, as round 3 did)
   const char* e = std::getenv("REPMODE_FRAG_STORE");
   return e ? std::atoi(e) != 0 : true;
@@ -1657,8 +1674,10 @@ void adam_step_impl(const std::vector<Tensor>& params, const std::vector<Tensor>
     std::lock_guard<std::mutex> lock(g_frag_mu);
     try {
     // entries whose parameters are gone (a network that was rebuilt or freed) give their operands back (advisor round 4)
-    for (auto it = g_frag_store.begin(); it != g_frag_store.end();)
-      it = (it->second.w5.expired() || it->second.w3.expired()) ? g_frag_store.erase(it) : std::next(it);
+    for (auto it = g_frag_store.begin(); it != g_frag_store.end();) {
+      if (it->second.w5.expired() || it->second.w3.expired()) it = g_frag_store.erase(it);
+      else ++it;
+    }
     for (auto& kv : g_frag_store) {
       FragEntry& fe = kv.second;
       if (!fe.used) continue;
@@ -1845,6 +1864,7 @@ void op_prepare_filters(const std::vector<Tensor>& k5, const std::vector<Tensor>
             fe.wd_valid = fe.wd.defined();
           }
           fe.used = true;
+          if (capturing) fe.pinned = true;       // (the graph holds wf / wd by address from here on)
           if (!ready) {
             x5.push_back(K5.data_ptr<float>()); x3.push_back(K3.data_ptr<float>());
             xwf.push_back(fe.wf.data_ptr()); xwd.push_back(fe.wd.defined() ? fe.wd.data_ptr() : nullptr);
@@ -2086,6 +2106,7 @@ TORCH_LIBRARY(repmode, m) {
   m.def("adam_step_dev(Tensor[] params, Tensor[] grads, Tensor[] exp_avgs, Tensor[] exp_avg_sqs, float lr, float beta1, float beta2, "
         "float eps, Tensor(a!) step_dev, Tensor(b!) hyper_dev) -> ()", &rm::op_adam_step_dev);
   m.def("clear_frag_store() -> ()", &rm::op_clear_frag_store);
+  m.def("pinned_operands() -> Tensor[]", &rm::op_pinned_operands);
   m.def("set_frag_store(bool on) -> ()", &rm::op_set_frag_store);
   m.def("frag_store_size() -> int", &rm::op_frag_store_size);
   m.def("set_frag_verify(bool on) -> ()", &rm::op_set_frag_verify);

@@ -11,7 +11,8 @@ per bucket as soon as the bucket's gradients exist.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU); a ring all-reduce is bound by one link, so
 buckets are sized to keep several collectives in flight under the remaining backward work instead
-of one large tail transfer: 48 MB fp32 buckets (~10 per step).  88 % of the gradient bytes belong
+of one large tail transfer: fp32 buckets with a 48 MB cap (a tensor larger than the cap is a bucket of its own: the 5x5x5
+experts of levels 3-4 are 16-131 MB each, so DDP builds 6-7 buckets per step; ``comm_info`` reports their sizes).  88 % of the gradient bytes belong
 to the deep levels (enc4 / bottleneck / dec4) whose backward finishes in the first third of the
 backward pass -- the level 0-1 encoder backward (most of the FLOPs) hides their transfer.
 
@@ -51,12 +52,34 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+class GradDtypeSwitch:
+    """State of the switchable communication hook: ``dtype`` None = float32 buckets, 'bf16' = bfloat16 on the wire.  One
+    wrapper for the whole run: the buckets' dtype rule (Model._apply_grad_dtype_rule) flips this instead of building a second
+    DistributedDataParallel over the same network (the rebuild broadcast rank 0's parameters AND BatchNorm
+    running statistics to every rank, against the per-rank-statistics rule, while the first wrapper's hooks were still alive)."""
+
+    def __init__(self, dtype=None):
+        self.dtype = dtype
+
+
+def _switch_hook(state, bucket):
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    if state.dtype == 'bf16':
+        # buckets travel as bfloat16 (half the bytes per xGMI link: a ring all-reduce of 495 MB of float32 gradients is
+        # bound by ONE ~153 GB/s link); the sum is formed in bf16 by the collective, the result returns to float32
+        return default_hooks.bf16_compress_hook(None, bucket)
+    return default_hooks.allreduce_hook(None, bucket)
+
+
 def wrap_ddp(net, device=None, grad_compress=None):
     """DistributedDataParallel with the settings the MoDE path wants:
       * every parameter gets a gradient every step (all experts and the whole gate matrix take part;
         unused task columns receive exact zeros) -> ``find_unused_parameters=False``;
       * BatchNorm running statistics stay per rank -> ``broadcast_buffers=False``;
       * gradients live inside the communication buckets -> ``gradient_as_bucket_view=True``.
+    ``grad_compress``: None = float32 buckets through the wrapper's own all-reduce (the default: what the reference's
+    DataParallel + Adam average in, fnet_model.py:40-44, 112); 'bf16' / 'auto' = the switchable hook above, starting as
+    bfloat16 / float32 (``ddp.grad_dtype_switch``).
     """
     from torch.nn.parallel import DistributedDataParallel as DDP
     kwargs = dict(broadcast_buffers=False, find_unused_parameters=False, gradient_as_bucket_view=True,
@@ -65,13 +88,12 @@ def wrap_ddp(net, device=None, grad_compress=None):
         ddp = DDP(net, device_ids=[device.index], output_device=device.index, **kwargs)
     else:
         ddp = DDP(net, **kwargs)
-    if grad_compress in ('bf16', torch.bfloat16):
-        # buckets travel as bfloat16 (half the bytes per xGMI link: a ring all-reduce of 495 MB of float32 gradients is
-        # bound by ONE ~153 GB/s link); the sum is formed in bf16 by the collective, the result returns to float32
-        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-        ddp.register_comm_hook(None, default_hooks.bf16_compress_hook)
+    ddp.grad_dtype_switch = None
+    if grad_compress in ('bf16', torch.bfloat16, 'auto'):
+        ddp.grad_dtype_switch = GradDtypeSwitch('bf16' if grad_compress != 'auto' else None)
+        ddp.register_comm_hook(ddp.grad_dtype_switch, _switch_hook)
     elif grad_compress:
-        raise ValueError('grad_compress: None or "bf16", got %r' % (grad_compress,))
+        raise ValueError('grad_compress: None, "bf16" or "auto", got %r' % (grad_compress,))
     return ddp
 
 
@@ -117,10 +139,14 @@ def comm_info(model):
     elif model.ddp is not None:
         info['scheme'] = 'DistributedDataParallel'
         try:
+            # the buckets DDP actually built (bytes each): a tensor larger than the cap travels as a bucket of its own -- the
+            # 5x5x5 experts of levels 3-4 are 16-131 MB each, so 495 MB of gradients are 6-7 buckets, not 495 / 48
             data = model.ddp._get_ddp_logging_data()
             sizes = data.get('rebuilt_bucket_sizes') or data.get('bucket_sizes') or ''
-            info['n_buckets'] = len([v for v in str(sizes).split(',') if v.strip()])
-        except Exception:                         # (a private accessor: the count is informative only)
+            sizes = [int(v) for v in str(sizes).split(',') if v.strip()]
+            info['n_buckets'] = len(sizes)
+            info['bucket_mbytes'] = [round(v / 2 ** 20, 1) for v in sizes]
+        except Exception:                         # (a private accessor: informative only)
             info['n_buckets'] = None
     return info
 

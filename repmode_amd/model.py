@@ -70,12 +70,13 @@ class Model(object):
         self.mult_chan = mult_chan
         self.dtype = dtype
         self.distributed = distributed
-        # grad_compress='bf16' (or REPMODE_GRAD_COMPRESS=bf16): the gradient buckets cross the links as bfloat16
-        # The buckets' dtype is chosen by RULE (distributed.pick_grad_dtype): float32 until two measured
-        # backward passes say that the per-link ring estimate of the float32 all-reduce exceeds 0.6 of the backward it has to hide
-        # under; then the wrapper is rebuilt with bfloat16 buckets.  grad_compress='bf16' / 'fp32' (or REPMODE_GRAD_COMPRESS)
-        # pins it instead.
-        gc = grad_compress or os.environ.get('REPMODE_GRAD_COMPRESS') or 'auto'
+        # The gradient buckets are float32 by default -- what the reference averages in (DataParallel + Adam, fnet_model.py:40-44,
+        # 112) -- and stay float32 unless the caller opts in: grad_compress='bf16' (or REPMODE_GRAD_COMPRESS=bf16) sends them as
+        # bfloat16; 'auto' lets the RULE decide (distributed.pick_grad_dtype): float32 until two measured
+        # backward passes say that the per-link ring estimate of the float32 all-reduce exceeds 0.6 of the backward it has to
+        # hide under, then bfloat16 (the decision is printed; the measured backward includes the wait for the collectives it
+        # overlaps, which only makes the rule keep float32 longer).
+        gc = grad_compress or os.environ.get('REPMODE_GRAD_COMPRESS') or 'fp32'
         if gc in (torch.bfloat16, 'bf16', 'bfloat16'):     # one spelling for both data-parallel paths (a typo must not run silently)
             gc = 'bf16'
         elif gc in ('none', 'fp32', 'f32', torch.float32):
@@ -116,7 +117,8 @@ class Model(object):
             self.reducer = dist_.GradReducer(self.net, always_reduce=self.distributed == 'reducer-always',
                                              comm_dtype=torch.bfloat16 if self.grad_compress == 'bf16' else None)
         elif self.distributed:
-            self.ddp = dist_.wrap_ddp(self.net, self.device, grad_compress=self.grad_compress)
+            self.ddp = dist_.wrap_ddp(self.net, self.device,
+                                      grad_compress='auto' if self.grad_compress_rule.startswith('auto') else self.grad_compress)
         # process-wide (one training process per GPU): where the MoDE gradient kernels put the parameter gradients
         ops_.set_grad_sink(self.reducer)
         ops_.torch_ops().clear_frag_store()          # (expert operands kept across steps belong to the previous network)
@@ -232,13 +234,15 @@ class Model(object):
         pick = dist_.pick_grad_dtype(nbytes, world, bwd, tdist.get_backend())
         self.grad_compress_rule = 'auto: ring estimate %.2f ms vs backward %.2f ms -> %s' % (
             dist_.ring_allreduce_ms(nbytes, world), bwd, pick or 'float32')
+        if tdist.get_rank() == 0:
+            import sys
+            print('repmode_amd: gradient buckets -- %s' % self.grad_compress_rule, file=sys.stderr, flush=True)
         if pick == 'bf16' and self.grad_compress != 'bf16':
             self.grad_compress = 'bf16'
             if self.reducer is not None:
                 self.reducer.comm_dtype = torch.bfloat16
             elif self.ddp is not None:
-                self.ddp = None             # (the float32 wrapper's autograd hooks go before the next one registers its own)
-                self.ddp = dist_.wrap_ddp(self.net, self.device, grad_compress='bf16')      # (the comm hook is fixed at construction)
+                self.ddp.grad_dtype_switch.dtype = 'bf16'      # (one wrapper for the whole run: the hook reads this flag)
 
     def loss_log(self):
         """The dict the reference hands to ``wandb.log`` and its per-sample DataFrame (fnet_model.py:115-130) for the last
@@ -320,6 +324,9 @@ class Model(object):
             with torch.cuda.graph(graph, stream=cs, pool=self._graph_pool):
                 st['out'] = self._train_step(st['signal'], st['target'], st['plan'])
             st['graph'], st['last_loss'] = graph, self.last_loss
+            # the per-expert blocks' operands kept across steps were captured BY ADDRESS: whoever holds the graph holds them
+            # (the store may drop its entries -- another optimizer steps, another Model is built -- while replays go on)
+            st['operands'] = ops_.torch_ops().pinned_operands()
             st['log'] = self._last_log[:4]
             st['plan'].bn_counted = False
         else:

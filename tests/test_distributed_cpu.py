@@ -34,7 +34,7 @@ def _worker(rank, world, port, out_dir, how='ddp'):
     net = orc.Net(Opts(), mult_chan=2)
     compress = how.endswith('-bf16')
     if how.startswith('ddp'):
-        ddp = dist_.wrap_ddp(net, None, grad_compress='bf16' if compress else None)
+        ddp = dist_.wrap_ddp(net, None, grad_compress='auto' if how == 'ddp-switch-bf16' else 'bf16' if compress else None)
     else:
         if rank == 1:                       # the reducer must bring rank 1 onto rank 0's parameters itself
             with torch.no_grad():
@@ -48,14 +48,17 @@ def _worker(rank, world, port, out_dir, how='ddp'):
     tasks = torch.tensor([1, 4, 4, 9])
     lo, hi = dist_.shard_batch(4, rank, world)
     ddp.train()
-    if how == 'ddp-rewrap-bf16':
-        # what Model._apply_grad_dtype_rule does when the rule picks bfloat16 after the first steps: a float32 wrapper has
-        # run (the gradients are views of ITS buckets), it is dropped and a bfloat16 one built over the same network
+    if how == 'ddp-switch-bf16':
+        # what Model._apply_grad_dtype_rule does when the rule picks bfloat16 after the first steps: the ONE wrapper has run a
+        # float32 step, then its communication hook's flag flips (no second wrapper, no broadcast of parameters or buffers)
+        assert ddp.grad_dtype_switch is not None and ddp.grad_dtype_switch.dtype is None
+        bn_before = [b.clone() for b in net.buffers()]
         torch.nn.functional.mse_loss(ddp(x[lo:hi], tasks[lo:hi]), t[lo:hi]).backward()
         net.zero_grad(set_to_none=True)
-        ddp = None
-        ddp = dist_.wrap_ddp(net, None, grad_compress='bf16')
-        ddp.train()
+        ddp.grad_dtype_switch.dtype = 'bf16'
+        with torch.no_grad():                 # (the float32 step moved the running statistics: put them back for the comparison)
+            for b, b0 in zip(net.buffers(), bn_before):
+                b.copy_(b0)
     loss = torch.nn.functional.mse_loss(ddp(x[lo:hi], tasks[lo:hi]), t[lo:hi])
     loss.backward()
     if not how.startswith('ddp'):
@@ -70,7 +73,7 @@ def _worker(rank, world, port, out_dir, how='ddp'):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('how', ['reducer', 'ddp', 'reducer-bf16', 'ddp-bf16', 'ddp-rewrap-bf16'])
+@pytest.mark.parametrize('how', ['reducer', 'ddp', 'reducer-bf16', 'ddp-bf16', 'ddp-switch-bf16'])
 def test_two_rank_ddp_equals_single_process(tmp_path, how):
     world = 2
     mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), how), nprocs=world, join=True,
@@ -95,6 +98,66 @@ def test_two_rank_ddp_equals_single_process(tmp_path, how):
         # (bf16 buckets: each rank's gradient is rounded to 8 bits of mantissa before the sum, and the sum once more)
         tol = 1e-5 if not how.endswith('-bf16') else 2e-2
         assert (g0[k] - ref).abs().max() <= tol * max(1.0, float(ref.abs().max())) + 1e-7, k
+
+
+def _worker8(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from repmode_amd import distributed as dist_
+    from oracle import repmode_oracle as orc
+    dist_.init_from_env(backend='gloo')
+    torch.manual_seed(0)
+    net = orc.Net(Opts(), mult_chan=2)
+    ddp = dist_.wrap_ddp(net, None)
+    x, t, tasks = _batch8()
+    lo, hi = dist_.shard_batch(x.shape[0], rank, world)
+    ddp.train()
+    torch.nn.functional.mse_loss(ddp(x[lo:hi], tasks[lo:hi]), t[lo:hi]).backward()
+    # the buckets' dtype rule: every rank measures its own backward, all take the MAX -> the same decision everywhere
+    bwd = dist_.max_over_ranks(5.0 + rank, torch.device('cpu'))
+    nbytes = 4 * 123877633
+    pick = dist_.pick_grad_dtype(nbytes, world, bwd, 'nccl')
+    torch.save({'grads': {k: p.grad.clone() for k, p in net.named_parameters()}, 'bwd': bwd, 'pick': pick,
+                'running_mean': net.state_dict()['encoder_block1.conv_more.conv1.subsequent_layer.0.running_mean'].clone()},
+               os.path.join(out_dir, 'g%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+def _batch8():
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(16, 1, 16, 16, 16, generator=g)
+    t = torch.randn(16, 1, 16, 16, 16, generator=g)
+    tasks = torch.tensor([0, 0, 1, 5, 11, 3, 7, 7, 2, 9, 4, 4, 6, 10, 8, 1])      # a different task mix on every rank
+    return x, t, tasks
+
+
+@pytest.mark.timeout(900)
+def test_eight_rank_ddp_equals_single_process(tmp_path):
+    """The target topology (BASELINE configs[3]: eight ranks), on CPU over gloo at mult_chan 2: every rank with its own task
+    mix, gradients == single-process training on the concatenated batch with per-shard BatchNorm statistics, BatchNorm running
+    statistics stay per rank, and every rank takes the same decision of the buckets' dtype rule from different local timings."""
+    world = 8
+    mp.start_processes(_worker8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    got = [torch.load(tmp_path / ('g%d.pt' % r)) for r in range(world)]
+    from oracle import repmode_oracle as orc
+    from repmode_amd.distributed import shard_batch
+    torch.manual_seed(0)
+    net = orc.Net(Opts(), mult_chan=2)
+    x, t, tasks = _batch8()
+    net.train()
+    loss = 0
+    for r in range(world):
+        lo, hi = shard_batch(16, r, world)
+        loss = loss + torch.nn.functional.mse_loss(net(x[lo:hi], tasks[lo:hi]), t[lo:hi]) / world
+    loss.backward()
+    for k, p in net.named_parameters():
+        for r in range(1, world):
+            assert torch.equal(got[0]['grads'][k], got[r]['grads'][k]), k
+        assert (got[0]['grads'][k] - p.grad).abs().max() <= 1e-5 * max(1.0, float(p.grad.abs().max())) + 1e-7, k
+    assert all(g['bwd'] == 12.0 for g in got) and len({g['pick'] for g in got}) == 1
+    # per-rank BatchNorm statistics: the ranks saw different shards, nothing broadcast them
+    assert not torch.equal(got[0]['running_mean'], got[5]['running_mean'])
 
 
 def test_shard_batch():

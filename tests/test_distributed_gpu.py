@@ -143,14 +143,15 @@ def test_reducer_buckets_hold_the_kernels_gradients_single_process():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('rule', ['as measured', 'bf16 branch'])
+@pytest.mark.parametrize('rule', ['default', 'bf16 branch'])
 def test_bench_two_ranks_share_one_gpu(rule):
     """bench.py's N > 1 branch (BASELINE configs[3]'s code path: one process per rank through torch.distributed.run, the
     DistributedDataParallel step, the max-over-ranks clock, the no_sync() leg behind ``config.no_comm_value``, ``config.comm``)
     on a one-GPU box: both ranks on cuda:0 over gloo (REPMODE_BENCH_SHARE_GPU=1 -- a check of the code path, never a
     measurement).  The line must parse and describe a two-rank job.  'bf16 branch': the buckets' dtype rule is made to pick
-    bfloat16 (threshold 0, gloo admitted), so that the wrapper is rebuilt mid-run -- in the steps before the timed region --
-    and the remaining steps travel as bfloat16: the branch an 8-GPU job takes at 8 patches per rank."""
+    bfloat16 (``--grad-compress auto``, threshold 0, gloo admitted), so that the wrapper's communication hook switches mid-run --
+    in the steps before the timed region -- and the remaining steps travel as bfloat16: the branch an 8-GPU job that opts into
+    the rule takes at 8 patches per rank.  'default': float32 buckets, pinned."""
     import json
     import subprocess
     import sys
@@ -162,7 +163,7 @@ def test_bench_two_ranks_share_one_gpu(rule):
            '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '1',
            '--batch', '2', '--no-cpu-baseline']
     if rule == 'bf16 branch':
-        cmd.append('--no-fwd')          # ('as measured' keeps rank 0's forward-only leg: the other rank waits for it at the final barrier)
+        cmd += ['--no-fwd', '--grad-compress', 'auto']      # ('default' keeps rank 0's forward-only leg: the other rank waits for it at the final barrier)
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -177,12 +178,15 @@ def test_bench_two_ranks_share_one_gpu(rule):
     comm = cfg['comm']
     assert comm['backend'] == 'gloo' and comm['world_size'] == 2 and comm['ranks_seen'] == 2
     assert comm['scheme'] == 'DistributedDataParallel' and comm['bucket_mb'] == 48
-    assert comm['dtype_rule'].startswith('auto: ring estimate')  # (the rule ran: in the 3 setup steps + 1 warmup step)
-    assert cfg['setup_steps_before_warmup'] == 3
+    assert comm['n_buckets'] == len(comm['bucket_mbytes']) >= 4 and abs(sum(comm['bucket_mbytes']) - 4 * 123877633 / 2 ** 20) < 2
+    assert 0 < comm['efficiency'] and cfg['ms_per_step_unprofiled'] > 0
     if rule == 'bf16 branch':
+        assert comm['dtype_rule'].startswith('auto: ring estimate')  # (the rule ran: in the 3 setup steps + 1 warmup step)
+        assert cfg['setup_steps_before_warmup'] == 3
         assert comm['dtype'] == 'bf16' and comm['dtype_rule'].endswith('-> bf16')
     else:
-        assert comm['dtype'] == 'f32' and comm['dtype_rule'].endswith('-> float32')    # (gloo: the link model is xGMI's)
+        # the default: float32 buckets, pinned (what the reference averages in) -- no rule, no setup steps
+        assert comm['dtype'] == 'f32' and comm['dtype_rule'] == 'pinned' and cfg['setup_steps_before_warmup'] == 0
     assert 0 < cfg['final_loss'] < 10
-    assert ('fwd' in d) == (rule == 'as measured')
+    assert ('fwd' in d) == (rule == 'default')
     assert abs(comm['grad_bytes_fp32'] - 4 * 123877633) < 8

@@ -196,3 +196,43 @@ def test_batchnorm_pass_as_one_launch(shape, in_dtype, out_dtype):
         e = (nrm_err if low and 1 <= i <= 3 else rel_err)(a, b)
         assert e < (2e-2 if low else 1e-5), (i, e)
     assert rel_err(rm, res[0][4]) < 1e-6 and rel_err(rv, res[0][5]) < 1e-6
+
+
+def test_captured_operands_outlive_the_store():
+    """a captured train step reads and writes the per-expert blocks' stored operands BY ADDRESS.  When the store
+    drops its entries (another optimizer steps, another Model is built, a launch fails) the buffers must stay alive for the
+    replays: the Model holds them beside its graph.  Here the store is emptied after the capture and the freed memory is handed
+    to tensors full of NaN; the replays must go on producing the losses of a model that steps launch by launch."""
+    from conftest import Opts
+    from repmode_amd.model import Model
+    ops = _ops()
+    gen = torch.Generator().manual_seed(4)
+    n, shape = 4, (16, 32, 32)
+    tasks = torch.tensor([2, 6, 9, 2])
+    xs = [torch.randn(n, 1, *shape, generator=gen) for _ in range(8)]
+    ts = [torch.randn(n, 1, *shape, generator=gen) for _ in range(8)]
+    torch.manual_seed(0)
+    g = Model(Opts(), lr=1e-3, gpu_ids=0, mult_chan=8, dtype=torch.bfloat16, hip_graph=True)
+    torch.manual_seed(0)
+    e = Model(Opts(), lr=1e-3, gpu_ids=0, mult_chan=8, dtype=torch.bfloat16, hip_graph=False)
+    e.net.load_state_dict(g.net.state_dict())
+    lg, le, junk = [], [], []
+    for i in range(8):
+        g.do_train_iter(xs[i], ts[i], tasks)
+        lg.append(float(g.last_loss))
+        if i == Model.GRAPH_WARMUP:                                   # the step that captured
+            st = next(iter(g._graphs.values()))
+            assert st['graph'] is not None and len(st['operands']) > 0
+            held = sum(t.numel() * t.element_size() for t in st['operands'])
+            ops.torch_ops().clear_frag_store()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            # whatever the allocator would have re-used: poison it
+            junk = [torch.full((max(1, held // 8),), float('nan'), device=DEV) for _ in range(4)]
+        e.do_train_iter(xs[i], ts[i], tasks)
+        le.append(float(e.last_loss))
+    del junk
+    record('captured_operands', graph=lg, eager=le)
+    assert all(l == l for l in lg), lg
+    for a, b in zip(lg, le):
+        assert abs(a - b) < 2e-2 * abs(b), (lg, le)
