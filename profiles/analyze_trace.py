@@ -60,6 +60,9 @@ FAMILIES = [('deep_mode level 3 forward (one launch per per-expert block)', ('de
             ('conv5_igemm level 2', 'conv5_igemm_kernel<unsigned short, Cfg<4, 4, 16'),
             ('conv5_igemm level 3', 'conv5_igemm_kernel<unsigned short, Cfg<4, 8, 8'),
             ('conv5_igemm level 4', 'conv5_igemm_kernel<unsigned short, Cfg<2, 4, 4'),
+            ('conv5_wgrad level 0-1', 'conv5_wgrad_col_kernel<8, 32'), ('conv5_wgrad level 2', 'conv5_wgrad_col_kernel<16, 16'),
+            ('conv5_wgrad level 2', 'conv5_wgrad_col_kernel<8, 16'), ('conv5_wgrad level 3', 'conv5_wgrad_col_kernel<8, 8'),
+            ('conv5_wgrad level 4', 'conv5_wgrad_col_kernel<4, 8'),
             ('conv5_wgrad level 0-1', 'conv5_wgrad_bf16_kernel<1, 8, 32'), ('conv5_wgrad level 2', 'conv5_wgrad_bf16_kernel<1, 8, 16'),
             ('conv5_wgrad level 3', 'conv5_wgrad_bf16_kernel<2, 8, 8'), ('conv5_wgrad level 4', 'conv5_wgrad_bf16_kernel<2, 4, 8'),
             ('conv5_wgrad_thin', 'wgrad_thin'), ('gatrep_fwd', 'gatrep_fwd'), ('gatrep_bwd', 'gatrep_bwd'),

@@ -1133,6 +1133,19 @@ extern "C" int repmode_conv5_wgrad_dual(const void* x, const void* dy_a, const v
   a.prezeroed = (mode_a & 8) ? 1 : 0;
   const int ma = mode_a & 7, mb = mode_b & 7;
   RM_REQUIRE(ma >= 0 && ma <= 3 && mb >= 0 && mb <= 3, "conv5_wgrad_dual: bad mode");
+  if (ma == 2 && mb == 3) {
+    // the column walk's dual form (csrc/conv5_wgrad_col.hip): both experts' gradients from one staging of x, several samples
+    // per step, the 3x3x3 job as 27 taps
+    WgColCall cc{x, dy_a, nullptr, dw_a, n, d, h, wdim, cin, cout, cin, 0, 1, 0, nullptr};
+    cc.dy2 = dy_b; cc.dw2 = dw_b;
+    if (repmode_wgrad_col_eligible(cc)) {
+      const int rc = repmode_wgrad_col_launch(cc, s);
+      if (rc != REPMODE_OK) return rc;
+      repmode_prof_end(s);
+      RM_LAUNCH_CHECK("conv5_wgrad_col (dual)");
+      return REPMODE_OK;
+    }
+  }
   a.dz_lo = (ma == 1 || ma == 3) ? 1 : 0;   a.ndz = (ma == 1 || ma == 3) ? 3 : 5;   a.layout = ma == 2 ? 1 : (ma == 3 ? 2 : 0);
   a.dz_lo2 = (mb == 1 || mb == 3) ? 1 : 0;  a.ndz2 = (mb == 1 || mb == 3) ? 3 : 5;  a.layout2 = mb == 2 ? 1 : (mb == 3 ? 2 : 0);
   int rc;

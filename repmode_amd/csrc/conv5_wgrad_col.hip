@@ -24,6 +24,12 @@
 // * z planes outside the volume: the dz reads a plane of zeros kept beside the ring (straight-line MFMA code: a second,
 //   branching body for the edge steps cost 200-700 spilled registers; with contiguous tap ranges the busiest wave of a step
 //   has all its planes inside the volume anyway, so skipping would not shorten a step).
+// * The per-expert levels (volumes <= 8 voxels wide: levels 3-4) take the same walk as
+//   repmode_conv5_wgrad_dual's launch: BOTH conv experts' filter gradients of a block from one staging of x -- the 125 taps
+//   of the 5x5x5 expert against its gate-scaled output gradient and the 27 centre taps of the 3x3x3 expert against the other
+//   (152 accumulator tiles, 38 per wave; the 3x3x3 job computes 27 taps, not 125) --, SEVERAL samples per step (the tile is
+//   2 samples x 8 x 8 or 4 samples x 4 x 8 voxels: a K extent of 128 per barrier instead of 64 / 32), and the experts' own
+//   [co][ci][125] / [co][ci][27] layouts written as 150-byte runs through an LDS transpose.  Whole units per workgroup only.
 #include "wgrad_col.h"
 
 #include <cstdlib>
@@ -41,57 +47,83 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int TY_, int TX_>
+template <int TY_, int TX_, int SPS_ = 1, int RING_ = 6, bool DUAL_ = false>
 struct ColTile {
-  static constexpr int TY = TY_, TX = TX_;
-  static constexpr int TV = TY * TX;                 // voxels of a tile = the K extent of a step
+  static constexpr int TY = TY_, TX = TX_, SPS = SPS_;   // SPS: samples per step (their tiles side by side in K)
+  static constexpr bool DUAL = DUAL_;                // two output gradients (5x5x5 + 3x3x3 experts), the experts' layouts
+  static constexpr int TV = SPS * TY * TX;           // voxels of a step's tile = its K extent
   static constexpr int HY = TY + 4;
   static constexpr int NGX = TX / 8;                 // 8-voxel groups per row
   static constexpr int GPR = 4 / NGX;                // tile rows per K step (32 voxels)
   static constexpr int RG = (TX + 4 + 7) / 8;        // 16-byte slots per stored halo row (x0-2 .. x0+TX+1)
+  // TX = 8: a lane's 16-lane quarter is a ROW (32 bytes further), not the next x group (16 bytes): the two slots of a halo row
+  // are swapped on odd channel rows, as in conv5_wgrad.hip's 8-wide tiles -- without it every window read took 8 LDS cycles
+  // instead of 4 (tools/lds_bank_check.py's model; measured: profiles/r06_wgrad_col.txt)
+  static constexpr bool SWZ = TX < 16;
   static constexpr int KSTEPS = TV / 32;
-  static constexpr int NWROW = TY - GPR + 5;         // distinct compile-time halo-row offsets of the windows of a plane
+  static constexpr int NWROW = TY - GPR + 5;         // distinct compile-time halo-row offsets of the windows of a sample plane
   static constexpr int NPAIR = TX / 2 + 2;           // x pairs of a halo row
-  static constexpr int PLANE = HY * RG * 16;         // bytes of one halo plane of one channel
-  static constexpr int RING = 6;
+  static constexpr int SPLANE = HY * RG * 16;        // bytes of one sample's halo plane of one channel
+  static constexpr int PLANE = SPS * SPLANE;         // ... of a step's SPS samples
+  // ring slots: a step reads planes z-2 .. z+2 while the plane three ahead is written (6); volumes of at most two planes get
+  // by with 4 (a column has two planes: two being read, the next column's two arriving)
+  static constexpr int RING = RING_;
   // (slot RING of a channel row is a plane of zeros: what a dz whose plane lies outside the volume reads)
   // channel rows an odd multiple of 32 bytes apart: conflict-free ds_read_b128 (conv5_wgrad.hip, tools/lds_bank_check.py)
   static constexpr int ROW_C = (RING + 1) * PLANE + (32 - ((RING + 1) * PLANE) % 64 + 64) % 64;
   static constexpr int DYS = TV * 2 + 32;
-  static constexpr int DYBUF = 16 * DYS;
-  static constexpr int LDS = 16 * ROW_C + 2 * DYBUF;
-  static constexpr int NIT_X = HY * NPAIR * 2;       // x items of a plane: (halo row, x pair, channel group of 8)
+  static constexpr int DYJOB = 16 * DYS;             // one job's dy tile
+  static constexpr int NJOB = DUAL ? 2 : 1;
+  static constexpr int DYBUF = NJOB * DYJOB;
+  static constexpr int NTAPS = DUAL ? 152 : 125;     // accumulator tiles of a unit
+  static constexpr int WLS = ((NTAPS + 3) / 4) | 1;  // floats per (co, ci) pair of a wave's transposition buffer (odd: no bank conflicts)
+  static constexpr int WLBUF = DUAL ? 4 * 64 * WLS * 4 : 0;
+  static constexpr int LDS = 16 * ROW_C + 2 * DYBUF + WLBUF;
+  static constexpr int NIT_X = SPS * HY * NPAIR * 2; // x items of a plane: (sample, halo row, x pair, channel group of 8)
   static constexpr int NX = (NIT_X + 255) / 256;
-  static constexpr int NIT_DY = (TV / 2) * 2;        // dy items: (voxel pair, channel group of 8)
+  static constexpr int NIT_DY = SPS * (TY * TX / 2) * 2;   // dy items: (sample, voxel pair, channel group of 8)
   static constexpr int NDY = (NIT_DY + 255) / 256;
   static_assert(TV % 32 == 0 && TX % 8 == 0 && TX <= 32 && NGX * GPR == 4 && RG >= NGX + 1, "tile shape");
+  static_assert(SPS == 1 || (TY % GPR == 0), "a K step must not straddle two samples");
   static_assert(ROW_C % 64 == 32 && DYS % 64 == 32, "channel rows an odd multiple of 32 bytes apart");
   static_assert(LDS <= 160 * 1024, "LDS");
 };
 
-// The taps of MFMA wave ROLE: [T0, T1) of the 125 (tap = dz * 25 + dy * 5 + dx), and which windows feed them.  Window w =
-// (dz, rr): the 12-element register window of halo row rr (+ the lane's own row) of plane dz; it feeds K step ks for the tap
-// row dy = rr - ks * GPR.
+// The accumulator tiles of MFMA wave ROLE: [T0, T1) of the unit's list -- the 125 taps of the 5x5x5 filter (tap = dz * 25 +
+// dy * 5 + dx; job A), then, in the dual form, the 27 centre taps of the 3x3x3 expert (job B: its own dy operand) -- and which
+// windows feed them.  Window w = (dz, sample j, rr): the 12-element register window of halo row rr (+ the lane's own row) of
+// sample j's plane dz; it feeds K step ks (of sample j) for the tap row dy = rr - (first row of the step).
 template <typename G, int ROLE>
 struct RolePlan {
-  static constexpr int T0 = ROLE == 0 ? 0 : 32 + 31 * (ROLE - 1);
-  static constexpr int T1 = 32 + 31 * ROLE;
+  static constexpr int NTOT = G::NTAPS;
+  static constexpr int T0 = NTOT * ROLE / 4;
+  static constexpr int T1 = NTOT * (ROLE + 1) / 4;
   static constexpr int NT = T1 - T0;
-  static constexpr int NW = 5 * G::NWROW;
-  static constexpr bool mine(int dz, int dyi, int dxi) {
-    const int t = dz * 25 + dyi * 5 + dxi;
-    return dyi >= 0 && dyi < 5 && t >= T0 && t < T1;
+  static constexpr int NW = 5 * G::SPS * G::NWROW;
+  // index of tap (dz, dyi, dxi) of job `b` in the unit's list, -1: not a tap of that job
+  static constexpr int index(int b, int dz, int dyi, int dxi) {
+    if (dyi < 0 || dyi >= 5) return -1;
+    if (b == 0) return dz * 25 + dyi * 5 + dxi;
+    if (!G::DUAL || dz < 1 || dz > 3 || dyi < 1 || dyi > 3 || dxi < 1 || dxi > 3) return -1;
+    return 125 + ((dz - 1) * 3 + (dyi - 1)) * 3 + (dxi - 1);
+  }
+  static constexpr bool mine(int b, int dz, int dyi, int dxi) {
+    const int u = index(b, dz, dyi, dxi);
+    return u >= T0 && u < T1;
   }
   static constexpr bool row_mine(int dz, int dyi) {
-    for (int dxi = 0; dxi < 5; ++dxi)
-      if (mine(dz, dyi, dxi)) return true;
+    for (int b = 0; b < G::NJOB; ++b)
+      for (int dxi = 0; dxi < 5; ++dxi)
+        if (mine(b, dz, dyi, dxi)) return true;
     return false;
   }
+  static constexpr int ks_sample(int ks) { return (ks * G::GPR) / G::TY; }
+  static constexpr int ks_row0(int ks) { return (ks * G::GPR) % G::TY; }
   static constexpr bool nonempty(int w) {
     if (w < 0 || w >= NW) return false;
-    const int dz = w / G::NWROW, rr = w % G::NWROW;
+    const int dz = w / (G::SPS * G::NWROW), j = (w / G::NWROW) % G::SPS, rr = w % G::NWROW;
     for (int ks = 0; ks < G::KSTEPS; ++ks)
-      if (row_mine(dz, rr - ks * G::GPR)) return true;
+      if (ks_sample(ks) == j && row_mine(dz, rr - ks_row0(ks))) return true;
     return false;
   }
   static constexpr int next(int w) {                   // the next non-empty window behind w, -1: none
@@ -103,60 +135,65 @@ struct RolePlan {
 
 struct ColArgs {
   const bf16_t* x;
-  const bf16_t* dy;
-  const int32_t* sample_slot;
-  float* dw;
+  const bf16_t* dy;              // job A's output gradient
+  const bf16_t* dy2;             // dual form: job B's
+  const int32_t* sample_slot;    // NULL: every sample in slot 0
+  float* dw;                     // slot layout [nslots][125][Cout][CinTot]; dual form: the 5x5x5 expert's [Cout][Cin][125]
+  float* dw2;                    // dual form: the 3x3x3 expert's [Cout][Cin][27]
   int N, D, H, W, Cin, Cout, CinTot, ci_off, nslots;
   int ncot, ncit, nty, ntx, ncol;
-  long total;                    // steps of the launch: N * ncot * ncit * ncol * D
+  long total;                    // steps of the launch (one sample per slot group of SPS)
   int aligned;                   // 1: a workgroup takes WHOLE units (an equal range of the unit list): plain stores only
 };
 
-// where a walk stands in the launch's sequence (all wave-uniform)
+// where a walk stands in the launch's sequence (all wave-uniform); k: the group of SPS samples of the slot
 struct ColCursor {
-  int slot, cot, cit, k, cnt, n, col;
+  int slot, cot, cit, k, cnt, ngrp, col;
   unsigned long long mask;
 };
 
 // two x-adjacent voxels (8 channels each) -> eight 4-byte stores, one per channel row
-__device__ __forceinline__ void put8(unsigned char* dst, int stride, const u32x4& v0, const u32x4& v1) {
+// (odd_delta: what the odd channel rows' position differs by -- the swapped slots of the 8-wide tiles)
+__device__ __forceinline__ void put8(unsigned char* dst, int stride, const u32x4& v0, const u32x4& v1, int odd_delta = 0) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     *reinterpret_cast<uint32_t*>(dst + (2 * j) * stride) = __builtin_amdgcn_perm(v1[j], v0[j], 0x05040100u);
-    *reinterpret_cast<uint32_t*>(dst + (2 * j + 1) * stride) = __builtin_amdgcn_perm(v1[j], v0[j], 0x07060302u);
+    *reinterpret_cast<uint32_t*>(dst + (2 * j + 1) * stride + odd_delta) = __builtin_amdgcn_perm(v1[j], v0[j], 0x07060302u);
   }
 }
 
-template <int TY, int TX>
+template <int TY, int TX, int SPS, int RING, bool DUAL>
 __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
-  using G = ColTile<TY, TX>;
+  using G = ColTile<TY, TX, SPS, RING, DUAL>;
   constexpr int NGX = G::NGX, GPR = G::GPR, RG = G::RG, KSTEPS = G::KSTEPS, NWROW = G::NWROW, NPAIR = G::NPAIR;
-  constexpr int PLANE = G::PLANE, ROW_C = G::ROW_C, DYS = G::DYS, DYBUF = G::DYBUF, NX = G::NX, NDY = G::NDY;
+  constexpr int PLANE = G::PLANE, SPLANE = G::SPLANE, ROW_C = G::ROW_C, DYS = G::DYS, DYBUF = G::DYBUF, DYJOB = G::DYJOB;
+  constexpr int NX = G::NX, NDY = G::NDY, NJOB = G::NJOB, HY = G::HY;
   __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS];
-  unsigned char* xT = smem;                            // [16 ci][6 ring planes][HY][RG * 16 B]
-  unsigned char* dyT = smem + 16 * ROW_C;              // [2][16 co][TV] bf16
+  unsigned char* xT = smem;                            // [16 ci][RING + 1 planes][SPS][HY][RG * 16 B]
+  unsigned char* dyT = smem + 16 * ROW_C;              // [2][NJOB][16 co][TV] bf16
 
   const int tid = (int)(threadIdx.x & 255), lane = tid & 63, wave = tid >> 6;
   const bool loader = threadIdx.x >= 256;
   const int D = a.D, H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
 
-  const int slot64 = a.sample_slot[min(lane, a.N - 1)];                 // (the host sends at most 64 samples here)
+  const int slot64 = a.sample_slot ? a.sample_slot[min(lane, a.N - 1)] : 0;     // (the host sends at most 64 samples here)
   auto mask_of = [&](int sl) -> unsigned long long { return __ballot(lane < a.N && slot64 == sl); };
-  auto kth = [&](unsigned long long m, int kk) -> int {
+  auto kth = [&](unsigned long long m, int kk) -> int {             // the kk-th sample of a slot, -1: it has fewer
     for (int i = 0; i < kk; ++i) m &= m - 1;
     return __ffsll((long long)m) - 1;
   };
+  auto groups = [&](int cnt) -> int { return (cnt + SPS - 1) / SPS; };
   const int G2 = a.ncot * a.ncit, colsteps = a.ncol * D;
   const long wg = xcd_remap(blockIdx.x, gridDim.x);    // neighbouring ranges (the same samples' planes) on one XCD
   long g0, g1;
   if (a.aligned) {
-    // whole units: units [U wg / G, U (wg + 1) / G) of the list (slot, cot, cit); a unit of slot s has cnt(s) * ncol * D steps
+    // whole units: units [U wg / G, U (wg + 1) / G) of the list (slot, cot, cit); a unit of slot s has groups(s) * ncol * D steps
     const long units = (long)a.nslots * G2;
     auto steps_before = [&](long u) -> long {
       const int su = (int)(u / G2);
       long acc = 0;
-      for (int sl = 0; sl < su; ++sl) acc += (long)__popcll(mask_of(sl)) * colsteps * G2;
-      if (su < a.nslots) acc += (u % G2) * (long)__popcll(mask_of(su)) * colsteps;
+      for (int sl = 0; sl < su; ++sl) acc += (long)groups(__popcll(mask_of(sl))) * colsteps * G2;
+      if (su < a.nslots) acc += (u % G2) * (long)groups(__popcll(mask_of(su))) * colsteps;
       return acc;
     };
     g0 = steps_before(units * wg / gridDim.x);
@@ -175,70 +212,79 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
     unsigned long long m;
     for (;;) {
       m = mask_of(sl); cnt = __popcll(m);
-      const long span = (long)cnt * colsteps * G2;
+      const long span = (long)groups(cnt) * colsteps * G2;
       if (rem < span) break;
       rem -= span; ++sl;
     }
-    const long per = (long)cnt * colsteps;
+    const long per = (long)groups(cnt) * colsteps;
     const int unit = (int)(rem / per);
     rem -= (long)unit * per;
-    c0.slot = sl; c0.mask = m; c0.cnt = cnt;
+    c0.slot = sl; c0.mask = m; c0.cnt = cnt; c0.ngrp = groups(cnt);
     c0.cot = unit / a.ncit; c0.cit = unit % a.ncit;
     c0.k = (int)(rem / colsteps);
     rem -= (long)c0.k * colsteps;
     c0.col = (int)(rem / D);
     zb = (int)(rem % D);
-    c0.n = kth(m, c0.k);
   }
   auto next_col = [&](ColCursor& c) {                  // (never called behind the launch's last column)
     if (++c.col < a.ncol) return;
     c.col = 0;
-    if (++c.k < c.cnt) { c.n = kth(c.mask, c.k); return; }
+    if (++c.k < c.ngrp) return;
     c.k = 0;
     if (++c.cit == a.ncit) {
       c.cit = 0;
       if (++c.cot == a.ncot) {
         c.cot = 0;
         do { ++c.slot; c.mask = mask_of(c.slot); c.cnt = __popcll(c.mask); } while (c.cnt == 0 && c.slot < a.nslots);
+        c.ngrp = groups(c.cnt);
       }
     }
-    c.n = kth(c.mask, 0);
   };
 
   if (loader) {
     // ---- loader waves.  The stream of ELEMENTS of this workgroup's range: per column the planes p = 0 .. D + 1 (the first
-    // column from max(0, zb - 2)); element p = x plane p (p < D) + dy plane p - 2 (p >= 2).  Step (column, z) needs the
-    // elements up to z + 2.  An element is fetched two elements ahead of its transposition into LDS (register sets a / b)
-    // and staged as early as the ring allows: x plane V = column * D + p goes to ring slot V % 6 once the step the MFMA
-    // waves are at no longer reads plane V - 6 (V <= lowest plane of that step + 5), a dy plane at most one step ahead.
+    // column from max(0, zb - 2)); element p = x plane p (p < D) + dy plane p - 2 (p >= 2), of the column's SPS samples.  Step
+    // (column, z) needs the elements up to z + 2.  An element is fetched two elements ahead of its transposition into LDS
+    // (register sets a / b) and staged as early as the ring allows: x plane V = column * D + p goes to ring slot V % RING once
+    // the step the MFMA waves are at no longer reads plane V - RING (V <= lowest plane of that step + RING - 1), a dy plane
+    // at most one step ahead.
     constexpr uint32_t OOB = 0x80000000u;
-    struct ElemRegs { u32x4 x0[NX], x1[NX], d0[NDY], d1[NDY]; };
+    struct ElemRegs { u32x4 x0[NX], x1[NX], d0[NJOB][NDY], d1[NJOB][NDY]; };
     struct ElemMeta { int hasx, hasdy, v, dystep; };
     ElemRegs ra, rb;
     ElemMeta ma{}, mb{};
     // this thread's items
-    int x_hy[NX], x_px[NX], x_cg8[NX], x_dst[NX];
+    int x_hy[NX], x_px[NX], x_cg8[NX], x_dst[NX], x_j[NX], x_odd[NX];
     bool x_on[NX];
 #pragma unroll
     for (int u = 0; u < NX; ++u) {
       const int it = u * 256 + tid;
-      const int pr = it % NPAIR, r = it / NPAIR;
-      const int cg = r & 1, hy = r >> 1;
+      const int pr = it % NPAIR;
+      int r = it / NPAIR;
+      const int cg = r & 1; r >>= 1;
+      const int hy = r % HY, j = r / HY;
       x_on[u] = it < G::NIT_X;
-      x_hy[u] = hy - 2; x_px[u] = 2 * pr - 2; x_cg8[u] = cg * 8;
-      x_dst[u] = (cg * 8) * ROW_C + (hy * RG + (pr >> 2)) * 16 + (pr & 3) * 4;
+      x_hy[u] = hy - 2; x_px[u] = 2 * pr - 2; x_cg8[u] = cg * 8; x_j[u] = j;
+      x_dst[u] = (cg * 8) * ROW_C + j * SPLANE + (hy * RG + (pr >> 2)) * 16 + (pr & 3) * 4;
+      x_odd[u] = G::SWZ ? (((pr >> 2) ^ 1) - (pr >> 2)) * 16 : 0;
     }
-    int d_yy[NDY], d_xx[NDY], d_cg8[NDY], d_dst[NDY];
+    int d_yy[NDY], d_xx[NDY], d_cg8[NDY], d_dst[NDY], d_j[NDY];
     bool d_on[NDY];
 #pragma unroll
     for (int u = 0; u < NDY; ++u) {
       const int it = u * 256 + tid;
-      const int q = it % (G::TV / 2), cg = it / (G::TV / 2);
+      const int q = it % (TY * TX / 2);
+      int r = it / (TY * TX / 2);
+      const int j = r % SPS, cg = r / SPS;
       d_on[u] = it < G::NIT_DY;
-      d_xx[u] = (2 * q) % TX; d_yy[u] = (2 * q) / TX; d_cg8[u] = cg * 8;
-      d_dst[u] = (cg * 8) * DYS + q * 4;
+      d_xx[u] = (2 * q) % TX; d_yy[u] = (2 * q) / TX; d_cg8[u] = cg * 8; d_j[u] = j;
+      d_dst[u] = (cg * 8) * DYS + (j * (TY * TX / 2) + q) * 4;
     }
-    const uint32_t xbytes = (uint32_t)((size_t)D * H * W * Cin * 2), dybytes = (uint32_t)((size_t)D * H * W * Cout * 2);
+    // one descriptor over the whole tensor (the host checks N * D * H * W * C * 2 < 2^31); a sample is an offset
+    const uint32_t xvol = (uint32_t)((size_t)D * H * W * Cin * 2), dyvol = (uint32_t)((size_t)D * H * W * Cout * 2);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.x), 0, (int)(xvol * (uint32_t)a.N), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.dy), 0, (int)(dyvol * (uint32_t)a.N), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(DUAL ? a.dy2 : a.dy), 0, (int)(dyvol * (uint32_t)a.N), 0x00020000);
 
     // fetch cursor = the next element of the stream
     ColCursor fc = c0;
@@ -255,14 +301,22 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
       m.v = fcoD + fp;
       m.dystep = ebase + fp - 2;
       const int y0 = (fc.col / a.ntx) * TY, x0 = (fc.col % a.ntx) * TX;
+      int ns[SPS];                                        // the column's samples (-1: the slot has no such sample)
+#pragma unroll
+      for (int j = 0; j < SPS; ++j) ns[j] = fc.k * SPS + j < fc.cnt ? kth(fc.mask, fc.k * SPS + j) : -1;
+      auto sample_of = [&](int j) -> int {
+        int n = ns[0];
+#pragma unroll
+        for (int q = 1; q < SPS; ++q) n = j == q ? ns[q] : n;
+        return n;
+      };
       if (m.hasx) {
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<bf16_t*>(a.x) + (size_t)fc.n * D * H * W * Cin, 0, (int)xbytes, 0x00020000);
 #pragma unroll
         for (int u = 0; u < NX; ++u) {
+          const int n = sample_of(x_j[u]);
           const int gy = y0 + x_hy[u], gx = x0 + x_px[u], c = fc.cit * 16 + x_cg8[u];
-          const bool row_ok = x_on[u] && (unsigned)gy < (unsigned)H && c < Cin;
-          const uint32_t off = (uint32_t)((((fp * H + gy) * W + gx) * Cin + c) * 2);
+          const bool row_ok = x_on[u] && n >= 0 && (unsigned)gy < (unsigned)H && c < Cin;
+          const uint32_t off = (uint32_t)n * xvol + (uint32_t)((((fp * H + gy) * W + gx) * Cin + c) * 2);
           r.x0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                       rx, (row_ok && (unsigned)gx < (unsigned)W) ? off : OOB, 0, 0));
           r.x1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -271,41 +325,46 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
       }
       if (m.hasdy) {
         const int z = fp - 2;
-        const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<bf16_t*>(a.dy) + (size_t)fc.n * D * H * W * Cout, 0, (int)dybytes, 0x00020000);
 #pragma unroll
         for (int u = 0; u < NDY; ++u) {
+          const int n = sample_of(d_j[u]);
           const int gy = y0 + d_yy[u], gx = x0 + d_xx[u], c = fc.cot * 16 + d_cg8[u];
-          const bool row_ok = d_on[u] && gy < H && c < Cout;
-          const uint32_t off = (uint32_t)((((z * H + gy) * W + gx) * Cout + c) * 2);
-          r.d0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (row_ok && gx < W) ? off : OOB, 0, 0));
-          r.d1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                      rdy, (row_ok && gx + 1 < W) ? off + (uint32_t)Cout * 2 : OOB, 0, 0));
+          const bool row_ok = d_on[u] && n >= 0 && gy < H && c < Cout;
+          const uint32_t off = (uint32_t)n * dyvol + (uint32_t)((((z * H + gy) * W + gx) * Cout + c) * 2);
+          const uint32_t o0 = (row_ok && gx < W) ? off : OOB, o1 = (row_ok && gx + 1 < W) ? off + (uint32_t)Cout * 2 : OOB;
+          r.d0[0][u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, o0, 0, 0));
+          r.d1[0][u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, o1, 0, 0));
+          if constexpr (DUAL) {
+            r.d0[1][u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy2, o0, 0, 0));
+            r.d1[1][u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy2, o1, 0, 0));
+          }
         }
       }
     };
     auto stage_from = [&](ElemRegs& r, const ElemMeta& m) {
       if (m.hasx) {
-        unsigned char* base = xT + (m.v % G::RING) * PLANE;
+        unsigned char* base = xT + (m.v % RING) * PLANE;
 #pragma unroll
         for (int u = 0; u < NX; ++u)
-          if (x_on[u]) put8(base + x_dst[u], ROW_C, r.x0[u], r.x1[u]);
+          if (x_on[u]) put8(base + x_dst[u], ROW_C, r.x0[u], r.x1[u], x_odd[u]);
       }
       if (m.hasdy) {
         unsigned char* base = dyT + (m.dystep & 1) * DYBUF;
 #pragma unroll
-        for (int u = 0; u < NDY; ++u)
-          if (d_on[u]) put8(base + d_dst[u], DYS, r.d0[u], r.d1[u]);
+        for (int b = 0; b < NJOB; ++b)
+#pragma unroll
+          for (int u = 0; u < NDY; ++u)
+            if (d_on[u]) put8(base + b * DYJOB + d_dst[u], DYS, r.d0[b][u], r.d1[b][u]);
       }
     };
     // the step the MFMA waves are at during interval i (i = -1: the prologue, nobody reads yet -- same bound as step 0)
     int scoD = 0, sz = zb, szs = max(0, zb - 2);
     auto allowed = [&](const ElemMeta& m, int i) -> bool {
       const int lo = scoD + max(sz - 2, szs);
-      return (!m.hasx || m.v <= lo + 5) && (!m.hasdy || m.dystep <= i + 1);
+      return (!m.hasx || m.v <= lo + RING - 1) && (!m.hasdy || m.dystep <= i + 1);
     };
     for (int i = tid; i < 16 * (PLANE / 16); i += 256)           // the plane of zeros (slot RING of every channel row)
-      *reinterpret_cast<u32x4*>(xT + (i / (PLANE / 16)) * ROW_C + G::RING * PLANE + (i % (PLANE / 16)) * 16) = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(xT + (i / (PLANE / 16)) * ROW_C + RING * PLANE + (i % (PLANE / 16)) * 16) = u32x4{0u, 0u, 0u, 0u};
     bool ha = elem_needed();
     if (ha) { fetch_to(ra, ma); elem_advance(); }
     bool hb = elem_needed();
@@ -333,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
     return;
   }
 
-  // ---- MFMA waves: wave w owns the taps of RolePlan<G, w>
+  // ---- MFMA waves: wave w owns the accumulator tiles of RolePlan<G, w>
   auto run_role = [&](auto ROLE) {
     using P = RolePlan<G, decltype(ROLE)::value>;
     f32x4 acc[P::NT];
@@ -343,28 +402,31 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
     const unsigned char* xlane = xT + l15 * ROW_C + ((kg / NGX) * RG + kg % NGX) * 16;
     const unsigned char* dlane = dyT + l15 * DYS + kg * 16;
     ColCursor sc = c0;
-    int z = zb, m6 = zb % G::RING;
+    int z = zb, m6 = zb % RING;
     bool head = sc.k == 0 && sc.col == 0 && zb == 0;    // the current unit started in this workgroup, at its first step
 
     for (int i = 0; i < steps; ++i) {
       asm volatile("s_barrier" ::: "memory");
       const unsigned char* db = dlane + (i & 1) * DYBUF;
-      bf16x8 bfr[KSTEPS];                                // B operand: dy[co = lane & 15][8 voxels of group kg]
+      bf16x8 bfr[NJOB][KSTEPS];                          // B operands: dy[co = lane & 15][8 voxels of group kg], per job
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) bfr[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(db + ks * 64));
+      for (int b = 0; b < NJOB; ++b)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+          bfr[b][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(db + b * DYJOB + ks * 64));
       const unsigned char* xs[5];
 #pragma unroll
       for (int dz = 0; dz < 5; ++dz) {
-        int sl = m6 + dz + 4;                            // plane z + dz - 2 -> ring slot (V + dz - 2) % 6
-        sl = sl >= 12 ? sl - 12 : sl >= 6 ? sl - 6 : sl;
-        if ((unsigned)(z + dz - 2) >= (unsigned)D) sl = G::RING;     // outside the volume: the plane of zeros
+        int sl = m6 + dz + 2 * RING - 2;                 // plane z + dz - 2 -> ring slot (V + dz - 2) % RING
+        sl = sl % RING;
+        if ((unsigned)(z + dz - 2) >= (unsigned)D) sl = RING;        // outside the volume: the plane of zeros
         xs[dz] = xlane + sl * PLANE;
       }
       auto read_window = [&](auto WI, u32x4& lo, u32x2& hi) {
         constexpr int w = decltype(WI)::value;
-        const unsigned char* xb = xs[w / NWROW] + (w % NWROW) * RG * 16;
-        lo = *reinterpret_cast<const u32x4*>(xb);          // elements 0..7 of the window (x0 + 8g - 2 ..)
-        hi = *reinterpret_cast<const u32x2*>(xb + 16);     // elements 8..11
+        const unsigned char* xb = xs[w / (SPS * NWROW)] + ((w / NWROW) % SPS) * SPLANE + (w % NWROW) * RG * 16;
+        lo = *reinterpret_cast<const u32x4*>(G::SWZ ? xb + (l15 & 1) * 16 : xb);               // elements 0..7 of the window (x0 + 8g - 2 ..)
+        hi = *reinterpret_cast<const u32x2*>(G::SWZ ? xb + 16 - (l15 & 1) * 16 : xb + 16);    // elements 8..11
       };
       {
         u32x4 lo_n;
@@ -373,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
         read_window(std::integral_constant<int, wfirst>{}, lo_n, hi_n);
         static_for<0, P::NW>([&](auto WI) {
           constexpr int w = decltype(WI)::value;
-          constexpr int dz = w / NWROW, rr = w % NWROW;
+          constexpr int dz = w / (SPS * NWROW), wj = (w / NWROW) % SPS, rr = w % NWROW;
           if constexpr (P::nonempty(w)) {
             u32x4 lo = lo_n;
             u32x2 hi = hi_n;
@@ -394,14 +456,14 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
                 __builtin_bit_cast(bf16x8, (u32x4{lo.z, lo.w, hi.x, hi.y}))};       // shift +2
             static_for<0, KSTEPS>([&](auto KS) {
               constexpr int ks = decltype(KS)::value;
-              constexpr int dyi = rr - ks * GPR;
-              if constexpr (dyi >= 0 && dyi < 5) {
-                static_for<0, 5>([&](auto DX) {
-                  constexpr int dxi = decltype(DX)::value;
-                  if constexpr (P::mine(dz, dyi, dxi)) {
-                    constexpr int t = dz * 25 + dyi * 5 + dxi - P::T0;
+              constexpr int dyi = rr - P::ks_row0(ks);
+              if constexpr (P::ks_sample(ks) == wj && dyi >= 0 && dyi < 5) {
+                static_for<0, 5 * NJOB>([&](auto DX) {
+                  constexpr int b = decltype(DX)::value / 5, dxi = decltype(DX)::value % 5;
+                  if constexpr (P::mine(b, dz, dyi, dxi)) {
+                    constexpr int t = P::index(b, dz, dyi, dxi) - P::T0;
                     // D[ci = 4 (lane >> 4) + r][co = lane & 15] += x window (A) * dy (B)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh[dxi], bfr[ks], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh[dxi], bfr[b][ks], acc[t], 0, 0, 0);
                   }
                 });
               }
@@ -410,27 +472,54 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
         });
       }
 
-      const bool last = z == D - 1 && sc.col == a.ncol - 1 && sc.k == sc.cnt - 1;     // the unit's last step
+      const bool last = z == D - 1 && sc.col == a.ncol - 1 && sc.k == sc.ngrp - 1;     // the unit's last step
       if (last || i + 1 == steps) {
-        const bool atomic = !(head && last);
         const int co = sc.cot * 16 + l15, ci0 = sc.cit * 16 + kg * 4;
-        if (co < Cout && ci0 < Cin) {
-          float* p = a.dw + (((size_t)sc.slot * REPMODE_TAPS + P::T0) * Cout + co) * a.CinTot + a.ci_off + ci0;
-          const size_t tstride = (size_t)Cout * a.CinTot;
-          if (atomic) {
+        if constexpr (!DUAL) {
+          const bool atomic = !(head && last);
+          if (co < Cout && ci0 < Cin) {
+            float* p = a.dw + (((size_t)sc.slot * REPMODE_TAPS + P::T0) * Cout + co) * a.CinTot + a.ci_off + ci0;
+            const size_t tstride = (size_t)Cout * a.CinTot;
+            if (atomic) {
 #pragma unroll
-            for (int t = 0; t < P::NT; ++t) {
+              for (int t = 0; t < P::NT; ++t) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) unsafeAtomicAdd(p + r, acc[t][r]);
-              p += tstride;
-            }
-          } else {
+                for (int r = 0; r < 4; ++r) unsafeAtomicAdd(p + r, acc[t][r]);
+                p += tstride;
+              }
+            } else {
 #pragma unroll
-            for (int t = 0; t < P::NT; ++t) {
-              *reinterpret_cast<f32x4*>(p) = acc[t];
-              p += tstride;
+              for (int t = 0; t < P::NT; ++t) {
+                *reinterpret_cast<f32x4*>(p) = acc[t];
+                p += tstride;
+              }
             }
           }
+        } else {
+          // The experts' own layouts ([co][ci][125], [co][ci][27]): a (co, ci) pair's taps are contiguous.  The wave transposes
+          // its tiles through LDS, one accumulator register (64 pairs) at a time, and stores runs of NT taps (whole units only:
+          // plain stores).
+          float* wl = reinterpret_cast<float*>(smem + 16 * ROW_C + 2 * DYBUF) + wave * (64 * G::WLS);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int pair = kg * 16 + l15;
+#pragma unroll
+            for (int t = 0; t < P::NT; ++t) wl[pair * G::WLS + t] = acc[t][r];
+            // (one wave writes and reads its own buffer: LDS operations of a wave complete in order)
+            for (int e = lane; e < 64 * P::NT; e += 64) {
+              const int pr = e / P::NT, t = e % P::NT, u = P::T0 + t;
+              const int oc = sc.cot * 16 + (pr & 15), ic = sc.cit * 16 + (pr >> 4) * 4 + r;
+              if (oc < Cout && ic < Cin) {
+                float* p = u < REPMODE_TAPS ? a.dw + ((size_t)oc * Cin + ic) * REPMODE_TAPS + u
+                                            : a.dw2 + ((size_t)oc * Cin + ic) * 27 + (u - REPMODE_TAPS);
+#ifdef COL_NOFLUSH
+                if (wl[pr * G::WLS + t] == 12345.678f)      // TIMING BUILD ONLY: sums computed, (practically) never written
+#endif
+                *p = wl[pr * G::WLS + t];
+              }
+            }
+          }
+          (void)co; (void)ci0;
         }
 #pragma unroll
         for (int t = 0; t < P::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -438,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
       }
       if (i + 1 < steps) {
         if (++z == D) { z = 0; next_col(sc); }
-        m6 = m6 == G::RING - 1 ? 0 : m6 + 1;
+        m6 = m6 == RING - 1 ? 0 : m6 + 1;
       }
     }
   };
@@ -448,7 +537,6 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
   else run_role(std::integral_constant<int, 3>{});
 }
 
-struct DevInfo { int cus; };
 int device_cus() {
   static int tab[32] = {};
   int dev = 0;
@@ -462,36 +550,38 @@ int device_cus() {
   return c;
 }
 
+long col_room() { return device_cus() - repmode_reserve_cus() > 8 ? device_cus() - repmode_reserve_cus() : 8; }
+
 // whole units per workgroup (plain stores only) when the unit list fills three quarters of the chip
 bool col_aligned(const WgColCall& c) {
   const long units = (long)c.nslots * ceil_div(c.Cout, 16) * ceil_div(c.Cin, 16);
-  const long room = device_cus() - repmode_reserve_cus() > 8 ? device_cus() - repmode_reserve_cus() : 8;
-  return 4 * units >= 3 * room;
+  return 4 * units >= 3 * col_room();
 }
 
-template <int TY, int TX>
+template <int TY, int TX, int SPS, int RING, bool DUAL>
 int launch_col(const WgColCall& c, hipStream_t s) {
   ColArgs a{};
-  a.x = static_cast<const bf16_t*>(c.x); a.dy = static_cast<const bf16_t*>(c.dy);
-  a.sample_slot = c.sample_slot; a.dw = c.dw;
+  a.x = static_cast<const bf16_t*>(c.x); a.dy = static_cast<const bf16_t*>(c.dy); a.dy2 = static_cast<const bf16_t*>(c.dy2);
+  a.sample_slot = c.sample_slot; a.dw = c.dw; a.dw2 = c.dw2;
   a.N = c.N; a.D = c.D; a.H = c.H; a.W = c.W; a.Cin = c.Cin; a.Cout = c.Cout; a.CinTot = c.CinTot; a.ci_off = c.ci_off;
   a.nslots = c.nslots;
   a.ncot = ceil_div(c.Cout, 16); a.ncit = ceil_div(c.Cin, 16);
   a.nty = ceil_div(c.H, TY); a.ntx = ceil_div(c.W, TX); a.ncol = a.nty * a.ntx;
-  a.total = (long)c.N * a.ncot * a.ncit * a.ncol * c.D;
-  const long room = device_cus() - repmode_reserve_cus() > 8 ? device_cus() - repmode_reserve_cus() : 8;
+  const long room = col_room();
   // Enough units to fill three quarters of the chip: a workgroup takes WHOLE units (an equal range of the unit list; the grid
   // is the smallest that gives every workgroup ceil(units / CUs) of them) -- every flush is plain stores, dw needs no clearing,
   // whatever the slots' sample counts.  Otherwise: an equal split of the step sequence; shared units are added with float
-  // atomics onto the cleared dw.
+  // atomics onto the cleared dw.  The dual form (the experts' layouts) always takes whole units.
   const long units = (long)c.nslots * a.ncot * a.ncit;
-  const bool direct = col_aligned(c);
+  const bool direct = DUAL || col_aligned(c);
   long g;
   if (direct) {
     const long per = (units + room - 1) / room;
     g = (units + per - 1) / per;
     a.aligned = 1;
   } else {
+    // (sample groups: only the whole-unit form knows the slots' counts; SPS == 1 here)
+    a.total = (long)c.N * a.ncot * a.ncit * a.ncol * c.D;
     g = room;
     if (g > a.total / 4) g = a.total / 4;
     if (g < 1) g = 1;
@@ -500,7 +590,7 @@ int launch_col(const WgColCall& c, hipStream_t s) {
   if (!direct && !c.prezeroed)
     RM_HIP(hipMemsetAsync(c.dw, 0, (size_t)c.nslots * REPMODE_TAPS * c.Cout * c.CinTot * sizeof(float), s));
   repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * c.N * c.D * c.H * c.W * (double)c.Cin * c.Cout * REPMODE_TAPS, s);
-  hipLaunchKernelGGL((conv5_wgrad_col_kernel<TY, TX>), dim3((unsigned)g), dim3(512), 0, s, a);
+  hipLaunchKernelGGL((conv5_wgrad_col_kernel<TY, TX, SPS, RING, DUAL>), dim3((unsigned)g), dim3(512), 0, s, a);
   return REPMODE_OK;
 }
 
@@ -513,8 +603,18 @@ extern "C" int repmode_get_wgrad_col(void) { return g_wgrad_col; }
 
 bool repmode_wgrad_col_eligible(const WgColCall& c) {
   if (g_wgrad_col == 0 || repmode_deterministic()) return false;
-  if (c.W < 16 || (c.Cin & 7) || (c.Cout & 7) || (c.CinTot & 3) || (c.ci_off & 3) || c.N > 64 || !c.sample_slot) return false;
-  if ((size_t)c.D * c.H * c.W * (c.Cin > c.Cout ? c.Cin : c.Cout) * 2 >= ((size_t)1 << 31)) return false;
+  if ((c.Cin & 7) || (c.Cout & 7) || c.N > 64) return false;
+  if ((size_t)c.N * c.D * c.H * c.W * (c.Cin > c.Cout ? c.Cin : c.Cout) * 2 >= ((size_t)1 << 31)) return false;
+  if (c.dy2) {
+    // the dual form (both conv experts' gradients of a per-expert block): volumes up to 15 voxels wide
+    if (c.W >= 16 || c.nslots != 1) return false;
+    // Measured SLOWER than conv5_wgrad.hip's dual launch on every layer of levels 3-4 (profiles/r06_wgrad_col.txt: 81 vs 70 us
+    // at 256 -> 256, 187 vs 96 us at level 4's 512 -> 512; the same with the stores taken out): a 16-channel tile uses 32 of a
+    // voxel's 512-1024 bytes, so a step's staging is ~1000 L2 requests of 16 useful bytes each and the loaders run at the L2's
+    // request rate, not at its bandwidth -- 4-10 us per step against 1.4 us of MFMAs.  Kept as a tested experiment: mode 2 only.
+    return g_wgrad_col >= 2;
+  }
+  if (c.W < 16 || (c.CinTot & 3) || (c.ci_off & 3) || !c.sample_slot) return false;
   if (g_wgrad_col >= 2) return true;
   // mode 1: the shapes it was measured to win on (profiles/r06_wgrad_col.txt) -- level 2 of the network (volumes 16 .. 31
   // voxels wide) with enough units for whole-unit workgroups; where units are shared through float atomics (levels 0-1 at
@@ -523,7 +623,11 @@ bool repmode_wgrad_col_eligible(const WgColCall& c) {
 }
 
 int repmode_wgrad_col_launch(const WgColCall& c, hipStream_t s) {
-  if (c.W >= 32) return launch_col<8, 32>(c, s);
-  if (c.H > 8) return launch_col<16, 16>(c, s);
-  return launch_col<8, 16>(c, s);
+  if (c.dy2) {
+    if (c.H <= 4 && c.D <= 2) return launch_col<4, 8, 4, 4, true>(c, s);
+    return launch_col<8, 8, 2, 6, true>(c, s);
+  }
+  if (c.W >= 32) return launch_col<8, 32, 1, 6, false>(c, s);
+  if (c.H > 8) return launch_col<16, 16, 1, 6, false>(c, s);
+  return launch_col<8, 16, 1, 6, false>(c, s);
 }

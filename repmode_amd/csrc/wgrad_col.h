@@ -11,6 +11,10 @@ struct WgColCall {
   int N, D, H, W, Cin, Cout, CinTot, ci_off, nslots;
   int prezeroed;                 // dw is known to be all zero (no memset before a launch that adds with atomics)
   int* plan_out;                 // not NULL: do not launch, report 1 when every element is written by plain stores
+  // The dual form (repmode_conv5_wgrad_dual with the experts' layouts, nslots == 1, sample_slot NULL): dy = the 5x5x5 expert's
+  // gate-scaled output gradient, dw = its gradient [Cout][Cin][125]; dy2 / dw2 = the 3x3x3 expert's ([Cout][Cin][27]).
+  const void* dy2 = nullptr;
+  float* dw2 = nullptr;
 };
 
 // REPMODE_WGRAD_COL / repmode_set_wgrad_col: 0 never, 1 (default) on the shapes it was measured to win, 2 wherever eligible
