@@ -519,6 +519,13 @@ int repmode_get_wgrad_ws(void);
  * reports it); otherwise workgroups share units through float atomics onto the cleared dw. */
 int repmode_set_wgrad_col(int mode);
 int repmode_get_wgrad_col(void);
+/* The column form's tap split (also REPMODE_WGRAD_COL_Q): the 125 taps of a (slot, 16 co, 16 ci) unit are cut into q parts, one
+ * workgroup each -- every part walks the unit's whole voxel range with 1 / q of the accumulators, so a layer with too few units
+ * for the chip (level 1 at batch 8: 128) is divided without two workgroups ever sharing an output element: plain stores, no
+ * cleared dw, at the price of staging x and dy q times.  1 (default): no split; 2: two workgroups per unit (volumes >= 16
+ * voxels wide).  Measured slower than the stream-K grid on level 1 (csrc/conv5_wgrad_col.hip): a tested experiment. */
+int repmode_set_wgrad_col_split(int q);
+int repmode_get_wgrad_col_split(void);
 
 /* ---- sliding-window inference (fnet/fnet_model.py:149-223): the two ends of a batch of patches, SURVEY.md section 8f.3 ----
  * patch_gather: :196-205 -- out[n][pd][ph][pw] = vol[starts[3n..3n+2] + (z, y, x)], the batch's crops of the device-resident

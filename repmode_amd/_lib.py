@@ -40,6 +40,8 @@ _SIGNATURES = {
     'repmode_set_wgrad_ws': [_I],
     'repmode_get_wgrad_ws': [],
     'repmode_set_wgrad_col': [_I],
+    'repmode_set_wgrad_col_split': [_I],
+    'repmode_get_wgrad_col_split': [],
     'repmode_set_bn_fused': [_I],
     'repmode_get_bn_fused': [],
     'repmode_get_wgrad_col': [],

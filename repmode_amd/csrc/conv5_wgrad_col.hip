@@ -93,11 +93,14 @@ struct ColTile {
 // dy * 5 + dx; job A), then, in the dual form, the 27 centre taps of the 3x3x3 expert (job B: its own dy operand) -- and which
 // windows feed them.  Window w = (dz, sample j, rr): the 12-element register window of halo row rr (+ the lane's own row) of
 // sample j's plane dz; it feeds K step ks (of sample j) for the tap row dy = rr - (first row of the step).
-template <typename G, int ROLE>
+// Tap split (Q, part): the unit's list is cut into Q parts, one WORKGROUP each -- every part walks the unit's whole K with 1 / Q
+// of the accumulators, so a unit that is too long for one workgroup is divided without sharing any output element (no
+// atomics, no cleared dw), at the price of staging x and dy Q times.
+template <typename G, int ROLE, int Q = 1, int PART = 0>
 struct RolePlan {
   static constexpr int NTOT = G::NTAPS;
-  static constexpr int T0 = NTOT * ROLE / 4;
-  static constexpr int T1 = NTOT * (ROLE + 1) / 4;
+  static constexpr int T0 = NTOT * (PART * 4 + ROLE) / (4 * Q);
+  static constexpr int T1 = NTOT * (PART * 4 + ROLE + 1) / (4 * Q);
   static constexpr int NT = T1 - T0;
   static constexpr int NW = 5 * G::SPS * G::NWROW;
   // index of tap (dz, dyi, dxi) of job `b` in the unit's list, -1: not a tap of that job
@@ -148,7 +151,7 @@ struct ColArgs {
 
 // where a walk stands in the launch's sequence (all wave-uniform); k: the group of SPS samples of the slot
 struct ColCursor {
-  int slot, cot, cit, k, cnt, ngrp, col;
+  int slot, cot, cit, q, k, cnt, ngrp, col;         // q: the unit's tap part (0 .. Q-1)
   unsigned long long mask;
 };
 
@@ -162,7 +165,7 @@ __device__ __forceinline__ void put8(unsigned char* dst, int stride, const u32x4
   }
 }
 
-template <int TY, int TX, int SPS, int RING, bool DUAL>
+template <int TY, int TX, int SPS, int RING, bool DUAL, int Q>
 __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
   using G = ColTile<TY, TX, SPS, RING, DUAL>;
   constexpr int NGX = G::NGX, GPR = G::GPR, RG = G::RG, KSTEPS = G::KSTEPS, NWROW = G::NWROW, NPAIR = G::NPAIR;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
     return __ffsll((long long)m) - 1;
   };
   auto groups = [&](int cnt) -> int { return (cnt + SPS - 1) / SPS; };
-  const int G2 = a.ncot * a.ncit, colsteps = a.ncol * D;
+  const int G2 = a.ncot * a.ncit * Q, colsteps = a.ncol * D;        // units of a slot: (cot, cit, tap part)
   const long wg = xcd_remap(blockIdx.x, gridDim.x);    // neighbouring ranges (the same samples' planes) on one XCD
   long g0, g1;
   if (a.aligned) {
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
     const int unit = (int)(rem / per);
     rem -= (long)unit * per;
     c0.slot = sl; c0.mask = m; c0.cnt = cnt; c0.ngrp = groups(cnt);
-    c0.cot = unit / a.ncit; c0.cit = unit % a.ncit;
+    c0.q = unit % Q; c0.cit = (unit / Q) % a.ncit; c0.cot = unit / (Q * a.ncit);
     c0.k = (int)(rem / colsteps);
     rem -= (long)c0.k * colsteps;
     c0.col = (int)(rem / D);
@@ -231,6 +234,8 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
     c.col = 0;
     if (++c.k < c.ngrp) return;
     c.k = 0;
+    if (++c.q < Q) return;
+    c.q = 0;
     if (++c.cit == a.ncit) {
       c.cit = 0;
       if (++c.cot == a.ncot) {
@@ -392,20 +397,19 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
     return;
   }
 
-  // ---- MFMA waves: wave w owns the accumulator tiles of RolePlan<G, w>
-  auto run_role = [&](auto ROLE) {
-    using P = RolePlan<G, decltype(ROLE)::value>;
+  // ---- MFMA waves: wave w owns the accumulator tiles of RolePlan<G, w, Q, part> of the unit it is at.  One call of run_unit
+  // = the steps of ONE unit that fall into this workgroup's range (the tap lists are compile-time: another part is another body)
+  struct StepState { int i, z, m6; bool head; ColCursor sc; };
+  const int l15 = lane & 15, kg = lane >> 4;
+  const unsigned char* xlane = xT + l15 * ROW_C + ((kg / NGX) * RG + kg % NGX) * 16;
+  const unsigned char* dlane = dyT + l15 * DYS + kg * 16;
+  auto run_unit = [&](auto PART, auto ROLE, StepState& st) {
+    using P = RolePlan<G, decltype(ROLE)::value, Q, decltype(PART)::value>;
     f32x4 acc[P::NT];
 #pragma unroll
     for (int t = 0; t < P::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int l15 = lane & 15, kg = lane >> 4;
-    const unsigned char* xlane = xT + l15 * ROW_C + ((kg / NGX) * RG + kg % NGX) * 16;
-    const unsigned char* dlane = dyT + l15 * DYS + kg * 16;
-    ColCursor sc = c0;
-    int z = zb, m6 = zb % RING;
-    bool head = sc.k == 0 && sc.col == 0 && zb == 0;    // the current unit started in this workgroup, at its first step
-
-    for (int i = 0; i < steps; ++i) {
+    for (;;) {
+      const int i = st.i, z = st.z;
       asm volatile("s_barrier" ::: "memory");
       const unsigned char* db = dlane + (i & 1) * DYBUF;
       bf16x8 bfr[NJOB][KSTEPS];                          // B operands: dy[co = lane & 15][8 voxels of group kg], per job
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
       const unsigned char* xs[5];
 #pragma unroll
       for (int dz = 0; dz < 5; ++dz) {
-        int sl = m6 + dz + 2 * RING - 2;                 // plane z + dz - 2 -> ring slot (V + dz - 2) % RING
+        int sl = st.m6 + dz + 2 * RING - 2;              // plane z + dz - 2 -> ring slot (V + dz - 2) % RING
         sl = sl % RING;
         if ((unsigned)(z + dz - 2) >= (unsigned)D) sl = RING;        // outside the volume: the plane of zeros
         xs[dz] = xlane + sl * PLANE;
@@ -472,11 +476,13 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
         });
       }
 
+      const ColCursor& sc = st.sc;
       const bool last = z == D - 1 && sc.col == a.ncol - 1 && sc.k == sc.ngrp - 1;     // the unit's last step
-      if (last || i + 1 == steps) {
+      const bool done = last || i + 1 == steps;
+      if (done) {
         const int co = sc.cot * 16 + l15, ci0 = sc.cit * 16 + kg * 4;
         if constexpr (!DUAL) {
-          const bool atomic = !(head && last);
+          const bool atomic = !(st.head && last);
           if (co < Cout && ci0 < Cin) {
             float* p = a.dw + (((size_t)sc.slot * REPMODE_TAPS + P::T0) * Cout + co) * a.CinTot + a.ci_off + ci0;
             const size_t tstride = (size_t)Cout * a.CinTot;
@@ -521,20 +527,28 @@ __global__ __launch_bounds__(512, 2) void conv5_wgrad_col_kernel(ColArgs a) {
           }
           (void)co; (void)ci0;
         }
-#pragma unroll
-        for (int t = 0; t < P::NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        head = true;
+        st.head = true;
       }
-      if (i + 1 < steps) {
-        if (++z == D) { z = 0; next_col(sc); }
-        m6 = m6 == RING - 1 ? 0 : m6 + 1;
+      ++st.i;
+      if (st.i < steps) {
+        if (++st.z == D) { st.z = 0; next_col(st.sc); }
+        st.m6 = st.m6 == RING - 1 ? 0 : st.m6 + 1;
       }
+      if (done) return;
     }
   };
-  if (wave == 0) run_role(std::integral_constant<int, 0>{});
-  else if (wave == 1) run_role(std::integral_constant<int, 1>{});
-  else if (wave == 2) run_role(std::integral_constant<int, 2>{});
-  else run_role(std::integral_constant<int, 3>{});
+  StepState st{0, zb, zb % RING, c0.k == 0 && c0.col == 0 && zb == 0, c0};
+  while (st.i < steps) {
+    const int part = st.sc.q;
+    static_for<0, Q>([&](auto PART) {
+      if (part == decltype(PART)::value) {
+        if (wave == 0) run_unit(PART, std::integral_constant<int, 0>{}, st);
+        else if (wave == 1) run_unit(PART, std::integral_constant<int, 1>{}, st);
+        else if (wave == 2) run_unit(PART, std::integral_constant<int, 2>{}, st);
+        else run_unit(PART, std::integral_constant<int, 3>{}, st);
+      }
+    });
+  }
 }
 
 int device_cus() {
@@ -553,12 +567,22 @@ int device_cus() {
 long col_room() { return device_cus() - repmode_reserve_cus() > 8 ? device_cus() - repmode_reserve_cus() : 8; }
 
 // whole units per workgroup (plain stores only) when the unit list fills three quarters of the chip
-bool col_aligned(const WgColCall& c) {
-  const long units = (long)c.nslots * ceil_div(c.Cout, 16) * ceil_div(c.Cin, 16);
+bool col_aligned(const WgColCall& c, int q = 1) {
+  const long units = (long)c.nslots * ceil_div(c.Cout, 16) * ceil_div(c.Cin, 16) * q;
   return 4 * units >= 3 * col_room();
 }
+// REPMODE_WGRAD_COL_Q / repmode_set_wgrad_col_split: 1 (default) no tap split, 2 the taps of a unit over two workgroups.
+// Measured (profiles/r06_wgrad_col.txt): level 1 at batch 8 (128 units -> 256 workgroups of whole half-units, plain stores)
+// 146 us against the stream-K grid's 115 -- a step is then 62 taps x 8 = 1000 MFMA cycles short of what the loader waves
+// need for a plane of x and one of dy (2.2 us: 16-channel slices use 32 bytes of every 128-byte line they pull through the
+// L2), and four-way 277 us.  Kept as a tested experiment; never chosen by default.
+int g_col_q = []() { const char* e = getenv("REPMODE_WGRAD_COL_Q"); return e ? atoi(e) : 1; }();
+int col_tap_split(const WgColCall& c) {
+  if (c.dy2 || c.W < 16) return 1;
+  return g_col_q == 2 && (c.W >= 32 || c.H > 8) ? 2 : 1;
+}
 
-template <int TY, int TX, int SPS, int RING, bool DUAL>
+template <int TY, int TX, int SPS, int RING, bool DUAL, int Q = 1>
 int launch_col(const WgColCall& c, hipStream_t s) {
   ColArgs a{};
   a.x = static_cast<const bf16_t*>(c.x); a.dy = static_cast<const bf16_t*>(c.dy); a.dy2 = static_cast<const bf16_t*>(c.dy2);
@@ -572,8 +596,8 @@ int launch_col(const WgColCall& c, hipStream_t s) {
   // is the smallest that gives every workgroup ceil(units / CUs) of them) -- every flush is plain stores, dw needs no clearing,
   // whatever the slots' sample counts.  Otherwise: an equal split of the step sequence; shared units are added with float
   // atomics onto the cleared dw.  The dual form (the experts' layouts) always takes whole units.
-  const long units = (long)c.nslots * a.ncot * a.ncit;
-  const bool direct = DUAL || col_aligned(c);
+  const long units = (long)c.nslots * a.ncot * a.ncit * Q;
+  const bool direct = DUAL || Q > 1 || col_aligned(c);
   long g;
   if (direct) {
     const long per = (units + room - 1) / room;
@@ -590,7 +614,7 @@ int launch_col(const WgColCall& c, hipStream_t s) {
   if (!direct && !c.prezeroed)
     RM_HIP(hipMemsetAsync(c.dw, 0, (size_t)c.nslots * REPMODE_TAPS * c.Cout * c.CinTot * sizeof(float), s));
   repmode_prof_begin(REPMODE_PROF_WGRAD, 2.0 * c.N * c.D * c.H * c.W * (double)c.Cin * c.Cout * REPMODE_TAPS, s);
-  hipLaunchKernelGGL((conv5_wgrad_col_kernel<TY, TX, SPS, RING, DUAL>), dim3((unsigned)g), dim3(512), 0, s, a);
+  hipLaunchKernelGGL((conv5_wgrad_col_kernel<TY, TX, SPS, RING, DUAL, Q>), dim3((unsigned)g), dim3(512), 0, s, a);
   return REPMODE_OK;
 }
 
@@ -600,6 +624,8 @@ int repmode_wgrad_col_mode() { return g_wgrad_col; }
 
 extern "C" int repmode_set_wgrad_col(int mode) { g_wgrad_col = mode; return REPMODE_OK; }
 extern "C" int repmode_get_wgrad_col(void) { return g_wgrad_col; }
+extern "C" int repmode_set_wgrad_col_split(int q) { g_col_q = q; return REPMODE_OK; }
+extern "C" int repmode_get_wgrad_col_split(void) { return g_col_q; }
 
 bool repmode_wgrad_col_eligible(const WgColCall& c) {
   if (g_wgrad_col == 0 || repmode_deterministic()) return false;
@@ -619,7 +645,7 @@ bool repmode_wgrad_col_eligible(const WgColCall& c) {
   // mode 1: the shapes it was measured to win on (profiles/r06_wgrad_col.txt) -- level 2 of the network (volumes 16 .. 31
   // voxels wide) with enough units for whole-unit workgroups; where units are shared through float atomics (levels 0-1 at
   // batch 8: 8 and 2-4 workgroups per unit) conv5_wgrad.hip's stream-K grid is faster
-  return c.W < 32 && col_aligned(c);
+  return c.W < 32 && col_aligned(c, col_tap_split(c));
 }
 
 int repmode_wgrad_col_launch(const WgColCall& c, hipStream_t s) {
@@ -627,7 +653,14 @@ int repmode_wgrad_col_launch(const WgColCall& c, hipStream_t s) {
     if (c.H <= 4 && c.D <= 2) return launch_col<4, 8, 4, 4, true>(c, s);
     return launch_col<8, 8, 2, 6, true>(c, s);
   }
-  if (c.W >= 32) return launch_col<8, 32, 1, 6, false>(c, s);
-  if (c.H > 8) return launch_col<16, 16, 1, 6, false>(c, s);
+  const int q = col_tap_split(c);
+  if (c.W >= 32) {
+    if (q == 2) return launch_col<8, 32, 1, 6, false, 2>(c, s);
+    return launch_col<8, 32, 1, 6, false>(c, s);
+  }
+  if (c.H > 8) {
+    if (q >= 2) return launch_col<16, 16, 1, 6, false, 2>(c, s);
+    return launch_col<16, 16, 1, 6, false>(c, s);
+  }
   return launch_col<8, 16, 1, 6, false>(c, s);
 }

@@ -182,6 +182,15 @@ def get_wgrad_col():
     return int(_lib.load().repmode_get_wgrad_col())
 
 
+def set_wgrad_col_split(q):
+    """The column form's tap split: 0 (default) chosen by the library, 1 / 2 / 4 that many workgroups per unit."""
+    _lib.call('repmode_set_wgrad_col_split', int(q))
+
+
+def get_wgrad_col_split():
+    return int(_lib.load().repmode_get_wgrad_col_split())
+
+
 def set_thin_kernels(on):
     """The one-channel first / last layers through their own kernels (csrc/thin_conv.hip; default) or round 2's fold of the x
     taps around the general kernel (REPMODE_THIN=0).  The operator library's switch (the ``thin_conv_*`` wrappers here

@@ -72,6 +72,52 @@ def test_conv5_wgrad_column_form_vs_oracle(case):
     assert rel_err(got[0], got[1]) < 1e-4
 
 
+WGRAD_SPLIT_CASES = [
+    # (N, D, H, W, Cin, Cout, tasks, q): the taps of a unit split over q workgroups (plain stores only, whatever the unit count)
+    (8, 16, 32, 32, 64, 64, [0, 1, 2, 3, 4, 5, 6, 7], 2),       # level 1 at the benchmarked batch: 128 units x 2 parts = 256 workgroups
+    (8, 16, 32, 32, 32, 64, [0, 1, 2, 3, 4, 5, 6, 7], 2),       # its first layer: 64 units x 2 parts on half the chip
+    (3, 5, 9, 35, 16, 48, [5, 9, 5], 2),                        # few units: a workgroup owns parts of several units, one after the other
+    (6, 2, 8, 32, 40, 72, [3, 3, 7, 3, 0, 7], 2),
+    (4, 4, 12, 16, 32, 64, [2, 2, 3, 3], 2),                    # the 16 x 16 tile
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_SPLIT_CASES)
+def test_conv5_wgrad_column_form_tap_split_vs_oracle(case):
+    """The column form with a unit's 125 taps split over q workgroups (each walks the unit's whole voxel range with 1 / q of the
+    accumulators): every element written once, by plain stores, into a buffer that starts out full of NaN -- against the oracle."""
+    ops = _ops()
+    from repmode_amd import _lib
+    n, d, h, w, cin, cout, tasks, q = case
+    gen = torch.Generator().manual_seed(sum(case[:6]) + q)
+    plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+    x = torch.randn(n, cin, d, h, w, generator=gen).bfloat16().float()
+    dy = torch.randn(n, cout, d, h, w, generator=gen).bfloat16().float()
+    wt = torch.zeros(plan.nslots, cout, cin, 5, 5, 5, requires_grad=True)
+    slots = torch.tensor([plan.slot_task_host.index(t) for t in tasks])
+    (orc.conv_per_sample(x, wt[slots]) * dy).sum().backward()
+    dw_ref = wt.grad.reshape(plan.nslots, cout, cin, 125).permute(0, 3, 1, 2)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    mode, split = ops.get_wgrad_col(), ops.get_wgrad_col_split()
+    try:
+        ops.set_wgrad_col(2)
+        ops.set_wgrad_col_split(q)
+        direct = ctypes.c_int(-1)
+        _lib.call('repmode_conv5_wgrad_plan', plan.nslots, n, d, h, w, cin, cout, _lib.BF16, 0, ctypes.byref(direct))
+        assert direct.value == 1
+        dw = torch.full((plan.nslots, 125, cout, cin), float('nan'), device=DEV)
+        _lib.call('repmode_conv5_wgrad_ex', x_cl.data_ptr(), dy_cl.data_ptr(), plan.sample_slot.data_ptr(), plan.nslots,
+                  dw.data_ptr(), n, d, h, w, cin, cout, _lib.BF16, 8, torch.cuda.current_stream().cuda_stream)
+    finally:
+        ops.set_wgrad_col(mode)
+        ops.set_wgrad_col_split(split)
+    assert torch.isfinite(dw).all()
+    e = rel_err(dw.cpu(), dw_ref)
+    record('wgrad_col_split', case=list(case[:6]) + [q], err=e)
+    assert e < TOL_BF16_ACC
+
+
 @pytest.mark.parametrize('tasks', [list(range(8)), [3, 3, 3, 5, 9, 9, 3, 5], list(range(12)) * 2])
 def test_conv5_wgrad_column_form_plain_stores_into_uninitialised_memory(tasks):
     """With enough units to fill the chip a workgroup takes whole units and the planner promises plain stores only

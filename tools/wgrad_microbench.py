@@ -15,7 +15,7 @@ dev = 'cuda:0'
 tasks = torch.arange(batch) % 12
 plan = ops.TaskPlan(tasks, 12, dev, training=True)
 SHAPES = [(32, 32, 32, 64, 64), (64, 64, 16, 32, 32), (32, 64, 16, 32, 32), (128, 128, 8, 16, 16), (64, 128, 8, 16, 16)]
-modes = [int(m) for m in os.environ.get('WGRAD_MODES', '0,2').split(',')]
+modes = [int(m) for m in os.environ.get('WGRAD_MODES', '0,2').split(',')]      # (REPMODE_WGRAD_COL_Q / _QMAX: the column form's tap split)
 for cin, cout, d, h, w in SHAPES:
     x = torch.randn(batch, d, h, w, cin, device=dev).bfloat16()
     dy = torch.randn(batch, d, h, w, cout, device=dev).bfloat16()
