@@ -1222,6 +1222,104 @@ __global__ __launch_bounds__(256) void conv5_wgrad_thin_kernel(ThinArgs a) {
 
   const int t_begin = chunk * a.tiles_per_block;
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_block);
+  // ---- K loop of a staged tile: one tile row (32 voxels = 4 groups of 8) per step
+  auto mma_tile = [&]() {
+#pragma unroll 2
+    for (int ry = 0; ry < TH_TY; ++ry) {
+      u32x4 bf[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        bf[c] = *reinterpret_cast<const u32x4*>(aT + (c * 16 + l15) * TH_AS + (ry * TH_TX + kg * 8) * 2);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        // window of 8 elements of b starting at element e0 (2-byte granularity)
+        const int e0 = ry * TH_RL + kg * 8 + shift[t];
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(bh) + (e0 >> 1);
+        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
+        const uint32_t sh = (e0 & 1) * 16;
+        const u32x4 af = u32x4{__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
+                               __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh)};
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+          acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af),
+                                                              __builtin_bit_cast(bf16x8, bf[c]), acc[t][c], 0, 0, 0);
+      }
+    }
+  };
+  if (vec && (W & 1) == 0) {
+    // Round 6: the tile sequence is software-pipelined (the NEXT tile's global loads travel while this one is multiplied)
+    // and the single-channel halo is fetched as dwords (two x-adjacent voxels: x0 - 2 is even and W is even, so a pair is
+    // inside or outside the volume together).  Before: per tile two barriers around a stage-then-compute body whose halo
+    // came in as 11 two-byte loads per thread -- 45 us per launch for 67 MB (1.5 TB/s).
+    constexpr int NA = (TH_TY * TH_TX / 2) * 4 / 256;          // A items per thread (2)
+    constexpr int NB = (5 * TH_HY * (TH_RL / 2) + 255) / 256;  // halo dwords per thread (6)
+    u32x4 a0[NA], a1[NA];
+    uint32_t bw[NB];
+    auto fetch = [&](int n, int tile) {
+      const int txi = tile % a.ntx, t2 = tile / a.ntx;
+      const int tyi = t2 % a.nty, z = t2 / a.nty;
+      const int y0 = tyi * TH_TY, x0 = txi * TH_TX;
+      const bf16_t* __restrict__ an = a.a + (size_t)n * D * H * W * C;
+      const bf16_t* __restrict__ bn = a.b + (size_t)n * D * H * W;
+#pragma unroll
+      for (int u = 0; u < NA; ++u) {
+        const int it = u * 256 + tid;
+        const int q = it % (TH_TY * TH_TX / 2), cg = it / (TH_TY * TH_TX / 2);
+        const int m = 2 * q, xx = m % TH_TX, yy = m / TH_TX;
+        const int gy = y0 + yy, gx = x0 + xx, c = ct * 32 + cg * 8;
+        a0[u] = a1[u] = u32x4{0u, 0u, 0u, 0u};
+        if (gy < H && c < C) {
+          const bf16_t* rowp = an + ((size_t)(z * H + gy) * W) * C + c;
+          if (gx < W) a0[u] = *reinterpret_cast<const u32x4*>(rowp + (size_t)gx * C);
+          if (gx + 1 < W) a1[u] = *reinterpret_cast<const u32x4*>(rowp + (size_t)(gx + 1) * C);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int it = u * 256 + tid;
+        const int dwx = it % (TH_RL / 2), r = it / (TH_RL / 2);
+        const int yy = r % TH_HY, pz = r / TH_HY;
+        const int gz = z + pz - 2, gy = y0 + yy - 2, gx = x0 + 2 * dwx - 2;
+        bw[u] = 0u;
+        if (it < 5 * TH_HY * (TH_RL / 2) && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+          bw[u] = *reinterpret_cast<const uint32_t*>(bn + ((size_t)gz * H + gy) * W + gx);
+      }
+    };
+    auto stage = [&]() {
+#pragma unroll
+      for (int u = 0; u < NA; ++u) {
+        const int it = u * 256 + tid;
+        const int q = it % (TH_TY * TH_TX / 2), cg = it / (TH_TY * TH_TX / 2);
+        unsigned char* dst = aT + (cg * 8) * TH_AS + q * 4;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          *reinterpret_cast<uint32_t*>(dst + k * TH_AS) = bf16_elem(a0[u], k) | (bf16_elem(a1[u], k) << 16);
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int it = u * 256 + tid;
+        if (it < 5 * TH_HY * (TH_RL / 2)) reinterpret_cast<uint32_t*>(bh)[it] = bw[u];
+      }
+    };
+    // the work sequence: (sample of this slot, tile of this chunk)
+    int n = -1, tile = t_end;
+    auto advance = [&]() -> bool {
+      if (++tile < t_end) return true;
+      tile = t_begin;
+      do { ++n; } while (n < a.N && a.sample_slot[n] != slot);
+      return n < a.N && t_begin < t_end;
+    };
+    bool have = advance();
+    if (have) fetch(n, tile);
+    while (have) {
+      __syncthreads();          // every wave is done with the previous tile in LDS
+      stage();
+      __syncthreads();
+      have = advance();
+      if (have) fetch(n, tile); // in flight during the MFMAs below
+      mma_tile();
+    }
+  } else {
   for (int n = 0; n < a.N; ++n) {
     if (a.sample_slot[n] != slot) continue;
     const bf16_t* __restrict__ an = a.a + (size_t)n * D * H * W * C;
@@ -1258,29 +1356,9 @@ __global__ __launch_bounds__(256) void conv5_wgrad_thin_kernel(ThinArgs a) {
         bh[it] = v;
       }
       __syncthreads();
-      // ---- K loop: one tile row (32 voxels = 4 groups of 8) per step
-#pragma unroll 2
-      for (int ry = 0; ry < TH_TY; ++ry) {
-        u32x4 bf[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-          bf[c] = *reinterpret_cast<const u32x4*>(aT + (c * 16 + l15) * TH_AS + (ry * TH_TX + kg * 8) * 2);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          // window of 8 elements of b starting at element e0 (2-byte granularity)
-          const int e0 = ry * TH_RL + kg * 8 + shift[t];
-          const uint32_t* p = reinterpret_cast<const uint32_t*>(bh) + (e0 >> 1);
-          const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3], d4 = p[4];
-          const uint32_t sh = (e0 & 1) * 16;
-          const u32x4 af = u32x4{__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh),
-                                 __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh)};
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-            acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af),
-                                                                __builtin_bit_cast(bf16x8, bf[c]), acc[t][c], 0, 0, 0);
-        }
-      }
+      mma_tile();
     }
+  }
   }
   // 16x16 C/D layout: column (channel) = lane & 15, row (tap within the tile) = (lane >> 4) * 4 + r
 #pragma unroll

@@ -334,3 +334,32 @@ def test_conv5_wgrad_column_form_dual_experts_vs_oracle(case):
     assert torch.isfinite(got[0][0]).all() and torch.isfinite(got[0][1]).all()
     assert e5 < TOL_BF16_ACC and e3 < TOL_BF16_ACC
     assert rel_err(got[0][0], got[1][0]) < 1e-4 and rel_err(got[0][1], got[1][1]) < 1e-4
+
+
+@pytest.mark.parametrize('case', [
+    # (N, D, H, W, Cin, Cout, tasks): the one-channel ends' filter gradient on even widths -- the software-pipelined path
+    (2, 4, 8, 32, 32, 1, [3, 3]),
+    (3, 6, 9, 40, 1, 32, [1, 4, 1]),          # first layer, ragged in z / y, a width that is no multiple of the tile
+    (3, 5, 12, 64, 24, 1, [7, 7, 2]),         # last layer, 24 channels (one channel tile, 8 dead rows)
+    (2, 3, 8, 34, 1, 16, [0, 5]),
+    (4, 2, 16, 64, 1, 32, [2, 2, 2, 9]),      # a slot of three samples
+])
+def test_conv5_wgrad_thin_pipelined_vs_oracle(case):
+    """conv5_wgrad_thin (the 125 taps take the place of the missing channel dimension): the software-pipelined tile loop with
+    the single-channel halo fetched as dwords, against autograd of the per-sample convolution (RepMode.py:207)."""
+    ops = _ops()
+    n, d, h, w, cin, cout, tasks = case
+    gen = torch.Generator().manual_seed(sum(case[:6]) + 1)
+    plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+    x = torch.randn(n, cin, d, h, w, generator=gen).bfloat16().float()
+    dy = torch.randn(n, cout, d, h, w, generator=gen).bfloat16().float()
+    wt = torch.zeros(plan.nslots, cout, cin, 5, 5, 5, requires_grad=True)
+    slots = torch.tensor([plan.slot_task_host.index(t) for t in tasks])
+    (orc.conv_per_sample(x, wt[slots]) * dy).sum().backward()
+    dw_ref = wt.grad.reshape(plan.nslots, cout, cin, 125).permute(0, 3, 1, 2)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    got = ops.conv5_wgrad(x_cl, dy_cl, plan, cout).cpu()
+    e = rel_err(got, dw_ref)
+    record('wgrad_thin', case=list(case[:6]), err=e)
+    assert e < TOL_BF16_ACC

@@ -1,7 +1,7 @@
-# Regenerates, under gpurun_out/${REPMODE_PROFILE_TAG:-r05}/, every artefact that gets copied into profiles/ (run through gpurun, ~6 GPU-minutes):
+# Regenerates, under gpurun_out/${REPMODE_PROFILE_TAG:-r06}/, every artefact that gets copied into profiles/ (run through gpurun, ~6 GPU-minutes):
 #   bash tools/refresh_profiles.sh          then locally:  bash tools/collect_profiles.sh
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${REPMODE_PROFILE_TAG:-r05}; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${REPMODE_PROFILE_TAG:-r06}; rm -rf $O; mkdir -p $O
 cd $R
 python bench.py --no-cpu-baseline --no-fwd --prof-all --dump-launches $O/launches_last_step.json > $O/bench_profall.json 2>> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
@@ -28,7 +28,7 @@ for b in 8 24; do
   rm -rf $O/pmc_b$b/pmc_*
 done
 # the bench lines last: roofline.traffic is read from profiles/*_pmc_traffic.json, which must be THIS build's pass
-cp $O/pmc_traffic_b8.json $R/profiles/${REPMODE_PROFILE_TAG:-r05}_pmc_traffic.json; cp $O/pmc_traffic_b24.json $R/profiles/${REPMODE_PROFILE_TAG:-r05}_b24_pmc_traffic.json
+cp $O/pmc_traffic_b8.json $R/profiles/${REPMODE_PROFILE_TAG:-r06}_pmc_traffic.json; cp $O/pmc_traffic_b24.json $R/profiles/${REPMODE_PROFILE_TAG:-r06}_b24_pmc_traffic.json
 cd $R
 python bench.py > $O/bench_line.json 2> $O/bench.err
 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_line_driver_args.json 2>> $O/bench.err
