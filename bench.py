@@ -30,7 +30,8 @@ Also reported in the same line:
   roofline      the MoDE convolution, forward + data-gradient launches, of every block but the two one-channel ends (the
                 dominant kernel family): conv5_ws_kernel (levels 0-2: 22 launches, 93 % of the conv FLOPs) and deep_mode_kernel
                 (levels 3-4, round 5: a per-expert block as one launch per direction), together and each under ``by_kernel``;
-                beside them the filter gradient conv5_wgrad_bf16_kernel, the step's second-largest family, with its own
+                beside them the filter gradient (entry `conv5_wgrad_bf16_kernel`: that kernel on levels 0-1 and 3-4 and, since
+                round 6, conv5_wgrad_col_kernel on level 2 -- all 20 multi-channel filter-gradient launches), the step's second-largest family, with its own
                 algorithmic bytes: algorithmic FLOPs (the layer's merged 125-tap convolution, 2 * voxels * Cin * Cout * 125,
                 once per layer and direction) / HIP-event duration on the launch stream, against the dense bf16 MFMA peak;
                 ``all_conv_kernels``: the same + the one-channel layers' kernels (+ conv5_deep / conv5_igemm where round 4's
