@@ -371,6 +371,14 @@ int repmode_k2_frags(const float* w, int rows, int red, int red_major, int dtype
 int repmode_k2_frags2(const float* w, int rows, int red, int red_major, int dtype, void* out, void* out_t,
                       void* stream);
 
+/* The same for n <= REPMODE_K2_FRAGS_MULTI_MAX filters in ONE launch (ABI 11): the operands of every stride-2 stage of a forward
+ * pass (RepMode.py:81, 98) ahead of the pass instead of one layout launch in front of each stage.  w / rows / red / red_major /
+ * out / out_t: arrays of n (HOST arrays, copied into the launch's arguments); out_t[i] may be NULL. */
+#define REPMODE_K2_FRAGS_MULTI_MAX 16
+int repmode_k2_frags_multi(int n, const float* const* w, const int* rows, const int* red, const int* red_major, int dtype,
+                           void* const* out, void* const* out_t, void* stream);
+
+
 /* ---- gate mixing of the per-expert formulation (linearity of RepMode.py:184-188 + :207).  p: float [5][n][v][c]
  * expert outputs, g: float [n][5][c] gate probabilities per SAMPLE.
  *   fwd: y[n][v][c] = sum_e g[n][e][c] * p[e][n][v][c]

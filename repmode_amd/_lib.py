@@ -85,6 +85,7 @@ _SIGNATURES = {
     'repmode_k2s2_wgrad_ex': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     'repmode_k2_frags': [_P, _I, _I, _I, _I, _P, _P],
     'repmode_k2_frags2': [_P, _I, _I, _I, _I, _P, _P, _P],
+    'repmode_k2_frags_multi': [_I, _P, _P, _P, _P, _I, _P, _P, _P],
     'repmode_expert_mix_fwd': [_P, _P, _P, _I, _c.c_long, _I, _P],
     'repmode_expert_mix_bwd': [_P, _P, _P, _P, _P, _P, _I, _c.c_long, _I, _I, _P],
     'repmode_expert_mix_bwd_ex': [_P, _P, _P, _P, _P, _P, _c.c_long, _I, _c.c_long, _I, _I, _P],

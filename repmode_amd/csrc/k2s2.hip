@@ -669,6 +669,83 @@ __global__ void k2_frags_kernel(const float* __restrict__ w, int rows, int red, 
 }
 }  // namespace
 
+// ---- the same for SEVERAL filters in one launch (round 6): the eight stride-2 stages of the U-Net laid their operands out with
+// one ~5 us launch each in front of their convolution -- eight launches of pure latency per forward pass.
+namespace {
+constexpr int K2M_MAX = REPMODE_K2_FRAGS_MULTI_MAX;
+constexpr int K2M_CHUNK = 2048;                 // elements of one workgroup
+struct K2MultiArgs {
+  const float* w[K2M_MAX];
+  void* out[K2M_MAX];
+  void* out_t[K2M_MAX];
+  int rows[K2M_MAX], red[K2M_MAX], red_major[K2M_MAX];
+  int rowsP[K2M_MAX], redP[K2M_MAX], rowsP2[K2M_MAX], redP2[K2M_MAX];
+  int first[K2M_MAX + 1];
+  int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k2_frags_multi_kernel(K2MultiArgs a) {
+  int i = 0;
+  while (i + 1 < a.n && (int)blockIdx.x >= a.first[i + 1]) ++i;
+  const long b = (long)blockIdx.x - a.first[i];
+  const long first = b * K2M_CHUNK + threadIdx.x;
+  // (k2_frags_one walks `first, first + step, ...` up to the tensor's end: here one chunk per workgroup)
+  const long t1 = 8L * a.rowsP[i] * a.redP[i], t2 = 8L * a.rowsP2[i] * a.redP2[i];
+  constexpr int KC = sizeof(T) == 2 ? 16 : 8;
+  for (int role = 0; role < 2; ++role) {
+    T* __restrict__ out = static_cast<T*>(role ? a.out_t[i] : a.out[i]);
+    if (!out) continue;
+    const int rows = role ? a.red[i] : a.rows[i], red = role ? a.rows[i] : a.red[i];
+    const int rowsP = role ? a.rowsP2[i] : a.rowsP[i], redP = role ? a.redP2[i] : a.redP[i];
+    const int red_major = role ? !a.red_major[i] : a.red_major[i];
+    const long total = role ? t2 : t1;
+    const float* __restrict__ w = a.w[i];
+    for (long e = first; e < total && e < (b + 1) * K2M_CHUNK; e += 256) {
+      const int kk = (int)(e % KC);
+      long t = e / KC;
+      const int r32 = (int)(t % 32); t /= 32;
+      const int nkc = redP / KC;
+      const int kc = (int)(t % nkc); t /= nkc;
+      const int nrt = rowsP / 32;
+      const int rt = (int)(t % nrt);
+      const int p = (int)(t / nrt);
+      const int row = rt * 32 + r32, k = kc * KC + kk;
+      float v = 0.f;
+      if (row < rows && k < red) v = red_major ? w[((size_t)k * rows + row) * 8 + p] : w[((size_t)row * red + k) * 8 + p];
+      if constexpr (sizeof(T) == 2) out[e] = f32_to_bf16(v);
+      else out[e] = v;
+    }
+  }
+}
+}  // namespace
+
+// n <= REPMODE_K2_FRAGS_MULTI_MAX filters; out_t[i] may be NULL.  Same layouts as repmode_k2_frags2, element for element.
+extern "C" int repmode_k2_frags_multi(int n, const float* const* w, const int* rows, const int* red, const int* red_major, int dtype,
+                                      void* const* out, void* const* out_t, void* stream) {
+  RM_REQUIRE(n > 0 && n <= K2M_MAX && w && rows && red && red_major && out && out_t, "k2_frags_multi: bad arguments");
+  RM_REQUIRE(dtype == REPMODE_F32 || dtype == REPMODE_BF16, "k2_frags_multi: bad dtype %d", dtype);
+  K2MultiArgs a{};
+  a.n = n;
+  long blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    RM_REQUIRE(w[i] && out[i] && rows[i] > 0 && red[i] > 0, "k2_frags_multi: bad filter %d", i);
+    a.w[i] = w[i]; a.out[i] = out[i]; a.out_t[i] = out_t[i];
+    a.rows[i] = rows[i]; a.red[i] = red[i]; a.red_major[i] = red_major[i] ? 1 : 0;
+    a.rowsP[i] = repmode_padded_channels(rows[i], dtype, 0); a.redP[i] = repmode_padded_channels(red[i], dtype, 1);
+    a.rowsP2[i] = repmode_padded_channels(red[i], dtype, 0); a.redP2[i] = repmode_padded_channels(rows[i], dtype, 1);
+    const long t1 = 8L * a.rowsP[i] * a.redP[i], t2 = out_t[i] ? 8L * a.rowsP2[i] * a.redP2[i] : 0;
+    a.first[i] = (int)blocks;
+    blocks += ((t1 > t2 ? t1 : t2) + K2M_CHUNK - 1) / K2M_CHUNK;
+  }
+  a.first[n] = (int)blocks;
+  RM_REQUIRE(blocks > 0 && blocks < (1L << 31), "k2_frags_multi: grid out of range");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == REPMODE_BF16) hipLaunchKernelGGL(k2_frags_multi_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k2_frags_multi_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  RM_LAUNCH_CHECK("k2_frags_multi");
+  return REPMODE_OK;
+}
+
 extern "C" int repmode_k2_frags2(const float* w, int rows, int red, int red_major, int dtype, void* out, void* out_t,
                                  void* stream);
 

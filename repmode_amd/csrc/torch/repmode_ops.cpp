@@ -1194,7 +1194,59 @@ struct BnRelu : public torch::autograd::Function<BnRelu> {
 };
 
 // ---- the stride-2 2x2x2 stages
+// Operands laid out ahead of a forward pass for ALL stages in one launch (op_prepare_stage_filters, round 6: eight ~5 us
+// layout launches per pass before); a stage takes its entry, op_finish_prepared forgets what nobody took.
+struct K2Prep { Tensor out, out_t; at::ScalarType dt; bool red_major; uint32_t version; };
+std::mutex g_k2_prep_mu;
+std::unordered_map<void*, K2Prep> g_k2_prep;
+
+void op_prepare_stage_filters(const std::vector<Tensor>& weights, const std::vector<int64_t>& up, int64_t dtype, bool both) {
+  const size_t n = weights.size();
+  TORCH_CHECK(up.size() == n, "prepare_stage_filters: one `up` flag per weight");
+  if (n == 0) return;
+  const at::ScalarType dt = dtype == REPMODE_BF16 ? at::kBFloat16 : at::kFloat;
+  const int code = (int)dtype;
+  std::vector<K2Prep> ents(n);
+  for (size_t b0 = 0; b0 < n; b0 += REPMODE_K2_FRAGS_MULTI_MAX) {
+    const size_t cnt = std::min<size_t>(REPMODE_K2_FRAGS_MULTI_MAX, n - b0);
+    std::vector<const float*> w(cnt);
+    std::vector<int> rows(cnt), red(cnt), rm(cnt);
+    std::vector<void*> out(cnt), out_t(cnt);
+    for (size_t i = 0; i < cnt; ++i) {
+      const Tensor& W = weights[b0 + i];
+      TORCH_CHECK(W.is_cuda() && W.scalar_type() == at::kFloat && W.is_contiguous() && W.dim() == 5, "prepare_stage_filters: bad weight");
+      // Conv3d weight [Co][Ci][2][2][2]: rows = Co, red = Ci; ConvTranspose3d weight [Ci][Co][2][2][2]: rows = Co, red = Ci, red-major
+      const bool u = up[b0 + i] != 0;
+      rows[i] = (int)(u ? W.size(1) : W.size(0));
+      red[i] = (int)(u ? W.size(0) : W.size(1));
+      rm[i] = u ? 1 : 0;
+      K2Prep& e = ents[b0 + i];
+      e.dt = dt; e.red_major = u; e.version = W._version();
+      e.out = at::empty({8, padded(rows[i], code, false), padded(red[i], code, true)}, W.options().dtype(dt));
+      if (both) e.out_t = at::empty({8, padded(red[i], code, false), padded(rows[i], code, true)}, W.options().dtype(dt));
+      w[i] = W.data_ptr<float>();
+      out[i] = e.out.data_ptr();
+      out_t[i] = both ? e.out_t.data_ptr() : nullptr;
+    }
+    RM_CALL(repmode_k2_frags_multi, (int)cnt, w.data(), rows.data(), red.data(), rm.data(), code, out.data(), out_t.data(), stream_handle());
+  }
+  std::lock_guard<std::mutex> lock(g_k2_prep_mu);
+  g_k2_prep.clear();
+  for (size_t i = 0; i < n; ++i) g_k2_prep[weights[i].data_ptr()] = ents[i];
+}
+
 std::pair<Tensor, Tensor> k2_weight_frags(const Tensor& weight, int64_t rows, int64_t red, bool red_major, at::ScalarType dt, bool both) {
+  {
+    std::lock_guard<std::mutex> lock(g_k2_prep_mu);
+    auto it = g_k2_prep.find(weight.data_ptr());
+    if (it != g_k2_prep.end()) {
+      K2Prep e = it->second;
+      g_k2_prep.erase(it);
+      if (e.dt == dt && e.red_major == red_major && e.version == weight._version() && (!both || e.out_t.defined()) &&
+          e.out.size(1) == padded(rows, dtype_code(dt), false) && e.out.size(2) == padded(red, dtype_code(dt), true))
+        return {e.out, both ? e.out_t : Tensor()};
+    }
+  }
   const int code = dtype_code(dt);
   Tensor out = at::empty({8, padded(rows, code, false), padded(red, code, true)}, weight.options().dtype(dt));
   if (!both) {
@@ -1998,6 +2050,10 @@ void op_finish_prepared(const Tensor& like) {
     any = !g_prep.empty();
     g_prep.clear();
   }
+  {
+    std::lock_guard<std::mutex> lock(g_k2_prep_mu);
+    g_k2_prep.clear();
+  }
   if (!any || !like.is_cuda() || !g_overlap) return;
   const int dev = like.device().index();
   SideStreams& ss = side_streams(dev);
@@ -2101,6 +2157,7 @@ TORCH_LIBRARY(repmode, m) {
         "int[] need_dx, Tensor slot_task, Tensor sample_slot, Tensor sample_task, int nslots, int num_tasks, bool training, "
         "int dtype) -> ()", &rm::op_prepare_filters);
   m.def("finish_prepared(Tensor like) -> ()", &rm::op_finish_prepared);
+  m.def("prepare_stage_filters(Tensor[] weights, int[] up, int dtype, bool both) -> ()", &rm::op_prepare_stage_filters);
   m.def("adam_step(Tensor[] params, Tensor[] grads, Tensor[] exp_avgs, Tensor[] exp_avg_sqs, float lr, float beta1, float beta2, "
         "float eps, int step) -> ()", &rm::op_adam_step);
   m.def("adam_step_dev(Tensor[] params, Tensor[] grads, Tensor[] exp_avgs, Tensor[] exp_avg_sqs, float lr, float beta1, float beta2, "

@@ -253,3 +253,11 @@ class Net(torch.nn.Module):
             [m.expert_avg3x3_conv for m in mods], [m.expert_avg5x5_conv for m in mods], [m.gate.weight for m in mods],
             [m.gate.bias for m in mods], [x.shape[-1] >> l for _, l in blocks], need_dx, plan.slot_task, plan.sample_slot,
             plan.sample_task, plan.nslots, plan.num_tasks, plan.training, ops.dtype_code(dtype))
+        # the eight stride-2 stages' operands (RepMode.py:81, 98) from ONE launch as well (one ~5 us layout launch in front of
+        # each stage before); a stage takes its entry when it runs
+        stages = getattr(self, '_stage_convs', None)
+        if stages is None:
+            stages = [(m, isinstance(m, Up2)) for m in self.modules() if isinstance(m, (Down2, Up2))]
+            object.__setattr__(self, '_stage_convs', stages)
+        if stages:
+            ops.torch_ops().prepare_stage_filters([m.weight for m, _ in stages], [int(u) for _, u in stages], ops.dtype_code(dtype), grad)

@@ -363,3 +363,25 @@ def test_conv5_wgrad_thin_pipelined_vs_oracle(case):
     e = rel_err(got, dw_ref)
     record('wgrad_thin', case=list(case[:6]), err=e)
     assert e < TOL_BF16_ACC
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_stride2_operands_of_several_stages_from_one_launch(dtype):
+    """repmode_k2_frags_multi: the fragment-major operands (both roles) of several stride-2 stages' 2x2x2 filters (RepMode.py:81
+    Conv3d, :98 ConvTranspose3d) from ONE launch are, element for element, what one repmode_k2_frags2 launch per filter lays
+    out -- ragged channel counts included."""
+    from repmode_amd import _lib
+    ops = _ops()
+    gen = torch.Generator().manual_seed(12)
+    shapes = [(32, 32, False), (64, 64, False), (40, 24, False), (256, 512, True), (24, 40, True), (8, 8, True)]   # (rows = Co, red = Ci, up)
+    ws = [(torch.randn(ci, co, 2, 2, 2, generator=gen) if up else torch.randn(co, ci, 2, 2, 2, generator=gen)).to(DEV)
+          for co, ci, up in shapes]
+    want = [ops.k2_weight_frags(w, co, ci, up, dtype, both=True) for w, (co, ci, up) in zip(ws, shapes)]
+    outs = [(torch.full_like(a, float('nan')), torch.full_like(b, float('nan'))) for a, b in want]
+    n = len(ws)
+    P, I = ctypes.c_void_p * n, ctypes.c_int * n
+    _lib.call('repmode_k2_frags_multi', n, P(*[w.data_ptr() for w in ws]), I(*[s[0] for s in shapes]), I(*[s[1] for s in shapes]),
+              I(*[int(s[2]) for s in shapes]), _lib.BF16 if dtype == torch.bfloat16 else _lib.F32,
+              P(*[o[0].data_ptr() for o in outs]), P(*[o[1].data_ptr() for o in outs]), torch.cuda.current_stream().cuda_stream)
+    for (a, b), (x, y) in zip(want, outs):
+        assert torch.equal(a.float().cpu(), x.float().cpu()) and torch.equal(b.float().cpu(), y.float().cpu())
