@@ -61,12 +61,20 @@ class Adam(torch.optim.Adam):
         """As torch.optim.Adam; `step` counters that a fused / capturable optimizer kept on the device come to the host (one
         copy at load time, so that ``step()`` never reads the device to learn the step count)."""
         super().load_state_dict(state_dict)
-        self._step_dev = self._hyper_dev = None            # (re-created from the loaded counters by the next step)
         for group in self.param_groups:            # (a stock optimizer's groups say fused / capturable; this one's bookkeeping is neither)
             group['fused'], group['capturable'], group['foreach'] = False, False, False
         for st in self.state.values():
             if torch.is_tensor(st.get('step')) and st['step'].is_cuda:
                 st['step'] = st['step'].detach().cpu()
+        if self._step_dev is not None:
+            # A captured step holds the device count and the constants' buffer BY ADDRESS (ADVICE round 5): they stay where they
+            # are and take the loaded count in place.  Counters that disagree cannot be one device count: the buffers go, and the
+            # next step says so (as a first step would).
+            loaded = {int(st['step']) for st in self.state.values() if 'step' in st}
+            if len(loaded) <= 1:
+                self._step_dev.fill_(loaded.pop() if loaded else 0)
+            else:
+                self._step_dev = self._hyper_dev = None
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -385,3 +385,43 @@ def test_stride2_operands_of_several_stages_from_one_launch(dtype):
               P(*[o[0].data_ptr() for o in outs]), P(*[o[1].data_ptr() for o in outs]), torch.cuda.current_stream().cuda_stream)
     for (a, b), (x, y) in zip(want, outs):
         assert torch.equal(a.float().cpu(), x.float().cpu()) and torch.equal(b.float().cpu(), y.float().cpu())
+
+
+def test_capturable_adam_keeps_its_device_buffers_across_load_state_dict():
+    """a captured step holds the optimizer's device step count and constants BY ADDRESS; loading a state_dict
+    into the optimizer must keep those buffers and overwrite the count in place -- and the next update must be the one
+    torch.optim.Adam makes from the same state."""
+    from repmode_amd.optim import Adam
+    _ops()
+    gen = torch.Generator().manual_seed(8)
+    shapes = [(64, 32, 5, 5, 5), (64,), (17, 3)]
+    ps = [torch.randn(*s, generator=gen).to(DEV).requires_grad_(True) for s in shapes]
+    qs = [p.detach().clone().requires_grad_(True) for p in ps]
+    ours, stock = Adam(ps, lr=1e-2, capturable=True), torch.optim.Adam(qs, lr=1e-2)
+    for step in range(3):
+        gs = [torch.randn(*s, generator=gen).to(DEV) for s in shapes]
+        for p, q, g in zip(ps, qs, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        ours.step()
+        stock.step()
+    ptr_step, ptr_hyper = ours._step_dev.data_ptr(), ours._hyper_dev.data_ptr()
+    assert int(ours._step_dev.item()) == 3
+    for _ in range(2):                                   # the stock optimizer goes on alone: its state is at step 5
+        for q in qs:
+            q.grad = torch.randn(q.shape, generator=gen).to(DEV)
+        stock.step()
+    with torch.no_grad():
+        for p, q in zip(ps, qs):
+            p.copy_(q)
+    import copy
+    ours.load_state_dict(copy.deepcopy(stock.state_dict()))      # (load_state_dict keeps tensors that need no cast: no shared moments)
+    assert ours._step_dev.data_ptr() == ptr_step and ours._hyper_dev.data_ptr() == ptr_hyper
+    assert int(ours._step_dev.item()) == 5
+    gs = [torch.randn(*s, generator=gen).to(DEV) for s in shapes]
+    for p, q, g in zip(ps, qs, gs):
+        p.grad, q.grad = g.clone(), g.clone()
+    ours.step()
+    stock.step()
+    assert int(ours._step_dev.item()) == 6
+    for p, q in zip(ps, qs):
+        assert rel_err(p.detach().cpu(), q.detach().cpu()) < 1e-6
