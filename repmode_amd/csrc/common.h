@@ -92,6 +92,8 @@ constexpr size_t REPMODE_SCRATCH_GATE_OFF = 2 * REPMODE_SCRATCH_BN_HALF;    // g
 // departures; the last workgroup to leave puts the zeros back)
 constexpr size_t REPMODE_SCRATCH_BARRIER_OFF = REPMODE_ZERO_SCRATCH_FLOATS;
 constexpr size_t REPMODE_SCRATCH_TAIL_WORDS = 512;
+// (words [0, 320) of the tail: the barrier; [384, 384 + REPMODE_GATREP_MULTI_MAX): the operand check's sticky verdicts, gatrep.hip)
+constexpr size_t REPMODE_SCRATCH_VERIFY_WORD = 384;
 int repmode_bn_scratch_half(hipStream_t s);
 void repmode_prof_end(hipStream_t s);
 

@@ -12,6 +12,7 @@
 // (reduced over ci and taps), then the softmax Jacobian and the gate Linear's weight/bias grads.
 #include "common.h"
 
+#include <atomic>
 #include <cstdlib>
 #include "tail_jobs.h"
 
@@ -937,6 +938,8 @@ struct XfCheckArgs {
   bf16_t* wf[XM_MAX]; bf16_t* wd[XM_MAX];
   int co[XM_MAX], ci[XM_MAX], nrt_f[XM_MAX], nkc_f[XM_MAX], nrt_d[XM_MAX], nkc_d[XM_MAX];
   int* flags;
+  int* sticky;        // per block: the epoch of the last launch in which some workgroup found a difference (stream scratch)
+  int epoch;          // this launch's number (never 0)
 };
 __global__ __launch_bounds__(256) void expert_frags_verify_kernel(XfCheckArgs a) {
   __shared__ XfLds L;
@@ -965,9 +968,16 @@ __global__ __launch_bounds__(256) void expert_frags_verify_kernel(XfCheckArgs a)
       diff |= (a.wf[i][fi] != (bf16_t)(pack_bf16x2(a.k3[i][idx], 0.f) & 0xffffu));
     }
   }
-  const int bad = __syncthreads_or(diff);
+  // Check and repair share a launch with no barrier between workgroups: a workgroup that starts late would
+  // sample operands the early ones have already laid out again, find nothing wrong and skip ITS share of the repair.  So a
+  // workgroup that finds a difference says so BEFORE it repairs -- this launch's epoch into the block's sticky word -- and every
+  // workgroup also takes that word as a verdict: whoever can see repaired bytes can see the word that was stored before them.
+  const int seen = __hip_atomic_load(a.sticky + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == a.epoch;
+  const int bad = __syncthreads_or(diff | seen);
   if (j == 0 && tid == 0 && a.flags) a.flags[i] = bad ? 1 : 0;
   if (!bad) return;
+  if (tid == 0 && !seen) __hip_atomic_store(a.sticky + i, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();            // (the word is on its way before any of this workgroup's repair stores)
   // ---- repair (rare): this workgroup's share of the tile quarters of both roles
   const int ntf = nkc * nrt * 4;
   for (int t = j; t < ntf; t += XC_WGS) {
@@ -1014,6 +1024,13 @@ static int expert_frags_multi_impl(int nblocks, const float* const* k5, const fl
   RM_REQUIRE(total < (1L << 31), "expert_frags_multi: grid too large");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (verify) {
+    float* scratch = repmode_zero_scratch(s);
+    if (!scratch) return REPMODE_ELAUNCH;
+    static std::atomic<int> epoch{0};
+    int e = ++epoch;
+    if (e == 0) e = ++epoch;                      // (0 is what the scratch starts as)
+    c.sticky = reinterpret_cast<int*>(scratch + REPMODE_SCRATCH_BARRIER_OFF) + REPMODE_SCRATCH_VERIFY_WORD;
+    c.epoch = e;
     repmode_prof_begin(REPMODE_PROF_GATREP_FWD, (double)nblocks * XC_WGS * XC_SAMPLES * 2 * 6.0, s);
     hipLaunchKernelGGL(expert_frags_verify_kernel, dim3((unsigned)(nblocks * XC_WGS)), dim3(256), 0, s, c);
     RM_LAUNCH_CHECK("expert_frags_verify");
