@@ -292,6 +292,9 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
   const int tid = WS ? (int)(threadIdx.x & 255) : (int)threadIdx.x;       // index within the role (staging items, stamps)
   const int lane = tid & 63, wave = tid >> 6;
   const bool loader = WS && threadIdx.x >= 256;
+#ifdef RM_WS_PRIO
+  if (WS && !loader) __builtin_amdgcn_s_setprio(RM_WS_PRIO);      // experiment: the MFMA waves ahead of the loader wave of their SIMD
+#endif
   const int cq = wave & 1, ciq = wave >> 1;
   const int l15 = lane & 15, kg = lane >> 4;
   RM_WSTAMP(59);
@@ -437,7 +440,20 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
         if (!(z0 + TZ - 1 + dz - 2 < 0 || z0 + dz - 2 >= D)) return true;
       }
     };
-    auto fetch_to = [&](TileRegs& tr) {
+    // `real` false: the same twelve loads with every offset out of range (zeros, no memory traffic) -- the stream-K loader
+    // issues a fetch on EVERY path, because the compiler's s_waitcnt counts must hold on all of them: with the fetch of the
+    // tile after next under an `if`, it waited for vmcnt(0) before a transposition, i.e. for the loads issued a moment earlier
+    // (round 6: one tile's load latency exposed per step, 213 -> 17x us on level 0)
+    auto fetch_to = [&](TileRegs& tr, bool real = true) {
+#ifdef RM_WG_NOLOAD
+      {                                     // TIMING BUILD ONLY: the tile loop without its global loads (register contents as they are)
+#pragma unroll
+        for (int u = 0; u < NX; ++u) asm volatile("" : "=v"(tr.x0[u]), "=v"(tr.x1[u]));
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) asm volatile("" : "=v"(tr.d0[u]), "=v"(tr.d1[u]));
+        return;
+      }
+#endif
       const int txi = tile % a.ntx, t2 = tile / a.ntx;
       const int tyi = t2 % a.nty, tzi = t2 / a.nty;
       const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
@@ -456,7 +472,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
         const int hy = r % HY, zz = r / HY;
         const int zin = z0 + zz + dz - 2, gy = y0 + hy - 2, gx = x0 - 2 + 2 * p;
         const int c = cit * 32 + cg * 8;
-        const bool row_ok = it < NIT_X && (unsigned)zin < (unsigned)D && (unsigned)gy < (unsigned)H && c < Cin;
+        const bool row_ok = real && it < NIT_X && (unsigned)zin < (unsigned)D && (unsigned)gy < (unsigned)H && c < Cin;
         const uint32_t off = (uint32_t)((((zin * H + gy) * W + gx) * Cin + c) * 2);
         tr.x0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
                      rx, (row_ok && (unsigned)gx < (unsigned)W) ? off : OOB, 0, 0));
@@ -471,7 +487,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
         const int xx = m % TX, yy = (m / TX) % TY, zz = m / (TX * TY);
         const int gz = z0 + zz, gy = y0 + yy, gx = x0 + xx;
         const int c = cot * 32 + cg * 8;
-        const bool row_ok = it < NIT_DY && gz < D && gy < H && c < Cout;
+        const bool row_ok = real && it < NIT_DY && gz < D && gy < H && c < Cout;
         const uint32_t off = (uint32_t)((((gz * H + gy) * W + gx) * Cout + c) * 2);
         tr.d0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, (row_ok && gx < W) ? off : OOB, 0, 0));
         tr.d1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -479,6 +495,15 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
       }
     };
     auto stage_from = [&](TileRegs& tr, int boff) {
+#ifdef RM_WG_NOSTAGE
+      {                                     // TIMING BUILD ONLY: the loads are waited for, nothing is transposed into LDS
+#pragma unroll
+        for (int u = 0; u < NX; ++u) asm volatile("" :: "v"(tr.x0[u]), "v"(tr.x1[u]));
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) asm volatile("" :: "v"(tr.d0[u]), "v"(tr.d1[u]));
+        return;
+      }
+#endif
       int tid_ = tid;
       asm volatile("" : "+v"(tid_));
 #pragma unroll
@@ -555,11 +580,23 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
         k = (int)(rem / (t_hi - t_lo));
         tile = t_lo + (int)(rem % (t_hi - t_lo));
         n = kth(mask, k);
+        // the tile's coordinates (output plane, tile row, tile column) move along with `tile`: divisions only where it jumps
+        int zt = 0, tyi = 0, txi = 0;
+        auto decomp = [&]() {
+          zt = tile / tpp;
+          const int r = tile - zt * tpp;
+          tyi = r / a.ntx; txi = r - tyi * a.ntx;
+        };
+        auto step_coords = [&]() {
+          if (++txi == a.ntx) { txi = 0; if (++tyi == a.nty) { tyi = 0; ++zt; } }
+        };
+        decomp();
         bool head = k == 0 && tile == t_lo;                 // the current unit started in this workgroup, at its first step
         auto last_of_unit = [&]() -> bool { return tile + 1 >= t_hi && k + 1 >= cnt; };
         auto next = [&]() {                                 // the following step of the sequence (never called behind the last)
-          if (++tile < t_hi) return;
-          if (++k < cnt) { n = kth(mask, k); tile = t_lo; return; }
+          if (++tile < t_hi) { step_coords(); return; }
+          txi = 0; tyi = 0;
+          if (++k < cnt) { n = kth(mask, k); tile = t_lo; zt = zlo(dz); return; }
           k = 0;
           do {
             if (++dzi == a.ndz) {
@@ -571,7 +608,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
             }
             dz = a.dz_lo + dzi; t_lo = zlo(dz) * tpp; t_hi = zhi(dz) * tpp;
           } while (t_hi <= t_lo || cnt == 0);            // (a dz without input planes, a slot without samples: no steps)
-          tile = t_lo;
+          tile = t_lo; zt = zlo(dz);
           n = kth(mask, 0);
         };
         int boff = 0;
@@ -579,25 +616,142 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
           // two tiles in flight (register sets a / b): a tile step is 1.6 k (16-voxel tile) .. 3.2 k MFMA cycles, a fetch from
           // HBM / Infinity Cache 2-3 k -- with one tile ahead the level-2 launches ran at the loaders' pace (round 4: 90 us
           // stream-K against 83 us regular on 128 -> 128)
-          fetch_to(ra);
-          if (steps > 1) { next(); fetch_to(rb); }
-          for (int i = 0; i < steps; i += 2) {
-            stage_from(ra, boff);
-            if (i + 2 < steps) { next(); fetch_to(ra); }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            boff ^= LDS_SET;
-            if (i + 1 < steps) {
-              stage_from(rb, boff);
-              if (i + 3 < steps) { next(); fetch_to(rb); }
-              asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-              boff ^= LDS_SET;
-            }
+          //
+          // A wave issues one instruction per four cycles at best, and there is ONE loader wave per SIMD: round 5's loader ran
+          // ~950 instructions per tile (430 vector: the decomposition of every item index into pair / channel group / halo row,
+          // range checks, 3 operations per transposed dword; 430 scalar: tile index divisions, spilled-SGPR traffic) = 3.8 k
+          // cycles of issue alone beside 3.2 k cycles of MFMAs, and the launch ran at the loaders' pace (level 0: 213 us against
+          // 162 with the loads removed, 172 with the transposition removed, 174 with both -- profiles/r06_wgrad_loader.txt).
+          // Here everything that depends on the thread only is computed ONCE (the loader waves have the MFMA waves' register
+          // budget and no accumulators): per item its offset relative to the tile's origin, halo row, x pair and LDS address;
+          // a tile costs an add + compare per coordinate, v_perm_b32 per transposed dword, and scalar increments.
+          static_assert(!G::SWZ, "stream-K: tiles at least 16 voxels wide");
+          constexpr int BIG = 0x40000000;
+          uint32_t xrel[NX], drel[NDY];
+          int xhy[NX], xx2[NX], xlds[NX], dyy[NDY], dxx[NDY], dlds[NDY];
+#pragma unroll
+          for (int u = 0; u < NX; ++u) {
+            const int it = u * 256 + tid;
+            const int pp = it % NPAIR, r = it / NPAIR, cg = r & 3, hy = r >> 2;
+            xrel[u] = (uint32_t)(((hy * W + 2 * pp) * Cin + cg * 8) * 2);
+            xx2[u] = 2 * pp;
+            xlds[u] = (cg * 8) * ROW_C + x_pair_off(hy, pp, 0);
           }
+#pragma unroll
+          for (int u = 0; u < NDY; ++u) {
+            const int it = u * 256 + tid;
+            const int qq = it % (TV / 2), cg = it / (TV / 2), m = 2 * qq;
+            drel[u] = (uint32_t)((((m / TX) * W + m % TX) * Cout + cg * 8) * 2);
+            dxx[u] = m % TX;
+            dlds[u] = 32 * ROW_C + (cg * 8) * DYS + qq * 4;
+          }
+          // per unit: items whose channel group lies behind the tensors' channels (and the items behind the tile's last) get a
+          // halo row that fails every tile's range check
+          int cit_cur = -1, cot_cur = -1;
+          auto refresh = [&]() {
+            cit_cur = cit; cot_cur = cot;
+            const int crx = Cin - cit * 32, crd = Cout - cot * 32;
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+              const int r = (u * 256 + tid) / NPAIR, cg = r & 3, hy = r >> 2;
+              xhy[u] = (hy < HY && cg * 8 < crx) ? hy : BIG;
+            }
+#pragma unroll
+            for (int u = 0; u < NDY; ++u) {
+              const int it = u * 256 + tid;
+              const int cg = it / (TV / 2), m = 2 * (it % (TV / 2));
+              dyy[u] = (cg < 4 && cg * 8 < crd) ? m / TX : BIG;
+            }
+          };
+          auto fetch_lean = [&](TileRegs& tr, bool real) {
+            if (cit != cit_cur || cot != cot_cur) refresh();
+            const int y0 = tyi * TY, x0 = txi * TX, zin = zt + dz - 2;
+            const uint32_t xbytes = (uint32_t)((size_t)D * H * W * Cin * 2), dybytes = (uint32_t)((size_t)D * H * W * Cout * 2);
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<bf16_t*>(static_cast<const bf16_t*>(a.x)) + (size_t)n * D * H * W * Cin, 0, (int)xbytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<bf16_t*>(static_cast<const bf16_t*>(a.dy)) + (size_t)n * D * H * W * Cout, 0, (int)dybytes, 0x00020000);
+            const uint32_t xb = (uint32_t)((((zin * H + y0 - 2) * W + x0 - 2) * Cin + cit * 32) * 2);
+            const uint32_t db = (uint32_t)((((zt * H + y0) * W + x0) * Cout + cot * 32) * 2);
+            // Range checks as sign bits (a coordinate t is inside [0, n) iff neither t nor n - 1 - t is negative), OR-ed into bit 31
+            // of the offset: out of the buffer's range, the load returns zeros.  (Written with compare + select, the compiler
+            // turned the shared row check into branches around the loads -- and waited for vmcnt(0) inside them.)
+            const int Hm1 = real ? H - 1 : -1;                  // (a fetch behind the last step: every row fails)
+            const uint32_t cin2 = (uint32_t)Cin * 2, cout2 = (uint32_t)Cout * 2;
+#pragma unroll
+            for (int u = 0; u < NX; ++u) {
+              const int gy = xhy[u] + (y0 - 2), gx = xx2[u] + (x0 - 2), wx = (W - 1) - gx;
+              const int my = gy | (Hm1 - gy);
+              const uint32_t off = xrel[u] + xb;
+              const uint32_t o0 = ((uint32_t)(my | gx | wx) & OOB) | off;
+              const uint32_t o1 = ((uint32_t)(my | (gx + 1) | (wx - 1)) & OOB) | (off + cin2);
+              tr.x0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o0, 0, 0));
+              tr.x1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o1, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < NDY; ++u) {
+              const int gy = dyy[u] + y0, wx = (W - 1) - (dxx[u] + x0);      // (gy, gx never negative)
+              const int my = Hm1 - gy;
+              const uint32_t off = drel[u] + db;
+              const uint32_t o0 = ((uint32_t)(my | wx) & OOB) | off;
+              const uint32_t o1 = ((uint32_t)(my | (wx - 1)) & OOB) | (off + cout2);
+              tr.d0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, o0, 0, 0));
+              tr.d1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, o1, 0, 0));
+            }
+          };
+          // two x-adjacent voxels' eight channels -> eight dwords (channel k: voxel 0 in the low half), one v_perm_b32 each
+          auto put8 = [&](unsigned char* dst, int stride, const u32x4& v0, const u32x4& v1) {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+              *reinterpret_cast<uint32_t*>(dst + kk * stride) =
+                  __builtin_amdgcn_perm(v1[kk >> 1], v0[kk >> 1], (kk & 1) ? 0x07060302u : 0x05040100u);
+          };
+          auto stage_lean = [&](TileRegs& tr, int buf) {
+#pragma unroll
+            for (int u = 0; u < NX; ++u)
+              if ((u + 1) * 256 <= NIT_X || u * 256 + tid < NIT_X) put8(smem + buf + xlds[u], ROW_C, tr.x0[u], tr.x1[u]);
+#pragma unroll
+            for (int u = 0; u < NDY; ++u)
+              if ((u + 1) * 256 <= NIT_DY || u * 256 + tid < NIT_DY) put8(smem + buf + dlds[u], DYS, tr.d0[u], tr.d1[u]);
+          };
+          fetch_lean(ra, true);
+          { const bool more = steps > 1; if (more) next(); fetch_lean(rb, more); }
+          // (timing build: the loader's stamps go to slots 30 .. 57 -- per tile: before the transposition, behind it, behind the
+          // next fetch's issue, behind the barrier)
+#ifdef RM_CONV_TIMING
+#define RM_LSTAMP(k) do { if (i < 7) RM_WSTAMP(30 + i * 4 + (k)); } while (0)
+#else
+#define RM_LSTAMP(k) do {} while (0)
+#endif
+          // Pairs of steps -- register set a always lands in buffer 0, b in buffer 1 -- with every load on every path (a fetch
+          // behind the last step asks for out-of-range offsets): the compiler's s_waitcnt counts must hold on all paths, and
+          // with a fetch under an `if` it waited for vmcnt(0) before each transposition.  An odd last step behind the loop.
+          int i = 0;
+          for (; i + 1 < steps; i += 2) {
+            RM_LSTAMP(0);
+            stage_lean(ra, 0);
+            RM_LSTAMP(1);
+            { const bool more = i + 2 < steps; if (more) next(); fetch_lean(ra, more); }
+            RM_LSTAMP(2);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            RM_LSTAMP(3);
+            stage_lean(rb, LDS_SET);
+            { const bool more = i + 3 < steps; if (more) next(); fetch_lean(rb, more); }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          }
+          if (i < steps) {
+            stage_lean(ra, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          }
+#undef RM_LSTAMP
           return;
         }
         for (int i = 0; i < steps; ++i) {
+          RM_WSTAMP(i * 3 + 0);
           asm volatile("s_barrier" ::: "memory");
+          RM_WSTAMP(i * 3 + 1);
           mma_tile(boff);
+          RM_WSTAMP(i * 3 + 2);
           boff ^= LDS_SET;
           const bool last = last_of_unit();
           if (last || i + 1 == steps) {

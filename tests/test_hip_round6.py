@@ -425,3 +425,4 @@ def test_capturable_adam_keeps_its_device_buffers_across_load_state_dict():
     assert int(ours._step_dev.item()) == 6
     for p, q in zip(ps, qs):
         assert rel_err(p.detach().cpu(), q.detach().cpu()) < 1e-6
+
