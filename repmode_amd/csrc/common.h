@@ -1,5 +1,6 @@
 // Shared device/host helpers for librepmode_hip.so (gfx950 only; no other targets).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -65,6 +66,16 @@ template <>
 __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <>
 __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+
+// f(std::integral_constant<int, I>{}) for I = lo .. n - 1: loops whose index must be a compile-time constant in the body
+// (`if constexpr` plans of which instruction goes where; register arrays that must never be indexed at run time)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 // The dispatcher places workgroup b on XCD b % 8 (observed, speed only).  Remap so that each
 // XCD receives a contiguous range of logical ids: neighbouring bricks then share one L2.

@@ -348,6 +348,83 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
   const unsigned char* xlane = xT + (ciq * 16 + l15) * ROW_C + ((kg / NGX) * RG + kg % NGX) * 16;
   const unsigned char* alane = dyT + (cq * 16 + l15) * DYS + kg * 16;
   auto mma_tile = [&](int boff) {
+    if constexpr (!G::SWZ && !DENSE) {
+      // Round 6.  v_mfma_f32_16x16x32_bf16 issues back to back every ~17 cycles on a SIMD, about four issue slots: up to three
+      // other instructions per MFMA cost nothing, a block of them between two MFMAs does.  Round 3's form prepared a window's
+      // five operands as a block of 13 vector operations (5 v_alignbit + 8 moves: the shift-0 / shift+1 operands start at odd
+      // registers of the window's six words, and a 128-bit MFMA operand must start at an even one) between the MFMAs of two
+      // windows -- ~40 cycles of idle matrix pipe per window, 12 windows a tile (stamps: 3980 cycles per 200 MFMAs).  Here the
+      // 16 operations of window w + 1 (each shifted operand into registers of its own: 2 x 4 v_alignbit, 2 x 4 moves) are
+      // placed one by one behind the MFMAs of window w, and windows are requested two ahead.
+      struct Win { u32x4 lo; u32x2 hi; };               // words 0..3 / 4, 5 of the window's six
+      struct Ops { u32x4 b1, b2, b3, b4; };             // shifts -1, 0, +1, +2 (shift -2 is `lo` itself)
+      bf16x8 afr[G::KSTEPS];
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks)
+        afr[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(alane + boff + ks * 64));
+      constexpr int NW = TZ * NWROW;
+      auto request = [&](int w, Win& o) {
+        const int zz = w / NWROW, rr = w % NWROW;
+        const unsigned char* xb = xlane + boff + ((zz * HY + rr) * RG) * 16;
+        o.lo = *reinterpret_cast<const u32x4*>(xb);
+        o.hi = *reinterpret_cast<const u32x2*>(xb + 16);
+      };
+      auto prep = [&](const Win& r, int i, Ops& o) {      // operation i of 16
+        const uint32_t w[6] = {r.lo.x, r.lo.y, r.lo.z, r.lo.w, r.hi.x, r.hi.y};
+        const int e = i & 3;
+        if (i < 4) o.b1[e] = __builtin_amdgcn_alignbit(w[e + 1], w[e], 16);            // elements 1..8
+        else if (i < 8) o.b3[e] = __builtin_amdgcn_alignbit(w[e + 2], w[e + 1], 16);   // elements 3..10
+        else if (i < 12) o.b2[e] = w[e + 1];                                            // elements 2..9
+        else o.b4[e] = w[e + 2];                                                        // elements 4..11
+      };
+      Win raw[3];
+      Ops ops[2];
+      request(0, raw[0]);
+      if (NW > 1) request(1, raw[1]);
+      static_for<0, 16>([&](auto I) { prep(raw[0], I.value, ops[0]); });
+      static_for<0, NW>([&](auto WI) {
+        constexpr int w = WI.value, zz = w / NWROW, rr = w % NWROW;
+        Win& cur = raw[w % 3];
+        Ops& op = ops[w & 1];
+        if constexpr (w + 2 < NW) request(w + 2, raw[(w + 2) % 3]);
+        RM_WSCHED_FENCE();
+        constexpr int nm = [] {                          // MFMAs of this window
+          int c = 0;
+          for (int k2 = 0; k2 < G::KSTEPS; ++k2) {
+            const int g2 = k2 * GPR, d2 = rr - g2 % TY;
+            if (g2 / TY == zz && d2 >= 0 && d2 < 5) c += 5;
+          }
+          return c;
+        }();
+        constexpr int per = nm > 0 ? (16 + nm - 1) / nm : 16;
+        const bf16x8 o0 = __builtin_bit_cast(bf16x8, cur.lo), o1 = __builtin_bit_cast(bf16x8, op.b1),
+                     o2 = __builtin_bit_cast(bf16x8, op.b2), o3 = __builtin_bit_cast(bf16x8, op.b3),
+                     o4 = __builtin_bit_cast(bf16x8, op.b4);
+        static_for<0, G::KSTEPS>([&](auto KS) {
+          constexpr int ks = KS.value, grb = ks * GPR, dyi = rr - grb % TY;
+          if constexpr (grb / TY == zz && dyi >= 0 && dyi < 5) {
+            constexpr int before = [] {                  // steps of this window ahead of this one
+              int c = 0;
+              for (int k2 = 0; k2 < ks; ++k2) {
+                const int g2 = k2 * GPR, d2 = rr - g2 % TY;
+                if (g2 / TY == zz && d2 >= 0 && d2 < 5) ++c;
+              }
+              return c;
+            }();
+            static_for<0, 5>([&](auto J) {
+              constexpr int j = J.value, m = before * 5 + j;
+              const bf16x8 bj = j == 0 ? o0 : j == 1 ? o1 : j == 2 ? o2 : j == 3 ? o3 : o4;
+              acc[dyi * 5 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], bj, acc[dyi * 5 + j], 0, 0, 0);
+              if constexpr (w + 1 < NW && m * per < 16) {
+                static_for<m * per, (m + 1) * per < 16 ? (m + 1) * per : 16>([&](auto I) { prep(raw[(w + 1) % 3], I.value, ops[(w + 1) & 1]); });
+                RM_WSCHED_FENCE();
+              }
+            });
+          }
+        });
+      });
+      return;
+    }
     // The B operands of step (ks, dyi) are the window of halo row yyb(ks) + dyi of plane zz(ks): steps with equal sums share
     // it (TX = 32: 40 steps, 12 windows).  So the loop runs over WINDOWS -- one ds_read_b128 + one ds_read_b64 and five
     // v_perm / alignbit each, requested one window ahead -- and every window feeds the MFMAs of all steps that use it.
@@ -664,6 +741,15 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
             }
           };
           auto fetch_lean = [&](TileRegs& tr, bool real) {
+#ifdef RM_WG_NOLOAD
+            {                                 // TIMING BUILD ONLY: the tile loop without its global loads
+#pragma unroll
+              for (int u = 0; u < NX; ++u) asm volatile("" : "=v"(tr.x0[u]), "=v"(tr.x1[u]));
+#pragma unroll
+              for (int u = 0; u < NDY; ++u) asm volatile("" : "=v"(tr.d0[u]), "=v"(tr.d1[u]));
+              return;
+            }
+#endif
             if (cit != cit_cur || cot != cot_cur) refresh();
             const int y0 = tyi * TY, x0 = txi * TX, zin = zt + dz - 2;
             const uint32_t xbytes = (uint32_t)((size_t)D * H * W * Cin * 2), dybytes = (uint32_t)((size_t)D * H * W * Cout * 2);
@@ -707,6 +793,15 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
                   __builtin_amdgcn_perm(v1[kk >> 1], v0[kk >> 1], (kk & 1) ? 0x07060302u : 0x05040100u);
           };
           auto stage_lean = [&](TileRegs& tr, int buf) {
+#ifdef RM_WG_NOSTAGE
+            {                                 // TIMING BUILD ONLY: the loads are waited for, nothing is transposed into LDS
+#pragma unroll
+              for (int u = 0; u < NX; ++u) asm volatile("" :: "v"(tr.x0[u]), "v"(tr.x1[u]));
+#pragma unroll
+              for (int u = 0; u < NDY; ++u) asm volatile("" :: "v"(tr.d0[u]), "v"(tr.d1[u]));
+              return;
+            }
+#endif
 #pragma unroll
             for (int u = 0; u < NX; ++u)
               if ((u + 1) * 256 <= NIT_X || u * 256 + tid < NIT_X) put8(smem + buf + xlds[u], ROW_C, tr.x0[u], tr.x1[u]);

@@ -39,14 +39,6 @@ namespace {
 
 int g_wgrad_col = []() { const char* e = getenv("REPMODE_WGRAD_COL"); return e ? atoi(e) : 1; }();
 
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
 template <int TY_, int TX_, int SPS_ = 1, int RING_ = 6, bool DUAL_ = false>
 struct ColTile {
   static constexpr int TY = TY_, TX = TX_, SPS = SPS_;   // SPS: samples per step (their tiles side by side in K)
