@@ -348,7 +348,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
   const unsigned char* xlane = xT + (ciq * 16 + l15) * ROW_C + ((kg / NGX) * RG + kg % NGX) * 16;
   const unsigned char* alane = dyT + (cq * 16 + l15) * DYS + kg * 16;
   auto mma_tile = [&](int boff) {
-    if constexpr (!G::SWZ && !DENSE) {
+    if constexpr (!G::SWZ && !DENSE) {        // (the TX = 8 tiles: 5.5 MFMAs per window, 16 operations per window measured slower than 13: 2700 -> 3050 cycles per tile)
       // Round 6.  v_mfma_f32_16x16x32_bf16 issues back to back every ~17 cycles on a SIMD, about four issue slots: up to three
       // other instructions per MFMA cost nothing, a block of them between two MFMAs does.  Round 3's form prepared a window's
       // five operands as a block of 13 vector operations (5 v_alignbit + 8 moves: the shift-0 / shift+1 operands start at odd
@@ -366,8 +366,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
       auto request = [&](int w, Win& o) {
         const int zz = w / NWROW, rr = w % NWROW;
         const unsigned char* xb = xlane + boff + ((zz * HY + rr) * RG) * 16;
-        o.lo = *reinterpret_cast<const u32x4*>(xb);
-        o.hi = *reinterpret_cast<const u32x2*>(xb + 16);
+        o.lo = *reinterpret_cast<const u32x4*>(G::SWZ ? xb + (l15 & 1) * 16 : xb);                 // words 0..3: elements 0..7
+        o.hi = *reinterpret_cast<const u32x2*>(G::SWZ ? xb + 16 - (l15 & 1) * 16 : xb + 16);      // words 4, 5: elements 8..11
       };
       auto prep = [&](const Win& r, int i, Ops& o) {      // operation i of 16
         const uint32_t w[6] = {r.lo.x, r.lo.y, r.lo.z, r.lo.w, r.hi.x, r.hi.y};
@@ -397,6 +397,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
           return c;
         }();
         constexpr int per = nm > 0 ? (16 + nm - 1) / nm : 16;
+        if constexpr (nm == 0 && w + 1 < NW)             // (no tile shape has such a window; kept correct)
+          static_for<0, 16>([&](auto I) { prep(raw[(w + 1) % 3], I.value, ops[(w + 1) & 1]); });
         const bf16x8 o0 = __builtin_bit_cast(bf16x8, cur.lo), o1 = __builtin_bit_cast(bf16x8, op.b1),
                      o2 = __builtin_bit_cast(bf16x8, op.b2), o3 = __builtin_bit_cast(bf16x8, op.b3),
                      o4 = __builtin_bit_cast(bf16x8, op.b4);
@@ -605,6 +607,134 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
     int tl_ = 0;
 #endif
     if constexpr (WS) {
+      // ---- The loader waves' tile fetch + transposition (round 6).  A wave issues one instruction per four cycles at best,
+      // and there is ONE loader wave per SIMD: round 5's loader (fetch_to / stage_from above) ran ~950 instructions per tile
+      // (430 vector: the decomposition of every item index into pair / channel group / halo row, range checks, 3 operations
+      // per transposed dword; 430 scalar: tile index divisions, spilled-SGPR traffic) = 3.8 k cycles of issue alone beside the
+      // 3.2 k (stamped: 4.0 k) cycles of a tile's MFMAs, and the launches ran at the loaders' pace (level 0 stream-K: 213 us
+      // against 162 with the loads removed, 172 with the transposition removed, 174 with both -- profiles/r06_wgrad_loader.txt).
+      // Here everything that depends on the thread only is computed ONCE (the loader waves have the MFMA waves' register
+      // budget and no accumulators): per item its offset relative to the tile's origin, its halo row / x pair / plane and its
+      // LDS address; a tile costs an add per coordinate, range checks as sign bits, one v_perm_b32 per transposed dword.
+      constexpr int BIG = 0x40000000;
+      uint32_t xrel[NX], drel[NDY];
+      int xhy[NX], xx2[NX], xzz[NX], xlds0[NX], xlds1[NX], dyy[NDY], dxx[NDY], dzz[NDY], dlds[NDY];
+      int cit_cur = -1, cot_cur = -1;
+      auto lean_init = [&]() {
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+          const int it = u * 256 + tid;
+          const int pp = it % NPAIR; int r = it / NPAIR;
+          const int cg = r & 3; r >>= 2;
+          const int hy = r % HY, zz = r / HY;
+          xrel[u] = (uint32_t)((((zz * H + hy) * W + 2 * pp) * Cin + cg * 8) * 2);
+          xx2[u] = 2 * pp; xzz[u] = zz;
+          xlds0[u] = (cg * 8) * ROW_C + x_pair_off(zz * HY + hy, pp, 0);
+          xlds1[u] = (cg * 8) * ROW_C + x_pair_off(zz * HY + hy, pp, 1);
+        }
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) {
+          const int it = u * 256 + tid;
+          const int qq = it % (TV / 2), cg = it / (TV / 2), m = 2 * qq;
+          const int xx = m % TX, yy = (m / TX) % TY, zz = m / (TX * TY);
+          drel[u] = (uint32_t)((((zz * H + yy) * W + xx) * Cout + cg * 8) * 2);
+          dxx[u] = xx; dzz[u] = zz;
+          dlds[u] = 32 * ROW_C + (cg * 8) * DYS + qq * 4;
+        }
+      };
+      // per unit: items whose channel group lies behind the tensors' channels (and the items behind the tile's last) get a
+      // halo row that fails every tile's range check
+      auto lean_refresh = [&]() {
+        cit_cur = cit; cot_cur = cot;
+        const int crx = Cin - cit * 32, crd = Cout - cot * 32;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+          int r = (u * 256 + tid) / NPAIR;
+          const int cg = r & 3; r >>= 2;
+          xhy[u] = (r / HY < TZ && cg * 8 < crx) ? r % HY : BIG;
+        }
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) {
+          const int it = u * 256 + tid;
+          const int cg = it / (TV / 2), m = 2 * (it % (TV / 2));
+          dyy[u] = (cg < 4 && cg * 8 < crd) ? (m / TX) % TY : BIG;
+        }
+      };
+      // the tile at output voxel (z0, y0, x0) of sample n_, for this workgroup's dz / cit / cot
+      auto fetch_lean = [&](TileRegs& tr, bool real, int n_, int z0, int y0, int x0) {
+#ifdef RM_WG_NOLOAD
+        {                                 // TIMING BUILD ONLY: the tile loop without its global loads
+#pragma unroll
+          for (int u = 0; u < NX; ++u) asm volatile("" : "=v"(tr.x0[u]), "=v"(tr.x1[u]));
+#pragma unroll
+          for (int u = 0; u < NDY; ++u) asm volatile("" : "=v"(tr.d0[u]), "=v"(tr.d1[u]));
+          return;
+        }
+#endif
+        if (cit != cit_cur || cot != cot_cur) lean_refresh();
+        const int zin = z0 + dz - 2;
+        const uint32_t xbytes = (uint32_t)((size_t)D * H * W * Cin * 2), dybytes = (uint32_t)((size_t)D * H * W * Cout * 2);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(static_cast<const bf16_t*>(a.x)) + (size_t)n_ * D * H * W * Cin, 0, (int)xbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<bf16_t*>(static_cast<const bf16_t*>(a.dy)) + (size_t)n_ * D * H * W * Cout, 0, (int)dybytes, 0x00020000);
+        const uint32_t xb = (uint32_t)((((zin * H + y0 - 2) * W + x0 - 2) * Cin + cit * 32) * 2);
+        const uint32_t db = (uint32_t)((((z0 * H + y0) * W + x0) * Cout + cot * 32) * 2);
+        // Range checks as sign bits (a coordinate t is inside [0, n) iff neither t nor n - 1 - t is negative), OR-ed into bit 31
+        // of the offset: out of the buffer's range, the load returns zeros.  (Written with compare + select, the compiler
+        // turned the shared row check into branches around the loads -- and waited for vmcnt(0) inside them.)
+        const int Hm1 = real ? H - 1 : -1;                  // (a fetch behind the last step: every row fails)
+        const uint32_t cin2 = (uint32_t)Cin * 2, cout2 = (uint32_t)Cout * 2;
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+          const int gy = xhy[u] + (y0 - 2), gx = xx2[u] + (x0 - 2), wx = (W - 1) - gx;
+          int my = gy | (Hm1 - gy);
+          if constexpr (TZ > 1) { const int gz = xzz[u] + zin; my |= gz | ((D - 1) - gz); }       // (TZ = 1: the step exists only where the plane does)
+          const uint32_t off = xrel[u] + xb;
+          const uint32_t o0 = ((uint32_t)(my | gx | wx) & OOB) | off;
+          const uint32_t o1 = ((uint32_t)(my | (gx + 1) | (wx - 1)) & OOB) | (off + cin2);
+          tr.x0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o0, 0, 0));
+          tr.x1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o1, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < NDY; ++u) {
+          const int gy = dyy[u] + y0, wx = (W - 1) - (dxx[u] + x0);      // (gy, gx, gz never negative)
+          int my = Hm1 - gy;
+          if constexpr (TZ > 1) my |= (D - 1) - (dzz[u] + z0);
+          const uint32_t off = drel[u] + db;
+          const uint32_t o0 = ((uint32_t)(my | wx) & OOB) | off;
+          const uint32_t o1 = ((uint32_t)(my | (wx - 1)) & OOB) | (off + cout2);
+          tr.d0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, o0, 0, 0));
+          tr.d1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, o1, 0, 0));
+        }
+      };
+      // two x-adjacent voxels' eight channels -> eight dwords (channel k: voxel 0 in the low half), one v_perm_b32 each;
+      // even channel rows at dst0, odd ones at dst1 (the swizzled TX = 8 tile; the same address otherwise)
+      auto put8 = [&](unsigned char* dst0, unsigned char* dst1, int stride, const u32x4& v0, const u32x4& v1) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+          *reinterpret_cast<uint32_t*>(((kk & 1) ? dst1 : dst0) + kk * stride) =
+              __builtin_amdgcn_perm(v1[kk >> 1], v0[kk >> 1], (kk & 1) ? 0x07060302u : 0x05040100u);
+      };
+      auto stage_lean = [&](TileRegs& tr, int buf) {
+#ifdef RM_WG_NOSTAGE
+        {                                 // TIMING BUILD ONLY: the loads are waited for, nothing is transposed into LDS
+#pragma unroll
+          for (int u = 0; u < NX; ++u) asm volatile("" :: "v"(tr.x0[u]), "v"(tr.x1[u]));
+#pragma unroll
+          for (int u = 0; u < NDY; ++u) asm volatile("" :: "v"(tr.d0[u]), "v"(tr.d1[u]));
+          return;
+        }
+#endif
+#pragma unroll
+        for (int u = 0; u < NX; ++u)
+          if ((u + 1) * 256 <= NIT_X || u * 256 + tid < NIT_X)
+            put8(smem + buf + xlds0[u], smem + buf + (G::SWZ ? xlds1[u] : xlds0[u]), ROW_C, tr.x0[u], tr.x1[u]);
+#pragma unroll
+        for (int u = 0; u < NDY; ++u)
+          if ((u + 1) * 256 <= NIT_DY || u * 256 + tid < NIT_DY) put8(smem + buf + dlds[u], smem + buf + dlds[u], DYS, tr.d0[u], tr.d1[u]);
+      };
+      if (loader) lean_init();
       if constexpr (TZ == 1) {
       if (a.sk_total > 0) {
         // ---- stream-K (round 4): a launch is ONE sequence of tile steps -- units (slot, co tile, ci tile, dz plane) in the
@@ -693,124 +823,9 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
           // two tiles in flight (register sets a / b): a tile step is 1.6 k (16-voxel tile) .. 3.2 k MFMA cycles, a fetch from
           // HBM / Infinity Cache 2-3 k -- with one tile ahead the level-2 launches ran at the loaders' pace (round 4: 90 us
           // stream-K against 83 us regular on 128 -> 128)
-          //
-          // A wave issues one instruction per four cycles at best, and there is ONE loader wave per SIMD: round 5's loader ran
-          // ~950 instructions per tile (430 vector: the decomposition of every item index into pair / channel group / halo row,
-          // range checks, 3 operations per transposed dword; 430 scalar: tile index divisions, spilled-SGPR traffic) = 3.8 k
-          // cycles of issue alone beside 3.2 k cycles of MFMAs, and the launch ran at the loaders' pace (level 0: 213 us against
-          // 162 with the loads removed, 172 with the transposition removed, 174 with both -- profiles/r06_wgrad_loader.txt).
-          // Here everything that depends on the thread only is computed ONCE (the loader waves have the MFMA waves' register
-          // budget and no accumulators): per item its offset relative to the tile's origin, halo row, x pair and LDS address;
-          // a tile costs an add + compare per coordinate, v_perm_b32 per transposed dword, and scalar increments.
           static_assert(!G::SWZ, "stream-K: tiles at least 16 voxels wide");
-          constexpr int BIG = 0x40000000;
-          uint32_t xrel[NX], drel[NDY];
-          int xhy[NX], xx2[NX], xlds[NX], dyy[NDY], dxx[NDY], dlds[NDY];
-#pragma unroll
-          for (int u = 0; u < NX; ++u) {
-            const int it = u * 256 + tid;
-            const int pp = it % NPAIR, r = it / NPAIR, cg = r & 3, hy = r >> 2;
-            xrel[u] = (uint32_t)(((hy * W + 2 * pp) * Cin + cg * 8) * 2);
-            xx2[u] = 2 * pp;
-            xlds[u] = (cg * 8) * ROW_C + x_pair_off(hy, pp, 0);
-          }
-#pragma unroll
-          for (int u = 0; u < NDY; ++u) {
-            const int it = u * 256 + tid;
-            const int qq = it % (TV / 2), cg = it / (TV / 2), m = 2 * qq;
-            drel[u] = (uint32_t)((((m / TX) * W + m % TX) * Cout + cg * 8) * 2);
-            dxx[u] = m % TX;
-            dlds[u] = 32 * ROW_C + (cg * 8) * DYS + qq * 4;
-          }
-          // per unit: items whose channel group lies behind the tensors' channels (and the items behind the tile's last) get a
-          // halo row that fails every tile's range check
-          int cit_cur = -1, cot_cur = -1;
-          auto refresh = [&]() {
-            cit_cur = cit; cot_cur = cot;
-            const int crx = Cin - cit * 32, crd = Cout - cot * 32;
-#pragma unroll
-            for (int u = 0; u < NX; ++u) {
-              const int r = (u * 256 + tid) / NPAIR, cg = r & 3, hy = r >> 2;
-              xhy[u] = (hy < HY && cg * 8 < crx) ? hy : BIG;
-            }
-#pragma unroll
-            for (int u = 0; u < NDY; ++u) {
-              const int it = u * 256 + tid;
-              const int cg = it / (TV / 2), m = 2 * (it % (TV / 2));
-              dyy[u] = (cg < 4 && cg * 8 < crd) ? m / TX : BIG;
-            }
-          };
-          auto fetch_lean = [&](TileRegs& tr, bool real) {
-#ifdef RM_WG_NOLOAD
-            {                                 // TIMING BUILD ONLY: the tile loop without its global loads
-#pragma unroll
-              for (int u = 0; u < NX; ++u) asm volatile("" : "=v"(tr.x0[u]), "=v"(tr.x1[u]));
-#pragma unroll
-              for (int u = 0; u < NDY; ++u) asm volatile("" : "=v"(tr.d0[u]), "=v"(tr.d1[u]));
-              return;
-            }
-#endif
-            if (cit != cit_cur || cot != cot_cur) refresh();
-            const int y0 = tyi * TY, x0 = txi * TX, zin = zt + dz - 2;
-            const uint32_t xbytes = (uint32_t)((size_t)D * H * W * Cin * 2), dybytes = (uint32_t)((size_t)D * H * W * Cout * 2);
-            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<bf16_t*>(static_cast<const bf16_t*>(a.x)) + (size_t)n * D * H * W * Cin, 0, (int)xbytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<bf16_t*>(static_cast<const bf16_t*>(a.dy)) + (size_t)n * D * H * W * Cout, 0, (int)dybytes, 0x00020000);
-            const uint32_t xb = (uint32_t)((((zin * H + y0 - 2) * W + x0 - 2) * Cin + cit * 32) * 2);
-            const uint32_t db = (uint32_t)((((zt * H + y0) * W + x0) * Cout + cot * 32) * 2);
-            // Range checks as sign bits (a coordinate t is inside [0, n) iff neither t nor n - 1 - t is negative), OR-ed into bit 31
-            // of the offset: out of the buffer's range, the load returns zeros.  (Written with compare + select, the compiler
-            // turned the shared row check into branches around the loads -- and waited for vmcnt(0) inside them.)
-            const int Hm1 = real ? H - 1 : -1;                  // (a fetch behind the last step: every row fails)
-            const uint32_t cin2 = (uint32_t)Cin * 2, cout2 = (uint32_t)Cout * 2;
-#pragma unroll
-            for (int u = 0; u < NX; ++u) {
-              const int gy = xhy[u] + (y0 - 2), gx = xx2[u] + (x0 - 2), wx = (W - 1) - gx;
-              const int my = gy | (Hm1 - gy);
-              const uint32_t off = xrel[u] + xb;
-              const uint32_t o0 = ((uint32_t)(my | gx | wx) & OOB) | off;
-              const uint32_t o1 = ((uint32_t)(my | (gx + 1) | (wx - 1)) & OOB) | (off + cin2);
-              tr.x0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o0, 0, 0));
-              tr.x1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o1, 0, 0));
-            }
-#pragma unroll
-            for (int u = 0; u < NDY; ++u) {
-              const int gy = dyy[u] + y0, wx = (W - 1) - (dxx[u] + x0);      // (gy, gx never negative)
-              const int my = Hm1 - gy;
-              const uint32_t off = drel[u] + db;
-              const uint32_t o0 = ((uint32_t)(my | wx) & OOB) | off;
-              const uint32_t o1 = ((uint32_t)(my | (wx - 1)) & OOB) | (off + cout2);
-              tr.d0[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, o0, 0, 0));
-              tr.d1[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, o1, 0, 0));
-            }
-          };
-          // two x-adjacent voxels' eight channels -> eight dwords (channel k: voxel 0 in the low half), one v_perm_b32 each
-          auto put8 = [&](unsigned char* dst, int stride, const u32x4& v0, const u32x4& v1) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-              *reinterpret_cast<uint32_t*>(dst + kk * stride) =
-                  __builtin_amdgcn_perm(v1[kk >> 1], v0[kk >> 1], (kk & 1) ? 0x07060302u : 0x05040100u);
-          };
-          auto stage_lean = [&](TileRegs& tr, int buf) {
-#ifdef RM_WG_NOSTAGE
-            {                                 // TIMING BUILD ONLY: the loads are waited for, nothing is transposed into LDS
-#pragma unroll
-              for (int u = 0; u < NX; ++u) asm volatile("" :: "v"(tr.x0[u]), "v"(tr.x1[u]));
-#pragma unroll
-              for (int u = 0; u < NDY; ++u) asm volatile("" :: "v"(tr.d0[u]), "v"(tr.d1[u]));
-              return;
-            }
-#endif
-#pragma unroll
-            for (int u = 0; u < NX; ++u)
-              if ((u + 1) * 256 <= NIT_X || u * 256 + tid < NIT_X) put8(smem + buf + xlds[u], ROW_C, tr.x0[u], tr.x1[u]);
-#pragma unroll
-            for (int u = 0; u < NDY; ++u)
-              if ((u + 1) * 256 <= NIT_DY || u * 256 + tid < NIT_DY) put8(smem + buf + dlds[u], DYS, tr.d0[u], tr.d1[u]);
-          };
-          fetch_lean(ra, true);
-          { const bool more = steps > 1; if (more) next(); fetch_lean(rb, more); }
+          fetch_lean(ra, true, n, zt, tyi * TY, txi * TX);
+          { const bool more = steps > 1; if (more) next(); fetch_lean(rb, more, n, zt, tyi * TY, txi * TX); }
           // (timing build: the loader's stamps go to slots 30 .. 57 -- per tile: before the transposition, behind it, behind the
           // next fetch's issue, behind the barrier)
 #ifdef RM_CONV_TIMING
@@ -826,12 +841,12 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
             RM_LSTAMP(0);
             stage_lean(ra, 0);
             RM_LSTAMP(1);
-            { const bool more = i + 2 < steps; if (more) next(); fetch_lean(ra, more); }
+            { const bool more = i + 2 < steps; if (more) next(); fetch_lean(ra, more, n, zt, tyi * TY, txi * TX); }
             RM_LSTAMP(2);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             RM_LSTAMP(3);
             stage_lean(rb, LDS_SET);
-            { const bool more = i + 3 < steps; if (more) next(); fetch_lean(rb, more); }
+            { const bool more = i + 3 < steps; if (more) next(); fetch_lean(rb, more, n, zt, tyi * TY, txi * TX); }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
           }
           if (i < steps) {
@@ -884,14 +899,29 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
       // buffer is staged again only after the barrier behind the MFMAs that read it
       int boff = 0;
       if (loader) {
-        if (have) fetch();
-        while (have) {
-          stage(boff);                                   // (waits for the tile's loads, transposes it into the buffer)
-          have = advance();
-          if (have) fetch();                             // in flight across the barrier
+        // two tiles in flight (register sets a / b; a lands in buffer 0, b in buffer 1), every load on every path: a fetch
+        // behind the last tile asks for out-of-range offsets
+        auto tile_fetch = [&](TileRegs& tr, bool real) {
+          const int txi = tile % a.ntx, t2 = tile / a.ntx;
+          fetch_lean(tr, real, n, (t2 / a.nty) * TZ, (t2 % a.nty) * TY, txi * TX);
+        };
+        if (!have) return;
+        tile_fetch(ra, true);
+        bool have_b = advance();
+        tile_fetch(rb, have_b);
+        for (;;) {
+          stage_lean(ra, 0);
+          if (!have_b) break;
+          const bool have_a = advance();
+          tile_fetch(ra, have_a);
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-          boff ^= LDS_SET;
+          stage_lean(rb, LDS_SET);
+          if (!have_a) break;
+          have_b = advance();
+          tile_fetch(rb, have_b);
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         return;
       }
       while (have) {
@@ -1210,13 +1240,16 @@ int launch_wgrad_bf16(WgradArgs a, int n, hipStream_t s) {
   // own un-overlapped first fetch and epilogue: same box, both experts' gradients of a level-3 layer at batch 8, two-workgroup
   // form -> this one: 128 -> 256 (256 units) 58.8 -> 45.9 us, 256 -> 256 (512) 74.0 -> 69.3, 512 -> 256 (1024) 130 -> 131;
   // level 4 (2048 units of <= 8 short steps) 54.4 -> 64.4, 95.8 -> 120: taken for level 3 up to two rounds.
-  // REPMODE_WGRAD_WS8 (default 1).
+  // Round 6, with the loader waves' lean fetch (two tiles in flight, ~1/3 of the instructions): the MFMA waves no longer wait
+  // at the barrier (stamps: 900 -> 128 cycles per tile), 256 -> 256 71 -> 62 us, and the form also wins beyond two rounds
+  // (512 -> 256, 1024 units: 127.8 -> 109.7 us); level 4 unchanged (54.1 / 53.8, 95.7 / 100.3): level 3 always, level 4 never.
+  // REPMODE_WGRAD_WS8: 0 never, 1 (default) level 3, 2 wherever the layouts allow.
   static const int ws8_env = []() { const char* e = getenv("REPMODE_WGRAD_WS8"); return e ? atoi(e) : 1; }();
   bool ws8 = false;
   if constexpr (TZ == 2)      // (`vec` is off below WGRAD_PIPE_MINW: the two-workgroup form's own pipelining loses there)
     ws8 = ws8_env != 0 && (a.Cin & 7) == 0 && (a.Cout & 7) == 0 &&
           (size_t)a.D * a.H * a.W * (a.Cin > a.Cout ? a.Cin : a.Cout) * 2 < ((size_t)1 << 31) && a.layout != 0 &&
-          (!a.dy2 || a.layout2 != 0) && a.nchunks == 1 && TY == 8 && grid <= resident2;     // (two rounds of one workgroup per CU; measured: see above)
+          (!a.dy2 || a.layout2 != 0) && a.nchunks == 1 && (TY == 8 || ws8_env >= 2);
   if (ws8) {
     if constexpr (TZ == 2)
       hipLaunchKernelGGL((conv5_wgrad_bf16_kernel<TZ, TY, TX, true, false, true>), dim3((unsigned)grid), dim3(512), 0, s, a);

@@ -42,4 +42,20 @@ for cin, cout, d, h, w in SHAPES:
             ms = e0.elapsed_time(e1) / iters
             line += '  mode %d %.1f us (%.0f TF, %.2f TB/s written)' % (mode, ms * 1e3, fl / ms / 1e9, (d5.numel() + d3.numel()) * 4 / ms / 1e9)
     print(line, flush=True)
+    if os.environ.get('WGRAD_STAMPS'):      # timing build (-DRM_CONV_TIMING): the first workgroups' per-tile stamps of the last launch
+        import ctypes
+        import numpy as np
+        ops.set_wgrad_col(0)
+        run()
+        torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * (64 * 64))()
+        fn = _lib.load().repmode_debug_wgrad_timing
+        fn.argtypes = [ctypes.c_void_p]
+        assert fn(buf) == 0
+        t = np.frombuffer(buf, dtype=np.uint64).reshape(64, 64).astype(np.int64)
+        for b in (0, 9, 33):
+            row = t[b]
+            out = ['tile %d: barrier wait %d, mma %d, to next %d' % (k, row[3 * k + 1] - row[3 * k], row[3 * k + 2] - row[3 * k + 1],
+                                                                      row[3 * k + 3] - row[3 * k + 2]) for k in range(6)]
+            print('   wg %2d | start -> first barrier %d | ' % (b, row[0] - row[59]) + ' | '.join(out) + ' | end %d' % (row[61] - row[59]))
 ops.set_wgrad_col(1)
