@@ -220,6 +220,18 @@ struct WgTile {
   static constexpr int DYS = TV * 2 + 32;               // bytes per output channel
   static constexpr int LDS_OPERANDS = 32 * ROW_C + 32 * DYS;
   static constexpr int LDS = LDS_OPERANDS > 4 * 64 * 25 * 4 ? LDS_OPERANDS : 4 * 64 * 25 * 4;   // (the expert-layout epilogue's buffer)
+  // The K loop's plan (see the kernel: a K step = 32 voxels = GPR tile rows, a window = one halo row of a plane):
+  static constexpr int GPR = 4 / NGX;                // tile rows per K step
+  static constexpr int NWROW = TY - GPR + 5;         // distinct halo rows (relative to the lane's) the taps of a plane touch
+  static constexpr int NW = TZ * NWROW;              // windows of a tile
+  // tap row dy of K step ks in window w, or -1
+  static constexpr int dyi_of(int w, int ks) {
+    const int zz = w / NWROW, rr = w % NWROW, grb = ks * GPR, d = rr - grb % TY;
+    return (grb / TY == zz && d >= 0 && d < 5) ? d : -1;
+  }
+  static constexpr int mfmas_of(int w) { int c = 0; for (int k = 0; k < KSTEPS; ++k) if (dyi_of(w, k) >= 0) c += 5; return c; }
+  static constexpr int steps_before(int w, int ks) { int c = 0; for (int k = 0; k < ks; ++k) if (dyi_of(w, k) >= 0) ++c; return c; }
+  static constexpr int last_window_of(int ks) { int l = -1; for (int w = 0; w < NW; ++w) if (dyi_of(w, ks) >= 0) l = w; return l; }
   static_assert(TV % 32 == 0 && TX % 8 == 0 && TX <= 32 && (TX + 4) * 2 <= RG * 16, "tile shape");
   static_assert((ROW_C / 16) % 4 == 2 && (DYS / 16) % 4 == 2,
                 "channel rows an odd multiple of 32 bytes apart: 8 rows take the even (odd) 16-byte slots -> conflict-free ds_read_b128");
@@ -347,84 +359,97 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
   constexpr int NWROW = TY - GPR + 5;                // distinct halo rows (relative to the lane's) the taps of a plane touch
   const unsigned char* xlane = xT + (ciq * 16 + l15) * ROW_C + ((kg / NGX) * RG + kg % NGX) * 16;
   const unsigned char* alane = dyT + (cq * 16 + l15) * DYS + kg * 16;
-  auto mma_tile = [&](int boff) {
-    if constexpr (!G::SWZ && !DENSE) {        // (the TX = 8 tiles: 5.5 MFMAs per window, 16 operations per window measured slower than 13: 2700 -> 3050 cycles per tile)
-      // Round 6.  v_mfma_f32_16x16x32_bf16 issues back to back every ~17 cycles on a SIMD, about four issue slots: up to three
-      // other instructions per MFMA cost nothing, a block of them between two MFMAs does.  Round 3's form prepared a window's
-      // five operands as a block of 13 vector operations (5 v_alignbit + 8 moves: the shift-0 / shift+1 operands start at odd
-      // registers of the window's six words, and a 128-bit MFMA operand must start at an even one) between the MFMAs of two
-      // windows -- ~40 cycles of idle matrix pipe per window, 12 windows a tile (stamps: 3980 cycles per 200 MFMAs).  Here the
-      // 16 operations of window w + 1 (each shifted operand into registers of its own: 2 x 4 v_alignbit, 2 x 4 moves) are
-      // placed one by one behind the MFMAs of window w, and windows are requested two ahead.
-      struct Win { u32x4 lo; u32x2 hi; };               // words 0..3 / 4, 5 of the window's six
-      struct Ops { u32x4 b1, b2, b3, b4; };             // shifts -1, 0, +1, +2 (shift -2 is `lo` itself)
-      bf16x8 afr[G::KSTEPS];
-#pragma unroll
-      for (int ks = 0; ks < G::KSTEPS; ++ks)
-        afr[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(alane + boff + ks * 64));
-      constexpr int NW = TZ * NWROW;
-      auto request = [&](int w, Win& o) {
-        const int zz = w / NWROW, rr = w % NWROW;
-        const unsigned char* xb = xlane + boff + ((zz * HY + rr) * RG) * 16;
-        o.lo = *reinterpret_cast<const u32x4*>(G::SWZ ? xb + (l15 & 1) * 16 : xb);                 // words 0..3: elements 0..7
-        o.hi = *reinterpret_cast<const u32x2*>(G::SWZ ? xb + 16 - (l15 & 1) * 16 : xb + 16);      // words 4, 5: elements 8..11
-      };
-      auto prep = [&](const Win& r, int i, Ops& o) {      // operation i of 16
-        const uint32_t w[6] = {r.lo.x, r.lo.y, r.lo.z, r.lo.w, r.hi.x, r.hi.y};
-        const int e = i & 3;
-        if (i < 4) o.b1[e] = __builtin_amdgcn_alignbit(w[e + 1], w[e], 16);            // elements 1..8
-        else if (i < 8) o.b3[e] = __builtin_amdgcn_alignbit(w[e + 2], w[e + 1], 16);   // elements 3..10
-        else if (i < 12) o.b2[e] = w[e + 1];                                            // elements 2..9
-        else o.b4[e] = w[e + 2];                                                        // elements 4..11
-      };
-      Win raw[3];
-      Ops ops[2];
-      request(0, raw[0]);
-      if (NW > 1) request(1, raw[1]);
-      static_for<0, 16>([&](auto I) { prep(raw[0], I.value, ops[0]); });
-      static_for<0, NW>([&](auto WI) {
-        constexpr int w = WI.value, zz = w / NWROW, rr = w % NWROW;
-        Win& cur = raw[w % 3];
-        Ops& op = ops[w & 1];
-        if constexpr (w + 2 < NW) request(w + 2, raw[(w + 2) % 3]);
-        RM_WSCHED_FENCE();
-        constexpr int nm = [] {                          // MFMAs of this window
-          int c = 0;
-          for (int k2 = 0; k2 < G::KSTEPS; ++k2) {
-            const int g2 = k2 * GPR, d2 = rr - g2 % TY;
-            if (g2 / TY == zz && d2 >= 0 && d2 < 5) c += 5;
-          }
-          return c;
-        }();
-        constexpr int per = nm > 0 ? (16 + nm - 1) / nm : 16;
-        if constexpr (nm == 0 && w + 1 < NW)             // (no tile shape has such a window; kept correct)
-          static_for<0, 16>([&](auto I) { prep(raw[(w + 1) % 3], I.value, ops[(w + 1) & 1]); });
-        const bf16x8 o0 = __builtin_bit_cast(bf16x8, cur.lo), o1 = __builtin_bit_cast(bf16x8, op.b1),
-                     o2 = __builtin_bit_cast(bf16x8, op.b2), o3 = __builtin_bit_cast(bf16x8, op.b3),
-                     o4 = __builtin_bit_cast(bf16x8, op.b4);
-        static_for<0, G::KSTEPS>([&](auto KS) {
-          constexpr int ks = KS.value, grb = ks * GPR, dyi = rr - grb % TY;
-          if constexpr (grb / TY == zz && dyi >= 0 && dyi < 5) {
-            constexpr int before = [] {                  // steps of this window ahead of this one
-              int c = 0;
-              for (int k2 = 0; k2 < ks; ++k2) {
-                const int g2 = k2 * GPR, d2 = rr - g2 % TY;
-                if (g2 / TY == zz && d2 >= 0 && d2 < 5) ++c;
-              }
-              return c;
-            }();
-            static_for<0, 5>([&](auto J) {
-              constexpr int j = J.value, m = before * 5 + j;
-              const bf16x8 bj = j == 0 ? o0 : j == 1 ? o1 : j == 2 ? o2 : j == 3 ? o3 : o4;
-              acc[dyi * 5 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[ks], bj, acc[dyi * 5 + j], 0, 0, 0);
-              if constexpr (w + 1 < NW && m * per < 16) {
-                static_for<m * per, (m + 1) * per < 16 ? (m + 1) * per : 16>([&](auto I) { prep(raw[(w + 1) % 3], I.value, ops[(w + 1) & 1]); });
-                RM_WSCHED_FENCE();
-              }
-            });
-          }
-        });
+  // ---- Round 6: the tile's MFMAs as a pipeline of windows.  v_mfma_f32_16x16x32_bf16 issues back to back every ~17 cycles on
+  // a SIMD (tools/mfma_rate.hip: 16.9; 17.2 / 18.0 with one / two vector operations behind every MFMA, 22.3 with three), a block
+  // of other instructions between two MFMAs is idle matrix pipe.  Round 3's form prepared a window's five operands as a block
+  // of 13 vector operations (5 v_alignbit + 8 moves: the shift-0 / shift+1 operands start at odd registers of the window's six
+  // words, and a 128-bit MFMA operand must start at an even one) between the MFMAs of two windows (stamps: 3980 cycles per 200
+  // MFMAs).  Here the 16 operations of window w + 1 (each shifted operand into registers of its own: 2 x 4 v_alignbit, 2 x 4
+  // moves) are placed one by one behind the MFMAs of window w, and windows are requested two ahead.
+  // PIPE (the stream-K loop, NW a multiple of 6 so that the register rings line up): the pipeline runs ACROSS tiles.  A tile's
+  // last LDS read is the request of its last window, two windows before its end: there the MFMA waves wait for their LDS data,
+  // pass the barrier (the next tile is staged; this tile's buffer is free) and fetch the next tile's A fragments and first
+  // windows behind the remaining MFMAs -- the ~350 cycles a tile spent on its first LDS round trip and the first window's
+  // preparation (9 % of a 3980-cycle tile) overlap with MFMAs.
+  struct Win { u32x4 lo; u32x2 hi; };               // words 0..3 / 4, 5 of a window's six
+  struct Ops { u32x4 b1, b2, b3, b4; };             // shifts -1, 0, +1, +2 (shift -2 is `lo` itself)
+  constexpr int NW = G::NW;
+  static_assert(G::GPR == GPR && G::NWROW == NWROW, "WgTile's plan");
+  Win p_raw[3];
+  Ops p_ops[2];
+  bf16x8 p_afr[G::KSTEPS];
+  auto w_request = [&](int off, int w, Win& o) __attribute__((always_inline)) {
+    const int zz = w / NWROW, rr = w % NWROW;
+    const unsigned char* xb = xlane + off + ((zz * HY + rr) * RG) * 16;
+    o.lo = *reinterpret_cast<const u32x4*>(xb);
+    o.hi = *reinterpret_cast<const u32x2*>(xb + 16);
+  };
+  auto w_prep = [&](const Win& r, int i, Ops& o) __attribute__((always_inline)) {      // operation i of 16
+    const uint32_t w[6] = {r.lo.x, r.lo.y, r.lo.z, r.lo.w, r.hi.x, r.hi.y};
+    const int e = i & 3;
+    if (i < 4) o.b1[e] = __builtin_amdgcn_alignbit(w[e + 1], w[e], 16);            // elements 1..8
+    else if (i < 8) o.b3[e] = __builtin_amdgcn_alignbit(w[e + 2], w[e + 1], 16);   // elements 3..10
+    else {
+      // elements 2..9 / 4..11: moves, as instructions of their own (a plain element copy has no place in the instruction
+      // stream: the compiler emitted them in blocks of 3-6 in front of the MFMA that reads the operand)
+      uint32_t t;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"(i < 12 ? w[e + 1] : w[e + 2]));
+      if (i < 12) o.b2[e] = t; else o.b4[e] = t;
+    }
+  };
+  auto a_load = [&](int off, int ks) __attribute__((always_inline)) { p_afr[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(alane + off + ks * 64)); };
+  auto pipe_prologue = [&](int off) __attribute__((always_inline)) {
+    static_for<0, G::KSTEPS>([&](auto KS) { a_load(off, KS.value); });
+    w_request(off, 0, p_raw[0]);
+    if constexpr (NW > 1) w_request(off, 1, p_raw[1]);
+    static_for<0, 16>([&](auto I) { w_prep(p_raw[0], I.value, p_ops[0]); });
+  };
+  auto pipe_body = [&](int off, int noff, auto PIPE_) __attribute__((always_inline)) {
+    constexpr bool PIPE = decltype(PIPE_)::value;
+    static_for<0, NW>([&](auto WI) {
+      constexpr int w = WI.value;
+      Win& cur = p_raw[w % 3];
+      Ops& op = p_ops[w & 1];
+      if constexpr (PIPE && w == 0)                    // the A fragments still in use when the previous tile fetched the others
+        static_for<0, G::KSTEPS>([&](auto KS) { if constexpr (G::last_window_of(KS.value) >= NW - 2) a_load(off, KS.value); });
+      if constexpr (w + 2 < NW) w_request(off, w + 2, p_raw[(w + 2) % 3]);
+      if constexpr (PIPE && w == NW - 2) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // this tile is in registers; the next one is staged
+        static_for<0, G::KSTEPS>([&](auto KS) { if constexpr (G::last_window_of(KS.value) < NW - 2) a_load(noff, KS.value); });
+        w_request(noff, 0, p_raw[NW % 3]);
+      }
+      if constexpr (PIPE && w == NW - 1) w_request(noff, 1, p_raw[(NW + 1) % 3]);
+      RM_WSCHED_FENCE();
+      constexpr int nm = G::mfmas_of(w);
+      constexpr int per = nm > 0 ? (16 + nm - 1) / nm : 16;
+      constexpr bool has_next = w + 1 < NW || PIPE;      // (PIPE: the next tile's window 0 takes ring slots NW % 3 = 0, NW & 1 = 0)
+      if constexpr (nm == 0 && has_next)                 // (no tile shape has such a window; kept correct)
+        static_for<0, 16>([&](auto I) { w_prep(p_raw[(w + 1) % 3], I.value, p_ops[(w + 1) & 1]); });
+      const bf16x8 o0 = __builtin_bit_cast(bf16x8, cur.lo), o1 = __builtin_bit_cast(bf16x8, op.b1),
+                   o2 = __builtin_bit_cast(bf16x8, op.b2), o3 = __builtin_bit_cast(bf16x8, op.b3),
+                   o4 = __builtin_bit_cast(bf16x8, op.b4);
+      static_for<0, G::KSTEPS>([&](auto KS) {
+        constexpr int ks = KS.value, dyi = G::dyi_of(w, ks);
+        if constexpr (dyi >= 0) {
+          constexpr int before = G::steps_before(w, ks);
+          static_for<0, 5>([&](auto J) {
+            constexpr int j = J.value, m = before * 5 + j;
+            const bf16x8 bj = j == 0 ? o0 : j == 1 ? o1 : j == 2 ? o2 : j == 3 ? o3 : o4;
+            acc[dyi * 5 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p_afr[ks], bj, acc[dyi * 5 + j], 0, 0, 0);
+            if constexpr (has_next && m * per < 16) {
+              static_for<m * per, (m + 1) * per < 16 ? (m + 1) * per : 16>([&](auto I) { w_prep(p_raw[(w + 1) % 3], I.value, p_ops[(w + 1) & 1]); });
+              RM_WSCHED_FENCE();
+            }
+          });
+        }
       });
+    });
+  };
+  constexpr bool SK_PIPE = WS && TZ == 1 && !G::SWZ && !DENSE && NW % 6 == 0;      // (the stream-K loop's cross-tile form)
+  auto mma_tile = [&](int boff) __attribute__((always_inline)) {      // (called from two loops: without the attribute one instantiation kept it as a FUNCTION)
+    if constexpr (!G::SWZ && !DENSE) {        // (the TX = 8 tiles: 5.5 MFMAs per window, 16 operations per window measured slower than 13: 2700 -> 3050 cycles per tile)
+      pipe_prologue(boff);
+      pipe_body(boff, 0, std::false_type{});
       return;
     }
     // The B operands of step (ks, dyi) are the window of halo row yyb(ks) + dyi of plane zz(ks): steps with equal sums share
@@ -507,15 +532,24 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
 
     // work sequence: (sample of this slot, tile of this chunk), skipping tiles whose input planes for this dz are
     // all padding.  Everything here is wave-uniform (scalar loads of sample_slot).
+    // The tile's coordinates (tile plane / row / column: atz, aty, atx) move along with `tile` -- the divisions once per
+    // workgroup (round 6: with them in every call, the MFMA waves of the per-expert levels spent 800 cycles between two tiles
+    // of 2700).
     int n = -1, tile = t_end;
+    int atz = 0, aty = 0, atx = 0;
+    const int bz0 = t_begin / max(a.ntx * a.nty, 1), by0 = (t_begin - bz0 * a.ntx * a.nty) / max(a.ntx, 1),
+              bx0 = t_begin - (bz0 * a.nty + by0) * a.ntx;
     auto advance = [&]() -> bool {
       for (;;) {
         if (++tile >= t_end) {
-          tile = t_begin;
+          tile = t_begin; atz = bz0; aty = by0; atx = bx0;
           do { ++n; } while (n < a.N && !in_slot(n));
           if (n >= a.N) return false;
+        } else if (++atx == a.ntx) {
+          atx = 0;
+          if (++aty == a.nty) { aty = 0; ++atz; }
         }
-        const int z0 = (tile / (a.ntx * a.nty)) * TZ;
+        const int z0 = atz * TZ;
         if (!(z0 + TZ - 1 + dz - 2 < 0 || z0 + dz - 2 >= D)) return true;
       }
     };
@@ -533,9 +567,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
         return;
       }
 #endif
-      const int txi = tile % a.ntx, t2 = tile / a.ntx;
-      const int tyi = t2 % a.nty, tzi = t2 / a.nty;
-      const int z0 = tzi * TZ, y0 = tyi * TY, x0 = txi * TX;
+      const int z0 = atz * TZ, y0 = aty * TY, x0 = atx * TX;            // (the tile `advance` stands on)
       const uint32_t xbytes = (uint32_t)((size_t)D * H * W * Cin * 2), dybytes = (uint32_t)((size_t)D * H * W * Cout * 2);
       const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<bf16_t*>(static_cast<const bf16_t*>(a.x)) + (size_t)n * D * H * W * Cin, 0, (int)xbytes, 0x00020000);
@@ -661,7 +693,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
         }
       };
       // the tile at output voxel (z0, y0, x0) of sample n_, for this workgroup's dz / cit / cot
-      auto fetch_lean = [&](TileRegs& tr, bool real, int n_, int z0, int y0, int x0) {
+      auto fetch_lean = [&](TileRegs& tr, bool real, int n_, int z0, int y0, int x0) __attribute__((always_inline)) {
 #ifdef RM_WG_NOLOAD
         {                                 // TIMING BUILD ONLY: the tile loop without its global loads
 #pragma unroll
@@ -710,13 +742,13 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
       };
       // two x-adjacent voxels' eight channels -> eight dwords (channel k: voxel 0 in the low half), one v_perm_b32 each;
       // even channel rows at dst0, odd ones at dst1 (the swizzled TX = 8 tile; the same address otherwise)
-      auto put8 = [&](unsigned char* dst0, unsigned char* dst1, int stride, const u32x4& v0, const u32x4& v1) {
+      auto put8 = [&](unsigned char* dst0, unsigned char* dst1, int stride, const u32x4& v0, const u32x4& v1) __attribute__((always_inline)) {
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
           *reinterpret_cast<uint32_t*>(((kk & 1) ? dst1 : dst0) + kk * stride) =
               __builtin_amdgcn_perm(v1[kk >> 1], v0[kk >> 1], (kk & 1) ? 0x07060302u : 0x05040100u);
       };
-      auto stage_lean = [&](TileRegs& tr, int buf) {
+      auto stage_lean = [&](TileRegs& tr, int buf) __attribute__((always_inline)) {
 #ifdef RM_WG_NOSTAGE
         {                                 // TIMING BUILD ONLY: the loads are waited for, nothing is transposed into LDS
 #pragma unroll
@@ -853,14 +885,20 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
             stage_lean(ra, 0);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
           }
+          if constexpr (SK_PIPE) asm volatile("s_barrier" ::: "memory");      // (the last tile's barrier "for the next tile")
 #undef RM_LSTAMP
           return;
         }
+        if constexpr (SK_PIPE) {
+          asm volatile("s_barrier" ::: "memory");
+          pipe_prologue(boff);
+        }
         for (int i = 0; i < steps; ++i) {
           RM_WSTAMP(i * 3 + 0);
-          asm volatile("s_barrier" ::: "memory");
+          if constexpr (!SK_PIPE) asm volatile("s_barrier" ::: "memory");
           RM_WSTAMP(i * 3 + 1);
-          mma_tile(boff);
+          if constexpr (SK_PIPE) pipe_body(boff, boff ^ LDS_SET, std::true_type{});     // (with the barrier for the next tile inside)
+          else mma_tile(boff);
           RM_WSTAMP(i * 3 + 2);
           boff ^= LDS_SET;
           const bool last = last_of_unit();
@@ -901,10 +939,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, DENSE ? 3 : 2) void conv5_wgrad_bf1
       if (loader) {
         // two tiles in flight (register sets a / b; a lands in buffer 0, b in buffer 1), every load on every path: a fetch
         // behind the last tile asks for out-of-range offsets
-        auto tile_fetch = [&](TileRegs& tr, bool real) {
-          const int txi = tile % a.ntx, t2 = tile / a.ntx;
-          fetch_lean(tr, real, n, (t2 / a.nty) * TZ, (t2 % a.nty) * TY, txi * TX);
-        };
+        auto tile_fetch = [&](TileRegs& tr, bool real) { fetch_lean(tr, real, n, atz * TZ, aty * TY, atx * TX); };
         if (!have) return;
         tile_fetch(ra, true);
         bool have_b = advance();
