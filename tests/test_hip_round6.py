@@ -426,3 +426,43 @@ def test_capturable_adam_keeps_its_device_buffers_across_load_state_dict():
     for p, q in zip(ps, qs):
         assert rel_err(p.detach().cpu(), q.detach().cpu()) < 1e-6
 
+
+
+def test_conv5_wgrad_forms_agree_on_random_shapes():
+    """The filter gradient's forms against each other on 48 seeded random shapes (ragged volumes 16 .. 70 voxels wide, 1 .. 12
+    planes, channel counts off the 32-channel tiles, 1 .. 8 slots with uneven sample counts): stream-K with the cross-tile
+    window pipeline (mode 3), the wave-specialised grid (2) and the column walk (col mode 2, where eligible) against the regular
+    grid (0) -- same products, another split of the voxel sums (each form is checked against the oracle on fixed cases; this
+    one looks for shapes a form mishandles).  tools/wgrad_fuzz.py is the same loop for any number of cases."""
+    import random
+    ops = _ops()
+    rng = random.Random(20261001)
+    ws, col = ops.get_wgrad_ws(), ops.get_wgrad_col()
+    worst = 0.0
+    try:
+        for it in range(48):
+            n = rng.choice([1, 2, 3, 5, 8, 11])
+            d, h = rng.choice([1, 2, 3, 4, 7, 12]), rng.choice([3, 4, 8, 9, 16, 21])
+            w = rng.choice([16, 17, 24, 32, 33, 40, 64, 70])
+            cin, cout = rng.choice([8, 16, 24, 32, 40, 64, 96]), rng.choice([8, 16, 32, 48, 64, 72])
+            ntask = rng.choice([1, 2, 3, n])
+            tasks = [rng.randrange(12) % ntask for _ in range(n)]
+            plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+            g = torch.Generator(device=DEV).manual_seed(it)
+            x = torch.randn(n, d, h, w, cin, device=DEV, generator=g).bfloat16()
+            dy = torch.randn(n, d, h, w, cout, device=DEV, generator=g).bfloat16()
+            ops.set_wgrad_col(0)
+            ops.set_wgrad_ws(0)
+            ref = ops.conv5_wgrad(x, dy, plan, cout).float()
+            scale = ref.abs().max().item() + 1e-30
+            for ws_mode, col_mode in ((3, 0), (2, 0), (3, 2)):
+                ops.set_wgrad_ws(ws_mode)
+                ops.set_wgrad_col(col_mode)
+                got = ops.conv5_wgrad(x, dy, plan, cout).float()
+                e = (got - ref).abs().max().item() / scale
+                worst = max(worst, e)
+                assert e < 1e-4, (it, (n, d, h, w, cin, cout, tasks), ws_mode, col_mode, e)
+    finally:
+        ops.set_wgrad_ws(ws)
+        ops.set_wgrad_col(col)
+    record('wgrad_forms_random', cases=48, worst=worst)
