@@ -466,3 +466,44 @@ def test_conv5_wgrad_forms_agree_on_random_shapes():
         ops.set_wgrad_ws(ws)
         ops.set_wgrad_col(col)
     record('wgrad_forms_random', cases=48, worst=worst)
+
+
+@pytest.mark.parametrize('case', [
+    # (N, D, H, W, Cin, Cout, tasks): stream-K ranges of one, two and three tile steps on the 8 x 32 tile (the cross-tile window
+    # pipeline's prologue / last-tile paths: a workgroup whose first tile is also its last), and a unit boundary in mid-range
+    (1, 1, 8, 32, 32, 32, [2]),              # one sample, one plane: only dz = 2 has a step -- ONE step in the launch
+    (1, 2, 8, 32, 32, 32, [2]),              # dz = 1, 2, 3: four steps
+    (1, 1, 16, 64, 8, 8, [7]),               # four tiles of one plane, half-filled channel tiles
+    (2, 1, 8, 32, 40, 72, [3, 5]),           # two slots, 2 x 3 channel tiles: every workgroup crosses unit boundaries
+    (3, 3, 9, 33, 32, 32, [1, 1, 1]),        # ragged tiles whose second x tile holds one voxel column
+])
+def test_conv5_wgrad_stream_k_short_ranges_vs_oracle(case):
+    """The stream-K filter gradient with the window pipeline running across tiles (csrc/conv5_wgrad.hip, SK_PIPE) where a
+    workgroup's range is a step or two: the prologue's tile is the last one, the in-tile barrier "for the next tile" has no
+    next tile -- against the oracle (autograd of the per-sample convolution, RepMode.py:207) and the regular grid."""
+    ops = _ops()
+    n, d, h, w, cin, cout, tasks = case
+    gen = torch.Generator().manual_seed(sum(case[:6]) + 31)
+    plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+    x = torch.randn(n, cin, d, h, w, generator=gen).bfloat16().float()
+    dy = torch.randn(n, cout, d, h, w, generator=gen).bfloat16().float()
+    wt = torch.zeros(plan.nslots, cout, cin, 5, 5, 5, requires_grad=True)
+    slots = torch.tensor([plan.slot_task_host.index(t) for t in tasks])
+    (orc.conv_per_sample(x, wt[slots]) * dy).sum().backward()
+    dw_ref = wt.grad.reshape(plan.nslots, cout, cin, 125).permute(0, 3, 1, 2)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous().to(DEV, torch.bfloat16)
+    got = []
+    ws, col = ops.get_wgrad_ws(), ops.get_wgrad_col()
+    try:
+        ops.set_wgrad_col(0)
+        for mode in (3, 0):
+            ops.set_wgrad_ws(mode)
+            got.append(ops.conv5_wgrad(x_cl, dy_cl, plan, cout).cpu())
+    finally:
+        ops.set_wgrad_ws(ws)
+        ops.set_wgrad_col(col)
+    e = rel_err(got[0], dw_ref)
+    record('wgrad_sk_short', case=list(case[:6]), err=e)
+    assert e < TOL_BF16_ACC
+    assert rel_err(got[0], got[1]) < 1e-4
