@@ -507,3 +507,81 @@ def test_conv5_wgrad_stream_k_short_ranges_vs_oracle(case):
     record('wgrad_sk_short', case=list(case[:6]), err=e)
     assert e < TOL_BF16_ACC
     assert rel_err(got[0], got[1]) < 1e-4
+
+
+def test_conv5_forms_agree_on_random_shapes():
+    """The forward / data-gradient convolution's forms against each other on 40 seeded random shapes (ragged volumes 8 .. 70
+    voxels wide, channel counts off the 16- / 32-channel tiles, uneven slots): the wave-specialised pipeline with its default
+    switches (conv_pipe 57: 32- and 16-voxel bricks, row-stationary taps on 32-channel layers, forced onto grids smaller than the
+    chip) against the two-workgroup kernel (conv_pipe 0) -- same products; the row-stationary order sums the 125 taps in
+    another order (float rounding, then one bf16 rounding of the output: 2e-2 of the tensor's max at bf16's 8 bits is loose;
+    measured ~4e-3)."""
+    import random
+    ops = _ops()
+    rng = random.Random(20261002)
+    pipe = ops.get_conv_pipe()
+    worst = 0.0
+    try:
+        for it in range(40):
+            n = rng.choice([1, 2, 3, 5, 8])
+            d, h = rng.choice([1, 2, 4, 5, 9]), rng.choice([3, 4, 8, 9, 16])
+            w = rng.choice([8, 15, 16, 17, 24, 32, 33, 40, 64, 70])
+            cin, cout = rng.choice([8, 16, 24, 32, 40, 64]), rng.choice([8, 16, 32, 48, 64])
+            ntask = rng.choice([1, 2, n])
+            tasks = [rng.randrange(12) % ntask for _ in range(n)]
+            plan = ops.TaskPlan(torch.tensor(tasks), 12, DEV, training=True)
+            g = torch.Generator(device=DEV).manual_seed(1000 + it)
+            x = torch.randn(n, d, h, w, cin, device=DEV, generator=g).bfloat16()
+            experts = [torch.randn(cout, cin, k, k, k, device=DEV, generator=g) * 0.1 for k in (5, 3, 1, 1, 1)]
+            gate = torch.softmax(torch.randn(plan.nslots, 5, cout, device=DEV, generator=g), dim=1)
+            wf, _ = ops.gatrep_merge(*experts, gate, torch.bfloat16)
+            ops.set_conv_pipe(0)
+            ref = ops.conv5(x, wf, plan.sample_slot, cout).float()
+            ops.set_conv_pipe(57 | 4)
+            got = ops.conv5(x, wf, plan.sample_slot, cout).float()
+            e = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+            worst = max(worst, e)
+            assert e < 2e-2, (it, (n, d, h, w, cin, cout, tasks), e)
+    finally:
+        ops.set_conv_pipe(pipe)
+    record('conv5_forms_random', cases=40, worst=worst)
+
+
+def test_bn_relu_one_launch_agrees_with_two_launches_on_random_shapes():
+    """BatchNorm3d + ReLU, training mode, forward and backward: the one-launch passes (grid-wide barrier; set_bn_fused(1))
+    against the two-launch passes (0) on 30 seeded random shapes -- tensors from a few rows to the largest the one-launch form
+    takes, 8 .. 512 channels, bf16 and float: outputs, running statistics and all three gradients within float summation
+    order (1e-5 of the tensor's max; bf16 outputs: one rounding step)."""
+    import copy
+    import random
+    ops = _ops()
+    rng = random.Random(20261003)
+    fused = ops.get_bn_fused()
+    worst = 0.0
+    try:
+        for it in range(30):
+            c = rng.choice([8, 16, 32, 64, 128, 256, 512])
+            n, d, h, w = rng.choice([1, 2, 8]), rng.choice([1, 2, 4, 8, 16]), rng.choice([2, 4, 8, 16, 32]), rng.choice([4, 8, 16, 32])
+            dtype = rng.choice([torch.bfloat16, torch.float32])
+            g = torch.Generator(device=DEV).manual_seed(2000 + it)
+            x = (torch.randn(n, d, h, w, c, device=DEV, generator=g) * 1.5 + 0.3).to(dtype)
+            dy = torch.randn(n, d, h, w, c, device=DEV, generator=g).to(dtype)
+            res = []
+            for mode in (1, 0):
+                ops.set_bn_fused(mode)
+                bn = torch.nn.BatchNorm3d(c).to(DEV)
+                with torch.no_grad():
+                    bn.weight.copy_(torch.linspace(0.5, 1.5, c)); bn.bias.copy_(torch.linspace(-0.2, 0.2, c))
+                bn.train()
+                xi = x.clone().requires_grad_(True)
+                y = ops.bn_relu(xi, bn)
+                y.backward(dy)
+                res.append([y.float(), xi.grad.float(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone()])
+            tol = 1e-2 if dtype == torch.bfloat16 else 1e-5
+            for a, b in zip(*res):
+                e = (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+                worst = max(worst, e if dtype == torch.float32 else 0.0)
+                assert e < tol, (it, (n, d, h, w, c, dtype), e)
+    finally:
+        ops.set_bn_fused(fused)
+    record('bn_fused_random', cases=30, worst_f32=worst)
