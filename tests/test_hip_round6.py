@@ -585,3 +585,43 @@ def test_bn_relu_one_launch_agrees_with_two_launches_on_random_shapes():
     finally:
         ops.set_bn_fused(fused)
     record('bn_fused_random', cases=30, worst_f32=worst)
+
+
+def test_per_expert_block_agrees_with_round4_launches_on_random_shapes():
+    """A per-expert MoDE block through the operator library -- one launch per direction (deep_mode 15), the dual filter-gradient
+    launch in its wave-specialised form with the lean loader on two-plane tiles -- against round 4's launches (deep_mode 0) on 14
+    seeded random shapes: ragged volumes up to 6 x 10 x 12, 8 .. 128 channels, 1 .. 6 samples of mixed tasks.  Output, data
+    gradient and all parameter gradients within 1e-2 (bf16: a summation-order difference can flip a rounding), as
+    test_deep_mode_in_the_operator's fixed cases (which also pin the form to the oracle)."""
+    import random
+    from test_hip_round5 import _rand_experts
+    ops = _ops()
+    rng = random.Random(20261004)
+    before = ops.get_deep_mode()
+    worst = 0.0
+    try:
+        for it in range(14):
+            ci, co = 8 * rng.randint(1, 16), 8 * rng.randint(1, 16)
+            shape = (rng.choice([1, 2, 3, 4, 6]), rng.choice([2, 4, 5, 8, 10]), rng.choice([4, 7, 8, 12]))
+            n = rng.randint(1, 6)
+            gen = torch.Generator().manual_seed(3000 + it)
+            ps = _rand_experts(co, ci, gen)
+            tasks = [rng.randrange(12) for _ in range(n)]
+            x = torch.randn(n, *shape, ci, generator=gen).bfloat16()
+            r = torch.randn(n, *shape, co, generator=gen)
+            res = []
+            for mask in (15, 0):
+                ops.set_deep_mode(mask)
+                dev = [p.to(DEV).requires_grad_(True) for p in ps]
+                xd = x.to(DEV).requires_grad_(True)
+                plan = ops.TaskPlan(tasks, 12, DEV, training=True)
+                y = ops.mode_conv3d(xd, *dev, plan, mode='unmerged')
+                (y.float() * r.to(DEV)).sum().backward()
+                res.append([y.detach().float().cpu(), xd.grad.float().cpu()] + [p.grad.cpu() for p in dev])
+            for a, b in zip(*res):
+                e = rel_err(a, b)
+                worst = max(worst, e)
+                assert e < 1e-2, (it, (ci, co, shape, n, tasks), e)
+    finally:
+        ops.set_deep_mode(before)
+    record('per_expert_block_random', cases=14, worst=worst)
